@@ -1,0 +1,21 @@
+"""CPU oracle for the ProbPose top-down inference hot path.
+
+TEST INFRASTRUCTURE ONLY. This package restates, on the CPU (numpy / scipy / torch-CPU /
+plain C), the arithmetic of the reference's hot path so that the HIP implementation in
+``probpose_code_amd`` can be checked against it. It is never the thing shipped or
+measured: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import, call, link or execute anything under ``oracle/``. The product
+package must not (``tests/test_no_oracle_in_product.py`` enforces that).
+
+Pinning status (DESIGN.md §Oracle has the full table):
+
+* decode (``decode_ref``; reference ``mmpose/codecs/utils/post_processing.py:13-39,308-430``,
+  ``mmpose/codecs/probmap.py:170-220``, ``mmpose/models/utils/tta.py:35-39``) -- PINNED:
+  checked bit-for-bit against outputs of the reference's own functions imported in
+  isolation in the build container (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``).
+* Sparsemax (PyPI ``sparsemax``, un-vendored, unpinned in ``requirements/build.txt:4``),
+  ViT backbone (``mmpretrain==1.2.0`` ``VisionTransformer``, un-vendored), ``ProbMapHead``
+  network (needs mmcv/mmengine, not importable) -- PARITY UNPINNED: restated from the
+  published algorithm / the cited reference lines; no reference test or golden vector
+  exists for them. Known-answer tests pin the restatement itself.
+"""

@@ -1,0 +1,85 @@
+"""Isolated import of the reference's hot-path modules (THIS container only).
+
+`import mmpose` fails here (mmengine/mmcv/cv2/... are absent), so the
+reference files on the decode path are loaded one by one behind minimal stubs:
+
+* ``cv2``                       -> empty module (only used by gaussian_blur*, never by decode)
+* ``mmpose``, ``mmpose.codecs`` -> bare package shells (their ``__init__`` must not run)
+* ``mmengine.utils.is_method_overridden`` -> 3-line functional stub
+* ``mmpose.registry.KEYPOINT_CODECS``     -> dict-backed register/build
+
+Used ONLY by ``tests/golden/make_golden.py`` to produce committed fixtures. Nothing in
+``tests/``'s collected tests, ``bench.py`` or ``__graft_entry__`` imports this file:
+``/root/reference`` does not exist on the GPU box.
+"""
+import importlib
+import importlib.util
+import os
+import sys
+import types
+
+REF = os.environ.get("PROBPOSE_REFERENCE", "/root/reference")
+
+
+def _shell(name, path=None):
+    m = types.ModuleType(name)
+    if path is not None:
+        m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _DictRegistry:
+    def __init__(self):
+        self.module_dict = {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.module_dict[name or cls.__name__] = cls
+            return cls
+
+        return deco if module is None else deco(module)
+
+    def build(self, cfg):
+        cfg = dict(cfg)
+        return self.module_dict[cfg.pop("type")](**cfg)
+
+
+def load_reference():
+    """Returns a namespace with the reference's own functions/classes."""
+    if not os.path.isdir(REF):
+        raise RuntimeError(f"reference tree not found at {REF}")
+    if "cv2" not in sys.modules:
+        _shell("cv2")
+    _shell("mmpose", os.path.join(REF, "mmpose"))
+    _shell("mmpose.codecs", os.path.join(REF, "mmpose/codecs"))
+    mmengine = _shell("mmengine")
+    mmengine_utils = _shell("mmengine.utils")
+
+    def is_method_overridden(method, base_class, derived_class):
+        if not isinstance(derived_class, type):
+            derived_class = derived_class.__class__
+        return getattr(derived_class, method) != getattr(base_class, method)
+
+    mmengine_utils.is_method_overridden = is_method_overridden
+    mmengine.utils = mmengine_utils
+    reg = _shell("mmpose.registry")
+    reg.KEYPOINT_CODECS = _DictRegistry()
+
+    ns = types.SimpleNamespace()
+    # real package: mmpose/codecs/utils/__init__.py imports only numpy/scipy/torch/cv2 users
+    ns.utils = importlib.import_module("mmpose.codecs.utils")
+    ns.post = sys.modules["mmpose.codecs.utils.post_processing"]
+    ns.base = _load("mmpose.codecs.base", "mmpose/codecs/base.py")
+    ns.probmap = _load("mmpose.codecs.probmap", "mmpose/codecs/probmap.py")
+    ns.tta = _load("_ref_tta", "mmpose/models/utils/tta.py")
+    ns.KEYPOINT_CODECS = reg.KEYPOINT_CODECS
+    return ns
