@@ -1,0 +1,88 @@
+"""ctypes binding of ``libprobpose_mi355x.so`` (the C ABI in ``include/probpose_mi355x.h``).
+
+The shared library is the product: there is no Python/PyTorch fallback for any stage of
+the hot path. If the library is missing or a symbol is absent, importing this module
+raises -- loudly -- instead of degrading to a CPU path.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libprobpose_mi355x.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+PP_OK = 0
+PP_ERR_INVALID_ARG = -1
+PP_ERR_UNSUPPORTED = -2
+PP_ERR_HIP = -3
+PP_ERR_WORKSPACE = -4
+PP_MAX_RADIUS = 9
+PP_MAX_TAPS = 2 * PP_MAX_RADIUS + 1
+
+
+class ProbPoseLibraryError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, fn, status, message):
+        super().__init__(f"{fn} failed with {status}: {message}")
+        self.status = status
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found. Build it first: `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C probpose_code_amd/csrc`. There is no CPU fallback for the ProbPose hot path."
+        )
+    return ctypes.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+# name -> (restype, argtypes); mirrors include/probpose_mi355x.h one to one.
+_P = c_void_p
+SIGNATURES = {
+    "pp_abi_version": (c_int, []),
+    "pp_last_error": (c_char_p, []),
+    "pp_status_string": (c_char_p, [c_int]),
+    "pp_device_cu_count": (c_int, []),
+    "pp_probmap_decode": (
+        c_int,
+        [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P, _P, _P, _P, _P, _P],
+    ),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == header/library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error() -> str:
+    return lib.pp_last_error().decode("utf-8", "replace")
+
+
+def check(fn_name: str, status: int) -> None:
+    if status != PP_OK:
+        name = lib.pp_status_string(status).decode()
+        raise ProbPoseLibraryError(fn_name, name, last_error())
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C ABI takes dense row-major buffers"
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device` as an integer handle."""
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def call(fn_name: str, *args):
+    check(fn_name, getattr(lib, fn_name)(*args))

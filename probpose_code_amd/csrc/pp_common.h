@@ -1,0 +1,47 @@
+// Shared host-side helpers of libprobpose_mi355x.so: status codes, thread-local error
+// string, launch checking. gfx950 only -- no dual paths, no CUDA shims.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/probpose_mi355x.h"
+
+namespace pp {
+
+void set_error(const char* fmt, ...);
+
+inline int fail(int code, const char* what) {
+    set_error("%s", what);
+    return code;
+}
+
+#define PP_REQUIRE(cond, code, msg)          \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::pp::set_error("%s", (msg));    \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+#define PP_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            ::pp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),     \
+                            __FILE__, __LINE__);                                        \
+            return PP_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+// Called after every kernel launch: surfaces launch-configuration errors without syncing.
+#define PP_LAUNCH_CHECK() PP_HIP_CHECK(hipGetLastError())
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+}  // namespace pp

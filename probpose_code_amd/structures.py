@@ -1,0 +1,154 @@
+"""Output containers of the hot path (reference: ``mmpose/structures/pose_data_sample.py:9-104``
+on top of mmengine's ``BaseDataElement`` / ``InstanceData`` / ``PixelData``).
+
+With mmengine importable the real classes are re-exported so results are the very types
+``demo/image_demo.py`` and ``CocoMetric.process`` expect. Without it (this container, the
+GPU box) the look-alikes below provide the slice of behaviour the path touches:
+attribute + item access, ``set_field``, ``metainfo`` / ``set_metainfo``, ``keys`` /
+``all_items``, ``in``.
+"""
+from typing import Any, Dict, Iterator, Tuple
+
+try:  # pragma: no cover - exercised only in a real MMPose install
+    from mmengine.structures import BaseDataElement, InstanceData, PixelData  # type: ignore
+    from mmpose.structures import PoseDataSample  # type: ignore
+
+    USING_MMENGINE = True
+except Exception:  # noqa: BLE001
+    USING_MMENGINE = False
+
+    class BaseDataElement:
+        def __init__(self, *, metainfo: Dict[str, Any] = None, **kwargs):
+            object.__setattr__(self, "_metainfo_fields", set())
+            object.__setattr__(self, "_data_fields", set())
+            if metainfo is not None:
+                self.set_metainfo(metainfo)
+            for k, v in kwargs.items():
+                setattr(self, k, v)
+
+        # -- metainfo
+        def set_metainfo(self, metainfo: Dict[str, Any]) -> None:
+            assert isinstance(metainfo, dict), f"metainfo should be a ``dict`` but got {type(metainfo)}"
+            for k, v in metainfo.items():
+                self.set_field(v, k, field_type="metainfo")
+
+        @property
+        def metainfo(self) -> Dict[str, Any]:
+            return {k: getattr(self, k) for k in self._metainfo_fields}
+
+        def metainfo_keys(self):
+            return list(self._metainfo_fields)
+
+        # -- data
+        def set_field(self, value: Any, name: str, dtype=None, field_type: str = "data") -> None:
+            assert field_type in ("metainfo", "data")
+            if dtype is not None:
+                assert isinstance(value, dtype), f"{value} should be a {dtype} but got {type(value)}"
+            if field_type == "metainfo":
+                if name in self._data_fields:
+                    raise AttributeError(f"Cannot set {name} to be a field of metainfo because it is a data field")
+                self._metainfo_fields.add(name)
+            else:
+                if name in self._metainfo_fields:
+                    raise AttributeError(f"Cannot set {name} to be a field of data because it is a metainfo field")
+                self._data_fields.add(name)
+            object.__setattr__(self, name, value)
+
+        def __setattr__(self, name: str, value: Any) -> None:
+            if name in ("_metainfo_fields", "_data_fields"):
+                raise AttributeError(f"{name} has been used as a private attribute, which is immutable.")
+            self.set_field(value, name)
+
+        def __delattr__(self, name: str) -> None:
+            object.__delattr__(self, name)
+            self._data_fields.discard(name)
+            self._metainfo_fields.discard(name)
+
+        __setitem__ = lambda self, k, v: setattr(self, k, v)  # noqa: E731
+
+        def __getitem__(self, name: str) -> Any:
+            return getattr(self, name)
+
+        def __contains__(self, name: str) -> bool:
+            return name in self._data_fields or name in self._metainfo_fields
+
+        def get(self, name: str, default=None):
+            return getattr(self, name, default)
+
+        def keys(self):
+            private = {"_" + k for k in self._data_fields}  # property-backed fields
+            return [k for k in self._data_fields if k not in private]
+
+        def values(self):
+            return [getattr(self, k) for k in self.keys()]
+
+        def items(self) -> Iterator[Tuple[str, Any]]:
+            for k in self.keys():
+                yield k, getattr(self, k)
+
+        def all_keys(self):
+            return self.metainfo_keys() + self.keys()
+
+        def all_items(self) -> Iterator[Tuple[str, Any]]:
+            for k in self.all_keys():
+                yield k, getattr(self, k)
+
+        def __repr__(self):
+            body = ", ".join(f"{k}={type(v).__name__}" for k, v in self.all_items())
+            return f"<{self.__class__.__name__}({body})>"
+
+    class InstanceData(BaseDataElement):
+        """Instance-level fields; all values share their first dimension."""
+
+        def __len__(self) -> int:
+            vals = self.values()
+            return len(vals[0]) if vals else 0
+
+    class PixelData(BaseDataElement):
+        """Pixel-level fields of shape (C, H, W)."""
+
+        @property
+        def shape(self):
+            vals = self.values()
+            return tuple(vals[0].shape[-2:]) if vals else None
+
+    def _prop(private, dtype):
+        def getter(self):
+            return getattr(self, private)
+
+        def setter(self, value):
+            self.set_field(value, private, dtype=dtype)
+
+        def deleter(self):
+            delattr(self, private)
+
+        return property(getter, setter, deleter)
+
+    class PoseDataSample(BaseDataElement):
+        """pose_data_sample.py:9-104: gt_instances / pred_instances / gt_fields / pred_fields."""
+
+        gt_instances = _prop("_gt_instances", InstanceData)
+        gt_instance_labels = _prop("_gt_instance_labels", InstanceData)
+        pred_instances = _prop("_pred_instances", InstanceData)
+        gt_fields = _prop("_gt_fields", PixelData)
+        pred_fields = _prop("_pred_heatmaps", PixelData)
+
+        def __setattr__(self, name, value):
+            p = getattr(type(self), name, None)
+            if isinstance(p, property):
+                p.fset(self, value)
+            else:
+                super().__setattr__(name, value)
+
+        def __contains__(self, name):
+            priv = {
+                "gt_instances": "_gt_instances",
+                "pred_instances": "_pred_instances",
+                "gt_fields": "_gt_fields",
+                "pred_fields": "_pred_heatmaps",
+                "gt_instance_labels": "_gt_instance_labels",
+            }.get(name, name)
+            return super().__contains__(priv)
+
+
+__all__ = ["BaseDataElement", "InstanceData", "PixelData", "PoseDataSample", "USING_MMENGINE"]

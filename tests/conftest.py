@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def lib_built():
+    """Build the HIP library once per session if it is not there (hipcc cross-compiles on CPU)."""
+    so = os.path.join(ROOT, "probpose_code_amd", "libprobpose_mi355x.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+
+        g.build()
+    return so
