@@ -83,6 +83,98 @@ int pp_probmap_decode(const float* hm, const float* hm_flip, const int32_t* flip
                       float* avg_out, float* conv_out,
                       float* locs, double* keypoints, float* scores, void* stream);
 
+/* Same as pp_probmap_decode but starting from the LOGITS of the head's final 1x1 conv: the
+ * kernel first applies  x / temperature -> Sparsemax over the H*W pixels of each (b, k) row ->
+ * * normalize -> clamp(0, 1)  (probmap_head.py:637-646; Sparsemax = PyPI `sparsemax` [3P],
+ * probmap_head.py:11,251), to the row itself and -- under the flip test -- to the mirror
+ * partner's row, then averages and decodes as above. Logits are read from HBM once; the
+ * probability maps only leave the CU when avg_out is requested. H*W <= 7168. */
+int pp_probmap_head_decode(const float* logits, const float* logits_flip, const int32_t* flip_indices,
+                           const double* taps, const int32_t* radius,
+                           int B, int K, int H, int W, double in_w, double in_h,
+                           float temperature, float normalize,
+                           float* avg_out, float* conv_out,
+                           float* locs, double* keypoints, float* scores, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Operand precision of the MFMA kernels.
+ *   PP_PREC_BF16: bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) -- throughput mode.
+ *   PP_PREC_F32 : fp32 operands, fp32 accumulate (v_mfma_f32_16x16x4_f32, exact fp32
+ *                 products) -- the mode whose results are compared with the fp32 reference.
+ * ---------------------------------------------------------------------------------- */
+enum { PP_PREC_BF16 = 0, PP_PREC_F32 = 1 };
+enum { PP_ACT_NONE = 0, PP_ACT_GELU = 1, PP_ACT_RELU = 2 };
+enum { PP_CONV3X3 = 1, PP_DECONV4X4S2 = 2 };
+
+/* Dense layer  out[m, n] = act_fn(sum_k act[m, k] * weight[n, k] + bias[n]) + residual[r(m), n].
+ *
+ * Stands in for every nn.Linear of the backbone (mmpretrain VisionTransformer [3P]; call site
+ * mmpose/models/pose_estimators/base.py:206, ctor args config :56-67): qkv, proj, FFN.
+ * act/weight are bf16 or fp32 according to `prec`; bias and residual are fp32 (or NULL);
+ * `out` is bf16 when out_bf16 != 0 else fp32. K must be a multiple of 64 (bf16) / 32 (fp32);
+ * lda/ldw multiples of 8 elements; ldc a multiple of 4. act_fn: PP_ACT_GELU is the exact erf form
+ * (nn.GELU()). residual may alias out (in-place residual stream); r(m) = m, or m % res_mod when
+ * res_mod > 0 (a (res_mod, N) table broadcast over the batch: the ViT pos_embed added to the
+ * patch-embed output). planar_P > 0 stores fp32 planes out[((m / P) * N + n) * P + m % P]
+ * instead of rows: the final 1x1 conv of the heatmap branch (probmap_head.py:244-249) emits
+ * (B, K, H*W) logits, the layout the Sparsemax/decode kernel streams. */
+int pp_gemm(int prec, const void* act, const void* weight, const float* bias, const float* residual,
+            int res_mod, void* out, int M, int N, int K, int lda, int ldw, int ldc, int act_fn,
+            int out_bf16, int planar_P, void* stream);
+
+/* Convolutions of ProbMapHead as implicit GEMMs on NHWC activations (no im2col buffer):
+ *   PP_CONV3X3     : Conv2d(Cin->Cout, k3, s1, p1) of the scalar towers
+ *                    (mmpose/models/heads/hybrid_heads/probmap_head.py:261-410);
+ *                    weight[n, (ky*3+kx)*Cin + c] = w_torch[n, c, ky, kx]; out NHWC (B,H,W,Cout).
+ *   PP_DECONV4X4S2 : one output phase (py, px) of ConvTranspose2d(Cin->Cout, k4, s2, p1)
+ *                    (probmap_head.py:435-472): writes out[b, 2y+py, 2x+px, :] of a (B,2H,2W,Cout)
+ *                    tensor; weight[n, (ty*2+tx)*Cin + c] = w_torch[c, n, 3-2ty-py, 3-2tx-px].
+ * BatchNorm is folded into weight/bias by the caller; act_fn applies after bias. `groups`
+ * launches several independent convolutions at once (the four towers): operand g is at
+ * base + g * stride_*_g elements. ldc = row stride of out in elements. */
+int pp_conv_gemm(int prec, int kind, const void* act_nhwc, const void* weight, const float* bias, void* out,
+                 int B, int H, int W, int Cin, int Cout, int py, int px, int groups,
+                 long long stride_act_g, long long stride_w_g, long long stride_out_g,
+                 long long stride_bias_g, int ldc, int act_fn, int out_bf16, void* stream);
+
+/* Multi-head self-attention of the backbone (mmpretrain MultiheadAttention [3P]:
+ * softmax(q k^T * scale) v per head). qkv: (n_seq * seq_len, 3 * heads * head_dim) rows as the
+ * qkv Linear emits them ([q | k | v], head-major inside each); out: (n_seq * seq_len, heads *
+ * head_dim). Both bf16 or fp32 per `prec`. Supported (seq_len, head_dim): {192, 432} x {32, 64}
+ * (fp32 432 x 64 exceeds one CU's LDS). */
+int pp_attention(int prec, const void* qkv, void* out, int n_seq, int seq_len, int heads, int head_dim,
+                 float scale, void* stream);
+
+/* Input side of the backbone: PoseDataPreprocessor (mmpose/models/data_preprocessors/
+ * data_preprocessor.py:79-104 + mmengine ImgDataPreprocessor [3P]: BGR->RGB, float, (x-mean)/std),
+ * the flip-test copy `inputs.flip(-1)` (mmpose/models/pose_estimators/topdown.py:109-112) and the
+ * im2col of the ViT patch-embed Conv2d(3->E, k16, s16, zero pad `pad`) in one pass.
+ * img_u8: (B, 3, H, W) uint8 CHW; patches: (passes * B * Hp * Wp, 768) bf16/fp32, row order
+ * (pass, b, py, px), column order (c, i, j); pass 1 is the horizontally flipped crop.
+ * mean_host / std_host: 3 floats each, HOST pointers, in output-channel (RGB) order. */
+int pp_preproc_im2col(int prec, const uint8_t* img_u8, void* patches, int B, int passes, int H, int W,
+                      int patch, int pad, const float* mean_host, const float* std_host, int bgr_to_rgb,
+                      void* stream);
+
+/* LayerNorm over the last dim of an fp32 (M, E) matrix (nn.LayerNorm(E, eps) of the ViT, eps 1e-6);
+ * output bf16 or fp32. E in {384, 768, 1024}. */
+int pp_layernorm(const float* x, const float* gamma, const float* beta, void* y, int M, int E, float eps,
+                 int out_bf16, void* stream);
+
+/* MaxPool2d(kernel = stride = (ph, pw)) + ReLU on an NHWC tensor (the towers' pooling,
+ * probmap_head.py:264,277-278): (N, H, W, C) -> (N, H/ph, W/pw, C). */
+int pp_maxpool_relu_nhwc(const void* in, int in_bf16, void* out, int out_bf16, int N, int H, int W, int C,
+                         int ph, int pw, void* stream);
+
+/* Last layer of the four scalar towers (Conv1x1 -> Sigmoid; ReLU for the error tower,
+ * probmap_head.py:280-290,405) on the 1x1 pooled feature, fused with the flip-test average of the
+ * scalars (probmap_head.py:766-774). feat: (4, passes * B, C); w: (4, K, C) fp32; bias: (4, K);
+ * out: (4, B, K) fp32 in tower order probability, visibility, oks, error; the error row is divided
+ * by err_div (pass 1 to keep it raw). */
+int pp_tower_final(const void* feat, int feat_bf16, const float* w, const float* bias,
+                   const int32_t* flip_indices, float* out, int B, int passes, int C, int K, float err_div,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ raises -- loudly -- instead of degrading to a CPU path.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libprobpose_mi355x.so"
@@ -51,6 +51,24 @@ SIGNATURES = {
         c_int,
         [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P, _P, _P, _P, _P, _P],
     ),
+    "pp_probmap_head_decode": (
+        c_int,
+        [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_float, c_float, _P, _P, _P, _P, _P, _P],
+    ),
+    "pp_gemm": (
+        c_int,
+        [c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    ),
+    "pp_conv_gemm": (
+        c_int,
+        [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_longlong, c_longlong, c_longlong, c_longlong, c_int, c_int, c_int, _P],
+    ),
+    "pp_attention": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "pp_preproc_im2col": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "pp_layernorm": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_int, _P]),
+    "pp_maxpool_relu_nhwc": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pp_tower_final": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

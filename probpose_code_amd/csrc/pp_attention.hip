@@ -1,0 +1,225 @@
+// Multi-head self-attention of the ViT backbone for gfx950 (mmpretrain VisionTransformer [3P]:
+// softmax(q k^T / sqrt(hd)) v per head, no mask, no dropout in eval).
+//
+// Sequence lengths on this path are tiny (192 tokens @256x192, 432 @384x288) so K and V of one
+// (crop, head) stay resident in LDS and each query tile sees the whole score row at once: no
+// online-softmax rescaling, no second pass.
+//
+//   * one 256-thread workgroup per (crop-pass, head); the 4 waves split the 16-query tiles;
+//   * Q fragments go straight from HBM to registers (each is used by exactly one wave);
+//     K is staged row-major [S][hd], V transposed [hd][S] so that both MFMA operands are
+//     K-contiguous 16-byte reads;
+//   * S^T = K Q^T with K as the MFMA "A" operand: a lane ends up with 4 consecutive keys of one
+//     query in each 16x16 tile, the softmax row reduction is 47 in-register ops + 2 DPP hops, and
+//     P in that layout IS the "B" operand of the O^T = V^T P^T MFMA (the key order inside a
+//     K-block is a permutation shared by both operands) -- P never leaves registers;
+//   * operand precision is a template parameter (bf16 -> v_mfma_f32_16x16x32_bf16, fp32 ->
+//     v_mfma_f32_16x16x4_f32); softmax statistics are fp32 in both;
+//   * blockIdx is remapped so that the heads of one crop (adjacent columns of the same qkv
+//     rows) land on the same XCD / L2.
+#include "pp_common.h"
+
+namespace pp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int ATT_THREADS = 256;
+
+__device__ __forceinline__ f32x4 att_mma(const u32x4& a, const u32x4& b, f32x4 c, __bf16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+}
+__device__ __forceinline__ f32x4 att_mma(const u32x4& a, const u32x4& b, f32x4 c, float) {
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], c, 0, 0, 0);
+    return c;
+}
+
+template <typename T, int HD, int NT>
+struct AttCfg {
+    static constexpr int S = NT * 16;
+    static constexpr int NTP = (NT + 1) & ~1;           // key tiles padded to an even count
+    static constexpr int SP = NTP * 16;
+    static constexpr int SPV = SP + 8;                  // V^T row pitch (elements): 8 * odd -> conflict-free reads
+    static constexpr int CH = 16 / (int)sizeof(T);      // elements per 16-byte chunk
+    static constexpr int RC = HD / CH;                  // chunks per K row
+    static constexpr int NG = HD / (4 * CH);            // 4-chunk groups (one MFMA K-block each) per row
+    static constexpr int DT = HD / 16;                  // output d tiles
+    static constexpr size_t K_BYTES = (size_t)SP * HD * sizeof(T);
+    static constexpr size_t V_BYTES = (size_t)HD * SPV * sizeof(T);
+    static constexpr size_t LDS = K_BYTES + V_BYTES;
+};
+
+template <int RC>
+__device__ __forceinline__ int kswz(int row, int chunk) {
+    return RC >= 8 ? (chunk ^ (row & (RC - 1))) : chunk;
+}
+
+template <typename T, int HD, int NT>
+__global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                                int n_seq, int heads, float scale_log2e) {
+    using C = AttCfg<T, HD, NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                                        // [SP][HD], chunk-swizzled
+    T* Vt = reinterpret_cast<T*>(smem + C::K_BYTES);        // [HD][SPV]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    // XCD-aware remap: hardware round-robins consecutive block ids over the 8 XCDs
+    int id = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
+    const int seq = id / heads, head = id - seq * heads;
+    const int E = heads * HD;
+    const size_t row_stride = (size_t)3 * E;
+    const T* base = qkv + (size_t)seq * C::S * row_stride + (size_t)head * HD;
+
+    // ---- stage K (row-major, swizzled) and V (transposed); zero the padded key rows
+    for (int i = tid; i < C::SP * C::RC; i += ATT_THREADS) {
+        const int r = i / C::RC, c = i - r * C::RC;
+        u32x4 kv = u32x4{0, 0, 0, 0}, vv = u32x4{0, 0, 0, 0};
+        if (r < C::S) {
+            kv = *reinterpret_cast<const u32x4*>(base + (size_t)r * row_stride + E + c * C::CH);
+            vv = *reinterpret_cast<const u32x4*>(base + (size_t)r * row_stride + 2 * E + c * C::CH);
+        }
+        *reinterpret_cast<u32x4*>(Ks + ((size_t)r * C::RC + kswz<C::RC>(r, c)) * 16) = kv;
+        T ve[C::CH];
+        *reinterpret_cast<u32x4*>(ve) = vv;
+#pragma unroll
+        for (int j = 0; j < C::CH; ++j) Vt[(c * C::CH + j) * C::SPV + r] = ve[j];
+    }
+    __syncthreads();
+
+    for (int qt = wave; qt < NT; qt += ATT_THREADS / 64) {
+        // Q fragment of this lane: query row 16 qt + fr, chunks g*4 + fg
+        const T* qrow = base + (size_t)(qt * 16 + fr) * row_stride;
+        u32x4 qf[C::NG];
+#pragma unroll
+        for (int g = 0; g < C::NG; ++g) qf[g] = *reinterpret_cast<const u32x4*>(qrow + (g * 4 + fg) * C::CH);
+
+        // ---- scores: s[kt][i] = q . k for key 16 kt + 4 fg + i
+        f32x4 s[C::NTP];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < C::NG; ++g) {
+                const int r = kt * 16 + fr;
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + ((size_t)r * C::RC + kswz<C::RC>(r, g * 4 + fg)) * 16);
+                acc = att_mma(kf, qf[g], acc, T{});
+            }
+            s[kt] = acc;
+        }
+        // ---- softmax over the 16 NT keys of this lane's query (fp32)
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[kt][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mb = mx * scale_log2e;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p = exp2f(__builtin_fmaf(s[kt][i], scale_log2e, -mb));
+                s[kt][i] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (C::NTP > NT) s[C::NTP - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- O^T = V^T P^T
+        f32x4 o[C::DT];
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int blk = 0; blk < C::NTP / 2; ++blk) {
+                const f32x4 p0 = s[2 * blk], p1 = s[2 * blk + 1];
+                const bf16x8 pf = {(__bf16)p0[0], (__bf16)p0[1], (__bf16)p0[2], (__bf16)p0[3],
+                                   (__bf16)p1[0], (__bf16)p1[1], (__bf16)p1[2], (__bf16)p1[3]};
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) {
+                    const T* vrow = Vt + (dt * 16 + fr) * C::SPV + blk * 32 + 4 * fg;
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);
+                    const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const u32x4 pf = __builtin_bit_cast(u32x4, s[kt]);
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) {
+                    const u32x4 vf = *reinterpret_cast<const u32x4*>(Vt + (dt * 16 + fr) * C::SPV + kt * 16 + 4 * fg);
+                    o[dt] = att_mma(vf, pf, o[dt], T{});
+                }
+            }
+        }
+        // ---- normalise and store: lane holds d = 16 dt + 4 fg + (0..3) of query 16 qt + fr
+        const float inv = 1.0f / sum;
+        T* orow = out + ((size_t)seq * C::S + qt * 16 + fr) * E + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            const f32x4 v = o[dt] * inv;
+            if constexpr (sizeof(T) == 2) {
+                const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(orow + dt * 16 + 4 * fg) = ov;
+            } else {
+                *reinterpret_cast<f32x4*>(orow + dt * 16 + 4 * fg) = v;
+            }
+        }
+    }
+}
+
+template <typename T, int HD, int NT>
+static int launch_attention(const void* qkv, void* out, int n_seq, int heads, float scale, hipStream_t s) {
+    using C = AttCfg<T, HD, NT>;
+    static_assert(C::LDS <= 160 * 1024, "K/V of one head must fit in one CU's LDS");
+    auto kern = attention_kernel<T, HD, NT>;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)C::LDS));
+    hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(ATT_THREADS), C::LDS, s, reinterpret_cast<const T*>(qkv),
+                       reinterpret_cast<T*>(out), n_seq, heads, scale * 1.44269504088896340736f);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // namespace pp
+
+extern "C" int pp_attention(int prec, const void* qkv, void* out, int n_seq, int seq_len, int heads, int head_dim,
+                            float scale, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(qkv && out, PP_ERR_INVALID_ARG, "pp_attention: qkv and out must be non-NULL");
+    PP_REQUIRE(n_seq > 0 && heads > 0, PP_ERR_INVALID_ARG, "pp_attention: n_seq and heads must be positive");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define PP_ATT_CASE(T, HD, NT) \
+    if (head_dim == HD && seq_len == NT * 16) return launch_attention<T, HD, NT>(qkv, out, n_seq, heads, scale, s);
+    if (prec == PP_PREC_BF16) {
+        PP_ATT_CASE(__bf16, 32, 12)  // ProbPose-S 256x192
+        PP_ATT_CASE(__bf16, 64, 12)  // ViT-B 256x192
+        PP_ATT_CASE(__bf16, 32, 27)  // ProbPose-S 384x288
+        PP_ATT_CASE(__bf16, 64, 27)  // ViT-B 384x288
+    } else if (prec == PP_PREC_F32) {
+        PP_ATT_CASE(float, 32, 12)
+        PP_ATT_CASE(float, 64, 12)
+        PP_ATT_CASE(float, 32, 27)
+    } else {
+        return fail(PP_ERR_INVALID_ARG, "pp_attention: unknown precision");
+    }
+#undef PP_ATT_CASE
+    return fail(PP_ERR_UNSUPPORTED,
+                "pp_attention: (seq_len, head_dim) not instantiated: supported 192/432 tokens x 32/64 "
+                "(fp32 at 432 x 64 exceeds one CU's LDS)");
+}

@@ -1,0 +1,31 @@
+// Internal interface of the MFMA GEMM family (pp_gemm.hip).
+#pragma once
+#include "pp_common.h"
+
+namespace pp {
+
+enum { G_LINEAR = 0, G_CONV3 = 1, G_DECONV = 2 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+
+struct GemmParams {
+    const void* A;          // activations: [M, lda] row-major, or NHWC tensor for the conv gathers
+    const void* W;          // weights: [N, ldw] row-major, K contiguous
+    void* C;                // output: [rows, ldc]
+    const float* bias;      // [N] fp32 or NULL
+    const float* residual;  // fp32, same indexing as C, or NULL
+    int M, N, K;
+    int lda, ldw, ldc;
+    int H, Wd, Cin;         // conv gathers: input spatial size and channels
+    int py, px;             // deconv output phase
+    int act;                // ACT_*
+    int out_bf16;           // 1: store bf16, 0: store fp32
+    int gather;             // G_*
+    int res_mod;            // >0: residual row = m % res_mod (broadcast over the batch, e.g. pos_embed)
+    int ldres;              // row stride of residual (elements); 0 -> ldc
+    int planar_P;           // >0: store planar, out[((m / P) * N + n) * P + m % P]  (NHWC rows -> (B, N, P) planes)
+    long long strideA_z, strideW_z, strideC_z, strideBias_z;  // grouped launch (blockIdx.z), in elements
+};
+
+int gemm(const GemmParams& p, int prec, int groups, hipStream_t s);
+
+}  // namespace pp

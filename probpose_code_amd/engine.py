@@ -1,0 +1,231 @@
+"""The launch plan of the hot path: uint8 crops in HBM -> keypoints + per-keypoint scalars.
+
+``ProbPoseEngine`` owns the packed weights and the per-batch-size workspace (device memory
+comes from torch, that is all torch does here) and enqueues the hand-written HIP kernels of
+``libprobpose_mi355x.so`` on torch's current stream, in the order of
+``TopdownPoseEstimator.predict`` (mmpose/models/pose_estimators/topdown.py:86-126):
+
+  preprocess + flip copy + patch im2col -> patch-embed GEMM (+bias +pos_embed)
+  -> L x [LN -> qkv GEMM -> attention -> proj GEMM (+residual) -> LN -> fc1 GEMM (GELU) -> fc2 GEMM (+residual)]
+  -> final LN -> deconv x2 (4 phase GEMMs each, BN folded, ReLU) -> 1x1 conv (planar logits)
+  -> fused Sparsemax + flip-average + OKS-conv + argmax + sub-pixel decode
+  and, from the same features, the four scalar towers (grouped implicit-GEMM 3x3 convs,
+  MaxPool+ReLU, final 1x1 + sigmoid/ReLU + flip-average).
+
+Both flip-test passes run as one batch of 2B sequences. Activations are token-major / NHWC
+throughout, so the ViT output *is* the NHWC feature map the head convolutions gather from.
+"""
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .codecs import oks_kernel_taps
+from .weights import PackedWeights, pack
+
+PREC = {"bf16": 0, "f32": 1}
+_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32}
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+CONV3X3, DECONV = 1, 2
+
+
+class ProbPoseEngine:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], num_heads: int, img_size=(256, 192), patch_size: int = 16,
+                 patch_padding: int = 2, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375),
+                 bgr_to_rgb: bool = True, temperature: float = 0.5, normalize: Optional[float] = 1.0,
+                 input_size: Optional[Sequence[int]] = None, ln_eps: float = 1e-6, precision: str = "bf16",
+                 device="cuda"):
+        if precision not in PREC:
+            raise ValueError(f"precision must be one of {list(PREC)}, got {precision!r}")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ProbPoseEngine runs on the MI355X only; there is no CPU fallback")
+        self.precision = precision
+        self.prec = PREC[precision]
+        self.dtype = _DTYPE[precision]
+        self.w: PackedWeights = pack(state_dict, self.dtype, self.device)
+        self.heads = num_heads
+        self.H, self.W = img_size
+        self.P, self.pad = patch_size, patch_padding
+        self.Hp = (self.H + 2 * self.pad - self.P) // self.P + 1
+        self.Wp = (self.W + 2 * self.pad - self.P) // self.P + 1
+        self.Np = self.Hp * self.Wp
+        assert self.w["pos_embed"].shape[0] == self.Np, "pos_embed does not match img_size / patch grid"
+        self.E = self.w.embed_dims
+        self.hd = self.E // num_heads
+        self.K = self.w.num_keypoints
+        self.up = 2 ** len(self.w.deconv_channels)
+        self.Hh, self.Wh = self.Hp * self.up, self.Wp * self.up  # heatmap size
+        self.input_size = tuple(input_size) if input_size is not None else (self.W, self.H)
+        self.mean = (np.asarray(mean, np.float32)).copy()
+        self.std = (np.asarray(std, np.float32)).copy()
+        self.bgr_to_rgb = bool(bgr_to_rgb)
+        self.temperature = float(temperature)
+        self.normalize = normalize
+        self.ln_eps = float(ln_eps)
+        taps, radius = oks_kernel_taps(self.K, self.Hh, self.Wh)
+        self.taps = torch.from_numpy(taps).to(self.device)
+        self.radius = torch.from_numpy(radius).to(self.device)
+        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self._flip: Dict[tuple, torch.Tensor] = {}
+        # tower pooling schedule (probmap_head.py:264) and the spatial sizes it produces
+        self.pools = ((4, 3), (2, 2), (2, 2))
+        hs, ws_ = self.Hp, self.Wp
+        self.tower_hw = []
+        for ph, pw_ in self.pools:
+            self.tower_hw.append((hs, ws_))
+            hs, ws_ = hs // ph, ws_ // pw_
+        if (hs, ws_) != (1, 1):
+            raise ValueError(
+                f"scalar towers reduce the {self.Hp}x{self.Wp} feature map to {hs}x{ws_}; the reference "
+                "reshapes them to (B, 1, K) (probmap_head.py:780-783), which needs 1x1"
+            )
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, B: int, passes: int) -> Dict[str, torch.Tensor]:
+        key = (B, passes)
+        if key in self._ws:
+            return self._ws[key]
+        dev, T, f32 = self.device, self.dtype, torch.float32
+        nb = B * passes
+        M = nb * self.Np
+        E, Fd = self.E, self.w.ffn_dims
+        e = lambda *s, dt=T: torch.empty(s, dtype=dt, device=dev)  # noqa: E731
+        ws = dict(
+            patches=e(M, 3 * self.P * self.P), x=e(M, E, dt=f32), h=e(M, E), qkv=e(M, 3 * E), f=e(M, Fd),
+            feat=e(M, E), logits=e(nb, self.K, self.Hh * self.Wh, dt=f32),
+            scalars=e(4, B, self.K, dt=f32), locs=e(B, self.K, 2, dt=f32),
+            keypoints=e(B, self.K, 2, dt=torch.float64), scores=e(B, self.K, dt=f32),
+            heatmaps=e(B, self.K, self.Hh, self.Wh, dt=f32),
+        )
+        hh, ww = self.Hp, self.Wp
+        for j, c in enumerate(self.w.deconv_channels):
+            hh, ww = hh * 2, ww * 2
+            ws[f"d{j}"] = e(nb, hh, ww, c)
+        for j, (th, tw) in enumerate(self.tower_hw):
+            ph, pw_ = self.pools[j]
+            ws[f"t{j}"] = e(4, nb, th, tw, E)
+            ws[f"p{j}"] = e(4, nb, th // ph, tw // pw_, E)
+        self._ws[key] = ws
+        return ws
+
+    def _flip_indices(self, flip_indices) -> torch.Tensor:
+        key = tuple(int(i) for i in flip_indices)
+        if key not in self._flip:
+            assert len(key) == self.K
+            self._flip[key] = torch.tensor(key, dtype=torch.int32, device=self.device)
+        return self._flip[key]
+
+    # ------------------------------------------------------------------ launches
+    def _gemm(self, st, a, w, bias, out, M, N, K, act=ACT_NONE, residual=None, res_mod=0, out_bf16=None, planar=0,
+              ldc=None):
+        ob = int(out.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
+        _lib.call("pp_gemm", self.prec, a.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), res_mod,
+                  out.data_ptr(), M, N, K, K, K, N if ldc is None else ldc, act, ob, planar, st)
+
+    def backbone(self, imgs_u8: torch.Tensor, passes: int, ws, st) -> torch.Tensor:
+        """uint8 (B,3,H,W) -> final-LN features, token-major (passes*B*Np, E) == NHWC (passes*B, Hp, Wp, E)."""
+        B = imgs_u8.shape[0]
+        M = B * passes * self.Np
+        E, Fd, w = self.E, self.w.ffn_dims, self.w
+        ob = int(self.dtype == torch.bfloat16)
+        _lib.call("pp_preproc_im2col", self.prec, imgs_u8.data_ptr(), ws["patches"].data_ptr(), B, passes, self.H,
+                  self.W, self.P, self.pad, self.mean.ctypes.data, self.std.ctypes.data, int(self.bgr_to_rgb), st)
+        Kp = 3 * self.P * self.P
+        self._gemm(st, ws["patches"], w["patch_w"], w["patch_b"], ws["x"], M, E, Kp, residual=w["pos_embed"],
+                   res_mod=self.Np)
+        scale = self.hd ** -0.5
+        for i in range(w.num_layers):
+            _lib.call("pp_layernorm", ws["x"].data_ptr(), w[f"l{i}.ln1.w"].data_ptr(), w[f"l{i}.ln1.b"].data_ptr(),
+                      ws["h"].data_ptr(), M, E, self.ln_eps, ob, st)
+            self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], ws["qkv"], M, 3 * E, E)
+            _lib.call("pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), B * passes, self.Np,
+                      self.heads, self.hd, scale, st)
+            self._gemm(st, ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], ws["x"], M, E, E, residual=ws["x"])
+            _lib.call("pp_layernorm", ws["x"].data_ptr(), w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(),
+                      ws["h"].data_ptr(), M, E, self.ln_eps, ob, st)
+            self._gemm(st, ws["h"], w[f"l{i}.fc1.w"], w[f"l{i}.fc1.b"], ws["f"], M, Fd, E, act=ACT_GELU)
+            self._gemm(st, ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], ws["x"], M, E, Fd, residual=ws["x"])
+        _lib.call("pp_layernorm", ws["x"].data_ptr(), w["ln_f.w"].data_ptr(), w["ln_f.b"].data_ptr(),
+                  ws["feat"].data_ptr(), M, E, self.ln_eps, ob, st)
+        return ws["feat"]
+
+    def heatmap_logits(self, feat: torch.Tensor, nb: int, ws, st) -> torch.Tensor:
+        """NHWC features -> planar logits (nb, K, Hh*Wh) fp32 (deconv x n + BN + ReLU, final 1x1 conv)."""
+        w = self.w
+        ob = int(self.dtype == torch.bfloat16)
+        src, cin, hh, ww = feat, self.E, self.Hp, self.Wp
+        for j, cout in enumerate(w.deconv_channels):
+            dst = ws[f"d{j}"]
+            wj = w[f"deconv{j}.w"]
+            for py in range(2):
+                for px in range(2):
+                    _lib.call("pp_conv_gemm", self.prec, DECONV, src.data_ptr(), wj[py, px].data_ptr(),
+                              w[f"deconv{j}.b"].data_ptr(), dst.data_ptr(), nb, hh, ww, cin, cout, py, px, 1, 0, 0, 0,
+                              0, cout, ACT_RELU, ob, st)
+            src, cin, hh, ww = dst, cout, hh * 2, ww * 2
+        P = hh * ww
+        self._gemm(st, src, w["final.w"], w["final.b"], ws["logits"], nb * P, self.K, cin, planar=P, out_bf16=0)
+        return ws["logits"]
+
+    def towers(self, feat: torch.Tensor, B: int, passes: int, flip_indices, ws, st) -> torch.Tensor:
+        """NHWC features -> (4, B, K) fp32: probability, visibility, oks, error (error NOT yet / diagonal)."""
+        w, E = self.w, self.E
+        nb = B * passes
+        ob = int(self.dtype == torch.bfloat16)
+        src, stride_src = feat, 0  # the four towers share the backbone features
+        for j, (th, tw) in enumerate(self.tower_hw):
+            ph, pw_ = self.pools[j]
+            out = ws[f"t{j}"]
+            _lib.call("pp_conv_gemm", self.prec, CONV3X3, src.data_ptr(), w[f"tower{j}.w"].data_ptr(),
+                      w[f"tower{j}.b"].data_ptr(), out.data_ptr(), nb, th, tw, E, E, 0, 0, 4, stride_src,
+                      E * 9 * E, nb * th * tw * E, E, E, ACT_NONE, ob, st)
+            _lib.call("pp_maxpool_relu_nhwc", out.data_ptr(), ob, ws[f"p{j}"].data_ptr(), ob, 4 * nb, th, tw, E, ph,
+                      pw_, st)
+            src = ws[f"p{j}"]
+            stride_src = nb * (th // ph) * (tw // pw_) * E
+        fi = self._flip_indices(flip_indices) if passes == 2 else None
+        _lib.call("pp_tower_final", src.data_ptr(), ob, w["tower_out.w"].data_ptr(), w["tower_out.b"].data_ptr(),
+                  _lib.ptr(fi), ws["scalars"].data_ptr(), B, passes, E, self.K, 1.0, st)
+        return ws["scalars"]
+
+    # ------------------------------------------------------------------ public
+    @torch.no_grad()
+    def forward(self, imgs_u8: torch.Tensor, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False,
+                return_features: bool = False) -> Dict[str, torch.Tensor]:
+        """imgs_u8: (B, 3, H, W) uint8 on the device (BGR CHW as PackPoseInputs emits). Returns device
+        tensors (views into the cached workspace, valid until the next call with the same batch size):
+        ``keypoints`` (B,K,2) f64 input-pixel space, ``scores`` (B,K) f32 (keypoints_conf), ``locs``,
+        ``scalars`` (4,B,K) f32 [probability, visibility, oks, raw error], optionally ``heatmaps``."""
+        assert imgs_u8.dtype == torch.uint8 and imgs_u8.dim() == 4 and imgs_u8.is_cuda, "expects uint8 (B,3,H,W) on GPU"
+        assert tuple(imgs_u8.shape[1:]) == (3, self.H, self.W), f"crop shape {tuple(imgs_u8.shape)} != (B,3,{self.H},{self.W})"
+        imgs_u8 = imgs_u8.contiguous()
+        B = imgs_u8.shape[0]
+        passes = 2 if flip_test else 1
+        if flip_test and flip_indices is None:
+            raise ValueError("flip_test needs flip_indices (dataset meta)")
+        ws = self._workspace(B, passes)
+        with torch.cuda.device(self.device):
+            st = _lib.stream_ptr(self.device)
+            feat = self.backbone(imgs_u8, passes, ws, st)
+            logits = self.heatmap_logits(feat, B * passes, ws, st)
+            fi = self._flip_indices(flip_indices) if flip_test else None
+            lf = logits[B:] if flip_test else None
+            if self.normalize is not None:
+                _lib.call("pp_probmap_head_decode", logits.data_ptr(), _lib.ptr(lf), _lib.ptr(fi), self.taps.data_ptr(),
+                          self.radius.data_ptr(), B, self.K, self.Hh, self.Wh, float(self.input_size[0]),
+                          float(self.input_size[1]), self.temperature, float(self.normalize),
+                          ws["heatmaps"].data_ptr() if return_heatmaps else None, None, ws["locs"].data_ptr(),
+                          ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), st)
+            else:
+                raise NotImplementedError("normalize=None (no Sparsemax) is not a ProbPose configuration")
+            scalars = self.towers(feat, B, passes, flip_indices, ws, st)
+        out = dict(keypoints=ws["keypoints"], scores=ws["scores"], locs=ws["locs"], scalars=scalars)
+        if return_heatmaps:
+            out["heatmaps"] = ws["heatmaps"]
+        if return_features:
+            out["features"] = feat.view(B * passes, self.Hp, self.Wp, self.E)
+            out["logits"] = logits
+        return out

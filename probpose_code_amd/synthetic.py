@@ -1,0 +1,107 @@
+"""Seeded synthetic weights and inputs for tests and ``bench.py`` (there is no network for
+the published ``ProbPose-s.pth``, reference ``README.md:119-120``).
+
+The state dict uses the reference's own key names (``backbone.*`` as
+mmpretrain's ``VisionTransformer`` names them, ``head.*`` from ``probmap_head.py``), so the
+same loader path that would ingest the real checkpoint is exercised.
+
+Why not the reference's default init (``probmap_head.py:592-598``: Normal std 0.001)? It gives
+logits ~ 0, Sparsemax ~ uniform 1/3072 and an argmax that is pure rounding noise,
+which makes keypoint parity meaningless. The init below keeps activations O(1) through the
+network and scales the last 1x1 conv so that logits have a spread of a few units: after
+``/temperature`` + Sparsemax the maps are sparse and peaked like a trained model's. BatchNorm
+running statistics and affine parameters are randomised so that BN folding is really tested.
+"""
+import math
+from typing import Dict, Sequence
+
+import torch
+
+COCO_FLIP_INDICES = (0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15)
+IMG_MEAN = (123.675, 116.28, 103.53)
+IMG_STD = (58.395, 57.12, 57.375)
+
+ARCHS = {
+    # config :58 (explicit dict): embed 384, 12 layers, 12 heads (head_dim 32), FFN 1536
+    "small": dict(embed_dims=384, num_layers=12, num_heads=12, feedforward_channels=1536),
+    # mmpretrain preset "base" (BASELINE config 4): 768 / 12 / 12 heads (head_dim 64) / 3072
+    "base": dict(embed_dims=768, num_layers=12, num_heads=12, feedforward_channels=3072),
+}
+
+
+def synthetic_state_dict(arch: str = "small", img_size=(256, 192), num_keypoints: int = 17,
+                         deconv_out_channels: Sequence[int] = (256, 256), seed: int = 0,
+                         logit_scale: float = 3.0) -> Dict[str, torch.Tensor]:
+    a = ARCHS[arch] if isinstance(arch, str) else arch
+    E, L, Fd = a["embed_dims"], a["num_layers"], a["feedforward_channels"]
+    g = torch.Generator().manual_seed(seed)
+    n = lambda *s, std=1.0: torch.randn(*s, generator=g) * std  # noqa: E731
+    u = lambda *s, lo=0.5, hi=1.5: torch.rand(*s, generator=g) * (hi - lo) + lo  # noqa: E731
+    xav = lambda o, i: n(o, i, std=math.sqrt(2.0 / (o + i)))  # noqa: E731
+    sd: Dict[str, torch.Tensor] = {}
+    P = 16
+    Hp, Wp = (img_size[0] + 4 - P) // P + 1, (img_size[1] + 4 - P) // P + 1
+    sd["backbone.patch_embed.projection.weight"] = n(E, 3, P, P, std=math.sqrt(1.0 / (3 * P * P)))
+    sd["backbone.patch_embed.projection.bias"] = n(E, std=0.1)
+    sd["backbone.pos_embed"] = n(1, Hp * Wp, E, std=0.3)
+    for i in range(L):
+        p = f"backbone.layers.{i}."
+        for ln in ("ln1", "ln2"):
+            sd[p + ln + ".weight"] = 1.0 + n(E, std=0.1)
+            sd[p + ln + ".bias"] = n(E, std=0.1)
+        sd[p + "attn.qkv.weight"] = n(3 * E, E, std=1.5 / math.sqrt(E))
+        sd[p + "attn.qkv.bias"] = n(3 * E, std=0.1)
+        sd[p + "attn.proj.weight"] = xav(E, E)
+        sd[p + "attn.proj.bias"] = n(E, std=0.05)
+        sd[p + "ffn.layers.0.0.weight"] = xav(Fd, E)
+        sd[p + "ffn.layers.0.0.bias"] = n(Fd, std=0.1)
+        sd[p + "ffn.layers.1.weight"] = xav(E, Fd)
+        sd[p + "ffn.layers.1.bias"] = n(E, std=0.05)
+    sd["backbone.ln1.weight"] = 1.0 + n(E, std=0.1)
+    sd["backbone.ln1.bias"] = n(E, std=0.1)
+
+    def bn(prefix, c):
+        sd[prefix + ".weight"] = u(c)
+        sd[prefix + ".bias"] = n(c, std=0.2)
+        sd[prefix + ".running_mean"] = n(c, std=0.2)
+        sd[prefix + ".running_var"] = u(c)
+        sd[prefix + ".num_batches_tracked"] = torch.tensor(1000)
+
+    cin = E
+    for j, cout in enumerate(deconv_out_channels):
+        # ConvTranspose2d weight is (Cin, Cout, 4, 4); each output pixel sees 2x2 taps x Cin inputs
+        sd[f"head.deconv_layers.{3 * j}.weight"] = n(cin, cout, 4, 4, std=math.sqrt(2.0 / (4 * cin)))
+        bn(f"head.deconv_layers.{3 * j + 1}", cout)
+        cin = cout
+    sd["head.final_layer.weight"] = n(num_keypoints, cin, 1, 1, std=logit_scale / math.sqrt(cin))
+    sd["head.final_layer.bias"] = n(num_keypoints, std=0.1)
+    for t in ("probability", "visibility", "oks", "error"):
+        for j in range(3):
+            sd[f"head.{t}_layers.{4 * j}.weight"] = n(E, E, 3, 3, std=math.sqrt(2.0 / (9 * E)))
+            sd[f"head.{t}_layers.{4 * j}.bias"] = n(E, std=0.1)
+            bn(f"head.{t}_layers.{4 * j + 1}", E)
+        sd[f"head.{t}_layers.12.weight"] = n(num_keypoints, E, 1, 1, std=1.0 / math.sqrt(E))
+        sd[f"head.{t}_layers.12.bias"] = n(num_keypoints, std=0.3)
+    return sd
+
+
+def synthetic_crops(batch: int, img_size=(256, 192), seed: int = 0) -> torch.Tensor:
+    """uint8 BGR crops (B,3,H,W), uniform [0,255] as ``mmpose/testing/_utils.py:117`` does, but
+    low-pass filtered a little so that neighbouring patches correlate like an image's."""
+    g = torch.Generator().manual_seed(seed)
+    H, W = img_size
+    coarse = torch.rand((batch, 3, H // 8, W // 8), generator=g)
+    fine = torch.rand((batch, 3, H, W), generator=g)
+    img = 0.6 * torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=False) + 0.4 * fine
+    return (img * 255).round().clamp(0, 255).to(torch.uint8)
+
+
+def whole_image_bbox_meta(batch: int, img_size=(256, 192), padding: float = 1.25):
+    """input_center / input_scale of a whole-image bbox (apis/inference.py:168 + TopdownAffine
+    padding, topdown_transforms.py:96-101): centre (W/2, H/2), scale (W, H) * 1.25."""
+    import numpy as np
+
+    H, W = img_size
+    center = np.tile(np.array([W / 2, H / 2], np.float32), (batch, 1))
+    scale = np.tile(np.array([W * padding, H * padding], np.float32), (batch, 1))
+    return center, scale

@@ -1,0 +1,128 @@
+"""Checkpoint -> packed device weights for the HIP pipeline.
+
+Accepts a state dict with the reference's key names: ``backbone.*`` as
+mmpretrain's ``VisionTransformer`` names them and ``head.*`` from
+``mmpose/models/heads/hybrid_heads/probmap_head.py:219,247,290,325,371,406``. Honours the two
+state-dict pre-hooks of the reference: ``keypoint_head.* -> head.*`` and dropping
+``data_preprocessor.mean/std`` (``mmpose/models/pose_estimators/base.py:212-243``).
+
+Packing (all on the host, once, in fp32; then cast to the operand precision):
+  * every nn.Linear / 1x1 conv -> [N, K] row-major, K contiguous (what pp_gemm consumes);
+  * patch-embed Conv2d(3->E, k16) -> [E, 768], column order (c, i, j);
+  * ConvTranspose2d(k4, s2, p1, bias=False) + BatchNorm (eval) -> BN folded, then split into the
+    four output phases: Wph[py, px][n, (ty*2+tx)*Cin + c] = w[c, n, 3-2ty-py, 3-2tx-px] * scale[n];
+  * tower Conv2d(k3, p1) + BatchNorm -> folded, [tower][n, (ky*3+kx)*Cin + c];
+  * tower Conv1x1 -> [tower][K, C] fp32.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import torch
+
+TOWERS = ("probability", "visibility", "oks", "error")
+BN_EPS = 1e-5  # nn.BatchNorm2d default, probmap_head.py:276
+
+
+def normalize_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    if "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    out = {}
+    for k, v in sd.items():
+        if k in ("data_preprocessor.mean", "data_preprocessor.std"):
+            continue
+        if k.startswith("keypoint_head."):
+            k = "head." + k[len("keypoint_head."):]
+        out[k] = v
+    return out
+
+
+@dataclass
+class PackedWeights:
+    dtype: torch.dtype
+    embed_dims: int
+    num_layers: int
+    ffn_dims: int
+    num_keypoints: int
+    deconv_channels: List[int]
+    t: Dict[str, torch.Tensor] = field(default_factory=dict)
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+
+def _bn_fold(sd, name):
+    scale = sd[name + ".weight"].float() / torch.sqrt(sd[name + ".running_var"].float() + BN_EPS)
+    shift = sd[name + ".bias"].float() - sd[name + ".running_mean"].float() * scale
+    return scale, shift
+
+
+def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device) -> PackedWeights:
+    sd = {k: v.detach().cpu() for k, v in normalize_state_dict(sd).items()}
+    f32 = lambda x: x.float().contiguous().to(device)  # noqa: E731
+    op = lambda x: x.float().contiguous().to(dtype).to(device)  # noqa: E731
+    pw = sd["backbone.patch_embed.projection.weight"]
+    E = pw.shape[0]
+    L = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("backbone.layers."))
+    Fd = sd["backbone.layers.0.ffn.layers.0.0.weight"].shape[0]
+    K = sd["head.final_layer.weight"].shape[0]
+    t: Dict[str, torch.Tensor] = {}
+    t["patch_w"] = op(pw.reshape(E, -1))
+    t["patch_b"] = f32(sd["backbone.patch_embed.projection.bias"])
+    t["pos_embed"] = f32(sd["backbone.pos_embed"].reshape(-1, E))
+    for i in range(L):
+        p = f"backbone.layers.{i}."
+        for ln in ("ln1", "ln2"):
+            t[f"l{i}.{ln}.w"] = f32(sd[p + ln + ".weight"])
+            t[f"l{i}.{ln}.b"] = f32(sd[p + ln + ".bias"])
+        t[f"l{i}.qkv.w"] = op(sd[p + "attn.qkv.weight"])
+        qb = sd.get(p + "attn.qkv.bias")
+        t[f"l{i}.qkv.b"] = f32(qb if qb is not None else torch.zeros(3 * E))
+        t[f"l{i}.proj.w"] = op(sd[p + "attn.proj.weight"])
+        t[f"l{i}.proj.b"] = f32(sd[p + "attn.proj.bias"])
+        t[f"l{i}.fc1.w"] = op(sd[p + "ffn.layers.0.0.weight"])
+        t[f"l{i}.fc1.b"] = f32(sd[p + "ffn.layers.0.0.bias"])
+        t[f"l{i}.fc2.w"] = op(sd[p + "ffn.layers.1.weight"])
+        t[f"l{i}.fc2.b"] = f32(sd[p + "ffn.layers.1.bias"])
+    t["ln_f.w"] = f32(sd["backbone.ln1.weight"])
+    t["ln_f.b"] = f32(sd["backbone.ln1.bias"])
+
+    # ---- heatmap branch
+    deconv_channels = []
+    j = 0
+    while f"head.deconv_layers.{3 * j}.weight" in sd:
+        w = sd[f"head.deconv_layers.{3 * j}.weight"].float()  # (Cin, Cout, 4, 4)
+        assert w.shape[2:] == (4, 4), "only deconv kernel 4 / stride 2 / pad 1 (the ProbPose config) is packed"
+        scale, shift = _bn_fold(sd, f"head.deconv_layers.{3 * j + 1}")
+        w = w * scale.view(1, -1, 1, 1)
+        cin, cout = w.shape[:2]
+        ph = torch.empty((2, 2, cout, 4 * cin))
+        for py in range(2):
+            for px in range(2):
+                for ty in range(2):
+                    for tx in range(2):
+                        tap = ty * 2 + tx
+                        ph[py, px, :, tap * cin : (tap + 1) * cin] = w[:, :, 3 - 2 * ty - py, 3 - 2 * tx - px].t()
+        t[f"deconv{j}.w"] = op(ph)
+        t[f"deconv{j}.b"] = f32(shift)
+        deconv_channels.append(cout)
+        j += 1
+    t["final.w"] = op(sd["head.final_layer.weight"].reshape(K, -1))
+    t["final.b"] = f32(sd["head.final_layer.bias"])
+
+    # ---- scalar towers
+    for c in range(3):
+        ws, bs = [], []
+        for tw in TOWERS:
+            base = f"head.{tw}_layers."
+            w = sd[base + f"{4 * c}.weight"].float()  # (Cout, Cin, 3, 3)
+            b = sd[base + f"{4 * c}.bias"].float()
+            scale, shift = _bn_fold(sd, base + f"{4 * c + 1}")
+            w = w * scale.view(-1, 1, 1, 1)
+            ws.append(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))  # [n, (ky, kx, c)]
+            bs.append(b * scale + shift)
+        t[f"tower{c}.w"] = op(torch.stack(ws))
+        t[f"tower{c}.b"] = f32(torch.stack(bs))
+    t["tower_out.w"] = f32(torch.stack([sd[f"head.{tw}_layers.12.weight"].float().reshape(K, -1) for tw in TOWERS]))
+    t["tower_out.b"] = f32(torch.stack([sd[f"head.{tw}_layers.12.bias"].float() for tw in TOWERS]))
+    return PackedWeights(dtype=dtype, embed_dims=E, num_layers=L, ffn_dims=Fd, num_keypoints=K,
+                         deconv_channels=deconv_channels, t=t)

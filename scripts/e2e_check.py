@@ -1,0 +1,50 @@
+"""Dev script: engine (HIP) vs oracle (torch CPU fp32) end to end; prints error statistics."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from probpose_code_amd import synthetic as S
+from probpose_code_amd.engine import ProbPoseEngine
+from oracle import model_ref as M
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+arch = sys.argv[2] if len(sys.argv) > 2 else "small"
+img_size = (256, 192) if len(sys.argv) <= 3 else (384, 288)
+logit_scale = float(os.environ.get("LOGIT_SCALE", "3.0"))
+torch.set_num_threads(os.cpu_count())
+sd = S.synthetic_state_dict(arch, img_size=img_size, seed=0, logit_scale=logit_scale)
+x = S.synthetic_crops(B, img_size=img_size, seed=1)
+heads = S.ARCHS[arch]["num_heads"]
+isz = (img_size[1], img_size[0])
+t = time.time()
+ref = M.predict(sd, x, heads, S.IMG_MEAN, S.IMG_STD, input_size=isz)
+print(f"oracle {time.time()-t:.2f}s")
+with torch.no_grad():
+    xn = M.preprocess(x, S.IMG_MEAN, S.IMG_STD)
+    f0 = M.vit_forward(sd, xn, heads); f1 = M.vit_forward(sd, xn.flip(-1), heads)
+    _, lg0 = M.head_heatmap(sd, f0, return_logits=True)
+for prec in ("f32", "bf16"):
+    eng = ProbPoseEngine(sd, heads, img_size=img_size, precision=prec, input_size=isz)
+    out = eng.forward(x.cuda(), True, S.COCO_FLIP_INDICES, return_heatmaps=True, return_features=True)
+    torch.cuda.synchronize()
+    feat = out["features"].float().cpu()[:B].permute(0, 3, 1, 2)
+    print(f"[{prec}] feat max|d| {(feat - f0).abs().max():.3e}  (ref std {f0.std():.3f})")
+    lg = out["logits"].cpu()[:B].reshape(lg0.shape)
+    print(f"[{prec}] logits max|d| {(lg - lg0).abs().max():.3e} (ref std {lg0.std():.3f})")
+    hm = out["heatmaps"].cpu().numpy()
+    print(f"[{prec}] heatmap max|d| {np.abs(hm - ref['heatmaps']).max():.3e}  nnz/map {np.mean((ref['heatmaps']>0).reshape(B,17,-1).sum(-1)):.1f}")
+    kp = out["keypoints"].cpu().numpy()[:, None]
+    d = np.abs(kp - ref["keypoints_input_space"]).max(-1)
+    same = d < 1.0
+    print(f"[{prec}] keypoints: argmax-agree {same.mean()*100:.1f}%  Linf(agree) {d[same].max():.3e} px(input space)  median {np.median(d[same]):.2e}")
+    sc = out["scalars"].cpu().numpy()
+    for i, n in enumerate(["keypoints_probs", "keypoints_visible", "keypoints_oks"]):
+        print(f"[{prec}] {n} max|d| {np.abs(sc[i][:, None] - ref[n]).max():.3e}")
+    print(f"[{prec}] keypoints_error max|d| {np.abs(sc[3][:, None] / np.sqrt(eng.Hh**2 + eng.Wh**2) - ref['keypoints_error']).max():.3e}")
+    print(f"[{prec}] conf max|d| {np.abs(out['scores'].cpu().numpy()[:, None] - ref['keypoints_conf'])[same].max():.3e}")
+    # timing
+    for _ in range(3): eng.forward(x.cuda(), True, S.COCO_FLIP_INDICES)
+    torch.cuda.synchronize(); t = time.time()
+    xs = x.cuda()
+    for _ in range(10): eng.forward(xs, True, S.COCO_FLIP_INDICES)
+    torch.cuda.synchronize(); dt = (time.time() - t) / 10
+    print(f"[{prec}] {dt*1e3:.2f} ms / batch of {B} -> {B/dt:.0f} crops/s")
