@@ -149,12 +149,14 @@ int pp_attention(int prec, const void* qkv, void* out, int n_seq, int seq_len, i
  * data_preprocessor.py:79-104 + mmengine ImgDataPreprocessor [3P]: BGR->RGB, float, (x-mean)/std),
  * the flip-test copy `inputs.flip(-1)` (mmpose/models/pose_estimators/topdown.py:109-112) and the
  * im2col of the ViT patch-embed Conv2d(3->E, k16, s16, zero pad `pad`) in one pass.
- * img_u8: (B, 3, H, W) uint8 CHW; patches: (passes * B * Hp * Wp, 768) bf16/fp32, row order
- * (pass, b, py, px), column order (c, i, j); pass 1 is the horizontally flipped crop.
+ * img: (B, 3, H, W) CHW, uint8 (raw crops; normalised here) or -- img_is_f32 != 0 -- fp32 that is
+ * already preprocessed (the reference backbone's own input contract; mean/std/bgr_to_rgb ignored).
+ * patches: (passes * B * Hp * Wp, 768) bf16/fp32, row order (pass, b, py, px), column order
+ * (c, i, j); pass 1 is the horizontally flipped crop.
  * mean_host / std_host: 3 floats each, HOST pointers, in output-channel (RGB) order. */
-int pp_preproc_im2col(int prec, const uint8_t* img_u8, void* patches, int B, int passes, int H, int W,
-                      int patch, int pad, const float* mean_host, const float* std_host, int bgr_to_rgb,
-                      void* stream);
+int pp_preproc_im2col(int prec, const void* img, int img_is_f32, void* patches, int B, int passes, int H,
+                      int W, int patch, int pad, const float* mean_host, const float* std_host,
+                      int bgr_to_rgb, void* stream);
 
 /* LayerNorm over the last dim of an fp32 (M, E) matrix (nn.LayerNorm(E, eps) of the ViT, eps 1e-6);
  * output bf16 or fp32. E in {384, 768, 1024}. */

@@ -177,7 +177,7 @@ def predict(sd, imgs_u8_bgr: torch.Tensor, num_heads: int, mean, std, input_size
     out["keypoint_scores"] = out["keypoints_conf"] if freeze_oks else out["keypoints_oks"]  # :797-798
     if input_center is not None:
         out["keypoints"] = np.stack([
-            D.to_image_space(kpts[b], np.array(input_size), np.asarray(input_scale[b]), np.asarray(input_center[b]))
+            D.to_image_space(kpts[b], np.array(input_size), np.asarray(input_center[b]), np.asarray(input_scale[b]))
             for b in range(B)
         ])
     else:

@@ -65,7 +65,7 @@ SIGNATURES = {
          c_longlong, c_longlong, c_longlong, c_longlong, c_int, c_int, c_int, _P],
     ),
     "pp_attention": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
-    "pp_preproc_im2col": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "pp_preproc_im2col": (c_int, [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "pp_layernorm": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_int, _P]),
     "pp_maxpool_relu_nhwc": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pp_tower_final": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),

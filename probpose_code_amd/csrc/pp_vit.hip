@@ -17,8 +17,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   zero padding acts on the NORMALISED image), src_c = 2 - c when bgr_to_rgb,
 //   xs = P px + j - pad for pass 0 and W - 1 - (P px + j - pad) for pass 1.
 // One thread per (m, c, i): 16 source bytes -> 16 outputs.
-template <typename T>
-__global__ __launch_bounds__(256) void preproc_im2col_kernel(const uint8_t* __restrict__ img, T* __restrict__ A, int B,
+// TIn = uint8_t: raw crops, normalised here; TIn = float: an already preprocessed (B,3,H,W) tensor
+// (the reference backbone's own input contract), copied as is.
+template <typename T, typename TIn>
+__global__ __launch_bounds__(256) void preproc_im2col_kernel(const TIn* __restrict__ img, T* __restrict__ A, int B,
                                                              int passes, int H, int W, int Hp, int Wp, int pad,
                                                              float m0, float m1, float m2, float s0, float s1, float s2,
                                                              int bgr_to_rgb) {
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void preproc_im2col_kernel(const uint8_t* __re
     const int py = pp_ / Wp, px = pp_ - py * Wp;
     const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
     const float stdv = c == 0 ? s0 : (c == 1 ? s1 : s2);
-    const int sc = bgr_to_rgb ? 2 - c : c;
+    const int sc = (sizeof(TIn) == 1 && bgr_to_rgb) ? 2 - c : c;
     const int y = P * py + i - pad;
     float v[P];
 #pragma unroll
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void preproc_im2col_kernel(const uint8_t* __re
         float val = 0.f;
         if (y >= 0 && y < H && x >= 0 && x < W) {
             const float u = (float)img[(((size_t)b * 3 + sc) * H + y) * W + xs];
-            val = (u - mean) / stdv;
+            val = sizeof(TIn) == 1 ? (u - mean) / stdv : u;
         }
         v[j] = val;
     }
@@ -128,11 +130,18 @@ static int launch_ln(const float* x, const float* g, const float* b, void* y, in
 
 }  // namespace pp
 
-extern "C" int pp_preproc_im2col(int prec, const uint8_t* img_u8, void* patches, int B, int passes, int H, int W,
-                                 int patch, int pad, const float* mean_host, const float* std_host, int bgr_to_rgb,
-                                 void* stream) {
+extern "C" int pp_preproc_im2col(int prec, const void* img, int img_is_f32, void* patches, int B, int passes, int H,
+                                 int W, int patch, int pad, const float* mean_host, const float* std_host,
+                                 int bgr_to_rgb, void* stream) {
     using namespace pp;
-    PP_REQUIRE(img_u8 && patches && mean_host && std_host, PP_ERR_INVALID_ARG, "pp_preproc_im2col: NULL argument");
+    PP_REQUIRE(img && patches, PP_ERR_INVALID_ARG, "pp_preproc_im2col: NULL argument");
+    PP_REQUIRE(img_is_f32 || (mean_host && std_host), PP_ERR_INVALID_ARG,
+               "pp_preproc_im2col: mean/std are required for uint8 input");
+    const float zeros[3] = {0.f, 0.f, 0.f}, ones[3] = {1.f, 1.f, 1.f};
+    if (img_is_f32) {
+        mean_host = zeros;
+        std_host = ones;
+    }
     PP_REQUIRE(patch == 16, PP_ERR_UNSUPPORTED, "pp_preproc_im2col: patch size must be 16");
     PP_REQUIRE(passes == 1 || passes == 2, PP_ERR_INVALID_ARG, "pp_preproc_im2col: passes must be 1 or 2");
     PP_REQUIRE(B > 0 && H > 0 && W > 0 && pad >= 0, PP_ERR_INVALID_ARG, "pp_preproc_im2col: bad shape");
@@ -140,16 +149,17 @@ extern "C" int pp_preproc_im2col(int prec, const uint8_t* img_u8, void* patches,
     const long long total = (long long)passes * B * Hp * Wp * 3 * patch;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (prec == PP_PREC_BF16)
-        hipLaunchKernelGGL(preproc_im2col_kernel<__bf16>, grid, block, 0, s, img_u8, reinterpret_cast<__bf16*>(patches),
-                           B, passes, H, W, Hp, Wp, pad, mean_host[0], mean_host[1], mean_host[2], std_host[0],
-                           std_host[1], std_host[2], bgr_to_rgb);
-    else if (prec == PP_PREC_F32)
-        hipLaunchKernelGGL(preproc_im2col_kernel<float>, grid, block, 0, s, img_u8, reinterpret_cast<float*>(patches), B,
-                           passes, H, W, Hp, Wp, pad, mean_host[0], mean_host[1], mean_host[2], std_host[0],
-                           std_host[1], std_host[2], bgr_to_rgb);
-    else
+#define PP_IM2COL(T, TIn)                                                                                         \
+    hipLaunchKernelGGL((preproc_im2col_kernel<T, TIn>), grid, block, 0, s, reinterpret_cast<const TIn*>(img),       \
+                       reinterpret_cast<T*>(patches), B, passes, H, W, Hp, Wp, pad, mean_host[0], mean_host[1],     \
+                       mean_host[2], std_host[0], std_host[1], std_host[2], bgr_to_rgb)
+    if (prec == PP_PREC_BF16) {
+        if (img_is_f32) PP_IM2COL(__bf16, float); else PP_IM2COL(__bf16, uint8_t);
+    } else if (prec == PP_PREC_F32) {
+        if (img_is_f32) PP_IM2COL(float, float); else PP_IM2COL(float, uint8_t);
+    } else
         return fail(PP_ERR_INVALID_ARG, "pp_preproc_im2col: unknown precision");
+#undef PP_IM2COL
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

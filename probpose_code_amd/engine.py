@@ -131,8 +131,9 @@ class ProbPoseEngine:
         M = B * passes * self.Np
         E, Fd, w = self.E, self.w.ffn_dims, self.w
         ob = int(self.dtype == torch.bfloat16)
-        _lib.call("pp_preproc_im2col", self.prec, imgs_u8.data_ptr(), ws["patches"].data_ptr(), B, passes, self.H,
-                  self.W, self.P, self.pad, self.mean.ctypes.data, self.std.ctypes.data, int(self.bgr_to_rgb), st)
+        _lib.call("pp_preproc_im2col", self.prec, imgs_u8.data_ptr(), int(imgs_u8.dtype == torch.float32),
+                  ws["patches"].data_ptr(), B, passes, self.H, self.W, self.P, self.pad, self.mean.ctypes.data,
+                  self.std.ctypes.data, int(self.bgr_to_rgb), st)
         Kp = 3 * self.P * self.P
         self._gemm(st, ws["patches"], w["patch_w"], w["patch_b"], ws["x"], M, E, Kp, residual=w["pos_embed"],
                    res_mod=self.Np)
@@ -192,40 +193,63 @@ class ProbPoseEngine:
         return ws["scalars"]
 
     # ------------------------------------------------------------------ public
+    def _check_imgs(self, imgs: torch.Tensor):
+        assert imgs.dim() == 4 and imgs.is_cuda, "expects a (B,3,H,W) tensor on the GPU"
+        assert imgs.dtype in (torch.uint8, torch.float32), "crops are uint8 (raw) or float32 (already preprocessed)"
+        assert tuple(imgs.shape[1:]) == (3, self.H, self.W), f"crop shape {tuple(imgs.shape)} != (B,3,{self.H},{self.W})"
+
     @torch.no_grad()
-    def forward(self, imgs_u8: torch.Tensor, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False,
-                return_features: bool = False) -> Dict[str, torch.Tensor]:
-        """imgs_u8: (B, 3, H, W) uint8 on the device (BGR CHW as PackPoseInputs emits). Returns device
-        tensors (views into the cached workspace, valid until the next call with the same batch size):
-        ``keypoints`` (B,K,2) f64 input-pixel space, ``scores`` (B,K) f32 (keypoints_conf), ``locs``,
-        ``scalars`` (4,B,K) f32 [probability, visibility, oks, raw error], optionally ``heatmaps``."""
-        assert imgs_u8.dtype == torch.uint8 and imgs_u8.dim() == 4 and imgs_u8.is_cuda, "expects uint8 (B,3,H,W) on GPU"
-        assert tuple(imgs_u8.shape[1:]) == (3, self.H, self.W), f"crop shape {tuple(imgs_u8.shape)} != (B,3,{self.H},{self.W})"
-        imgs_u8 = imgs_u8.contiguous()
-        B = imgs_u8.shape[0]
+    def run_backbone(self, imgs: torch.Tensor, flip_test: bool) -> torch.Tensor:
+        """(B,3,H,W) uint8 raw crops (or fp32 preprocessed) -> NHWC features (passes*B, Hp, Wp, E); with
+        flip_test rows [B:] are the features of the horizontally flipped crops (topdown.py:109-112)."""
+        self._check_imgs(imgs)
+        imgs = imgs.contiguous()
+        B, passes = imgs.shape[0], 2 if flip_test else 1
+        ws = self._workspace(B, passes)
+        with torch.cuda.device(self.device):
+            feat = self.backbone(imgs, passes, ws, _lib.stream_ptr(self.device))
+        return feat.view(B * passes, self.Hp, self.Wp, self.E)
+
+    @torch.no_grad()
+    def run_head(self, feat_nhwc: torch.Tensor, flip_test: bool, flip_indices=None,
+                 return_heatmaps: bool = False) -> Dict[str, torch.Tensor]:
+        """NHWC features (passes*B, Hp, Wp, E) in the engine's operand dtype -> decoded results
+        (ProbMapHead.forward + the flip-test merge + BaseHead.decode, probmap_head.py:746-779)."""
         passes = 2 if flip_test else 1
+        nb = feat_nhwc.shape[0]
+        assert nb % passes == 0 and tuple(feat_nhwc.shape[1:]) == (self.Hp, self.Wp, self.E)
+        assert feat_nhwc.dtype == self.dtype and feat_nhwc.is_contiguous() and feat_nhwc.is_cuda
         if flip_test and flip_indices is None:
             raise ValueError("flip_test needs flip_indices (dataset meta)")
+        if self.normalize is None:
+            raise NotImplementedError("normalize=None (no Sparsemax) is not a ProbPose configuration")
+        B = nb // passes
         ws = self._workspace(B, passes)
         with torch.cuda.device(self.device):
             st = _lib.stream_ptr(self.device)
-            feat = self.backbone(imgs_u8, passes, ws, st)
-            logits = self.heatmap_logits(feat, B * passes, ws, st)
+            logits = self.heatmap_logits(feat_nhwc, nb, ws, st)
             fi = self._flip_indices(flip_indices) if flip_test else None
             lf = logits[B:] if flip_test else None
-            if self.normalize is not None:
-                _lib.call("pp_probmap_head_decode", logits.data_ptr(), _lib.ptr(lf), _lib.ptr(fi), self.taps.data_ptr(),
-                          self.radius.data_ptr(), B, self.K, self.Hh, self.Wh, float(self.input_size[0]),
-                          float(self.input_size[1]), self.temperature, float(self.normalize),
-                          ws["heatmaps"].data_ptr() if return_heatmaps else None, None, ws["locs"].data_ptr(),
-                          ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), st)
-            else:
-                raise NotImplementedError("normalize=None (no Sparsemax) is not a ProbPose configuration")
-            scalars = self.towers(feat, B, passes, flip_indices, ws, st)
-        out = dict(keypoints=ws["keypoints"], scores=ws["scores"], locs=ws["locs"], scalars=scalars)
+            _lib.call("pp_probmap_head_decode", logits.data_ptr(), _lib.ptr(lf), _lib.ptr(fi), self.taps.data_ptr(),
+                      self.radius.data_ptr(), B, self.K, self.Hh, self.Wh, float(self.input_size[0]),
+                      float(self.input_size[1]), self.temperature, float(self.normalize),
+                      ws["heatmaps"].data_ptr() if return_heatmaps else None, None, ws["locs"].data_ptr(),
+                      ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), st)
+            scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, st)
+        out = dict(keypoints=ws["keypoints"], scores=ws["scores"], locs=ws["locs"], scalars=scalars, logits=logits)
         if return_heatmaps:
             out["heatmaps"] = ws["heatmaps"]
+        return out
+
+    @torch.no_grad()
+    def forward(self, imgs: torch.Tensor, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False,
+                return_features: bool = False) -> Dict[str, torch.Tensor]:
+        """imgs: (B, 3, H, W) uint8 on the device (BGR CHW as PackPoseInputs emits). Returns device
+        tensors (views into the cached workspace, valid until the next call with the same batch size):
+        ``keypoints`` (B,K,2) f64 input-pixel space, ``scores`` (B,K) f32 (keypoints_conf), ``locs``,
+        ``scalars`` (4,B,K) f32 [probability, visibility, oks, raw error], optionally ``heatmaps``."""
+        feat = self.run_backbone(imgs, flip_test)
+        out = self.run_head(feat, flip_test, flip_indices, return_heatmaps)
         if return_features:
-            out["features"] = feat.view(B * passes, self.Hp, self.Wp, self.E)
-            out["logits"] = logits
+            out["features"] = feat
         return out

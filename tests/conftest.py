@@ -11,6 +11,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    try:  # the GPU box has 256 host cores: torch-CPU oracles crawl when oversubscribed
+        import torch
+
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except Exception:  # noqa: BLE001
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

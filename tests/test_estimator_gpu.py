@@ -1,0 +1,130 @@
+"""GPU: the drop-in surface end to end -- config -> registry build -> load_state_dict (reference key names)
+-> test_step -> PoseDataSample.pred_instances -- against the torch-CPU oracle on identical crops.
+
+Tolerances (BASELINE.json north_star: keypoints / probabilities within 1e-3 of the reference CPU path):
+  * precision "f32" (exact-fp32 MFMA products, fp32 accumulate): every field <= 1e-3, keypoints in image px;
+  * precision "bf16": measured and bounded loosely; argmax flips are counted, not hidden.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "configs", "td-pm_ProbPose-small_mi355x_coco-256x192.py")
+FIELDS = ["keypoints_conf", "keypoints_probs", "keypoints_visible", "keypoints_oks", "keypoints_error", "keypoint_scores"]
+B = 6
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from oracle import model_ref as M
+    from probpose_code_amd import synthetic as S
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    sd = S.synthetic_state_dict("small", seed=3, logit_scale=2.0)
+    crops = S.synthetic_crops(B, seed=4)
+    rng = np.random.default_rng(5)
+    center = np.stack([rng.uniform(80, 400, B), rng.uniform(100, 500, B)], -1).astype(np.float32)
+    scale = (np.array([192, 256], np.float32) * rng.uniform(0.8, 2.5, (B, 1)).astype(np.float32) * 1.25).astype(np.float32)
+    ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD, input_size=(192, 256), input_center=center, input_scale=scale)
+    return sd, crops, center, scale, ref
+
+
+def _run(sd, crops, center, scale, precision, cfg_options=None):
+    from probpose_code_amd import apis
+
+    opts = {"model.precision": precision}
+    opts.update(cfg_options or {})
+    model = apis.init_model(CFG, {"state_dict": sd}, device="cuda:0", cfg_options=opts)
+    batch = apis.pack_crops(crops, center, scale, model.dataset_meta)
+    with torch.no_grad():
+        return model, model.test_step(batch)
+
+
+def test_f32_pred_instances_within_1e3(setup):
+    sd, crops, center, scale, ref = setup
+    model, results = _run(sd, crops, center, scale, "f32", {"model.test_cfg.output_heatmaps": True})
+    assert len(results) == B
+    flips = 0
+    for b, ds in enumerate(results):
+        pi = ds.pred_instances
+        assert pi.keypoints.shape == (1, 17, 2) and pi.keypoints.dtype == np.float64
+        for f in FIELDS:
+            assert getattr(pi, f).shape == (1, 17), f
+        d = np.abs(pi.keypoints - ref["keypoints"][b]).max(-1)[0]
+        same = d < 0.5 * float(scale[b].min()) / 48  # less than half a heatmap cell: same argmax
+        flips += int((~same).sum())
+        assert d[same].max() <= 1e-3, f"sample {b}: keypoint L_inf {d[same].max():.2e} image px"
+        for f in FIELDS[1:]:
+            assert np.abs(getattr(pi, f) - ref[f][b]).max() <= 1e-3, f
+        assert np.abs(pi.keypoints_conf - ref["keypoints_conf"][b])[0][same].max() <= 1e-3
+        assert np.array_equal(pi.bboxes, ds.gt_instances.bboxes) and np.array_equal(pi.bbox_scores, ds.gt_instances.bbox_scores)
+        hm = ds.pred_fields.heatmaps
+        assert tuple(hm.shape) == (17, 64, 48)
+        assert np.abs(hm.cpu().numpy() - ref["heatmaps"][b]).max() <= 1e-3
+    assert flips <= 1, f"{flips} argmax flips of {B * 17} keypoints in fp32 mode"
+    # keypoint_scores is the OKS branch since freeze_oks=False (probmap_head.py:797-798)
+    assert np.array_equal(results[0].pred_instances.keypoint_scores, results[0].pred_instances.keypoints_oks)
+
+
+def test_bf16_pred_instances_bounded(setup):
+    sd, crops, center, scale, ref = setup
+    _, results = _run(sd, crops, center, scale, "bf16")
+    flips, worst = 0, 0.0
+    for b, ds in enumerate(results):
+        pi = ds.pred_instances
+        d = np.abs(pi.keypoints - ref["keypoints"][b]).max(-1)[0]
+        same = d < 0.5 * float(scale[b].min()) / 48
+        flips += int((~same).sum())
+        worst = max(worst, float(d[same].max()))
+        for f in ("keypoints_probs", "keypoints_visible", "keypoints_oks"):
+            assert np.abs(getattr(pi, f) - ref[f][b]).max() <= 3e-2, f
+    print(f"bf16: keypoint L_inf (same argmax) {worst:.3e} image px, argmax flips {flips}/{B * 17}")
+    assert worst <= 0.5 and flips <= 0.15 * B * 17
+
+
+def test_module_level_interfaces(setup):
+    """backbone(inputs) -> (feat NCHW,), head.forward(feats) -> 5 tensors, head.predict([f, f_flip]) -- the
+    reference's own call structure (topdown.py:109-116) -- agree with the fused predict path."""
+    from oracle import model_ref as M
+    from probpose_code_amd import synthetic as S
+
+    sd, crops, center, scale, ref = setup
+    model, fused = _run(sd, crops, center, scale, "f32")
+    x = M.preprocess(crops, S.IMG_MEAN, S.IMG_STD).cuda()
+    with torch.no_grad():
+        feats = model.extract_feat(x)
+        assert isinstance(feats, tuple) and tuple(feats[0].shape) == (B, 384, 16, 12)
+        assert np.abs(feats[0].cpu().numpy() - ref["features"]).max() < 1e-4
+        feats = (feats[0].clone(),)
+        feats_flip = (model.extract_feat(x.flip(-1))[0].clone(),)
+        hm, prob, vis, oks, err = model.head.forward(feats)
+        assert tuple(hm.shape) == (B, 17, 64, 48) and tuple(prob.shape) == (B, 17, 1, 1)
+        assert torch.allclose(hm.sum((-1, -2)), torch.ones(B, 17, device="cuda"), atol=1e-5)
+        from probpose_code_amd import apis
+
+        batch = apis.pack_crops(crops, center, scale, model.dataset_meta)
+        preds = model.head.predict([feats, feats_flip], batch["data_samples"], test_cfg=model.test_cfg)
+    for b in range(B):
+        kp_fused_input = (fused[b].pred_instances.keypoints - center[b] + 0.5 * scale[b]) / scale[b] * (192, 256)
+        assert np.abs(preds[b].keypoints - kp_fused_input).max() < 1e-3
+        assert np.allclose(preds[b].keypoints_probs, fused[b].pred_instances.keypoints_probs, atol=1e-5)
+
+
+def test_errors_and_no_cpu_fallback(setup):
+    from probpose_code_amd import Config, build_pose_estimator
+
+    cfg = Config.fromfile(CFG)
+    model = build_pose_estimator(dict(cfg.model))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model.engine
+    with pytest.raises(RuntimeError, match="Invalid mode"):
+        model.forward(torch.zeros(1, 3, 256, 192), None, mode="bogus")
+    bad = dict(cfg.model)
+    bad["head"] = dict(bad["head"], deconv_out_channels=(256, 256), deconv_kernel_sizes=(4,))
+    with pytest.raises(ValueError, match="same length"):
+        build_pose_estimator(bad)

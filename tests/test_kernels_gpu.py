@@ -166,7 +166,7 @@ def test_preproc_im2col_vs_torch(prec):
     Hp, Wp = (H + 4 - 16) // 16 + 1, (W + 4 - 16) // 16 + 1
     out = torch.empty((2 * B * Hp * Wp, 768), dtype=_dt(prec), device="cuda")
     imgd = img.cuda()
-    L.call("pp_preproc_im2col", prec, imgd.data_ptr(), out.data_ptr(), B, 2, H, W, 16, 2, mean.ctypes.data,
+    L.call("pp_preproc_im2col", prec, imgd.data_ptr(), 0, out.data_ptr(), B, 2, H, W, 16, 2, mean.ctypes.data,
            std.ctypes.data, 1, None)
     x = M.preprocess(img, mean, std)
     both = torch.cat([x, x.flip(-1)])
@@ -176,6 +176,11 @@ def test_preproc_im2col_vs_torch(prec):
         assert torch.equal(out.cpu(), ref)  # same fp32 ops: bit-exact
     else:
         assert torch.equal(out.cpu(), ref.to(torch.bfloat16))
+    # fp32 input that is already preprocessed (the backbone's stand-alone contract): plain im2col
+    xd = x.contiguous().cuda()
+    out1 = torch.empty((B * Hp * Wp, 768), dtype=_dt(prec), device="cuda")
+    L.call("pp_preproc_im2col", prec, xd.data_ptr(), 1, out1.data_ptr(), B, 1, H, W, 16, 2, None, None, 0, None)
+    assert torch.equal(out1.cpu(), ref[: B * Hp * Wp].to(_dt(prec)))
 
 
 def test_maxpool_relu_and_tower_final():
