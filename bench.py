@@ -1,16 +1,21 @@
 #!/usr/bin/env python
-"""bench.py -- person-crops/sec of the ProbPose hot path on N MI355X (one process per GPU).
+"""bench.py -- person-crops/sec of the ProbPose top-down inference hot path on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--precision bf16|f32] [--no-graph]
 
-N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
---gpus N ...`; ranks shard the crops (64 per GPU, weak scaling), there is no data-path collective
-except the final all_gather of the fixed-layout keypoint results.
+One process per GPU. N>1 is launched by the driver as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`;
+the crops shard across ranks (64 per GPU per step, weak scaling, seeds offset by rank), there is no
+data-path collective except the all_gather of the fixed-layout keypoint results.
 
-One "step" = one pass of the hot path over one batch of synthetic crops already resident in HBM.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
-kernel (measured live with HIP events on the launch stream) and `cpu_baseline` (the oracle timed on
-this box's host cores, rank 0, N=1 only, bounded sample).
+One "step" = the whole hot path over one batch of synthetic uint8 crops ALREADY RESIDENT IN HBM:
+preprocess + flip copy -> ViT-S backbone (both flip-test passes) -> ProbMapHead (deconv heatmap branch +
+Sparsemax, 4 scalar towers, flip average) -> ProbMap decode -> result tensors copied to pinned host memory
+(+ RCCL all_gather of the results when N>1). Random-init (seeded) weights, synthetic crops.
+
+Rank 0 prints ONE JSON line with `roofline` for the dominant kernel -- its launches timed live with HIP events
+on the launch stream in an instrumented pass of the same step -- and `cpu_baseline`: the oracle (torch-CPU
+model + per-sample scipy decode loop, as the reference runs) timed on this box's host cores on a bounded sample.
 """
 import argparse
 import json
@@ -25,7 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks, HBM3E spec bandwidth
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+HBM_PEAK_GBS = 8000.0
+# BASELINE.md 3 / SURVEY 8d: algorithmic FLOPs of ProbPose-S @256x192, MAC = 2
+GFLOP_PER_CROP_FLIP = 26.877
 
 
 def parse():
@@ -34,31 +43,40 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying the HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     return ap.parse_args()
 
 
-def synthetic_maps(B, K, H, W, seed, device):
-    """Sparsemax-like probability maps (sparse, rows sum to 1), seeded."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    x = torch.rand((B, K, H * W), generator=g) ** 6
-    x = torch.clamp(x - 0.35, min=0)
-    x = x / x.sum(-1, keepdim=True).clamp_min(1e-12)
-    return x.reshape(B, K, H, W).to(device)
+def gemm_flops_per_step(eng, B, passes):
+    """Algorithmic FLOPs of the launches of the dominant kernel (pp_gemm: every nn.Linear, the patch embed and
+    the final 1x1 conv) in one step, and their count."""
+    M = B * passes * eng.Np
+    E, Fd, L = eng.E, eng.w.ffn_dims, eng.w.num_layers
+    fl = 2.0 * M * E * 768  # patch embed
+    fl += L * 2.0 * M * (3 * E * E + E * E + 2 * E * Fd)
+    P = eng.Hh * eng.Wh
+    fl += 2.0 * (B * passes * P) * eng.K * eng.w.deconv_channels[-1]
+    return fl, 1 + 4 * L + 1
 
 
-def cpu_baseline_decode(hm, hmf, n_crops):
-    """Oracle (port of the reference's per-sample scipy decode loop, base_head.py:69-77) on the host."""
-    from oracle import decode_ref as D
+def cpu_baseline(sd, crops_cpu, n_crops, threads):
+    from oracle import model_ref as M
+    from probpose_code_amd import synthetic as S
 
-    hm = hm[:n_crops].cpu().numpy()
-    hmf = hmf[:n_crops].cpu().numpy()
-    t0 = time.perf_counter()
-    avg = D.tta_average(hm, hmf)
-    for b in range(n_crops):
-        D.probmap_decode(avg[b], backend="scipy")
+    torch.set_num_threads(threads)
+    M.predict(sd, crops_cpu[:2], 12, S.IMG_MEAN, S.IMG_STD)  # warm-up (thread pool, allocator)
+    done, t0 = 0, time.perf_counter()
+    ref = None
+    while done < n_crops:
+        n = min(crops_cpu.shape[0], n_crops - done)
+        r = M.predict(sd, crops_cpu[:n], 12, S.IMG_MEAN, S.IMG_STD)
+        ref = ref or r
+        done += n
     dt = time.perf_counter() - t0
-    return n_crops / dt, dt
+    return done / dt, dt, ref
 
 
 def main():
@@ -73,19 +91,27 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev)
 
-    import probpose_code_amd as pp
-    from probpose_code_amd.codecs import ProbMap  # noqa: F401
+    from probpose_code_amd import synthetic as S
+    from probpose_code_amd.dist import ResultGather
+    from probpose_code_amd.engine import ProbPoseEngine
 
-    B, K, H, W = args.batch, 17, 64, 48
-    flip = [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]
-    codec = pp.KEYPOINT_CODECS.build(dict(type="ProbMap", input_size=(192, 256), heatmap_size=(48, 64), sigma=-1))
-    hm = synthetic_maps(B, K, H, W, 1000 + rank, dev)
-    hmf = synthetic_maps(B, K, H, W, 2000 + rank, dev)
+    B = args.batch
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)  # same weights on every rank
+    crops_cpu = S.synthetic_crops(B, seed=100 + rank)              # a different shard per rank
+    crops = crops_cpu.to(dev)
+    eng = ProbPoseEngine(sd, 12, precision=args.precision, device=dev)
+    flip = S.COCO_FLIP_INDICES
+    gather = ResultGather(B, eng.K, dev, world)  # fixed-layout result record, pinned host copy, RCCL all_gather
+    use_graph = not args.no_graph
+    if use_graph:
+        eng.capture(B, True, flip).copy_(crops)
 
     def step():
-        return codec.decode_device(hm, hmf, flip)
+        out = eng.forward_graph(crops, True, flip) if use_graph else eng.forward(crops, True, flip)
+        return gather(out)
 
     def barrier():
         if distributed:
@@ -93,33 +119,33 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        out = step()
+        step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        out = step()
-        ev[i][1].record()
+    for _ in range(args.steps):
+        step()
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # the one exchange the path has: fixed-layout results gathered over RCCL
-        res = torch.cat([out["keypoints"].float(), out["scores"][..., None]], -1)
-        gathered = torch.empty((world,) + tuple(res.shape), dtype=res.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, res)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # ---- instrumented pass: HIP events around every launch, on the launch stream (not inside the timed region)
+    eng.profile = {}
+    for _ in range(5):
+        eng.forward(crops, True, flip)
+    torch.cuda.synchronize()
+    prof = {k: [a.elapsed_time(b) for a, b in v] for k, v in eng.profile.items()}
+    eng.profile = None
 
     if rank == 0:
-        crops = B * world * args.steps
-        alg_bytes = B * K * H * W * 4 * 2  # two f32 maps per crop read once (417 792 B/crop)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        per_tag = {k: (float(np.sum(v)) / 5, len(v) // 5) for k, v in prof.items()}  # ms per step, launches per step
+        dom = max(per_tag, key=lambda k: per_tag[k][0])
+        dom_ms, dom_n = per_tag[dom]
         line = {
             "metric": "person-crops/sec @ 256x192 bs64",
-            "value": crops / dt,
+            "value": B * world * args.steps / dt,
             "unit": "crops/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -128,22 +154,59 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 maps, f64 accumulate",
+            "dtype": "bf16 operands / fp32 accumulate (fp32 LN, softmax, residual, Sparsemax; f64 decode)"
+            if args.precision == "bf16" else "f32 (exact-fp32 MFMA products, fp32 accumulate; f64 decode)",
             "data": "synthetic",
-            "config": {"workload": "PARTIAL PATH (round-1 first slice): fused flip-average + ProbMap decode, "
-                       f"bs{B}x17x64x48 probability maps per GPU; backbone/head not yet in the timed region",
-                       "crops_per_gpu": B, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "probmap_decode_kernel<true>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+            "config": {
+                "workload": f"ProbPose-small (ViT-S 12x384, 12 heads x 32) bs{B} random 256x192 uint8 crops per GPU, "
+                            "flip_test=True, seeded random-init weights: preprocess -> backbone x2 passes -> ProbMapHead "
+                            "(heatmap branch + Sparsemax + 4 towers) -> ProbMap decode -> results in pinned host memory",
+                "crops_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                "launch": "hipGraph replay" if use_graph else "eager launches",
+                "gflop_per_crop": GFLOP_PER_CROP_FLIP,
+            },
+            "path_tflops": B * world * args.steps * GFLOP_PER_CROP_FLIP / dt / 1e3,
+            "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_tag.items(), key=lambda kv: -kv[1][0])},
         }
+        if dom == "gemm":
+            fl, n = gemm_flops_per_step(eng, B, 2)
+            assert n == dom_n, (n, dom_n)
+            achieved = fl / n / (dom_ms / n * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.precision]
+            line["roofline"] = {
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": None, "kernel": f"pp::gemm_kernel<{'__bf16' if args.precision == 'bf16' else 'float'}, G_LINEAR>",
+                "launches_per_step": n, "avg_launch_ms": dom_ms / n, "algorithmic_gflop_per_launch": fl / n / 1e9,
+            }
+        else:  # pragma: no cover - a different kernel dominates: report its time, flag the roofline as undefined
+            line["roofline"] = {"bound": "mfma", "achieved": None, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                                "frac": None, "traffic": None, "kernel": dom, "avg_launch_ms": dom_ms / dom_n}
         if world == 1 and not args.no_cpu_baseline:
-            n = min(B, 32)
-            v, secs = cpu_baseline_decode(hm, hmf, n)
-            line["cpu_baseline"] = {"value": v, "unit": "crops/s", "cores": 1, "kind": "port",
-                                    "sample": f"{n} crops of the same batch, decode stage only, {secs:.1f} s, "
-                                              f"1 Python thread as the reference runs it ({os.cpu_count()} host cores present)"}
+            threads = min(16, len(os.sched_getaffinity(0)))
+            try:
+                q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if q != "max":
+                    threads = max(1, min(threads, int(int(q) / int(p))))
+            except Exception:  # noqa: BLE001
+                pass
+            v, secs, ref = cpu_baseline(sd, crops_cpu, 4 * B, threads)
+            line["cpu_baseline"] = {
+                "value": v, "unit": "crops/s", "cores": threads, "kind": "port",
+                "sample": f"{4 * B} crops (the same bs{B} batch x4) through the oracle: torch-CPU fp32 model on {threads} "
+                          f"threads + per-sample scipy decode loop on 1 thread, {secs:.1f} s; host has "
+                          f"{os.cpu_count()} logical CPUs, cgroup quota {threads}",
+            }
+            if not args.no_parity:
+                out = eng.forward(crops, True, flip)
+                kp = out["keypoints"].cpu().numpy()[:, None]
+                d = np.abs(kp - ref["keypoints_input_space"]).max(-1)
+                same = d < 2.0
+                line["parity_vs_oracle"] = {
+                    "precision": args.precision, "crops": B,
+                    "keypoint_linf_px_input_space_same_argmax": float(d[same].max()),
+                    "argmax_flips": int((~same).sum()), "keypoints": int(same.size),
+                    "probs_linf": float(np.abs(out["scalars"][0].cpu().numpy()[:, None] - ref["keypoints_probs"]).max()),
+                }
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

@@ -70,6 +70,8 @@ class ProbPoseEngine:
         self.radius = torch.from_numpy(radius).to(self.device)
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._flip: Dict[tuple, torch.Tensor] = {}
+        self._graphs: Dict[tuple, tuple] = {}
+        self.profile: Optional[Dict[str, list]] = None
         # tower pooling schedule (probmap_head.py:264) and the spatial sizes it produces
         self.pools = ((4, 3), (2, 2), (2, 2))
         hs, ws_ = self.Hp, self.Wp
@@ -119,11 +121,23 @@ class ProbPoseEngine:
         return self._flip[key]
 
     # ------------------------------------------------------------------ launches
+    def _call(self, tag: str, fn: str, *args):
+        """One C-ABI launch. With ``self.profile`` set (a dict), HIP events are recorded on the launch
+        stream around every launch and collected per kernel tag (bench.py reads them for the roofline)."""
+        if self.profile is None:
+            _lib.call(fn, *args)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.call(fn, *args)
+        b.record()
+        self.profile.setdefault(tag, []).append((a, b))
+
     def _gemm(self, st, a, w, bias, out, M, N, K, act=ACT_NONE, residual=None, res_mod=0, out_bf16=None, planar=0,
               ldc=None):
         ob = int(out.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
-        _lib.call("pp_gemm", self.prec, a.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), res_mod,
-                  out.data_ptr(), M, N, K, K, K, N if ldc is None else ldc, act, ob, planar, st)
+        self._call("gemm", "pp_gemm", self.prec, a.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(residual),
+                   res_mod, out.data_ptr(), M, N, K, K, K, N if ldc is None else ldc, act, ob, planar, st)
 
     def backbone(self, imgs_u8: torch.Tensor, passes: int, ws, st) -> torch.Tensor:
         """uint8 (B,3,H,W) -> final-LN features, token-major (passes*B*Np, E) == NHWC (passes*B, Hp, Wp, E)."""
@@ -131,7 +145,7 @@ class ProbPoseEngine:
         M = B * passes * self.Np
         E, Fd, w = self.E, self.w.ffn_dims, self.w
         ob = int(self.dtype == torch.bfloat16)
-        _lib.call("pp_preproc_im2col", self.prec, imgs_u8.data_ptr(), int(imgs_u8.dtype == torch.float32),
+        self._call("im2col", "pp_preproc_im2col", self.prec, imgs_u8.data_ptr(), int(imgs_u8.dtype == torch.float32),
                   ws["patches"].data_ptr(), B, passes, self.H, self.W, self.P, self.pad, self.mean.ctypes.data,
                   self.std.ctypes.data, int(self.bgr_to_rgb), st)
         Kp = 3 * self.P * self.P
@@ -139,17 +153,17 @@ class ProbPoseEngine:
                    res_mod=self.Np)
         scale = self.hd ** -0.5
         for i in range(w.num_layers):
-            _lib.call("pp_layernorm", ws["x"].data_ptr(), w[f"l{i}.ln1.w"].data_ptr(), w[f"l{i}.ln1.b"].data_ptr(),
+            self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), w[f"l{i}.ln1.w"].data_ptr(), w[f"l{i}.ln1.b"].data_ptr(),
                       ws["h"].data_ptr(), M, E, self.ln_eps, ob, st)
             self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], ws["qkv"], M, 3 * E, E)
-            _lib.call("pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), B * passes, self.Np,
+            self._call("attention", "pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), B * passes, self.Np,
                       self.heads, self.hd, scale, st)
             self._gemm(st, ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], ws["x"], M, E, E, residual=ws["x"])
-            _lib.call("pp_layernorm", ws["x"].data_ptr(), w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(),
+            self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(),
                       ws["h"].data_ptr(), M, E, self.ln_eps, ob, st)
             self._gemm(st, ws["h"], w[f"l{i}.fc1.w"], w[f"l{i}.fc1.b"], ws["f"], M, Fd, E, act=ACT_GELU)
             self._gemm(st, ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], ws["x"], M, E, Fd, residual=ws["x"])
-        _lib.call("pp_layernorm", ws["x"].data_ptr(), w["ln_f.w"].data_ptr(), w["ln_f.b"].data_ptr(),
+        self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), w["ln_f.w"].data_ptr(), w["ln_f.b"].data_ptr(),
                   ws["feat"].data_ptr(), M, E, self.ln_eps, ob, st)
         return ws["feat"]
 
@@ -163,7 +177,7 @@ class ProbPoseEngine:
             wj = w[f"deconv{j}.w"]
             for py in range(2):
                 for px in range(2):
-                    _lib.call("pp_conv_gemm", self.prec, DECONV, src.data_ptr(), wj[py, px].data_ptr(),
+                    self._call("deconv", "pp_conv_gemm", self.prec, DECONV, src.data_ptr(), wj[py, px].data_ptr(),
                               w[f"deconv{j}.b"].data_ptr(), dst.data_ptr(), nb, hh, ww, cin, cout, py, px, 1, 0, 0, 0,
                               0, cout, ACT_RELU, ob, st)
             src, cin, hh, ww = dst, cout, hh * 2, ww * 2
@@ -180,15 +194,15 @@ class ProbPoseEngine:
         for j, (th, tw) in enumerate(self.tower_hw):
             ph, pw_ = self.pools[j]
             out = ws[f"t{j}"]
-            _lib.call("pp_conv_gemm", self.prec, CONV3X3, src.data_ptr(), w[f"tower{j}.w"].data_ptr(),
+            self._call("conv3x3", "pp_conv_gemm", self.prec, CONV3X3, src.data_ptr(), w[f"tower{j}.w"].data_ptr(),
                       w[f"tower{j}.b"].data_ptr(), out.data_ptr(), nb, th, tw, E, E, 0, 0, 4, stride_src,
                       E * 9 * E, nb * th * tw * E, E, E, ACT_NONE, ob, st)
-            _lib.call("pp_maxpool_relu_nhwc", out.data_ptr(), ob, ws[f"p{j}"].data_ptr(), ob, 4 * nb, th, tw, E, ph,
+            self._call("maxpool", "pp_maxpool_relu_nhwc", out.data_ptr(), ob, ws[f"p{j}"].data_ptr(), ob, 4 * nb, th, tw, E, ph,
                       pw_, st)
             src = ws[f"p{j}"]
             stride_src = nb * (th // ph) * (tw // pw_) * E
         fi = self._flip_indices(flip_indices) if passes == 2 else None
-        _lib.call("pp_tower_final", src.data_ptr(), ob, w["tower_out.w"].data_ptr(), w["tower_out.b"].data_ptr(),
+        self._call("tower_final", "pp_tower_final", src.data_ptr(), ob, w["tower_out.w"].data_ptr(), w["tower_out.b"].data_ptr(),
                   _lib.ptr(fi), ws["scalars"].data_ptr(), B, passes, E, self.K, 1.0, st)
         return ws["scalars"]
 
@@ -230,7 +244,7 @@ class ProbPoseEngine:
             logits = self.heatmap_logits(feat_nhwc, nb, ws, st)
             fi = self._flip_indices(flip_indices) if flip_test else None
             lf = logits[B:] if flip_test else None
-            _lib.call("pp_probmap_head_decode", logits.data_ptr(), _lib.ptr(lf), _lib.ptr(fi), self.taps.data_ptr(),
+            self._call("head_decode", "pp_probmap_head_decode", logits.data_ptr(), _lib.ptr(lf), _lib.ptr(fi), self.taps.data_ptr(),
                       self.radius.data_ptr(), B, self.K, self.Hh, self.Wh, float(self.input_size[0]),
                       float(self.input_size[1]), self.temperature, float(self.normalize),
                       ws["heatmaps"].data_ptr() if return_heatmaps else None, None, ws["locs"].data_ptr(),
@@ -252,4 +266,37 @@ class ProbPoseEngine:
         out = self.run_head(feat, flip_test, flip_indices, return_heatmaps)
         if return_features:
             out["features"] = feat
+        return out
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def capture(self, B: int, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False):
+        """Capture the whole launch sequence for batch size B into a HIP graph (the ~110 launches of one
+        forward are launch-latency-bound from Python). Returns the static input buffer to fill."""
+        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps)
+        if key in self._graphs:
+            return self._graphs[key][1]
+        static_in = torch.zeros((B, 3, self.H, self.W), dtype=torch.uint8, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):  # warm-up: allocates the workspace, sets kernel attributes
+            for _ in range(2):
+                self.forward(static_in, flip_test, flip_indices, return_heatmaps)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.forward(static_in, flip_test, flip_indices, return_heatmaps)
+        self._graphs[key] = (graph, static_in, out)
+        return static_in
+
+    def forward_graph(self, imgs: torch.Tensor, flip_test: bool = True, flip_indices=None,
+                      return_heatmaps: bool = False) -> Dict[str, torch.Tensor]:
+        """Same contract as ``forward`` for uint8 crops, replaying the captured graph."""
+        B = imgs.shape[0]
+        static_in = self.capture(B, flip_test, flip_indices, return_heatmaps)
+        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps)
+        graph, _, out = self._graphs[key]
+        if imgs.data_ptr() != static_in.data_ptr():
+            static_in.copy_(imgs, non_blocking=True)
+        graph.replay()
         return out
