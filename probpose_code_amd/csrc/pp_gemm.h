@@ -23,6 +23,7 @@ struct GemmParams {
     int res_mod;            // >0: residual row = m % res_mod (broadcast over the batch, e.g. pos_embed)
     int ldres;              // row stride of residual (elements); 0 -> ldc
     int planar_P;           // >0: store planar, out[((m / P) * N + n) * P + m % P]  (NHWC rows -> (B, N, P) planes)
+    unsigned a_bytes, w_bytes;  // extent of the activation / weight tensor of ONE group (buffer-descriptor bound)
     long long strideA_z, strideW_z, strideC_z, strideBias_z;  // grouped launch (blockIdx.z), in elements
 };
 

@@ -64,53 +64,60 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c, fl
     return c;
 }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB_OFFSET = 0x7ffffff0u;  // >= num_records of every tensor (< 2 GiB): the DMA writes zeros
+
 template <typename T, int GATHER>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) {
-    constexpr int BK = Prec<T>::BK, CH = Prec<T>::CH;
+    constexpr int BK = Prec<T>::BK;
+    constexpr int ESZ = (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [2 buffers][W tile | Act tile]
+    // [2 buffers][W tile | Act tile], each tile 128 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const int z = blockIdx.z;
-    const int n0 = blockIdx.x * BN;
-    const int m0 = blockIdx.y * BM;
 
-    const T* __restrict__ Act = reinterpret_cast<const T*>(p.A) + (size_t)z * p.strideA_z;
-    const T* __restrict__ Wt = reinterpret_cast<const T*>(p.W) + (size_t)z * p.strideW_z;
+    // XCD-aware tile order: hardware deals consecutive block ids round-robin to the 8 XCDs; give each XCD a
+    // contiguous run of tiles so that the n-tiles sharing one activation panel hit the same L2.
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, ntiles = ntn * ntm;
+    int tile = blockIdx.x;
+    if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
+    const int n0 = (tile % ntn) * BN;
+    const int m0 = (tile / ntn) * BM;
 
-    // ---- staging assignment: thread -> chunk (tid & 7) of rows (tid >> 3) + 32 i, i = 0..3
-    const int s_chunk = tid & 7, s_row = tid >> 3;
-    size_t a_off[4];  // element offset of the row's source (pixel origin for the conv gathers)
+    const char* Act = reinterpret_cast<const char*>(p.A) + (size_t)z * p.strideA_z * ESZ;
+    const char* Wt = reinterpret_cast<const char*>(p.W) + (size_t)z * p.strideW_z * ESZ;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Act), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wt), 0, p.w_bytes, 0x00020000);
+
+    // ---- LDS-DMA staging: one `buffer_load_dwordx4 ... lds` moves 64 lanes x 16 B = 8 tile rows; wave w
+    // issues rows [32 w + 8 j, +8), j = 0..3, of both tiles. LDS destination is lane-linear, so the swizzle
+    // goes on the SOURCE: lane i lands in row 8j' + (i >> 3), slot (i & 7) and must fetch chunk (i & 7) ^ (i >> 3).
+    const int d_row = lane >> 3;
+    const unsigned d_chunk_bytes = (unsigned)(((lane & 7) ^ d_row) << 4);
+    unsigned a_voff[4], w_voff[4];
     int a_y[4], a_x[4];
-    bool a_ok[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + s_row + 32 * i;
-        a_ok[i] = m < p.M;
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave * 32 + j * 8 + d_row;
+        const int n = n0 + r, m = m0 + r;
+        w_voff[j] = n < p.N ? (unsigned)n * (unsigned)(p.ldw * ESZ) + d_chunk_bytes : OOB_OFFSET;
+        a_y[j] = a_x[j] = 0;
         if (GATHER == G_LINEAR) {
-            a_off[i] = (size_t)m * p.lda;
-            a_y[i] = a_x[i] = 0;
+            a_voff[j] = m < p.M ? (unsigned)m * (unsigned)(p.lda * ESZ) + d_chunk_bytes : OOB_OFFSET;
         } else {
             const int hw = p.H * p.Wd;
-            const int b = m / hw, r = m - b * hw;
-            a_y[i] = r / p.Wd;
-            a_x[i] = r - a_y[i] * p.Wd;
-            a_off[i] = (size_t)m * p.Cin;  // NHWC: ((b*H + y)*W + x) * Cin
+            const int b = m / hw, rr = m - b * hw;
+            a_y[j] = m < p.M ? rr / p.Wd : -100000;  // tail rows fail every bounds test below
+            a_x[j] = rr - (rr / p.Wd) * p.Wd;
+            a_voff[j] = (unsigned)m * (unsigned)(p.Cin * ESZ) + d_chunk_bytes;  // NHWC pixel origin
         }
     }
-    u32x4 ra[4], rw[4];
 
-    auto load_tiles = [&](int kt) {
+    auto stage = [&](int kt, int buf) {
         const int k0 = kt * BK;
-        // weights: rows n0 + s_row + 32 i
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + s_row + 32 * i;
-            if (n < p.N)
-                rw[i] = *reinterpret_cast<const u32x4*>(Wt + (size_t)n * p.ldw + k0 + s_chunk * CH);
-            else
-                rw[i] = u32x4{0, 0, 0, 0};
-        }
+        char* wdst = smem + buf * 2 * TILE_BYTES + wave * 4096;
+        char* adst = wdst + TILE_BYTES;
         int dy = 0, dx = 0, c0 = k0;
         if (GATHER != G_LINEAR) {
             const int tap = k0 / p.Cin;
@@ -123,29 +130,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
                 dx = (tap & 1) - 1 + p.px;
             }
         }
+        const unsigned kb = (unsigned)(k0 * ESZ);
+        const int tap_off = ((dy * p.Wd + dx) * p.Cin + c0) * ESZ;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bool ok = a_ok[i];
-            long long off = (long long)a_off[i] + c0 + s_chunk * CH;
-            if (GATHER != G_LINEAR) {
-                const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
-                off += ((long long)dy * p.Wd + dx) * p.Cin;
+        for (int j = 0; j < 4; ++j) {
+            const unsigned wv = w_voff[j] == OOB_OFFSET ? OOB_OFFSET : w_voff[j] + kb;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(wdst + j * 1024), 16, wv, 0, 0, 0);
+            unsigned av;
+            if (GATHER == G_LINEAR) {
+                av = a_voff[j] == OOB_OFFSET ? OOB_OFFSET : a_voff[j] + kb;
+            } else {
+                const int yy = a_y[j] + dy, xx = a_x[j] + dx;
+                const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+                av = ok ? (unsigned)((int)a_voff[j] + tap_off) : OOB_OFFSET;
             }
-            if (ok)
-                ra[i] = *reinterpret_cast<const u32x4*>(Act + off);
-            else
-                ra[i] = u32x4{0, 0, 0, 0};
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        char* wbase = smem + buf * 2 * TILE_BYTES;
-        char* abase = wbase + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = s_row + 32 * i;
-            *reinterpret_cast<u32x4*>(wbase + swz(r, s_chunk)) = rw[i];
-            *reinterpret_cast<u32x4*>(abase + swz(r, s_chunk)) = ra[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(adst + j * 1024), 16, av, 0, 0, 0);
         }
     };
 
@@ -156,13 +155,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
+    stage(0, 0);
+    __syncthreads();  // the workgroup release waits for the DMA (vmcnt(0)) before the barrier
     const int f_row = lane & 15, f_kg = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);  // global loads in flight under the MFMAs below
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);  // next tile's DMA flies under this tile's MFMAs
         const char* wbase = smem + buf * 2 * TILE_BYTES;
         const char* abase = wbase + TILE_BYTES;
 #pragma unroll
@@ -178,41 +176,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mma(fw[nf], fa[mf], acc[nf][mf], T{});
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds n = nbase + 4*f_kg + (0..3) for m = mbase + f_row
+    // ---- epilogue. Accumulator layout: lane holds n = nbase + 4*f_kg + (0..3) for m = mbase + f_row.
     const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias_z : nullptr;
     char* __restrict__ Cb = reinterpret_cast<char*>(p.C);
     const size_t c_z = (size_t)z * p.strideC_z;
+    // bias + activation in registers (bias depends on n only: 4 loads per lane, not 16)
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-        const int m = m0 + wx * 64 + mf * 16 + f_row;
-        if (m >= p.M) continue;
-        size_t orow = m;
-        if (GATHER == G_DECONV) {  // phase-interleaved output pixel (2y+py, 2x+px) of a (2H, 2W) map
-            const int hw = p.H * p.Wd;
-            const int b = m / hw, r = m - b * hw;
-            const int y = r / p.Wd, x = r - y * p.Wd;
-            orow = ((size_t)b * (2 * p.H) + 2 * y + p.py) * (2 * p.Wd) + 2 * x + p.px;
+    for (int nf = 0; nf < 4; ++nf) {
+        const int n = n0 + wy * 64 + nf * 16 + f_kg * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < p.N) bv[j] = bias[n + j];
         }
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int n = n0 + wy * 64 + nf * 16 + f_kg * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[nf][mf];
-            const bool full = n + 3 < p.N;
-            if (bias) {
-                if (full) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
-                    v += bv;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n + j < p.N) v[j] += bias[n + j];
-                }
-            }
+        for (int mf = 0; mf < 4; ++mf) {
+            f32x4 v = acc[nf][mf] + bv;
             if (p.act == ACT_GELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
@@ -220,35 +203,100 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
-            const size_t eoff = c_z + orow * p.ldc + n;
-            if (p.residual) {
-                const size_t roff = p.res_mod > 0 ? (size_t)(m % p.res_mod) * p.ldres + n : c_z + orow * p.ldres + n;
-                if (full) {
-                    v += *reinterpret_cast<const f32x4*>(p.residual + roff);
-                } else {
+            acc[nf][mf] = v;
+        }
+    }
+
+    if (p.planar_P > 0) {  // (B, N, P) fp32 planes from pixel-major rows (N is tiny: the 17 keypoint logits)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n + j < p.N) v[j] += p.residual[roff + j];
-                }
-            }
-            if (p.planar_P > 0) {  // (B, N, P) planes from pixel-major rows; fp32 only
-                const int img = m / p.planar_P, pix = m - img * p.planar_P;
+        for (int mf = 0; mf < 4; ++mf) {
+            const int m = m0 + wx * 64 + mf * 16 + f_row;
+            if (m >= p.M) continue;
+            const int img = m / p.planar_P, pix = m - img * p.planar_P;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int n = n0 + wy * 64 + nf * 16 + f_kg * 4;
                 float* o = reinterpret_cast<float*>(Cb) + c_z + ((size_t)img * p.N + n) * p.planar_P + pix;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (n + j < p.N) o[(size_t)j * p.planar_P] = v[j];
-            } else if (p.out_bf16) {
-                __bf16* o = reinterpret_cast<__bf16*>(Cb) + eoff;
-                if (full) {
-                    bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(o) = ov;
-                } else {
+                    if (n + j < p.N) o[(size_t)j * p.planar_P] = acc[nf][mf][j];
+            }
+        }
+        return;
+    }
+
+    // Row-major output: stage the 128x128 tile through LDS (the staging buffers are free now) so that every
+    // output row leaves the CU as one contiguous 256-B (bf16) / 512-B (fp32) run of 16-byte lane stores,
+    // instead of 32-byte scraps per MFMA fragment. Rows are padded by 16 B: conflict-free b64/b128 writes.
+    const int osz = p.out_bf16 ? 2 : 4;
+    const int crow = BN * osz + 16;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n + j < p.N) o[j] = (__bf16)v[j];
+    for (int mf = 0; mf < 4; ++mf) {
+        const int ml = wx * 64 + mf * 16 + f_row;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int nl = wy * 64 + nf * 16 + f_kg * 4;
+            const f32x4 v = acc[nf][mf];
+            if (p.out_bf16) {
+                const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(smem + ml * crow + nl * 2) = ov;
+            } else {
+                *reinterpret_cast<f32x4*>(smem + ml * crow + nl * 4) = v;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int lpr = BN * osz / 16;            // lanes per output row: 16 (bf16) or 32 (fp32)
+        const int epl = 16 / osz;                 // elements per lane: 8 or 4
+        const int rows_per_pass = GEMM_THREADS / lpr;
+        const int cl = tid % lpr, rl = tid / lpr;
+        const int n = n0 + cl * epl;
+        for (int r0 = 0; r0 < BM; r0 += rows_per_pass) {
+            const int ml = r0 + rl;
+            const int m = m0 + ml;
+            if (m >= p.M || n >= p.N) continue;
+            size_t orow = m;
+            if (GATHER == G_DECONV) {  // phase-interleaved output pixel (2y+py, 2x+px) of a (2H, 2W) map
+                const int hw = p.H * p.Wd;
+                const int b = m / hw, r = m - b * hw;
+                const int y = r / p.Wd, x = r - y * p.Wd;
+                orow = ((size_t)b * (2 * p.H) + 2 * y + p.py) * (2 * p.Wd) + 2 * x + p.px;
+            }
+            const size_t eoff = c_z + orow * p.ldc + n;
+            const bool full = n + epl <= p.N;
+            if (p.out_bf16) {
+                u32x4 raw = *reinterpret_cast<const u32x4*>(smem + ml * crow + cl * 16);
+                __bf16* o = reinterpret_cast<__bf16*>(Cb) + eoff;
+                if (p.residual) {  // bf16 output with an fp32 residual: add in fp32, round once
+                    bf16x8 cv = __builtin_bit_cast(bf16x8, raw);
+                    const size_t roff = p.res_mod > 0 ? (size_t)(m % p.res_mod) * p.ldres + n : c_z + orow * p.ldres + n;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (n + j < p.N) cv[j] = (__bf16)((float)cv[j] + p.residual[roff + j]);
+                    raw = __builtin_bit_cast(u32x4, cv);
+                }
+                if (full) {
+                    *reinterpret_cast<u32x4*>(o) = raw;
+                } else {
+                    const bf16x8 cv = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (n + j < p.N) o[j] = cv[j];
                 }
             } else {
+                f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * crow + cl * 16);
                 float* o = reinterpret_cast<float*>(Cb) + eoff;
+                if (p.residual) {
+                    const size_t roff = p.res_mod > 0 ? (size_t)(m % p.res_mod) * p.ldres + n : c_z + orow * p.ldres + n;
+                    if (full) {
+                        v += *reinterpret_cast<const f32x4*>(p.residual + roff);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (n + j < p.N) v[j] += p.residual[roff + j];
+                    }
+                }
                 if (full) {
                     *reinterpret_cast<f32x4*>(o) = v;
                 } else {
@@ -266,13 +314,16 @@ static int launch_gemm(const GemmParams& p, int groups, hipStream_t s) {
     constexpr int BK = Prec<T>::BK;
     PP_REQUIRE(p.K > 0 && p.K % BK == 0, PP_ERR_UNSUPPORTED, "pp gemm: K must be a positive multiple of the K-tile");
     PP_REQUIRE(p.M > 0 && p.N > 0, PP_ERR_INVALID_ARG, "pp gemm: M and N must be positive");
-    PP_REQUIRE(p.planar_P > 0 || p.ldc % 4 == 0, PP_ERR_UNSUPPORTED, "pp gemm: ldc must be a multiple of 4");
+    PP_REQUIRE(p.planar_P > 0 || p.ldc % (p.out_bf16 ? 8 : 4) == 0, PP_ERR_UNSUPPORTED,
+               "pp gemm: ldc must be a multiple of 8 (bf16 out) / 4 (fp32 out) elements");
     PP_REQUIRE(!(p.planar_P > 0 && p.out_bf16), PP_ERR_UNSUPPORTED, "pp gemm: planar output is fp32 only");
     if (p.gather != G_LINEAR)
         PP_REQUIRE(p.Cin % BK == 0 && p.H > 0 && p.Wd > 0, PP_ERR_UNSUPPORTED,
                    "pp gemm: conv gathers need Cin to be a multiple of the K-tile");
-    const dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, groups);
-    const size_t lds = 4 * TILE_BYTES;  // 64 KiB: 2 buffers x (W tile + Act tile)
+    const dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
+    PP_REQUIRE(p.a_bytes > 0 && p.w_bytes > 0 && p.a_bytes < OOB_OFFSET && p.w_bytes < OOB_OFFSET, PP_ERR_UNSUPPORTED,
+               "pp gemm: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    const size_t lds = 4 * TILE_BYTES + 2048;  // 2 buffers x (W tile + Act tile); the fp32 C tile needs 128 x 528 B
     void (*kern)(const GemmParams) = nullptr;
     switch (p.gather) {
         case G_LINEAR: kern = gemm_kernel<T, G_LINEAR>; break;
@@ -306,6 +357,11 @@ extern "C" int pp_gemm(int prec, const void* act, const void* weight, const floa
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
     p.act = act_fn; p.out_bf16 = out_bf16; p.gather = G_LINEAR;
     p.res_mod = res_mod; p.ldres = ldc; p.planar_P = planar_P;
+    const size_t esz = prec == PP_PREC_BF16 ? 2 : 4;
+    const size_t ab = ((size_t)(M - 1) * lda + K) * esz, wb = ((size_t)(N - 1) * ldw + K) * esz;
+    PP_REQUIRE(M > 0 && N > 0 && K > 0 && ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED,
+               "pp_gemm: operands must be non-empty and smaller than 2 GiB");
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     PP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, PP_ERR_UNSUPPORTED, "pp_gemm: lda/ldw must be multiples of 8 elements");
     return gemm(p, prec, 1, reinterpret_cast<hipStream_t>(stream));
 }
@@ -327,6 +383,11 @@ extern "C" int pp_conv_gemm(int prec, int kind, const void* act_nhwc, const void
     p.act = act_fn; p.out_bf16 = out_bf16;
     p.gather = kind == PP_CONV3X3 ? G_CONV3 : G_DECONV;
     p.ldres = ldc;
+    const size_t esz = prec == PP_PREC_BF16 ? 2 : 4;
+    const size_t ab = (size_t)B * H * W * Cin * esz, wb = (size_t)Cout * p.K * esz;
+    PP_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cout > 0 && ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED,
+               "pp_conv_gemm: operands must be non-empty and smaller than 2 GiB");
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     p.strideA_z = stride_act_g; p.strideW_z = stride_w_g; p.strideC_z = stride_out_g; p.strideBias_z = stride_bias_g;
     return gemm(p, prec, groups, reinterpret_cast<hipStream_t>(stream));
 }
