@@ -22,6 +22,8 @@ struct GemmParams {
     int gather;             // G_*
     int res_mod;            // >0: residual row = m % res_mod (broadcast over the batch, e.g. pos_embed)
     int ldres;              // row stride of residual (elements); 0 -> ldc
+    int groups;             // independent problems in one launch (the four towers); tiles of all groups share the persistent grid
+    int dbg;                // development knobs (PP_GEMM_DBG): 1 skip stores, 2 skip re-staging, 4 single K-tile
     int planar_P;           // >0: store planar, out[((m / P) * N + n) * P + m % P]  (NHWC rows -> (B, N, P) planes)
     unsigned a_bytes, w_bytes;  // extent of the activation / weight tensor of ONE group (buffer-descriptor bound)
     long long strideA_z, strideW_z, strideC_z, strideBias_z;  // grouped launch (blockIdx.z), in elements

@@ -4,24 +4,34 @@
 // either a plain row-major matrix or an implicit im2col view of an NHWC tensor (no im2col
 // buffer is ever materialised for the convolutions).
 //
-//   * 128x128 block tile, 256 threads = 4 waves as 2(n) x 2(m), each wave 64x64 = 4x4 MFMA
-//     16x16 fragments, fp32 accumulators in registers;
-//   * operand precision is a template parameter:
-//       bf16  -> v_mfma_f32_16x16x32_bf16, BK = 64 (128-byte LDS rows)
-//       f32   -> v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate), BK = 32
-//     both have the same 128-byte-per-row LDS image and the same C/D fragment layout, so the
-//     staging, swizzle and epilogue code is shared;
-//   * global -> registers -> LDS staging, issued one K-tile ahead of the MFMAs (loads fly
-//     under the matrix work; writes land after it), 2 LDS buffers, one barrier per K-tile;
-//   * LDS rows are 8 x 16-byte chunks, chunk index XOR-ed with (row & 7): the ds_read_b128
-//     fragment reads and the ds_write_b128 staging writes are both bank-conflict free;
+//   * PERSISTENT workgroups: the grid is sized to the chip (2 workgroups per CU), each
+//     workgroup walks a strided list of 128x128 output tiles. On this path K is short (384 -
+//     1536), so a tile is only 6 - 24 K-steps: launching one workgroup per tile spends more
+//     time on dispatch + prologue latency than on MFMAs (measured: ~5 us fixed per tile round
+//     vs 1.3 us of matrix work at K = 384). The persistent loop prefetches the first K-tile of
+//     the NEXT output tile while the current one runs its last MFMAs and its epilogue;
+//   * 256 threads = 4 waves as 2(n) x 2(m), each wave 64x64 = 4x4 MFMA 16x16 fragments, fp32
+//     accumulators; operand precision is a template parameter:
+//       bf16 -> v_mfma_f32_16x16x32_bf16, BK = 64;  f32 -> v_mfma_f32_16x16x4_f32 (exact fp32
+//     products), BK = 32. Both have the same 128-byte-per-row LDS image and C/D layout;
+//   * staging by LDS-DMA (`buffer_load_dwordx4 ... lds`): no VGPR round trip, no ds_write pass.
+//     The DMA destination is lane-linear, so the bank-conflict swizzle (16-byte chunk index
+//     XOR row & 7) is applied on the per-lane SOURCE address; out-of-range rows / conv padding
+//     taps use an out-of-bounds buffer offset, which makes the DMA write zeros;
+//   * 2 LDS buffers, next K-tile's DMA in flight under the current tile's MFMAs;
 //   * the weight tile is the MFMA "A" operand and the activation tile the "B" operand, so a
-//     lane ends up with 4 consecutive n for one m: bias/residual/output move as 16-byte
-//     (fp32) or 8-byte (bf16) vectors;
-//   * fused epilogue: + bias[n], exact-erf GELU or ReLU, + fp32 residual, fp32 or bf16 store,
-//     optional output-row remap (deconv phase interleave).
+//     lane ends up with 4 consecutive n for one m;
+//   * epilogue: + bias[n], exact-erf GELU or ReLU in registers, then the C tile is staged
+//     through the LDS buffer that was just consumed (XOR-swizzled, conflict-free) so every
+//     output row leaves the CU as contiguous 16-byte lane stores, + fp32 residual / broadcast
+//     pos_embed, fp32 or bf16 output, optional output-row remap (deconv phase interleave) or
+//     planar (B, N, P) store for the 17-channel logits;
+//   * tile order is XCD-aware: each XCD (private L2) gets a contiguous run of tiles, so the
+//     n-tiles that share one activation panel hit the same L2.
 #include "pp_common.h"
 #include "pp_gemm.h"
+
+#include <cstdlib>
 
 namespace pp {
 
@@ -29,23 +39,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int BM = 128, BN = 128;
 constexpr int GEMM_THREADS = 256;
 constexpr int ROW_BYTES = 128;                  // one K-tile row in LDS
 constexpr int TILE_BYTES = BM * ROW_BYTES;      // 16 KiB per operand per buffer
+constexpr int BUF_BYTES = 2 * TILE_BYTES;       // W tile + Act tile
+constexpr unsigned OOB_OFFSET = 0x7ffffff0u;    // >= num_records of every tensor (< 2 GiB): the DMA writes zeros
 
 template <typename T>
 struct Prec;
 template <>
 struct Prec<__bf16> {
-    static constexpr int BK = 64;   // elements per K-tile
-    static constexpr int CH = 8;    // elements per 16-byte chunk
+    static constexpr int BK = 64;  // elements per K-tile
 };
 template <>
 struct Prec<float> {
     static constexpr int BK = 32;
-    static constexpr int CH = 4;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
@@ -64,59 +75,67 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c, fl
     return c;
 }
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-constexpr unsigned OOB_OFFSET = 0x7ffffff0u;  // >= num_records of every tensor (< 2 GiB): the DMA writes zeros
-
-template <typename T, int GATHER>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) {
-    constexpr int BK = Prec<T>::BK;
-    constexpr int ESZ = (int)sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [2 buffers][W tile | Act tile], each tile 128 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wy = wave >> 1, wx = wave & 1;
-    const int z = blockIdx.z;
-
-    // XCD-aware tile order: hardware deals consecutive block ids round-robin to the 8 XCDs; give each XCD a
-    // contiguous run of tiles so that the n-tiles sharing one activation panel hit the same L2.
-    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, ntiles = ntn * ntm;
-    int tile = blockIdx.x;
-    if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
-    const int n0 = (tile % ntn) * BN;
-    const int m0 = (tile / ntn) * BM;
-
-    const char* Act = reinterpret_cast<const char*>(p.A) + (size_t)z * p.strideA_z * ESZ;
-    const char* Wt = reinterpret_cast<const char*>(p.W) + (size_t)z * p.strideW_z * ESZ;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Act), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wt), 0, p.w_bytes, 0x00020000);
-
-    // ---- LDS-DMA staging: one `buffer_load_dwordx4 ... lds` moves 64 lanes x 16 B = 8 tile rows; wave w
-    // issues rows [32 w + 8 j, +8), j = 0..3, of both tiles. LDS destination is lane-linear, so the swizzle
-    // goes on the SOURCE: lane i lands in row 8j' + (i >> 3), slot (i & 7) and must fetch chunk (i & 7) ^ (i >> 3).
-    const int d_row = lane >> 3;
-    const unsigned d_chunk_bytes = (unsigned)(((lane & 7) ^ d_row) << 4);
+// Per-tile staging state of one lane: byte offsets of its 4 + 4 source rows (chunk swizzle folded in)
+struct StageRows {
     unsigned a_voff[4], w_voff[4];
     int a_y[4], a_x[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = wave * 32 + j * 8 + d_row;
-        const int n = n0 + r, m = m0 + r;
-        w_voff[j] = n < p.N ? (unsigned)n * (unsigned)(p.ldw * ESZ) + d_chunk_bytes : OOB_OFFSET;
-        a_y[j] = a_x[j] = 0;
-        if (GATHER == G_LINEAR) {
-            a_voff[j] = m < p.M ? (unsigned)m * (unsigned)(p.lda * ESZ) + d_chunk_bytes : OOB_OFFSET;
-        } else {
-            const int hw = p.H * p.Wd;
-            const int b = m / hw, rr = m - b * hw;
-            a_y[j] = m < p.M ? rr / p.Wd : -100000;  // tail rows fail every bounds test below
-            a_x[j] = rr - (rr / p.Wd) * p.Wd;
-            a_voff[j] = (unsigned)m * (unsigned)(p.Cin * ESZ) + d_chunk_bytes;  // NHWC pixel origin
-        }
-    }
+    __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
+};
 
+template <typename T, int GATHER, bool OUT_BF16>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams p) {
+    constexpr int BK = Prec<T>::BK;
+    constexpr int ESZ = (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | Act tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int f_row = lane & 15, f_kg = lane >> 4;
+
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int tiles_per_group = ntn * ntm, ntiles = tiles_per_group * p.groups;
+    const int nk = (p.dbg & 4) ? 1 : p.K / BK;
+
+    // XCD-aware order: block b runs on XCD b % 8 and visits b, b + G, ... (G % 8 == 0 keeps it there);
+    // logical tile = (t % 8) * (ntiles / 8) + t / 8 gives each XCD a contiguous run of the tile list.
+    auto decode_tile = [&](int t, int& z, int& m0, int& n0) {
+        if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);
+        z = t / tiles_per_group;
+        const int r = t - z * tiles_per_group;
+        n0 = (r % ntn) * BN;
+        m0 = (r / ntn) * BM;
+    };
+
+    // ---- LDS-DMA staging: one `buffer_load_dwordx4 ... lds` moves 64 lanes x 16 B = 8 tile rows; wave w
+    // issues rows [32 w + 8 j, +8), j = 0..3, of both tiles. Lane i lands in row 8 j' + (i >> 3), slot
+    // (i & 7) and must therefore fetch source chunk (i & 7) ^ (i >> 3)  (row & 7 == i >> 3).
+    const int d_row = lane >> 3;
+    const unsigned d_chunk_bytes = (unsigned)(((lane & 7) ^ d_row) << 4);
+    StageRows sr;
+    auto setup_stage = [&](int z, int m0, int n0) {
+        const char* Act = reinterpret_cast<const char*>(p.A) + (size_t)z * p.strideA_z * ESZ;
+        const char* Wt = reinterpret_cast<const char*>(p.W) + (size_t)z * p.strideW_z * ESZ;
+        sr.a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Act), 0, p.a_bytes, 0x00020000);
+        sr.w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wt), 0, p.w_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wave * 32 + j * 8 + d_row;
+            const int n = n0 + r, m = m0 + r;
+            sr.w_voff[j] = n < p.N ? (unsigned)n * (unsigned)(p.ldw * ESZ) + d_chunk_bytes : OOB_OFFSET;
+            sr.a_y[j] = sr.a_x[j] = 0;
+            if (GATHER == G_LINEAR) {
+                sr.a_voff[j] = m < p.M ? (unsigned)m * (unsigned)(p.lda * ESZ) + d_chunk_bytes : OOB_OFFSET;
+            } else {
+                const int hw = p.H * p.Wd;
+                const int b = m / hw, rr = m - b * hw;
+                sr.a_y[j] = m < p.M ? rr / p.Wd : -100000;  // tail rows fail every bounds test below
+                sr.a_x[j] = rr - (rr / p.Wd) * p.Wd;
+                sr.a_voff[j] = (unsigned)m * (unsigned)(p.Cin * ESZ) + d_chunk_bytes;  // NHWC pixel origin
+            }
+        }
+    };
     auto stage = [&](int kt, int buf) {
         const int k0 = kt * BK;
-        char* wdst = smem + buf * 2 * TILE_BYTES + wave * 4096;
+        char* wdst = smem + buf * BUF_BYTES + wave * 4096;
         char* adst = wdst + TILE_BYTES;
         int dy = 0, dx = 0, c0 = k0;
         if (GATHER != G_LINEAR) {
@@ -134,68 +153,95 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
         const int tap_off = ((dy * p.Wd + dx) * p.Cin + c0) * ESZ;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const unsigned wv = w_voff[j] == OOB_OFFSET ? OOB_OFFSET : w_voff[j] + kb;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(wdst + j * 1024), 16, wv, 0, 0, 0);
+            const unsigned wv = sr.w_voff[j] == OOB_OFFSET ? OOB_OFFSET : sr.w_voff[j] + kb;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.w_rsrc, (lds_ptr_t)(wdst + j * 1024), 16, wv, 0, 0, 0);
             unsigned av;
             if (GATHER == G_LINEAR) {
-                av = a_voff[j] == OOB_OFFSET ? OOB_OFFSET : a_voff[j] + kb;
+                av = sr.a_voff[j] == OOB_OFFSET ? OOB_OFFSET : sr.a_voff[j] + kb;
             } else {
-                const int yy = a_y[j] + dy, xx = a_x[j] + dx;
+                const int yy = sr.a_y[j] + dy, xx = sr.a_x[j] + dx;
                 const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
-                av = ok ? (unsigned)((int)a_voff[j] + tap_off) : OOB_OFFSET;
+                av = ok ? (unsigned)((int)sr.a_voff[j] + tap_off) : OOB_OFFSET;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(adst + j * 1024), 16, av, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sr.a_rsrc, (lds_ptr_t)(adst + j * 1024), 16, av, 0, 0, 0);
         }
     };
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int z, m0, n0;
+    decode_tile(tile, z, m0, n0);
+    setup_stage(z, m0, n0);
     stage(0, 0);
     __syncthreads();  // the workgroup release waits for the DMA (vmcnt(0)) before the barrier
-    const int f_row = lane & 15, f_kg = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);  // next tile's DMA flies under this tile's MFMAs
-        const char* wbase = smem + buf * 2 * TILE_BYTES;
-        const char* abase = wbase + TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {  // two 4-chunk groups per 128-byte row
-            u32x4 fw[4], fa[4];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                fw[f] = *reinterpret_cast<const u32x4*>(wbase + swz(wy * 64 + f * 16 + f_row, ks * 4 + f_kg));
-                fa[f] = *reinterpret_cast<const u32x4*>(abase + swz(wx * 64 + f * 16 + f_row, ks * 4 + f_kg));
-            }
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-                for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mma(fw[nf], fa[mf], acc[nf][mf], T{});
-        }
-        __syncthreads();
-    }
+    int it = 0;       // global K-step counter: buffer parity runs across tile seams
 
-    // ---- epilogue. Accumulator layout: lane holds n = nbase + 4*f_kg + (0..3) for m = mbase + f_row.
-    const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias_z : nullptr;
-    char* __restrict__ Cb = reinterpret_cast<char*>(p.C);
-    const size_t c_z = (size_t)z * p.strideC_z;
-    // bias + activation in registers (bias depends on n only: 4 loads per lane, not 16)
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x4 acc[4][4];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-        const int n = n0 + wy * 64 + nf * 16 + f_kg * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (n + j < p.N) bv[j] = bias[n + j];
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        const int next_tile = tile + gridDim.x;
+        int nz = 0, nm0 = 0, nn0 = 0;
+        for (int kt = 0; kt < nk; ++kt, ++it) {
+            const int buf = it & 1;
+            // next K-tile's DMA flies under this tile's MFMAs -- across the seam it is the next OUTPUT tile's first
+            if (!(p.dbg & 2)) {
+                if (kt + 1 < nk) {
+                    stage(kt + 1, buf ^ 1);
+                } else if (next_tile < ntiles) {
+                    decode_tile(next_tile, nz, nm0, nn0);
+                    setup_stage(nz, nm0, nn0);
+                    stage(0, buf ^ 1);
+                }
+            }
+            const char* wbase = smem + buf * BUF_BYTES;
+            const char* abase = wbase + TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {  // two 4-chunk groups per 128-byte row
+                u32x4 fw[4], fa[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    fw[f] = *reinterpret_cast<const u32x4*>(wbase + swz(wy * 64 + f * 16 + f_row, ks * 4 + f_kg));
+                    fa[f] = *reinterpret_cast<const u32x4*>(abase + swz(wx * 64 + f * 16 + f_row, ks * 4 + f_kg));
+                }
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mma(fw[nf], fa[mf], acc[nf][mf], T{});
+            }
+            __syncthreads();
         }
+        // the buffer consumed last, (it - 1) & 1, is free: the C tile is staged there; the other one already
+        // holds the next output tile's first K-tile.
+        char* cst = smem + ((it - 1) & 1) * BUF_BYTES;
+
+        // ---- epilogue. Accumulator layout: lane holds n = nbase + 4*e_kg + (0..3) for m = mbase + e_row.
+        // (the lane id is laundered through an empty asm: otherwise LICM hoists every epilogue address out of the
+        // persistent tile loop, ~190 VGPRs stay live across the K-loop and the fragment reads serialise)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int e_row = lane_e & 15, e_kg = lane_e >> 4, tid_e = (tid & ~63) | lane_e;
+        const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias_z : nullptr;
+        char* __restrict__ Cb = reinterpret_cast<char*>(p.C);
+        const size_t c_z = (size_t)z * p.strideC_z;
+        // bias + activation are applied fragment by fragment right where a value is written out, so at most one
+        // erff expansion is in flight and the accumulators die as they go (keeps the kernel at 2 workgroups / CU)
+        f32x4 bvec[4];
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-            f32x4 v = acc[nf][mf] + bv;
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = n0 + wy * 64 + nf * 16 + e_kg * 4;
+            bvec[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < p.N) bvec[nf][j] = bias[n + j];
+            }
+        }
+        auto finish = [&](f32x4 v, int nf) -> f32x4 {
+            v += bvec[nf];
             if (p.act == ACT_GELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
@@ -203,114 +249,140 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
-            acc[nf][mf] = v;
-        }
-    }
+            __builtin_amdgcn_sched_barrier(0);
+            return v;
+        };
 
-    if (p.planar_P > 0) {  // (B, N, P) fp32 planes from pixel-major rows (N is tiny: the 17 keypoint logits)
+        if (p.planar_P > 0) {  // (B, N, P) fp32 planes from pixel-major rows (N is tiny: the 17 keypoint logits)
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-            const int m = m0 + wx * 64 + mf * 16 + f_row;
-            if (m >= p.M) continue;
-            const int img = m / p.planar_P, pix = m - img * p.planar_P;
+            for (int mf = 0; mf < 4; ++mf) {
+                const int m = m0 + wx * 64 + mf * 16 + e_row;
+                if (m < p.M) {
+                    const int img = m / p.planar_P, pix = m - img * p.planar_P;
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                const int n = n0 + wy * 64 + nf * 16 + f_kg * 4;
-                float* o = reinterpret_cast<float*>(Cb) + c_z + ((size_t)img * p.N + n) * p.planar_P + pix;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (n + j < p.N) o[(size_t)j * p.planar_P] = acc[nf][mf][j];
-            }
-        }
-        return;
-    }
-
-    // Row-major output: stage the 128x128 tile through LDS (the staging buffers are free now) so that every
-    // output row leaves the CU as one contiguous 256-B (bf16) / 512-B (fp32) run of 16-byte lane stores,
-    // instead of 32-byte scraps per MFMA fragment. Rows are padded by 16 B: conflict-free b64/b128 writes.
-    const int osz = p.out_bf16 ? 2 : 4;
-    const int crow = BN * osz + 16;
-#pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-        const int ml = wx * 64 + mf * 16 + f_row;
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int nl = wy * 64 + nf * 16 + f_kg * 4;
-            const f32x4 v = acc[nf][mf];
-            if (p.out_bf16) {
-                const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(smem + ml * crow + nl * 2) = ov;
-            } else {
-                *reinterpret_cast<f32x4*>(smem + ml * crow + nl * 4) = v;
-            }
-        }
-    }
-    __syncthreads();
-    {
-        const int lpr = BN * osz / 16;            // lanes per output row: 16 (bf16) or 32 (fp32)
-        const int epl = 16 / osz;                 // elements per lane: 8 or 4
-        const int rows_per_pass = GEMM_THREADS / lpr;
-        const int cl = tid % lpr, rl = tid / lpr;
-        const int n = n0 + cl * epl;
-        for (int r0 = 0; r0 < BM; r0 += rows_per_pass) {
-            const int ml = r0 + rl;
-            const int m = m0 + ml;
-            if (m >= p.M || n >= p.N) continue;
-            size_t orow = m;
-            if (GATHER == G_DECONV) {  // phase-interleaved output pixel (2y+py, 2x+px) of a (2H, 2W) map
-                const int hw = p.H * p.Wd;
-                const int b = m / hw, r = m - b * hw;
-                const int y = r / p.Wd, x = r - y * p.Wd;
-                orow = ((size_t)b * (2 * p.H) + 2 * y + p.py) * (2 * p.Wd) + 2 * x + p.px;
-            }
-            const size_t eoff = c_z + orow * p.ldc + n;
-            const bool full = n + epl <= p.N;
-            if (p.out_bf16) {
-                u32x4 raw = *reinterpret_cast<const u32x4*>(smem + ml * crow + cl * 16);
-                __bf16* o = reinterpret_cast<__bf16*>(Cb) + eoff;
-                if (p.residual) {  // bf16 output with an fp32 residual: add in fp32, round once
-                    bf16x8 cv = __builtin_bit_cast(bf16x8, raw);
-                    const size_t roff = p.res_mod > 0 ? (size_t)(m % p.res_mod) * p.ldres + n : c_z + orow * p.ldres + n;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (n + j < p.N) cv[j] = (__bf16)((float)cv[j] + p.residual[roff + j]);
-                    raw = __builtin_bit_cast(u32x4, cv);
-                }
-                if (full) {
-                    *reinterpret_cast<u32x4*>(o) = raw;
-                } else {
-                    const bf16x8 cv = __builtin_bit_cast(bf16x8, raw);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (n + j < p.N) o[j] = cv[j];
-                }
-            } else {
-                f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * crow + cl * 16);
-                float* o = reinterpret_cast<float*>(Cb) + eoff;
-                if (p.residual) {
-                    const size_t roff = p.res_mod > 0 ? (size_t)(m % p.res_mod) * p.ldres + n : c_z + orow * p.ldres + n;
-                    if (full) {
-                        v += *reinterpret_cast<const f32x4*>(p.residual + roff);
-                    } else {
+                    for (int nf = 0; nf < 4; ++nf) {
+                        const int n = n0 + wy * 64 + nf * 16 + e_kg * 4;
+                        float* o = reinterpret_cast<float*>(Cb) + c_z + ((size_t)img * p.N + n) * p.planar_P + pix;
+                        const f32x4 v = finish(acc[nf][mf], nf);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (n + j < p.N) v[j] += p.residual[roff + j];
+                            if (n + j < p.N) o[(size_t)j * p.planar_P] = v[j];
                     }
                 }
-                if (full) {
-                    *reinterpret_cast<f32x4*>(o) = v;
-                } else {
+            }
+        } else if (!((p.dbg & 1) && acc[0][0][0] != 12345.678f)) {
+            // Row-major output through LDS: 16-byte chunks of a row XOR-swizzled by (row & 15) -> the fragment
+            // writes and the row reads are both bank-conflict free. bf16: whole 128 x 256 B tile at once;
+            // fp32: two 64-row halves (64 x 512 B = one 32 KiB buffer each).
+            constexpr int halves = OUT_BF16 ? 1 : 2;
+            constexpr int lpr = OUT_BF16 ? 16 : 32;  // 16-byte lanes per output row
+            constexpr int epl = OUT_BF16 ? 8 : 4;    // elements per lane
+            constexpr int rows_per_pass = GEMM_THREADS / lpr;
+            const int cl = tid_e % lpr, rl = tid_e / lpr;
+            const int n = n0 + cl * epl;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n + j < p.N) o[j] = v[j];
+            for (int h = 0; h < halves; ++h) {
+                if (OUT_BF16 || wx == h) {
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf) {
+                        const int ml = (OUT_BF16 ? wx * 64 : 0) + mf * 16 + e_row;  // row inside the staged block
+#pragma unroll
+                        for (int nf = 0; nf < 4; ++nf) {
+                            const int nl = wy * 64 + nf * 16 + e_kg * 4;
+                            const f32x4 v = finish(acc[nf][mf], nf);
+                            if constexpr (OUT_BF16) {
+                                const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                                const int byte = nl * 2;
+                                *reinterpret_cast<bf16x4*>(cst + ml * 256 + ((((byte >> 4) ^ (ml & 15)) << 4) | (byte & 15))) = ov;
+                            } else {
+                                const int chunk = nl >> 2;
+                                *reinterpret_cast<f32x4*>(cst + ml * 512 + ((chunk ^ (ml & 15)) << 4)) = v;
+                            }
+                        }
+                    }
                 }
+                __syncthreads();
+                constexpr int nrows = OUT_BF16 ? BM : BM / 2;
+                for (int r0 = 0; r0 < nrows; r0 += rows_per_pass) {
+                    const int ml = r0 + rl;
+                    const int m = m0 + h * 64 + ml;
+                    if (m >= p.M || n >= p.N) continue;
+                    size_t orow = m;
+                    if (GATHER == G_DECONV) {  // phase-interleaved output pixel (2y+py, 2x+px) of a (2H, 2W) map
+                        const int hw = p.H * p.Wd;
+                        const int b = m / hw, r = m - b * hw;
+                        const int y = r / p.Wd, x = r - y * p.Wd;
+                        orow = ((size_t)b * (2 * p.H) + 2 * y + p.py) * (2 * p.Wd) + 2 * x + p.px;
+                    }
+                    const size_t eoff = c_z + orow * p.ldc + n;
+                    const bool full = n + epl <= p.N;
+                    const size_t roff = p.res_mod > 0 ? (size_t)(m % p.res_mod) * p.ldres + n : c_z + orow * p.ldres + n;
+                    if constexpr (OUT_BF16) {
+                        u32x4 raw = *reinterpret_cast<const u32x4*>(cst + ml * 256 + ((cl ^ (ml & 15)) << 4));
+                        __bf16* o = reinterpret_cast<__bf16*>(Cb) + eoff;
+                        if (p.residual) {  // bf16 output with an fp32 residual: add in fp32, round once more
+                            bf16x8 cv = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (n + j < p.N) cv[j] = (__bf16)((float)cv[j] + p.residual[roff + j]);
+                            raw = __builtin_bit_cast(u32x4, cv);
+                        }
+                        if (full) {
+                            *reinterpret_cast<u32x4*>(o) = raw;
+                        } else {
+                            const bf16x8 cv = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (n + j < p.N) o[j] = cv[j];
+                        }
+                    } else {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(cst + ml * 512 + ((cl ^ (ml & 15)) << 4));
+                        float* o = reinterpret_cast<float*>(Cb) + eoff;
+                        if (p.residual) {
+                            if (full) {
+                                v += *reinterpret_cast<const f32x4*>(p.residual + roff);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (n + j < p.N) v[j] += p.residual[roff + j];
+                            }
+                        }
+                        if (full) {
+                            *reinterpret_cast<f32x4*>(o) = v;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (n + j < p.N) o[j] = v[j];
+                        }
+                    }
+                }
+                __syncthreads();  // the staging buffer is reused (next half / next tile's K-steps)
             }
         }
+        z = nz;
+        m0 = nm0;
+        n0 = nn0;
     }
 }
 
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 template <typename T>
-static int launch_gemm(const GemmParams& p, int groups, hipStream_t s) {
+static int launch_gemm(const GemmParams& p_in, int groups, hipStream_t s) {
+    GemmParams p = p_in;
+    static const int dbg = getenv("PP_GEMM_DBG") ? atoi(getenv("PP_GEMM_DBG")) : 0;
+    p.dbg = dbg;
+    p.groups = groups;
     constexpr int BK = Prec<T>::BK;
     PP_REQUIRE(p.K > 0 && p.K % BK == 0, PP_ERR_UNSUPPORTED, "pp gemm: K must be a positive multiple of the K-tile");
     PP_REQUIRE(p.M > 0 && p.N > 0, PP_ERR_INVALID_ARG, "pp gemm: M and N must be positive");
@@ -320,20 +392,25 @@ static int launch_gemm(const GemmParams& p, int groups, hipStream_t s) {
     if (p.gather != G_LINEAR)
         PP_REQUIRE(p.Cin % BK == 0 && p.H > 0 && p.Wd > 0, PP_ERR_UNSUPPORTED,
                    "pp gemm: conv gathers need Cin to be a multiple of the K-tile");
-    const dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, groups);
     PP_REQUIRE(p.a_bytes > 0 && p.w_bytes > 0 && p.a_bytes < OOB_OFFSET && p.w_bytes < OOB_OFFSET, PP_ERR_UNSUPPORTED,
                "pp gemm: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
-    const size_t lds = 4 * TILE_BYTES + 2048;  // 2 buffers x (W tile + Act tile); the fp32 C tile needs 128 x 528 B
+    const long long ntiles = (long long)((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * groups;
+    PP_REQUIRE(ntiles < (1ll << 30), PP_ERR_UNSUPPORTED, "pp gemm: too many output tiles");
+    const size_t lds = 2 * BUF_BYTES;  // 64 KiB: two workgroups per CU
+    int slots = 2 * device_cus();      // persistent grid; a multiple of 8 keeps a workgroup's tiles on one XCD
+    slots -= slots % 8;
+    const int grid = (int)(ntiles < slots ? ntiles : slots);
     void (*kern)(const GemmParams) = nullptr;
+    const bool ob = p.out_bf16 != 0;
     switch (p.gather) {
-        case G_LINEAR: kern = gemm_kernel<T, G_LINEAR>; break;
-        case G_CONV3: kern = gemm_kernel<T, G_CONV3>; break;
-        case G_DECONV: kern = gemm_kernel<T, G_DECONV>; break;
+        case G_LINEAR: kern = ob ? gemm_kernel<T, G_LINEAR, true> : gemm_kernel<T, G_LINEAR, false>; break;
+        case G_CONV3: kern = ob ? gemm_kernel<T, G_CONV3, true> : gemm_kernel<T, G_CONV3, false>; break;
+        case G_DECONV: kern = ob ? gemm_kernel<T, G_DECONV, true> : gemm_kernel<T, G_DECONV, false>; break;
         default: return fail(PP_ERR_INVALID_ARG, "pp gemm: unknown gather mode");
     }
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), lds, s, p);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
@@ -358,9 +435,9 @@ extern "C" int pp_gemm(int prec, const void* act, const void* weight, const floa
     p.act = act_fn; p.out_bf16 = out_bf16; p.gather = G_LINEAR;
     p.res_mod = res_mod; p.ldres = ldc; p.planar_P = planar_P;
     const size_t esz = prec == PP_PREC_BF16 ? 2 : 4;
+    PP_REQUIRE(M > 0 && N > 0 && K > 0, PP_ERR_INVALID_ARG, "pp_gemm: M, N and K must be positive");
     const size_t ab = ((size_t)(M - 1) * lda + K) * esz, wb = ((size_t)(N - 1) * ldw + K) * esz;
-    PP_REQUIRE(M > 0 && N > 0 && K > 0 && ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED,
-               "pp_gemm: operands must be non-empty and smaller than 2 GiB");
+    PP_REQUIRE(ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_gemm: operands must be smaller than 2 GiB");
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     PP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, PP_ERR_UNSUPPORTED, "pp_gemm: lda/ldw must be multiples of 8 elements");
     return gemm(p, prec, 1, reinterpret_cast<hipStream_t>(stream));
@@ -374,6 +451,7 @@ extern "C" int pp_conv_gemm(int prec, int kind, const void* act_nhwc, const void
     PP_REQUIRE(act_nhwc && weight && out, PP_ERR_INVALID_ARG, "pp_conv_gemm: act, weight and out must be non-NULL");
     PP_REQUIRE(kind == PP_CONV3X3 || kind == PP_DECONV4X4S2, PP_ERR_INVALID_ARG, "pp_conv_gemm: unknown kind");
     PP_REQUIRE(groups >= 1 && B > 0, PP_ERR_INVALID_ARG, "pp_conv_gemm: bad groups/B");
+    PP_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cout > 0, PP_ERR_INVALID_ARG, "pp_conv_gemm: bad shape");
     GemmParams p{};
     p.A = act_nhwc; p.W = weight; p.C = out; p.bias = bias; p.residual = nullptr;
     p.M = B * H * W; p.N = Cout;
@@ -385,8 +463,7 @@ extern "C" int pp_conv_gemm(int prec, int kind, const void* act_nhwc, const void
     p.ldres = ldc;
     const size_t esz = prec == PP_PREC_BF16 ? 2 : 4;
     const size_t ab = (size_t)B * H * W * Cin * esz, wb = (size_t)Cout * p.K * esz;
-    PP_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cout > 0 && ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED,
-               "pp_conv_gemm: operands must be non-empty and smaller than 2 GiB");
+    PP_REQUIRE(ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_conv_gemm: operands must be smaller than 2 GiB");
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     p.strideA_z = stride_act_g; p.strideW_z = stride_w_g; p.strideC_z = stride_out_g; p.strideBias_z = stride_bias_g;
     return gemm(p, prec, groups, reinterpret_cast<hipStream_t>(stream));
