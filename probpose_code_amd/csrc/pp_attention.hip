@@ -61,7 +61,7 @@ __device__ __forceinline__ int kswz(int row, int chunk) {
 }
 
 template <typename T, int HD, int NT>
-__global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+__global__ __launch_bounds__(ATT_THREADS, (NT <= 12 ? 3 : 1)) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                                 int n_seq, int heads, float scale_log2e) {
     using C = AttCfg<T, HD, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,6 +79,17 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const T* __restr
     const size_t row_stride = (size_t)3 * E;
     const T* base = qkv + (size_t)seq * C::S * row_stride + (size_t)head * HD;
 
+    // ---- Q fragments of all of this wave's query tiles first: their HBM latency hides under the K/V staging
+    constexpr int QPW = (NT + ATT_THREADS / 64 - 1) / (ATT_THREADS / 64);
+    u32x4 qf_all[QPW][C::NG];
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+        const int qt = wave + t * (ATT_THREADS / 64);
+        const T* qrow = base + (size_t)((qt < NT ? qt : 0) * 16 + fr) * row_stride;
+#pragma unroll
+        for (int g = 0; g < C::NG; ++g) qf_all[t][g] = *reinterpret_cast<const u32x4*>(qrow + (g * 4 + fg) * C::CH);
+    }
+
     // ---- stage K (row-major, swizzled) and V (transposed); zero the padded key rows
     for (int i = tid; i < C::SP * C::RC; i += ATT_THREADS) {
         const int r = i / C::RC, c = i - r * C::RC;
@@ -95,12 +106,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_kernel(const T* __restr
     }
     __syncthreads();
 
-    for (int qt = wave; qt < NT; qt += ATT_THREADS / 64) {
-        // Q fragment of this lane: query row 16 qt + fr, chunks g*4 + fg
-        const T* qrow = base + (size_t)(qt * 16 + fr) * row_stride;
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+        const int qt = wave + t * (ATT_THREADS / 64);
+        if (qt >= NT) break;
         u32x4 qf[C::NG];
 #pragma unroll
-        for (int g = 0; g < C::NG; ++g) qf[g] = *reinterpret_cast<const u32x4*>(qrow + (g * 4 + fg) * C::CH);
+        for (int g = 0; g < C::NG; ++g) qf[g] = qf_all[t][g];
 
         // ---- scores: s[kt][i] = q . k for key 16 kt + 4 fg + i
         f32x4 s[C::NTP];
