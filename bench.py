@@ -50,16 +50,28 @@ def parse():
     return ap.parse_args()
 
 
-def gemm_flops_per_step(eng, B, passes):
-    """Algorithmic FLOPs of the launches of the dominant kernel (pp_gemm: every nn.Linear, the patch embed and
-    the final 1x1 conv) in one step, and their count."""
+def gemm_flops_per_step(eng, B, passes, tag):
+    """Algorithmic FLOPs (MAC = 2) and launch count per step of one instantiation of the dense-layer kernel
+    pp::gemm_kernel<T, G_LINEAR, OUT_BF16>:
+      gemm_f32out  : patch embed, proj and fc2 of every layer (fp32 residual stream out), final 1x1 conv;
+      gemm_bf16out : qkv and fc1 of every layer (bf16 activations out). In f32 precision everything is f32out."""
     M = B * passes * eng.Np
     E, Fd, L = eng.E, eng.w.ffn_dims, eng.w.num_layers
-    fl = 2.0 * M * E * 768  # patch embed
-    fl += L * 2.0 * M * (3 * E * E + E * E + 2 * E * Fd)
     P = eng.Hh * eng.Wh
-    fl += 2.0 * (B * passes * P) * eng.K * eng.w.deconv_channels[-1]
-    return fl, 1 + 4 * L + 1
+    res = 2.0 * M * E * 768 + L * 2.0 * M * (E * E + E * Fd) + 2.0 * (B * passes * P) * eng.K * eng.w.deconv_channels[-1]
+    act = L * 2.0 * M * (3 * E * E + E * Fd)
+    if eng.precision == "f32":
+        return res + act, 2 + 4 * L
+    return (res, 2 + 2 * L) if tag == "gemm_f32out" else (act, 2 * L)
+
+
+def pmc_traffic(kernel_mangled):
+    """HBM bytes per launch of `kernel_mangled` from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_bf16_bs64_hbm_traffic.json")
+    try:
+        return json.load(open(path))["kernels"][kernel_mangled]["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def cpu_baseline(sd, crops_cpu, n_crops, threads):
@@ -154,8 +166,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16 operands / fp32 accumulate (fp32 LN, softmax, residual, Sparsemax; f64 decode)"
-            if args.precision == "bf16" else "f32 (exact-fp32 MFMA products, fp32 accumulate; f64 decode)",
+            "dtype": args.precision,
+            "dtype_detail": "bf16 MFMA operands, fp32 accumulate; fp32 LayerNorm/softmax/residual stream/Sparsemax; f64 decode"
+            if args.precision == "bf16" else "exact-fp32 MFMA products (v_mfma_f32_16x16x4_f32), fp32 accumulate; f64 decode",
             "data": "synthetic",
             "config": {
                 "workload": f"ProbPose-small (ViT-S 12x384, 12 heads x 32) bs{B} random 256x192 uint8 crops per GPU, "
@@ -168,14 +181,20 @@ def main():
             "path_tflops": B * world * args.steps * GFLOP_PER_CROP_FLIP / dt / 1e3,
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_tag.items(), key=lambda kv: -kv[1][0])},
         }
-        if dom == "gemm":
-            fl, n = gemm_flops_per_step(eng, B, 2)
+        if dom.startswith("gemm_"):
+            fl, n = gemm_flops_per_step(eng, B, 2, dom)
             assert n == dom_n, (n, dom_n)
             achieved = fl / n / (dom_ms / n * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.precision]
+            tname = "DF16b" if args.precision == "bf16" else "f"
+            mangled = f"_ZN2pp11gemm_kernelI{tname}Li0ELb{1 if dom == 'gemm_bf16out' else 0}EEEvNS_10GemmParamsE"
+            traffic = pmc_traffic(mangled) if (args.precision == "bf16" and B == 64) else None
             line["roofline"] = {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": None, "kernel": f"pp::gemm_kernel<{'__bf16' if args.precision == 'bf16' else 'float'}, G_LINEAR>",
+                "traffic": traffic, "traffic_source": "profiles/r01_bf16_bs64_hbm_traffic.json (separate rocprofv3 --pmc passes)"
+                if traffic else None,
+                "kernel": f"pp::gemm_kernel<{'__bf16' if args.precision == 'bf16' else 'float'}, G_LINEAR, "
+                          f"OUT_BF16={'true' if dom == 'gemm_bf16out' else 'false'}>", "kernel_mangled": mangled,
                 "launches_per_step": n, "avg_launch_ms": dom_ms / n, "algorithmic_gflop_per_launch": fl / n / 1e9,
             }
         else:  # pragma: no cover - a different kernel dominates: report its time, flag the roofline as undefined

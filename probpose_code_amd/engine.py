@@ -136,7 +136,7 @@ class ProbPoseEngine:
     def _gemm(self, st, a, w, bias, out, M, N, K, act=ACT_NONE, residual=None, res_mod=0, out_bf16=None, planar=0,
               ldc=None):
         ob = int(out.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
-        self._call("gemm", "pp_gemm", self.prec, a.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(residual),
+        self._call("gemm_bf16out" if ob else "gemm_f32out", "pp_gemm", self.prec, a.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(residual),
                    res_mod, out.data_ptr(), M, N, K, K, K, N if ldc is None else ldc, act, ob, planar, st)
 
     def backbone(self, imgs_u8: torch.Tensor, passes: int, ws, st) -> torch.Tensor:
