@@ -1,11 +1,13 @@
-// ProbMap decode for gfx950: flip-test average -> separable OKS-kernel convolution (f64
-// accumulate, one rounding to f32) -> first-occurrence argmax -> one Newton sub-pixel step
-// -> rescale to input-pixel space. One 256-thread workgroup per (crop, keypoint); the whole
-// map lives in LDS, nothing but the inputs is read from HBM and nothing but the results
-// (plus the optional maps) is written.
+// ProbMap decode for gfx950, fused with the head's Sparsemax and the flip-test average:
+//   logits -> x / T -> Sparsemax over the H*W pixels -> * normalize -> clamp(0,1)      (probmap_head.py:637-646)
+//   -> flip-back + channel permutation + average of the two test-time passes           (tta.py:35-39, probmap_head.py:757-763)
+//   -> separable OKS-kernel convolution, f64 accumulate, one rounding to f32           (post_processing.py:13-39,347-352)
+//   -> first-occurrence argmax -> one Newton sub-pixel step in f32 -> rescale (f64)     (post_processing.py:354-430, probmap.py:218)
+// One 256-thread workgroup per (crop, keypoint); the whole map lives in LDS, the inputs are read from HBM exactly
+// once with 16-byte lane loads and only the results (plus the optional maps) are written.
 //
-// Arithmetic follows mmpose/codecs/utils/post_processing.py:308-430 and
-// mmpose/codecs/probmap.py:218 of the reference; see include/probpose_mi355x.h.
+// Everything data-dependent but wave-uniform is a template parameter so the hot loops are branch-free register
+// code: the OKS-kernel radius (0..9, dispatched by a scalar switch) and the row length per thread.
 #include "pp_common.h"
 
 // numpy evaluates the f32 sub-pixel expressions one rounding per operator; keep it so.
@@ -13,12 +15,13 @@
 
 namespace pp {
 
-constexpr int RM = PP_MAX_RADIUS;  // pad every map by the largest radius
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RM = PP_MAX_RADIUS;  // every map is padded by the largest radius
 constexpr int DEC_THREADS = 256;
 constexpr int GX = 6;  // outputs per work item in the row pass (sliding register window)
 constexpr int GY = 4;  // outputs per work item in the column pass
-constexpr int RED_BYTES = 512;   // cross-wave reduction scratch at the head of the dynamic LDS region
-constexpr int MAX_EPT = 28;      // Sparsemax keeps a whole row in registers: H*W <= 28 * 256
+constexpr int RED_BYTES = 512;  // cross-wave reduction scratch at the head of the dynamic LDS region
 
 struct ArgBest {
     float v;
@@ -32,10 +35,70 @@ __device__ __forceinline__ bool better(float v, int idx, float bv, int bidx) {
     return v > bv || (v == bv && idx < bidx);
 }
 
-// Block-wide reductions for the in-register Sparsemax (4 waves). `slot` alternates between two
-// scratch areas so that one barrier per reduction suffices.
+// ---- separable convolution passes, radius known at compile time
+template <int R>
+__device__ __forceinline__ void row_pass(const float* __restrict__ mapf, double* __restrict__ rowd,
+                                         const double* __restrict__ tap_g, int H, int W, int Wp, int tid) {
+    double tap[R + 1];  // the kernel is symmetric bit for bit (exp(-t^2/2s) / sum): R + 1 distinct factors, in SGPRs
+#pragma unroll
+    for (int j = 0; j <= R; ++j) tap[j] = tap_g[j];
+    const int nxg = (W + GX - 1) / GX;
+    for (int it = tid; it < H * nxg; it += DEC_THREADS) {
+        const int y = it / nxg, x0 = (it - y * nxg) * GX;
+        const float* p = mapf + y * Wp + x0 + (RM - R);  // window starts R samples left of output x0
+        double win[GX + 2 * R];
+#pragma unroll
+        for (int c = 0; c < GX + 2 * R; ++c) win[c] = (double)p[c];
+        double acc[GX];
+#pragma unroll
+        for (int g = 0; g < GX; ++g) acc[g] = 0.0;
+#pragma unroll
+        for (int j = 0; j <= 2 * R; ++j)  // t ascending, one fused multiply-add per tap
+#pragma unroll
+            for (int g = 0; g < GX; ++g) acc[g] = fma(win[g + j], tap[j <= R ? j : 2 * R - j], acc[g]);
+#pragma unroll
+        for (int g = 0; g < GX; ++g)
+            if (x0 + g < W) rowd[(y + RM) * W + x0 + g] = acc[g];
+    }
+}
+
+template <int R>
+__device__ __forceinline__ ArgBest col_pass(const double* __restrict__ rowd, float* __restrict__ convf,
+                                            const double* __restrict__ tap_g, int H, int W, int tid) {
+    double tap[R + 1];
+#pragma unroll
+    for (int j = 0; j <= R; ++j) tap[j] = tap_g[j];
+    ArgBest best{-__builtin_inff(), 0x7fffffff};
+    const int nyg = (H + GY - 1) / GY;
+    for (int it = tid; it < W * nyg; it += DEC_THREADS) {
+        const int yg = it / W, x = it - yg * W, y0 = yg * GY;
+        const double* p = rowd + (y0 + RM - R) * W + x;
+        double win[GY + 2 * R];
+#pragma unroll
+        for (int c = 0; c < GY + 2 * R; ++c) win[c] = (y0 + RM - R + c < H + 2 * RM) ? p[c * W] : 0.0;
+        double acc[GY];
+#pragma unroll
+        for (int g = 0; g < GY; ++g) acc[g] = 0.0;
+#pragma unroll
+        for (int j = 0; j <= 2 * R; ++j)
+#pragma unroll
+            for (int g = 0; g < GY; ++g) acc[g] = fma(win[g + j], tap[j <= R ? j : 2 * R - j], acc[g]);
+#pragma unroll
+        for (int g = 0; g < GY; ++g) {
+            if (y0 + g < H) {
+                const float v = (float)acc[g];  // the single rounding scipy does on output
+                const int idx = (y0 + g) * W + x;
+                convf[idx] = v;
+                if (better(v, idx, best.v, best.idx)) best = ArgBest{v, idx};
+            }
+        }
+    }
+    return best;
+}
+
+// ---- block-wide reductions for the in-register Sparsemax (4 waves)
 struct SmxStat {
-    double s0, s1;
+    float s0, s1;
     int n0, n1;
 };
 
@@ -78,10 +141,10 @@ __device__ __forceinline__ SmxStat block_sum_stat(SmxStat v, SmxStat* scratch) {
     return r;
 }
 
-// FROM_LOGITS: `hm` / `hm_flip` hold the raw outputs of the head's final 1x1 conv; the kernel then also
-// does  x / temperature -> Sparsemax over the H*W pixels -> * normalize -> clamp(0, 1)
-// (probmap_head.py:637-646) before the flip-test average, so logits are read from HBM exactly once.
-template <bool HAS_FLIP, bool FROM_LOGITS>
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+// NV = 16-byte vectors of the H*W row per thread (3 for 64x48, 7 for 96x72). Needs W % 4 == 0.
+template <bool HAS_FLIP, bool FROM_LOGITS, int NV>
 __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     const float* __restrict__ hm, const float* __restrict__ hm_flip, const int32_t* __restrict__ flip_indices,
     const double* __restrict__ taps, const int32_t* __restrict__ radius, int K, int H, int W, double in_w,
@@ -92,103 +155,117 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     const int bk = blockIdx.x;
     const int b = bk / K, k = bk - b * K;
     const int Wp = W + 2 * RM;
-    const int HW = H * W;
+    const int HW = H * W, HW4 = HW >> 2, W4 = W >> 2;
 
     // all LDS in the one dynamic region (16-B aligned carve offsets)
-    ArgBest* red = reinterpret_cast<ArgBest*>(smem);                                      // [4] cross-wave argmax
-    float* mapf = reinterpret_cast<float*>(smem + RED_BYTES);                             // [H][Wp]    averaged map, x-padded
-    double* rowd = reinterpret_cast<double*>(smem + RED_BYTES + ((H * Wp * 4 + 15) & ~15));  // [H+2RM][W] row pass, y-padded
-    float* convf = reinterpret_cast<float*>(rowd + (H + 2 * RM) * W);                     // [H][W]     convolved map (f32)
+    ArgBest* red = reinterpret_cast<ArgBest*>(smem);                                         // [4] cross-wave argmax
+    float* mapf = reinterpret_cast<float*>(smem + RED_BYTES);                                // [H][Wp] (+ slack) averaged map, x-padded
+    double* rowd = reinterpret_cast<double*>(smem + RED_BYTES + (((H * Wp + 32) * 4 + 15) & ~15));  // [H+2RM][W] row pass, y-padded
+    float* convf = reinterpret_cast<float*>(rowd + (H + 2 * RM) * W);                        // [H][W] convolved map (f32)
 
-    const int r = radius[k];
-    // taps centred at RM: tapc[RM + t] multiplies the sample at offset t, |t| <= r
-    double tapc[PP_MAX_TAPS];
-#pragma unroll
-    for (int j = 0; j < PP_MAX_TAPS; ++j) {
-        const int t = j - (RM - r);
-        tapc[j] = (t >= 0 && t <= 2 * r) ? taps[k * PP_MAX_TAPS + t] : 0.0;
-    }
+    const f32x4* src = reinterpret_cast<const f32x4*>(hm + (size_t)bk * HW);
+    const f32x4* srcf = nullptr;
+    if (HAS_FLIP) srcf = reinterpret_cast<const f32x4*>(hm_flip + ((size_t)b * K + flip_indices[k]) * HW);
 
-    // ---- load (+ flip-back + average), probmap_head.py:757-763 / tta.py:35-39
-    const float* src = hm + (size_t)bk * HW;
-    const float* srcf = nullptr;
-    if (HAS_FLIP) srcf = hm_flip + ((size_t)b * K + flip_indices[k]) * HW;
     if constexpr (!FROM_LOGITS) {
-        for (int i = tid; i < HW; i += DEC_THREADS) {
-            const int y = i / W, x = i - y * W;
-            float v = src[i];
-            if (HAS_FLIP) v = (v + srcf[y * W + (W - 1 - x)]) * 0.5f;
-            mapf[y * Wp + RM + x] = v;
-            if (avg_out) avg_out[(size_t)bk * HW + i] = v;
+        // ---- load + flip-back + average: partner of pixels (y, x..x+3) is the reversed vector at (y, W-4-x)
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const int i4 = tid + e * DEC_THREADS;
+            if (i4 < HW4) {
+                const int y = i4 / W4, x = (i4 - y * W4) * 4;
+                f32x4 v = src[i4];
+                if (HAS_FLIP) {
+                    const f32x4 f = srcf[y * W4 + (W4 - 1 - (x >> 2))];
+                    v = (v + f32x4{f[3], f[2], f[1], f[0]}) * 0.5f;
+                }
+                float* d = mapf + y * Wp + RM + x;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+                if (avg_out) reinterpret_cast<f32x4*>(avg_out + (size_t)bk * HW)[i4] = v;
+            }
         }
     } else {
-        // ---- Sparsemax of this keypoint's row and (flip test) of its mirror partner's row, in registers.
-        // Sort-free threshold search (Michelot): start from the candidates z > max - 1 (tau >= max - 1
-        // always), tau <- (sum_cand z - 1) / |cand|, drop z <= tau, repeat until nothing is dropped.
+        // ---- Sparsemax of this keypoint's row and (flip test) of its mirror partner's row, both in registers.
+        // Sort-free threshold search (Michelot): candidates z > tau, tau <- tau + (sum_cand (z - tau) - 1) / |cand|,
+        // starting from tau = max - 1 (a lower bound of the solution), until no candidate is dropped. The
+        // correction form keeps the sums O(1), so fp32 accumulation loses nothing against the fp32 reference.
         float* fscr = reinterpret_cast<float*>(smem);
         SmxStat* sscr = reinterpret_cast<SmxStat*>(smem + 64);
-        float z0[MAX_EPT], z1[MAX_EPT];
+        f32x4 z0[NV], z1[NV];
         float m0 = -__builtin_inff(), m1 = -__builtin_inff();
 #pragma unroll
-        for (int e = 0; e < MAX_EPT; ++e) {
-            const int i = tid + e * DEC_THREADS;
-            z0[e] = -__builtin_inff();
-            z1[e] = -__builtin_inff();
-            if (i < HW) {
-                z0[e] = src[i] / temperature;
-                if (HAS_FLIP) z1[e] = srcf[i] / temperature;
+        for (int e = 0; e < NV; ++e) {
+            const int i4 = tid + e * DEC_THREADS;
+            const float ninf = -__builtin_inff();
+            z0[e] = f32x4{ninf, ninf, ninf, ninf};
+            z1[e] = z0[e];
+            if (i4 < HW4) {
+                z0[e] = src[i4] / temperature;
+                if (HAS_FLIP) z1[e] = srcf[i4] / temperature;
             }
-            m0 = fmaxf(m0, z0[e]);
-            m1 = fmaxf(m1, z1[e]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m0 = fmaxf(m0, z0[e][j]);
+                m1 = fmaxf(m1, z1[e][j]);
+            }
         }
         block_max2(m0, m1, fscr);
-        float tau0 = -1.0f, tau1 = -1.0f;
-        int prev0 = -1, prev1 = -1;
 #pragma unroll
-        for (int e = 0; e < MAX_EPT; ++e) {
+        for (int e = 0; e < NV; ++e) {
             z0[e] -= m0;
             z1[e] -= m1;
         }
+        float tau0 = -1.0f, tau1 = -1.0f;
+        int prev0 = -1, prev1 = -1;
         for (int iter = 0; iter < 64; ++iter) {
-            SmxStat st{0.0, 0.0, 0, 0};
+            SmxStat st{0.f, 0.f, 0, 0};
 #pragma unroll
-            for (int e = 0; e < MAX_EPT; ++e) {
-                if (z0[e] > tau0) {
-                    st.s0 += (double)z0[e];
-                    st.n0 += 1;
+            for (int e = 0; e < NV; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d0 = z0[e][j] - tau0;
+                    if (d0 > 0.f) {
+                        st.s0 += d0;
+                        st.n0 += 1;
+                    }
+                    if (HAS_FLIP) {
+                        const float d1 = z1[e][j] - tau1;
+                        if (d1 > 0.f) {
+                            st.s1 += d1;
+                            st.n1 += 1;
+                        }
+                    }
                 }
-                if (HAS_FLIP && z1[e] > tau1) {
-                    st.s1 += (double)z1[e];
-                    st.n1 += 1;
-                }
-            }
             st = block_sum_stat(st, sscr + (iter & 1) * (DEC_THREADS / WAVE));
-            const bool done = st.n0 == prev0 && (!HAS_FLIP || st.n1 == prev1);
-            if (done) break;
+            if (st.n0 == prev0 && (!HAS_FLIP || st.n1 == prev1)) break;
             prev0 = st.n0;
             prev1 = st.n1;
-            tau0 = (float)((st.s0 - 1.0) / (double)st.n0);
-            if (HAS_FLIP) tau1 = (float)((st.s1 - 1.0) / (double)st.n1);
+            tau0 = tau0 + (st.s0 - 1.0f) / (float)st.n0;
+            if (HAS_FLIP) tau1 = tau1 + (st.s1 - 1.0f) / (float)st.n1;
         }
 #pragma unroll
-        for (int e = 0; e < MAX_EPT; ++e) {
-            const int i = tid + e * DEC_THREADS;
-            if (i < HW) {
-                const int y = i / W, x = i - y * W;
-                const float p = fminf(fmaxf(fmaxf(z0[e] - tau0, 0.0f) * normalize, 0.0f), 1.0f);
-                mapf[y * Wp + RM + x] = p;
+        for (int e = 0; e < NV; ++e) {
+            const int i4 = tid + e * DEC_THREADS;
+            if (i4 < HW4) {
+                const int y = i4 / W4, x = (i4 - y * W4) * 4;
+                float* d = mapf + y * Wp + RM + x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = clamp01(fmaxf(z0[e][j] - tau0, 0.0f) * normalize);
             }
         }
         if (HAS_FLIP) {
             __syncthreads();
 #pragma unroll
-            for (int e = 0; e < MAX_EPT; ++e) {
-                const int i = tid + e * DEC_THREADS;
-                if (i < HW) {
-                    const int y = i / W, xf = i - y * W;
-                    const float p = fminf(fmaxf(fmaxf(z1[e] - tau1, 0.0f) * normalize, 0.0f), 1.0f);
-                    float* cell = mapf + y * Wp + RM + (W - 1 - xf);  // exactly one thread owns each cell
-                    *cell = (*cell + p) * 0.5f;
+            for (int e = 0; e < NV; ++e) {
+                const int i4 = tid + e * DEC_THREADS;
+                if (i4 < HW4) {
+                    const int y = i4 / W4, xf = (i4 - y * W4) * 4;
+                    float* d = mapf + y * Wp + RM + (W - 1 - xf);  // pixel xf + j of the flipped pass lands at W-1-xf-j
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {                // exactly one thread owns each cell
+                        const float p = clamp01(fmaxf(z1[e][j] - tau1, 0.0f) * normalize);
+                        d[-j] = (d[-j] + p) * 0.5f;
+                    }
                 }
             }
         }
@@ -211,30 +288,20 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     }
     __syncthreads();
 
-    // ---- row pass: rowd[y][x] = sum_t map[y][x+t] * tap[t], t ascending, f64
-    {
-        const int nxg = (W + GX - 1) / GX;
-        for (int it = tid; it < H * nxg; it += DEC_THREADS) {
-            const int y = it / nxg, x0 = (it - y * nxg) * GX;
-            const float* p = mapf + y * Wp + x0;
-            double win[GX + 2 * RM];
-#pragma unroll
-            for (int c = 0; c < GX + 2 * RM; ++c) win[c] = (x0 + c < Wp) ? (double)p[c] : 0.0;
-            double acc[GX];
-#pragma unroll
-            for (int g = 0; g < GX; ++g) acc[g] = 0.0;
-#pragma unroll
-            for (int j = 0; j < PP_MAX_TAPS; ++j) {
-                if (j >= RM - r && j <= RM + r) {
-                    const double t = tapc[j];
-#pragma unroll
-                    for (int g = 0; g < GX; ++g) acc[g] = fma(win[g + j], t, acc[g]);
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < GX; ++g)
-                if (x0 + g < W) rowd[(y + RM) * W + x0 + g] = acc[g];
-        }
+    const int r = __builtin_amdgcn_readfirstlane(radius[k]);
+    const double* tap_g = taps + k * PP_MAX_TAPS;
+    // ---- row pass: rowd[y][x] = sum_t map[y][x+t] * tap[t], f64
+    switch (r) {
+        case 0: row_pass<0>(mapf, rowd, tap_g, H, W, Wp, tid); break;
+        case 1: row_pass<1>(mapf, rowd, tap_g, H, W, Wp, tid); break;
+        case 2: row_pass<2>(mapf, rowd, tap_g, H, W, Wp, tid); break;
+        case 3: row_pass<3>(mapf, rowd, tap_g, H, W, Wp, tid); break;
+        case 4: row_pass<4>(mapf, rowd, tap_g, H, W, Wp, tid); break;
+        case 5: row_pass<5>(mapf, rowd, tap_g, H, W, Wp, tid); break;
+        case 6: row_pass<6>(mapf, rowd, tap_g, H, W, Wp, tid); break;
+        case 7: row_pass<7>(mapf, rowd, tap_g, H, W, Wp, tid); break;
+        case 8: row_pass<8>(mapf, rowd, tap_g, H, W, Wp, tid); break;
+        default: row_pass<9>(mapf, rowd, tap_g, H, W, Wp, tid); break;
     }
     __syncthreads();
     // symmetric y-padding of the row-pass result
@@ -248,35 +315,18 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     __syncthreads();
 
     // ---- column pass + running argmax
-    ArgBest best{-__builtin_inff(), 0x7fffffff};
-    {
-        const int nyg = (H + GY - 1) / GY;
-        for (int it = tid; it < W * nyg; it += DEC_THREADS) {
-            const int yg = it / W, x = it - yg * W, y0 = yg * GY;
-            double win[GY + 2 * RM];
-#pragma unroll
-            for (int c = 0; c < GY + 2 * RM; ++c) win[c] = (y0 + c < H + 2 * RM) ? rowd[(y0 + c) * W + x] : 0.0;
-            double acc[GY];
-#pragma unroll
-            for (int g = 0; g < GY; ++g) acc[g] = 0.0;
-#pragma unroll
-            for (int j = 0; j < PP_MAX_TAPS; ++j) {
-                if (j >= RM - r && j <= RM + r) {
-                    const double t = tapc[j];
-#pragma unroll
-                    for (int g = 0; g < GY; ++g) acc[g] = fma(win[g + j], t, acc[g]);
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < GY; ++g) {
-                if (y0 + g < H) {
-                    const float v = (float)acc[g];  // the single rounding scipy does on output
-                    const int idx = (y0 + g) * W + x;
-                    convf[idx] = v;
-                    if (better(v, idx, best.v, best.idx)) best = ArgBest{v, idx};
-                }
-            }
-        }
+    ArgBest best;
+    switch (r) {
+        case 0: best = col_pass<0>(rowd, convf, tap_g, H, W, tid); break;
+        case 1: best = col_pass<1>(rowd, convf, tap_g, H, W, tid); break;
+        case 2: best = col_pass<2>(rowd, convf, tap_g, H, W, tid); break;
+        case 3: best = col_pass<3>(rowd, convf, tap_g, H, W, tid); break;
+        case 4: best = col_pass<4>(rowd, convf, tap_g, H, W, tid); break;
+        case 5: best = col_pass<5>(rowd, convf, tap_g, H, W, tid); break;
+        case 6: best = col_pass<6>(rowd, convf, tap_g, H, W, tid); break;
+        case 7: best = col_pass<7>(rowd, convf, tap_g, H, W, tid); break;
+        case 8: best = col_pass<8>(rowd, convf, tap_g, H, W, tid); break;
+        default: best = col_pass<9>(rowd, convf, tap_g, H, W, tid); break;
     }
     // wave-level then block-level argmax
 #pragma unroll
@@ -319,8 +369,17 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
 }
 
 static size_t decode_lds_bytes(int H, int W) {
-    const size_t mapf = ((size_t)H * (W + 2 * RM) * 4 + 15) & ~(size_t)15;
+    const size_t mapf = (((size_t)H * (W + 2 * RM) + 32) * 4 + 15) & ~(size_t)15;
     return RED_BYTES + mapf + (size_t)(H + 2 * RM) * W * 8 + (size_t)H * W * 4;
+}
+
+typedef void (*DecodeKernel)(const float*, const float*, const int32_t*, const double*, const int32_t*, int, int, int,
+                             double, double, float, float, float*, float*, float*, double*, float*);
+
+template <int NV>
+static DecodeKernel pick_kernel(bool from_logits, bool flip) {
+    if (from_logits) return flip ? probmap_decode_kernel<true, true, NV> : probmap_decode_kernel<false, true, NV>;
+    return flip ? probmap_decode_kernel<true, false, NV> : probmap_decode_kernel<false, false, NV>;
 }
 
 }  // namespace pp
@@ -338,16 +397,18 @@ static int decode_launch(bool from_logits, const float* hm, const float* hm_flip
                "pp_probmap_decode: flip_indices is required when hm_flip is given");
     PP_REQUIRE(H >= RM && W >= RM, PP_ERR_UNSUPPORTED,
                "pp_probmap_decode: heatmap smaller than the largest OKS-kernel radius (9)");
+    PP_REQUIRE(W % 4 == 0, PP_ERR_UNSUPPORTED, "pp_probmap_decode: heatmap width must be a multiple of 4");
     const size_t lds = decode_lds_bytes(H, W);
     PP_REQUIRE(lds <= 160 * 1024, PP_ERR_UNSUPPORTED, "pp_probmap_decode: heatmap too large for one CU's LDS");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (from_logits) {
-        PP_REQUIRE(H * W <= MAX_EPT * DEC_THREADS, PP_ERR_UNSUPPORTED,
-                   "pp_probmap_head_decode: H*W exceeds the in-register Sparsemax row capacity (7168)");
+    if (from_logits)
         PP_REQUIRE(temperature > 0.f, PP_ERR_INVALID_ARG, "pp_probmap_head_decode: temperature must be positive");
-    }
-    auto kern = from_logits ? (hm_flip ? probmap_decode_kernel<true, true> : probmap_decode_kernel<false, true>)
-                            : (hm_flip ? probmap_decode_kernel<true, false> : probmap_decode_kernel<false, false>);
+    const int nv = (H * W / 4 + DEC_THREADS - 1) / DEC_THREADS;
+    DecodeKernel kern = nullptr;
+    if (nv <= 3) kern = pick_kernel<3>(from_logits, hm_flip != nullptr);        // 64 x 48
+    else if (nv <= 7) kern = pick_kernel<7>(from_logits, hm_flip != nullptr);   // 96 x 72
+    else if (nv <= 12) kern = pick_kernel<12>(from_logits, hm_flip != nullptr);
+    PP_REQUIRE(kern != nullptr, PP_ERR_UNSUPPORTED, "pp_probmap_decode: H*W exceeds 12288 pixels");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * K), dim3(DEC_THREADS), lds, s, hm, hm_flip, flip_indices, taps, radius, K, H,
