@@ -78,6 +78,18 @@ def plateaus(rng, H, W):
     return out
 
 
+def cropcoco_maps(ns, rng, H, W, sharpen):
+    """CropCOCO-style targets (BASELINE config 5): the reference's own `generate_probmaps`
+    (mmpose/codecs/utils/oks_map.py:9-67) for ground-truth keypoints of which ~25 % lie OUTSIDE the
+    heatmap (crop cuts the person), then sharpened + renormalised to look like a Sparsemax output."""
+    kpts = np.stack([rng.uniform(-0.3 * W, 1.3 * W, K), rng.uniform(-0.3 * H, 1.3 * H, K)], -1)[None]
+    kpts[0, :4] = [[W / 2, H / 2], [0.0, 0.0], [W - 1.0, H - 1.0], [-6.0, H / 3]]
+    hm, _ = ns.utils.generate_probmaps((W, H), kpts, np.ones((1, K), np.float32), sigma=-1)
+    hm = np.maximum(hm - sharpen, 0).astype(np.float32)
+    s = hm.reshape(K, -1).sum(-1)[:, None, None]
+    return (hm / np.where(s > 0, s, 1)).astype(np.float32)
+
+
 def run_case(ns, codec, hm):
     locs, vals, conv = ns.post.get_heatmap_expected_value(hm.copy(), return_heatmap=True)
     kpts, scores = codec.decode(hm)
@@ -98,6 +110,8 @@ def main():
         "s_border": (codec_s, border_peaks(rng, 64, 48)),
         "s_plateau": (codec_s, plateaus(rng, 64, 48)),
         "s_noise": (codec_s, rng.random((K, 64, 48), dtype=np.float32)),
+        "s_cropcoco0": (codec_s, cropcoco_maps(ns, rng, 64, 48, 0.5)),
+        "s_cropcoco1": (codec_s, cropcoco_maps(ns, rng, 64, 48, 0.05)),
         "b_blobs0": (codec_b, blobs(rng, 96, 72, sigma=(0.8, 3.5))),
         "b_border": (codec_b, border_peaks(rng, 96, 72)),
     }

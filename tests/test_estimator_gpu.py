@@ -128,3 +128,28 @@ def test_errors_and_no_cpu_fallback(setup):
     bad["head"] = dict(bad["head"], deconv_out_channels=(256, 256), deconv_kernel_sizes=(4,))
     with pytest.raises(ValueError, match="same length"):
         build_pose_estimator(bad)
+
+
+def test_config4_vit_base_384x288_bf16():
+    """BASELINE config 4: ViT-B (768 / 12 heads x 64), 384x288 input, 96x72 heatmaps, bf16 operands. Bounded
+    against the fp32 oracle; exercises the 432-token attention, E = 768 LayerNorm, K = 3072 GEMMs and the
+    24x18 -> 6x6 -> 3x3 -> 1x1 tower pooling."""
+    from oracle import model_ref as M
+    from probpose_code_amd import ProbPoseEngine
+    from probpose_code_amd import synthetic as S
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    img = (384, 288)
+    sd = S.synthetic_state_dict("base", img_size=img, seed=0, logit_scale=2.0)
+    x = S.synthetic_crops(3, img_size=img, seed=1)
+    ref = M.predict(sd, x, 12, S.IMG_MEAN, S.IMG_STD, input_size=(288, 384))
+    eng = ProbPoseEngine(sd, 12, img_size=img, precision="bf16", input_size=(288, 384))
+    out = eng.forward(x.cuda(), True, S.COCO_FLIP_INDICES, return_heatmaps=True)
+    assert tuple(out["heatmaps"].shape) == (3, 17, 96, 72)
+    d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
+    same = d < 2.0
+    assert same.mean() >= 0.85 and d[same].max() < 0.5
+    assert np.abs(out["scalars"][0].cpu().numpy()[:, None] - ref["keypoints_probs"]).max() < 3e-2
+    with pytest.raises(Exception, match="not instantiated"):  # fp32 at 432 x 64 does not fit one CU's LDS
+        ProbPoseEngine(sd, 12, img_size=img, precision="f32", input_size=(288, 384)).forward(
+            x.cuda(), True, S.COCO_FLIP_INDICES)

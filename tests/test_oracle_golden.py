@@ -7,7 +7,8 @@ import pytest
 
 from oracle import decode_ref as D
 
-CASES = ["s_blobs0", "s_blobs1", "s_blobs_interior", "s_border", "s_plateau", "s_noise", "b_blobs0", "b_border"]
+CASES = ["s_blobs0", "s_blobs1", "s_blobs_interior", "s_border", "s_plateau", "s_noise", "s_cropcoco0", "s_cropcoco1",
+         "b_blobs0", "b_border"]
 
 
 @pytest.fixture(scope="module")
