@@ -129,6 +129,8 @@ int pp_gemm(int prec, const void* act, const void* weight, const float* bias, co
  *   PP_DECONV4X4S2 : one output phase (py, px) of ConvTranspose2d(Cin->Cout, k4, s2, p1)
  *                    (probmap_head.py:435-472): writes out[b, 2y+py, 2x+px, :] of a (B,2H,2W,Cout)
  *                    tensor; weight[n, (ty*2+tx)*Cin + c] = w_torch[c, n, 3-2ty-py, 3-2tx-px].
+ *                    py < 0 runs all four phases in one launch: `weight` then holds the four phase
+ *                    matrices back to back, order (py, px) = (0,0), (0,1), (1,0), (1,1).
  * BatchNorm is folded into weight/bias by the caller; act_fn applies after bias. `groups`
  * launches several independent convolutions at once (the four towers): operand g is at
  * base + g * stride_*_g elements. ldc = row stride of out in elements. */

@@ -111,7 +111,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
     const int d_row = lane >> 3;
     const unsigned d_chunk_bytes = (unsigned)(((lane & 7) ^ d_row) << 4);
     StageRows sr;
+    int st_py = p.py, st_px = p.px;  // deconv phase of the tile being staged (all-phases launch: group index)
     auto setup_stage = [&](int z, int m0, int n0) {
+        if (GATHER == G_DECONV && p.py < 0) {
+            st_py = z >> 1;
+            st_px = z & 1;
+        }
         const char* Act = reinterpret_cast<const char*>(p.A) + (size_t)z * p.strideA_z * ESZ;
         const char* Wt = reinterpret_cast<const char*>(p.W) + (size_t)z * p.strideW_z * ESZ;
         sr.a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Act), 0, p.a_bytes, 0x00020000);
@@ -145,8 +150,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
                 dy = tap / 3 - 1;
                 dx = tap - (tap / 3) * 3 - 1;
             } else {  // deconv k4 s2 p1, output phase (py, px): tap = ty*2 + tx reads (y + ty - 1 + py, x + tx - 1 + px)
-                dy = (tap >> 1) - 1 + p.py;
-                dx = (tap & 1) - 1 + p.px;
+                dy = (tap >> 1) - 1 + st_py;
+                dx = (tap & 1) - 1 + st_px;
             }
         }
         const unsigned kb = (unsigned)(k0 * ESZ);
@@ -312,7 +317,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
                         const int hw = p.H * p.Wd;
                         const int b = m / hw, r = m - b * hw;
                         const int y = r / p.Wd, x = r - y * p.Wd;
-                        orow = ((size_t)b * (2 * p.H) + 2 * y + p.py) * (2 * p.Wd) + 2 * x + p.px;
+                        const int py = p.py < 0 ? (z >> 1) : p.py, px = p.py < 0 ? (z & 1) : p.px;
+                        orow = ((size_t)b * (2 * p.H) + 2 * y + py) * (2 * p.Wd) + 2 * x + px;
                     }
                     const size_t eoff = c_z + orow * p.ldc + n;
                     const bool full = n + epl <= p.N;
@@ -451,6 +457,14 @@ extern "C" int pp_conv_gemm(int prec, int kind, const void* act_nhwc, const void
     PP_REQUIRE(act_nhwc && weight && out, PP_ERR_INVALID_ARG, "pp_conv_gemm: act, weight and out must be non-NULL");
     PP_REQUIRE(kind == PP_CONV3X3 || kind == PP_DECONV4X4S2, PP_ERR_INVALID_ARG, "pp_conv_gemm: unknown kind");
     PP_REQUIRE(groups >= 1 && B > 0, PP_ERR_INVALID_ARG, "pp_conv_gemm: bad groups/B");
+    if (kind == PP_DECONV4X4S2 && py < 0) {  // all four output phases in one launch: group g = phase (g >> 1, g & 1)
+        PP_REQUIRE(groups == 1, PP_ERR_INVALID_ARG, "pp_conv_gemm: py < 0 (all deconv phases) excludes explicit groups");
+        groups = 4;
+        stride_act_g = 0;
+        stride_out_g = 0;
+        stride_bias_g = 0;
+        stride_w_g = (long long)Cout * 4 * Cin;
+    }
     PP_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cout > 0, PP_ERR_INVALID_ARG, "pp_conv_gemm: bad shape");
     GemmParams p{};
     p.A = act_nhwc; p.W = weight; p.C = out; p.bias = bias; p.residual = nullptr;

@@ -175,11 +175,10 @@ class ProbPoseEngine:
         for j, cout in enumerate(w.deconv_channels):
             dst = ws[f"d{j}"]
             wj = w[f"deconv{j}.w"]
-            for py in range(2):
-                for px in range(2):
-                    self._call("deconv", "pp_conv_gemm", self.prec, DECONV, src.data_ptr(), wj[py, px].data_ptr(),
-                              w[f"deconv{j}.b"].data_ptr(), dst.data_ptr(), nb, hh, ww, cin, cout, py, px, 1, 0, 0, 0,
-                              0, cout, ACT_RELU, ob, st)
+            # all four output phases of the transposed conv in one persistent launch
+            self._call("deconv", "pp_conv_gemm", self.prec, DECONV, src.data_ptr(), wj.data_ptr(),
+                       w[f"deconv{j}.b"].data_ptr(), dst.data_ptr(), nb, hh, ww, cin, cout, -1, -1, 1, 0, 0, 0, 0, cout,
+                       ACT_RELU, ob, st)
             src, cin, hh, ww = dst, cout, hh * 2, ww * 2
         P = hh * ww
         self._gemm(st, src, w["final.w"], w["final.b"], ws["logits"], nb * P, self.K, cin, planar=P, out_bf16=0)
