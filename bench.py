@@ -60,9 +60,16 @@ def gemm_flops_per_step(eng, B, passes, tag):
     P = eng.Hh * eng.Wh
     res = 2.0 * M * E * 768 + L * 2.0 * M * (E * E + E * Fd) + 2.0 * (B * passes * P) * eng.K * eng.w.deconv_channels[-1]
     act = L * 2.0 * M * (3 * E * E + E * Fd)
+    # algorithmic HBM bytes of the same launches: operands read once, residual read once, output written once
+    esz = 4 if eng.precision == "f32" else 2
+    b_res = (M * 768 * esz + M * E * 4 + eng.Np * E * 4                                   # patch embed (+ pos_embed)
+             + L * (M * E * esz + 2 * M * E * 4) + L * (M * Fd * esz + 2 * M * E * 4)      # proj, fc2: A + x in + x out
+             + L * 2 * E * Fd * esz // 2 * 0                                               # (weights: < 1 % -- ignored)
+             + B * passes * P * eng.w.deconv_channels[-1] * esz + B * passes * P * eng.K * 4)  # final 1x1 conv
+    b_act = L * (M * E * esz + M * 3 * E * esz) + L * (M * E * esz + M * Fd * esz)         # qkv, fc1
     if eng.precision == "f32":
-        return res + act, 2 + 4 * L
-    return (res, 2 + 2 * L) if tag == "gemm_f32out" else (act, 2 * L)
+        return res + act, 2 + 4 * L, b_res + b_act
+    return (res, 2 + 2 * L, b_res) if tag == "gemm_f32out" else (act, 2 * L, b_act)
 
 
 def pmc_traffic(kernel_mangled):
@@ -182,7 +189,7 @@ def main():
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_tag.items(), key=lambda kv: -kv[1][0])},
         }
         if dom.startswith("gemm_"):
-            fl, n = gemm_flops_per_step(eng, B, 2, dom)
+            fl, n, alg_bytes = gemm_flops_per_step(eng, B, 2, dom)
             assert n == dom_n, (n, dom_n)
             achieved = fl / n / (dom_ms / n * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.precision]
@@ -196,6 +203,11 @@ def main():
                 "kernel": f"pp::gemm_kernel<{'__bf16' if args.precision == 'bf16' else 'float'}, G_LINEAR, "
                           f"OUT_BF16={'true' if dom == 'gemm_bf16out' else 'false'}>", "kernel_mangled": mangled,
                 "launches_per_step": n, "avg_launch_ms": dom_ms / n, "algorithmic_gflop_per_launch": fl / n / 1e9,
+                # these layers sit on the memory side of the ridge (intensity < 312 FLOP/B at bf16): HBM view beside it
+                "algorithmic_mbytes_per_launch": alg_bytes / n / 1e6,
+                "arithmetic_intensity_flop_per_byte": fl / alg_bytes,
+                "hbm_view": {"achieved_GBps": alg_bytes / n / (dom_ms / n * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                             "frac": alg_bytes / n / (dom_ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS},
             }
         else:  # pragma: no cover - a different kernel dominates: report its time, flag the roofline as undefined
             line["roofline"] = {"bound": "mfma", "achieved": None, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
