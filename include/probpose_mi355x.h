@@ -122,6 +122,19 @@ int pp_gemm(int prec, const void* act, const void* weight, const float* bias, co
             int res_mod, void* out, int M, int N, int K, int lda, int ldw, int ldc, int act_fn,
             int out_bf16, int planar_P, void* stream);
 
+/* Residual dense layer fused with the LayerNorm that follows it in the ViT block
+ * (mmpretrain TransformerEncoderLayer [3P]: x = x + attn(ln1(x)); x = ffn(ln2(x)) + x; final ln1):
+ *   x_out[m, :] = sum_k act[m, k] * weight[:, k] + bias + residual[r(m), :]        (fp32 residual stream)
+ *   h_out[m, :] = LayerNorm(x_out[m, :]; gamma, beta, eps)                          (bf16 or fp32 operand of the next GEMM)
+ * One workgroup owns 96 complete rows, so the row statistics never leave the CU and the separate
+ * LayerNorm pass over the stream disappears. N must be 384 (ViT-S); callers fall back to
+ * pp_gemm + pp_layernorm otherwise. residual may alias x_out; act may alias h_out (a workgroup
+ * has consumed its own rows of act before it writes them). r(m) as in pp_gemm (res_mod). */
+int pp_gemm_residual_layernorm(int prec, const void* act, const void* weight, const float* bias,
+                               const float* residual, int res_mod, float* x_out, const float* gamma,
+                               const float* beta, float eps, void* h_out, int h_bf16, int M, int N, int K,
+                               int lda, int ldw, void* stream);
+
 /* Convolutions of ProbMapHead as implicit GEMMs on NHWC activations (no im2col buffer):
  *   PP_CONV3X3     : Conv2d(Cin->Cout, k3, s1, p1) of the scalar towers
  *                    (mmpose/models/heads/hybrid_heads/probmap_head.py:261-410);

@@ -59,6 +59,10 @@ SIGNATURES = {
         c_int,
         [c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     ),
+    "pp_gemm_residual_layernorm": (
+        c_int,
+        [c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    ),
     "pp_conv_gemm": (
         c_int,
         [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -1,0 +1,238 @@
+// Fused  x <- x + act @ W^T + bias ;  h <- LayerNorm(x)  for the ViT residual stream on gfx950.
+//
+// In the backbone every residual GEMM (attention proj, FFN fc2, patch embed) is followed by a LayerNorm over the
+// E = 384 features of each token (mmpretrain VisionTransformer [3P]: x = x + attn(ln1(x)); x = ffn(ln2(x)) + x; the
+// last layer feeds the final ln1). These GEMMs are memory-bound (N = E is only 384: arithmetic intensity far below the
+// MFMA/HBM ridge), and a separate LayerNorm launch re-reads the fp32 stream it has just written. Here one workgroup owns
+// 96 complete rows, so the LayerNorm statistics are available in registers right after the K-loop:
+//
+//   * grid = M / 96 workgroups of 768 threads (12 waves, 3 per SIMD); at bs 64 with flip test M = 24 576 -> 256
+//     workgroups = one per CU, a single balanced round;
+//   * wave (rw, cw) owns rows 16 rw .. +15 x columns 192 cw .. +191: 12 MFMA 16x16 fragments, fp32 accumulators;
+//   * the activation K-tile (96 x 128 B) and the WHOLE weight K-tile (384 x 128 B) are staged by LDS-DMA into a
+//     2-deep ring (120 KiB), chunk-swizzled on the source side exactly as in pp_gemm.hip; each activation byte is
+//     read from HBM once, the weights stream from L2;
+//   * epilogue in registers: + bias + residual (fp32, optionally a broadcast table = pos_embed), row mean and
+//     centred variance by two 2-hop DPP reductions + one LDS exchange between the two column halves, then the fp32
+//     stream and the normalised operand (bf16 or fp32) are both written out.
+#include "pp_common.h"
+
+namespace pp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+namespace rl {
+
+constexpr int BM = 96, BN = 384;
+constexpr int WAVES = 12, THREADS = 64 * WAVES;
+constexpr int ROW_BYTES = 128;
+constexpr int W_TILE = BN * ROW_BYTES;            // 48 KiB
+constexpr int A_TILE = BM * ROW_BYTES;            // 12 KiB
+constexpr int STAGE = W_TILE + A_TILE;            // 60 KiB
+constexpr int DMA_PER_STAGE = (BN + BM) / 8;      // 60 instructions of 8 rows
+constexpr int DPW = DMA_PER_STAGE / WAVES;        // 5 per wave
+constexpr int STAT_BYTES = 2 * BM * 4;            // row statistics exchanged between the two column halves
+constexpr int LDS = 2 * STAGE + 2 * STAT_BYTES;
+constexpr unsigned OOB_OFFSET = 0x7ffffff0u;
+
+struct Params {
+    const void* A;         // [M, lda] activations (bf16 / fp32)
+    const void* W;         // [384, ldw] weights, K contiguous
+    const float* bias;     // [384] or NULL
+    const float* residual; // fp32 [M, 384] (may alias x_out) or a [res_mod, 384] table
+    float* x_out;          // fp32 [M, 384]
+    void* h_out;           // LayerNorm(x_out), bf16 or fp32 [M, 384]
+    const float* gamma;
+    const float* beta;
+    int M, K, lda, ldw, res_mod, h_bf16;
+    unsigned a_bytes, w_bytes;
+    float eps;
+};
+
+template <typename T>
+struct Prec;
+template <>
+struct Prec<__bf16> {
+    static constexpr int BK = 64;
+};
+template <>
+struct Prec<float> {
+    static constexpr int BK = 32;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c, __bf16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+}
+__device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c, float) {
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], c, 0, 0, 0);
+    return c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(THREADS, 3) void gemm_res_ln_kernel(const Params p) {
+    constexpr int BK = Prec<T>::BK;
+    constexpr int ESZ = (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][W tile | A tile] [stats]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rw = wv % 6, cw = wv / 6;
+    const int f_row = lane & 15, f_kg = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+
+    const __amdgpu_buffer_rsrc_t a_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, p.w_bytes, 0x00020000);
+    const int d_row = lane >> 3;
+    const unsigned d_chunk_bytes = (unsigned)(((lane & 7) ^ d_row) << 4);
+    unsigned s_voff[DPW];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int q = wv * DPW + j;
+        if (q < BN / 8) {
+            const int n = q * 8 + d_row;
+            s_voff[j] = (unsigned)n * (unsigned)(p.ldw * ESZ) + d_chunk_bytes;
+        } else {
+            const int m = m0 + (q - BN / 8) * 8 + d_row;
+            s_voff[j] = m < p.M ? (unsigned)m * (unsigned)(p.lda * ESZ) + d_chunk_bytes : OOB_OFFSET;
+        }
+    }
+    auto stage = [&](int kt, int buf) {
+        char* dst = smem + buf * STAGE + wv * DPW * 1024;
+        const unsigned kb = (unsigned)(kt * BK * ESZ);
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int q = wv * DPW + j;
+            const unsigned vo = s_voff[j] == OOB_OFFSET ? OOB_OFFSET : s_voff[j] + kb;
+            if (q < BN / 8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(dst + j * 1024), 16, vo, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(dst + j * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const char* wbase = smem + buf * STAGE;
+        const char* abase = wbase + W_TILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4 fa = *reinterpret_cast<const u32x4*>(abase + swz(rw * 16 + f_row, ks * 4 + f_kg));
+#pragma unroll
+            for (int nf = 0; nf < 12; ++nf) {
+                const u32x4 fw = *reinterpret_cast<const u32x4*>(wbase + swz(cw * 192 + nf * 16 + f_row, ks * 4 + f_kg));
+                acc[nf] = mma(fw, fa, acc[nf], T{});
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds columns n = 192 cw + 16 nf + 4 f_kg + (0..3) of row m = m0 + 16 rw + f_row
+    const int m = m0 + rw * 16 + f_row;
+    const bool valid = m < p.M;
+    const size_t xrow = (size_t)m * BN;
+    const size_t rrow = p.res_mod > 0 ? (size_t)(m % p.res_mod) * BN : xrow;
+    float s = 0.f;
+#pragma unroll
+    for (int nf = 0; nf < 12; ++nf) {
+        const int n = cw * 192 + nf * 16 + f_kg * 4;
+        f32x4 v = acc[nf];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.residual && valid) v += *reinterpret_cast<const f32x4*>(p.residual + rrow + n);
+        acc[nf] = v;
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    float* stat = reinterpret_cast<float*>(smem + 2 * STAGE);  // [2 passes][2 halves][96 rows]
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (f_kg == 0) stat[cw * BM + rw * 16 + f_row] = s;
+    __syncthreads();
+    const float mean = (stat[rw * 16 + f_row] + stat[BM + rw * 16 + f_row]) * (1.0f / BN);
+    float q = 0.f;
+#pragma unroll
+    for (int nf = 0; nf < 12; ++nf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = acc[nf][j] - mean;
+            q = __builtin_fmaf(d, d, q);
+        }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (f_kg == 0) stat[2 * BM + cw * BM + rw * 16 + f_row] = q;
+    __syncthreads();
+    const float var = (stat[2 * BM + rw * 16 + f_row] + stat[3 * BM + rw * 16 + f_row]) * (1.0f / BN);
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    if (!valid) return;
+#pragma unroll
+    for (int nf = 0; nf < 12; ++nf) {
+        const int n = cw * 192 + nf * 16 + f_kg * 4;
+        const f32x4 v = acc[nf];
+        *reinterpret_cast<f32x4*>(p.x_out + xrow + n) = v;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + n), b = *reinterpret_cast<const f32x4*>(p.beta + n);
+        f32x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = (v[j] - mean) * rstd * g[j] + b[j];
+        if (p.h_bf16) {
+            const bf16x4 hv = {(__bf16)h[0], (__bf16)h[1], (__bf16)h[2], (__bf16)h[3]};
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.h_out) + xrow + n) = hv;
+        } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.h_out) + xrow + n) = h;
+        }
+    }
+}
+
+}  // namespace rl
+}  // namespace pp
+
+extern "C" int pp_gemm_residual_layernorm(int prec, const void* act, const void* weight, const float* bias,
+                                          const float* residual, int res_mod, float* x_out, const float* gamma,
+                                          const float* beta, float eps, void* h_out, int h_bf16, int M, int N, int K,
+                                          int lda, int ldw, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(act && weight && x_out && gamma && beta && h_out, PP_ERR_INVALID_ARG,
+               "pp_gemm_residual_layernorm: NULL argument");
+    PP_REQUIRE(N == rl::BN, PP_ERR_UNSUPPORTED, "pp_gemm_residual_layernorm: the fused kernel is built for N = 384");
+    PP_REQUIRE(M > 0 && K > 0, PP_ERR_INVALID_ARG, "pp_gemm_residual_layernorm: M and K must be positive");
+    const int bk = prec == PP_PREC_BF16 ? 64 : 32;
+    const size_t esz = prec == PP_PREC_BF16 ? 2 : 4;
+    PP_REQUIRE(prec == PP_PREC_BF16 || prec == PP_PREC_F32, PP_ERR_INVALID_ARG, "pp_gemm_residual_layernorm: unknown precision");
+    PP_REQUIRE(K % bk == 0 && lda % 8 == 0 && ldw % 8 == 0, PP_ERR_UNSUPPORTED,
+               "pp_gemm_residual_layernorm: K must be a multiple of the K-tile, lda/ldw multiples of 8");
+    const size_t ab = ((size_t)(M - 1) * lda + K) * esz, wb = ((size_t)(N - 1) * ldw + K) * esz;
+    PP_REQUIRE(ab < rl::OOB_OFFSET && wb < rl::OOB_OFFSET, PP_ERR_UNSUPPORTED,
+               "pp_gemm_residual_layernorm: operands must be smaller than 2 GiB");
+    rl::Params p{};
+    p.A = act; p.W = weight; p.bias = bias; p.residual = residual; p.x_out = x_out; p.h_out = h_out;
+    p.gamma = gamma; p.beta = beta; p.M = M; p.K = K; p.lda = lda; p.ldw = ldw; p.res_mod = res_mod;
+    p.h_bf16 = h_bf16; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.eps = eps;
+    const dim3 grid((M + rl::BM - 1) / rl::BM), block(rl::THREADS);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (prec == PP_PREC_BF16) {
+        auto kern = rl::gemm_res_ln_kernel<__bf16>;
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, rl::LDS));
+        hipLaunchKernelGGL(kern, grid, block, rl::LDS, s, p);
+    } else {
+        auto kern = rl::gemm_res_ln_kernel<float>;
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, rl::LDS));
+        hipLaunchKernelGGL(kern, grid, block, rl::LDS, s, p);
+    }
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}

@@ -149,22 +149,33 @@ class ProbPoseEngine:
                   ws["patches"].data_ptr(), B, passes, self.H, self.W, self.P, self.pad, self.mean.ctypes.data,
                   self.std.ctypes.data, int(self.bgr_to_rgb), st)
         Kp = 3 * self.P * self.P
-        self._gemm(st, ws["patches"], w["patch_w"], w["patch_b"], ws["x"], M, E, Kp, residual=w["pos_embed"],
-                   res_mod=self.Np)
         scale = self.hd ** -0.5
-        for i in range(w.num_layers):
-            self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), w[f"l{i}.ln1.w"].data_ptr(), w[f"l{i}.ln1.b"].data_ptr(),
-                      ws["h"].data_ptr(), M, E, self.ln_eps, ob, st)
+        fused = E == 384  # residual GEMM + LayerNorm in one kernel (pp_gemm_ln.hip); other widths: GEMM then LN
+        L = w.num_layers
+
+        def res_ln(a, wk, bk, K, gamma, beta, h_out, residual=None, res_mod=0):
+            """x <- residual + a @ wk^T + bk ; h_out <- LN(x)."""
+            residual = ws["x"] if residual is None else residual
+            if fused:
+                self._call("gemm_res_ln", "pp_gemm_residual_layernorm", self.prec, a.data_ptr(), wk.data_ptr(),
+                           bk.data_ptr(), residual.data_ptr(), res_mod, ws["x"].data_ptr(), gamma.data_ptr(),
+                           beta.data_ptr(), self.ln_eps, h_out.data_ptr(), ob, M, E, K, K, K, st)
+            else:
+                self._gemm(st, a, wk, bk, ws["x"], M, E, K, residual=residual, res_mod=res_mod)
+                self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                           h_out.data_ptr(), M, E, self.ln_eps, ob, st)
+
+        res_ln(ws["patches"], w["patch_w"], w["patch_b"], Kp, w["l0.ln1.w"], w["l0.ln1.b"], ws["h"],
+               residual=w["pos_embed"], res_mod=self.Np)
+        for i in range(L):
             self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], ws["qkv"], M, 3 * E, E)
-            self._call("attention", "pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), B * passes, self.Np,
-                      self.heads, self.hd, scale, st)
-            self._gemm(st, ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], ws["x"], M, E, E, residual=ws["x"])
-            self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(),
-                      ws["h"].data_ptr(), M, E, self.ln_eps, ob, st)
+            self._call("attention", "pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), B * passes,
+                       self.Np, self.heads, self.hd, scale, st)
+            res_ln(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])
             self._gemm(st, ws["h"], w[f"l{i}.fc1.w"], w[f"l{i}.fc1.b"], ws["f"], M, Fd, E, act=ACT_GELU)
-            self._gemm(st, ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], ws["x"], M, E, Fd, residual=ws["x"])
-        self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), w["ln_f.w"].data_ptr(), w["ln_f.b"].data_ptr(),
-                  ws["feat"].data_ptr(), M, E, self.ln_eps, ob, st)
+            last = i + 1 == L
+            gn, bn = (w["ln_f.w"], w["ln_f.b"]) if last else (w[f"l{i + 1}.ln1.w"], w[f"l{i + 1}.ln1.b"])
+            res_ln(ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], Fd, gn, bn, ws["feat"] if last else ws["h"])
         return ws["feat"]
 
     def heatmap_logits(self, feat: torch.Tensor, nb: int, ws, st) -> torch.Tensor:

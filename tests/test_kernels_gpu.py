@@ -249,3 +249,29 @@ def test_fused_sparsemax_decode_vs_oracle(hw, B, flip):
         n_same += same.sum()
         assert np.abs(k_ref - k_self)[same].max() < 1e-3
     assert n_same >= 0.98 * B * K  # argmax flips only on near-ties
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("M,K,res_mod", [(192, 384, 0), (480, 1536, 0), (384, 768, 192)])
+def test_gemm_residual_layernorm_fused(prec, M, K, res_mod):
+    """x <- x + a W^T + b ; h <- LN(x): fused kernel vs torch, incl. the pos_embed-style broadcast residual,
+    a row count that is not a multiple of the 96-row tile, and act aliasing h_out."""
+    L = _lib()
+    E = 384
+    a, w, b = _rand(M, K, seed=41), _rand(E, K, seed=42, scale=1 / math.sqrt(K)), _rand(E, seed=43)
+    res = _rand(res_mod if res_mod else M, E, seed=44, scale=2.0)
+    g, be = 1 + 0.1 * _rand(E, seed=45), _rand(E, seed=46)
+    xref = _q(a, prec) @ _q(w, prec).t() + b.double() + (res.double().repeat(M // res_mod, 1) if res_mod else res.double())
+    href = F.layer_norm(xref, (E,), g.double(), be.double(), 1e-6)
+    ad, wd, bd, gd, bed = a.to(_dt(prec)).cuda(), w.to(_dt(prec)).cuda(), b.cuda(), g.cuda(), be.cuda()
+    if res_mod:
+        resd, x = res.cuda(), torch.full((M, E), float("nan"), device="cuda")
+    else:
+        x = res.clone().cuda()
+        resd = x  # in-place residual stream
+    alias = (K == E)  # h_out may alias act when shapes agree (proj: act = attention output buffer)
+    h = ad if alias else torch.empty((M, E), dtype=_dt(prec), device="cuda")
+    L.call("pp_gemm_residual_layernorm", prec, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), resd.data_ptr(), res_mod,
+           x.data_ptr(), gd.data_ptr(), bed.data_ptr(), 1e-6, h.data_ptr(), int(prec == BF16), M, E, K, K, K, None)
+    torch.testing.assert_close(x.cpu().double(), xref, **TOL[prec])
+    torch.testing.assert_close(h.cpu().double(), href, **(TOL[prec] if prec == F32 else dict(rtol=3e-2, atol=3e-2)))
