@@ -135,6 +135,16 @@ int pp_gemm_residual_layernorm(int prec, const void* act, const void* weight, co
                                const float* beta, float eps, void* h_out, int h_bf16, int M, int N, int K,
                                int lda, int ldw, void* stream);
 
+/* Whole feed-forward block of a ViT layer fused with the LayerNorm that follows it (bf16 operands):
+ *   x_out = residual + GELU(h_in W1^T + b1) W2^T + b2 ;  h_out = LayerNorm(x_out; gamma, beta, eps)
+ * (mmpretrain TransformerEncoderLayer.ffn [3P] = mmcv FFN: Linear(E, F) - GELU - Linear(F, E) + identity).
+ * The F-wide hidden activation stays on the CU. h_in, w1 (F, E), w2 (E, F), h_out are bf16; b1, b2,
+ * residual, x_out, gamma, beta fp32. E must be 384, F a multiple of 128. residual may alias x_out
+ * and h_in may alias h_out. */
+int pp_mlp_residual_layernorm(const void* h_in, const void* w1, const float* b1, const void* w2,
+                              const float* b2, const float* residual, float* x_out, const float* gamma,
+                              const float* beta, float eps, void* h_out, int M, int E, int F, void* stream);
+
 /* Convolutions of ProbMapHead as implicit GEMMs on NHWC activations (no im2col buffer):
  *   PP_CONV3X3     : Conv2d(Cin->Cout, k3, s1, p1) of the scalar towers
  *                    (mmpose/models/heads/hybrid_heads/probmap_head.py:261-410);

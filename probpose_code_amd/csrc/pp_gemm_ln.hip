@@ -120,16 +120,32 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_res_ln_kernel(const Params p)
         }
     };
 
+    // K-steps are walked in a per-workgroup rotation: every CU streams the same weight tiles, in lockstep they would
+    // all hit the same L2 lines at once.
+    const int nk = p.K / BK;
+    const int k_rot = blockIdx.x % nk;
+    auto kstep = [&](int i) { const int k = i + k_rot; return k >= nk ? k - nk : k; };
+    stage(kstep(0), 0);
+
+    // The accumulators start from residual + bias: those HBM reads fly under the first DMA stage and the whole
+    // K-loop instead of stalling the epilogue (lane layout: columns 192 cw + 16 nf + 4 f_kg + (0..3) of row m).
+    const int m = m0 + rw * 16 + f_row;
+    const bool valid = m < p.M;
+    const size_t xrow = (size_t)m * BN;
+    const size_t rrow = p.res_mod > 0 ? (size_t)(m % p.res_mod) * BN : xrow;
     f32x4 acc[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    stage(0, 0);
+    for (int nf = 0; nf < 12; ++nf) {
+        const int n = cw * 192 + nf * 16 + f_kg * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.residual && valid) v += *reinterpret_cast<const f32x4*>(p.residual + rrow + n);
+        acc[nf] = v;
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        if (kt + 1 < nk) stage(kstep(kt + 1), buf ^ 1);
         const char* wbase = smem + buf * STAGE;
         const char* abase = wbase + W_TILE;
 #pragma unroll
@@ -144,19 +160,11 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_res_ln_kernel(const Params p)
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds columns n = 192 cw + 16 nf + 4 f_kg + (0..3) of row m = m0 + 16 rw + f_row
-    const int m = m0 + rw * 16 + f_row;
-    const bool valid = m < p.M;
-    const size_t xrow = (size_t)m * BN;
-    const size_t rrow = p.res_mod > 0 ? (size_t)(m % p.res_mod) * BN : xrow;
+    // ---- epilogue: row statistics straight from the accumulators
     float s = 0.f;
 #pragma unroll
     for (int nf = 0; nf < 12; ++nf) {
-        const int n = cw * 192 + nf * 16 + f_kg * 4;
-        f32x4 v = acc[nf];
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.residual && valid) v += *reinterpret_cast<const f32x4*>(p.residual + rrow + n);
-        acc[nf] = v;
+        const f32x4 v = acc[nf];
         s += (v[0] + v[1]) + (v[2] + v[3]);
     }
     float* stat = reinterpret_cast<float*>(smem + 2 * STAGE);  // [2 passes][2 halves][96 rows]

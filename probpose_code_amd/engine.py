@@ -16,6 +16,7 @@ Both flip-test passes run as one batch of 2B sequences. Activations are token-ma
 throughout, so the ViT output *is* the NHWC feature map the head convolutions gather from.
 """
 import math
+import os
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -71,6 +72,7 @@ class ProbPoseEngine:
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._flip: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
+        self.fuse_mlp = os.environ.get("PP_FUSE_MLP", "1") != "0"
         self.profile: Optional[Dict[str, list]] = None
         # tower pooling schedule (probmap_head.py:264) and the spatial sizes it produces
         self.pools = ((4, 3), (2, 2), (2, 2))
@@ -172,10 +174,18 @@ class ProbPoseEngine:
             self._call("attention", "pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), B * passes,
                        self.Np, self.heads, self.hd, scale, st)
             res_ln(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])
-            self._gemm(st, ws["h"], w[f"l{i}.fc1.w"], w[f"l{i}.fc1.b"], ws["f"], M, Fd, E, act=ACT_GELU)
             last = i + 1 == L
             gn, bn = (w["ln_f.w"], w["ln_f.b"]) if last else (w[f"l{i + 1}.ln1.w"], w[f"l{i + 1}.ln1.b"])
-            res_ln(ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], Fd, gn, bn, ws["feat"] if last else ws["h"])
+            h_next = ws["feat"] if last else ws["h"]
+            if fused and self.precision == "bf16" and Fd % 128 == 0 and self.fuse_mlp:
+                # whole FFN + residual + next LayerNorm in one kernel: the 4x-wide hidden activation stays on the CU
+                self._call("mlp_res_ln", "pp_mlp_residual_layernorm", ws["h"].data_ptr(), w[f"l{i}.fc1.w"].data_ptr(),
+                           w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.w"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(),
+                           ws["x"].data_ptr(), ws["x"].data_ptr(), gn.data_ptr(), bn.data_ptr(), self.ln_eps,
+                           h_next.data_ptr(), M, E, Fd, st)
+            else:
+                self._gemm(st, ws["h"], w[f"l{i}.fc1.w"], w[f"l{i}.fc1.b"], ws["f"], M, Fd, E, act=ACT_GELU)
+                res_ln(ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], Fd, gn, bn, h_next)
         return ws["feat"]
 
     def heatmap_logits(self, feat: torch.Tensor, nb: int, ws, st) -> torch.Tensor:

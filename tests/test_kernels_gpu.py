@@ -275,3 +275,23 @@ def test_gemm_residual_layernorm_fused(prec, M, K, res_mod):
            x.data_ptr(), gd.data_ptr(), bed.data_ptr(), 1e-6, h.data_ptr(), int(prec == BF16), M, E, K, K, K, None)
     torch.testing.assert_close(x.cpu().double(), xref, **TOL[prec])
     torch.testing.assert_close(h.cpu().double(), href, **(TOL[prec] if prec == F32 else dict(rtol=3e-2, atol=3e-2)))
+
+
+@pytest.mark.parametrize("M", [96, 480])
+def test_fused_mlp_residual_layernorm(M):
+    """x <- x + GELU(h W1^T + b1) W2^T + b2 ; h' <- LN(x): fused bf16 kernel vs torch (fp64 on bf16-rounded operands,
+    hidden activation rounded to bf16 as the kernel does)."""
+    L = _lib()
+    E, Fd = 384, 1536
+    h, w1, b1 = _rand(M, E, seed=51), _rand(Fd, E, seed=52, scale=1 / math.sqrt(E)), _rand(Fd, seed=53, scale=0.3)
+    w2, b2 = _rand(E, Fd, seed=54, scale=1 / math.sqrt(Fd)), _rand(E, seed=55, scale=0.3)
+    x0, g, be = _rand(M, E, seed=56, scale=2.0), 1 + 0.1 * _rand(E, seed=57), _rand(E, seed=58)
+    hid = F.gelu(_q(h, BF16) @ _q(w1, BF16).t() + b1.double())
+    xref = x0.double() + _q(hid.float(), BF16) @ _q(w2, BF16).t() + b2.double()
+    href = F.layer_norm(xref, (E,), g.double(), be.double(), 1e-6)
+    hd, w1d, w2d = h.bfloat16().cuda(), w1.bfloat16().cuda(), w2.bfloat16().cuda()
+    b1d, b2d, gd, bed, x = b1.cuda(), b2.cuda(), g.cuda(), be.cuda(), x0.clone().cuda()
+    L.call("pp_mlp_residual_layernorm", hd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(),
+           x.data_ptr(), x.data_ptr(), gd.data_ptr(), bed.data_ptr(), 1e-6, hd.data_ptr(), M, E, Fd, None)
+    torch.testing.assert_close(x.cpu().double(), xref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(hd.cpu().double(), href, rtol=3e-2, atol=3e-2)
