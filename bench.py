@@ -50,26 +50,48 @@ def parse():
     return ap.parse_args()
 
 
-def gemm_flops_per_step(eng, B, passes, tag):
-    """Algorithmic FLOPs (MAC = 2) and launch count per step of one instantiation of the dense-layer kernel
-    pp::gemm_kernel<T, G_LINEAR, OUT_BF16>:
-      gemm_f32out  : patch embed, proj and fc2 of every layer (fp32 residual stream out), final 1x1 conv;
-      gemm_bf16out : qkv and fc1 of every layer (bf16 activations out). In f32 precision everything is f32out."""
+def kernel_work_per_step(eng, B, passes, tag):
+    """Algorithmic FLOPs (MAC = 2), algorithmic HBM bytes (operands read once, outputs written once; weights < 1 %
+    ignored), launch count and mangled name of one kernel of the launch plan, per step. Tags are the ones the engine
+    uses (probpose_code_amd/engine.py)."""
     M = B * passes * eng.Np
     E, Fd, L = eng.E, eng.w.ffn_dims, eng.w.num_layers
     P = eng.Hh * eng.Wh
-    res = 2.0 * M * E * 768 + L * 2.0 * M * (E * E + E * Fd) + 2.0 * (B * passes * P) * eng.K * eng.w.deconv_channels[-1]
-    act = L * 2.0 * M * (3 * E * E + E * Fd)
-    # algorithmic HBM bytes of the same launches: operands read once, residual read once, output written once
-    esz = 4 if eng.precision == "f32" else 2
-    b_res = (M * 768 * esz + M * E * 4 + eng.Np * E * 4                                   # patch embed (+ pos_embed)
-             + L * (M * E * esz + 2 * M * E * 4) + L * (M * Fd * esz + 2 * M * E * 4)      # proj, fc2: A + x in + x out
-             + L * 2 * E * Fd * esz // 2 * 0                                               # (weights: < 1 % -- ignored)
-             + B * passes * P * eng.w.deconv_channels[-1] * esz + B * passes * P * eng.K * 4)  # final 1x1 conv
-    b_act = L * (M * E * esz + M * 3 * E * esz) + L * (M * E * esz + M * Fd * esz)         # qkv, fc1
-    if eng.precision == "f32":
-        return res + act, 2 + 4 * L, b_res + b_act
-    return (res, 2 + 2 * L, b_res) if tag == "gemm_f32out" else (act, 2 * L, b_act)
+    f32 = eng.precision == "f32"
+    esz = 4 if f32 else 2
+    t = "f" if f32 else "DF16b"
+    fused_ln = E == 384
+    fused_mlp = fused_ln and not f32 and eng.fuse_mlp
+    c_last = eng.w.deconv_channels[-1]
+    final_fl, final_b = 2.0 * (B * passes * P) * eng.K * c_last, B * passes * P * (c_last * esz + eng.K * 4)
+    if tag == "mlp_res_ln":  # fc1 + GELU + fc2 + residual + LN per layer
+        return L * 4.0 * M * E * Fd, L * (M * E * 2 + 2 * M * E * 4 + M * E * 2), L, "_ZN2pp3mlp17mlp_res_ln_kernelENS0_6ParamsE"
+    if tag == "gemm_res_ln":  # patch embed, proj (and fc2 when the FFN is not fused) + residual + LN
+        fl = 2.0 * M * E * 768 + L * 2.0 * M * E * E
+        by = M * 768 * esz + M * E * (4 + esz) + L * (M * E * esz + 2 * M * E * 4 + M * E * esz)
+        n = 1 + L
+        if not fused_mlp:
+            fl += L * 2.0 * M * E * Fd
+            by += L * (M * Fd * esz + 2 * M * E * 4 + M * E * esz)
+            n += L
+        return fl, by, n, f"_ZN2pp2rl18gemm_res_ln_kernelI{t}EEvNS0_6ParamsE"
+    # plain dense layers: qkv (+ fc1 when the FFN is not fused) write the operand dtype; the final 1x1 conv (+ the
+    # residual GEMMs when E != 384) write fp32
+    act_fl, act_by, act_n = L * 2.0 * M * 3 * E * E, L * (M * E * esz + M * 3 * E * esz), L
+    if not fused_mlp:
+        act_fl += L * 2.0 * M * E * Fd
+        act_by += L * (M * E * esz + M * Fd * esz)
+        act_n += L
+    res_fl, res_by, res_n = final_fl, final_b, 1
+    if not fused_ln:
+        res_fl += 2.0 * M * E * 768 + L * 2.0 * M * (E * E + E * Fd)
+        res_by += M * 768 * esz + 2 * M * E * 4 + L * (M * E * esz + M * Fd * esz + 4 * M * E * 4)
+        res_n += 1 + 2 * L
+    if f32:  # every output is fp32: one instantiation
+        return act_fl + res_fl, act_by + res_by, act_n + res_n, "_ZN2pp11gemm_kernelIfLi0ELb0EEEvNS_10GemmParamsE"
+    if tag == "gemm_bf16out":
+        return act_fl, act_by, act_n, "_ZN2pp11gemm_kernelIDF16bLi0ELb1EEEvNS_10GemmParamsE"
+    return res_fl, res_by, res_n, "_ZN2pp11gemm_kernelIDF16bLi0ELb0EEEvNS_10GemmParamsE"
 
 
 def pmc_traffic(kernel_mangled):
@@ -188,26 +210,30 @@ def main():
             "path_tflops": B * world * args.steps * GFLOP_PER_CROP_FLIP / dt / 1e3,
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_tag.items(), key=lambda kv: -kv[1][0])},
         }
-        if dom.startswith("gemm_"):
-            fl, n, alg_bytes = gemm_flops_per_step(eng, B, 2, dom)
-            assert n == dom_n, (n, dom_n)
-            achieved = fl / n / (dom_ms / n * 1e-3) / 1e12
+        if dom in ("mlp_res_ln", "gemm_res_ln", "gemm_bf16out", "gemm_f32out"):
+            fl, alg_bytes, n, mangled = kernel_work_per_step(eng, B, 2, dom)
+            assert n == dom_n, (dom, n, dom_n)
+            secs = dom_ms / n * 1e-3
             peak = PEAK_TFLOPS[args.precision]
-            tname = "DF16b" if args.precision == "bf16" else "f"
-            mangled = f"_ZN2pp11gemm_kernelI{tname}Li0ELb{1 if dom == 'gemm_bf16out' else 0}EEEvNS_10GemmParamsE"
+            ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+            intensity = fl / alg_bytes
+            mfma_view = {"achieved_TFLOPs": fl / n / secs / 1e12, "peak_TFLOPs": peak, "frac": fl / n / secs / 1e12 / peak}
+            hbm_view = {"achieved_GBps": alg_bytes / n / secs / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                        "frac": alg_bytes / n / secs / 1e9 / HBM_PEAK_GBS}
+            bound = "mfma" if intensity >= ridge else "hbm"  # which side of the ridge the kernel's algorithm sits on
             traffic = pmc_traffic(mangled) if (args.precision == "bf16" and B == 64) else None
             line["roofline"] = {
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": traffic, "traffic_source": "profiles/r01_bf16_bs64_hbm_traffic.json (separate rocprofv3 --pmc passes)"
-                if traffic else None,
-                "kernel": f"pp::gemm_kernel<{'__bf16' if args.precision == 'bf16' else 'float'}, G_LINEAR, "
-                          f"OUT_BF16={'true' if dom == 'gemm_bf16out' else 'false'}>", "kernel_mangled": mangled,
-                "launches_per_step": n, "avg_launch_ms": dom_ms / n, "algorithmic_gflop_per_launch": fl / n / 1e9,
-                # these layers sit on the memory side of the ridge (intensity < 312 FLOP/B at bf16): HBM view beside it
-                "algorithmic_mbytes_per_launch": alg_bytes / n / 1e6,
-                "arithmetic_intensity_flop_per_byte": fl / alg_bytes,
-                "hbm_view": {"achieved_GBps": alg_bytes / n / (dom_ms / n * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
-                             "frac": alg_bytes / n / (dom_ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "bound": bound,
+                "achieved": mfma_view["achieved_TFLOPs"] if bound == "mfma" else hbm_view["achieved_GBps"],
+                "peak": peak if bound == "mfma" else HBM_PEAK_GBS,
+                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                "frac": mfma_view["frac"] if bound == "mfma" else hbm_view["frac"],
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_bf16_bs64_hbm_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
+                "kernel": dom, "kernel_mangled": mangled, "launches_per_step": n, "avg_launch_ms": dom_ms / n,
+                "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mbytes_per_launch": alg_bytes / n / 1e6,
+                "arithmetic_intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
+                "mfma_view": mfma_view, "hbm_view": hbm_view,
             }
         else:  # pragma: no cover - a different kernel dominates: report its time, flag the roofline as undefined
             line["roofline"] = {"bound": "mfma", "achieved": None, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
