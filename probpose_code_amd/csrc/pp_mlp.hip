@@ -2,20 +2,29 @@
 //     x <- x + GELU(h W1^T + b1) W2^T + b2 ;   h_next <- LayerNorm(x)
 // (mmpretrain TransformerEncoderLayer [3P]: x = ffn(ln2(x), identity = x), FFN = Linear - GELU(erf) - Linear, followed by
 // the next layer's ln1 or the final ln1). Done as two GEMM launches, the 4x-wide hidden activation (75 MB at bs 64)
-// is written to HBM and read back; it is a quarter of all the bytes a ViT-S layer moves. Here it never leaves the CU:
+// is written to HBM and read back; it is a quarter of all the bytes a ViT-S layer moves. Here it never leaves the CU.
 //
 //   * one workgroup owns 96 complete token rows (grid = M / 96 = one workgroup per CU at bs 64 with flip test),
-//     768 threads = 12 waves, wave (rw, cw): rows 16 rw .. +15, column half cw;
-//   * the LayerNorm-ed input rows h live in REGISTERS as MFMA operand fragments for the whole kernel (48 VGPRs);
-//   * the hidden layer is processed in 12 chunks of 128 units:
-//       phase A  P = h W1[chunk]^T       6 K-steps, W1 tile 128 x 64 streamed by LDS-DMA (16 KiB stages)
-//                G = GELU(P + b1) -> bf16 -> LDS as the operand tile of phase B (24 KiB)
-//       phase B  acc += G W2[:, chunk]^T  2 K-steps, W2 tile 384 x 64 streamed by LDS-DMA (48 KiB stages)
-//     with the next stage's DMA always in flight under the current stage's MFMAs;
-//   * the 96 x 384 output accumulators start from residual + b2 and end in the same LayerNorm epilogue as
-//     pp_gemm_ln.hip (row statistics in registers, one LDS exchange between the column halves).
-// GELU uses erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, well under bf16 resolution): libdevice erff costs as
-// many VALU cycles as the MFMAs of the whole block.
+//     512 threads = 8 waves = two per SIMD, wave (rg, cg): rows 48 rg .. +47, column quarter cg;
+//   * the LayerNorm-ed input rows h sit in LDS for the whole kernel (72 KiB, MFMA operand image);
+//   * the hidden layer is processed in chunks of 128 units, ten steps per chunk:
+//       phase A  P = h W1[chunk]^T        6 steps of k = 64, wave tile 48 rows x 32 units
+//                G = GELU(P + b1) -> bf16 -> LDS (24 KiB) as the operand of phase B
+//       phase B  acc += G W2[:, chunk]^T   4 steps of k = 32, wave tile 48 rows x 96 outputs
+//     software-pipelined across chunks: the loop body is [phase A of chunk c+1 | phase B of chunk c], and the GELU
+//     of chunk c is spread over the six phase-A steps of chunk c+1, one accumulator fragment per step, so its VALU
+//     instructions sit in the shadow of that chunk's MFMAs (sched_group_barrier pins the interleave);
+//   * W1 / W2 tiles arrive by LDS-DMA through ONE ring of eight 8 KiB slots (a phase-A tile is two slots, a phase-B
+//     tile three; 24 slots per chunk, so ring positions are compile-time constants). Every wave issues one DMA
+//     instruction per slot and waits with a COUNTED vmcnt, so five slots (40 KiB) stay in flight at all times;
+//   * operand fragments are double-buffered in registers: step s issues the ds_reads of tile s+1, then runs the
+//     MFMAs of tile s on fragments that were read a whole step earlier - no MFMA waits on its own LDS read, and a
+//     tile's ring slots are free for the DMA as soon as the step that consumes it begins (one barrier per step);
+//   * the 96 x 384 output accumulators start from residual + b2 and end in the LayerNorm epilogue (row statistics in
+//     registers, one LDS exchange between the column quarters).
+// LDS: 72 KiB h + 24 KiB G + 64 KiB ring = 160 KiB, the whole CU.
+// GELU uses a clamped odd polynomial for erf (|error| < 1.8e-4, a factor 60 under bf16 resolution): libdevice erff costs
+// as many VALU cycles as the MFMAs of the whole block.
 #include "pp_common.h"
 
 namespace pp {
@@ -28,19 +37,30 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 namespace mlp {
 
+#ifndef MLP_DBG
+#define MLP_DBG 0
+#endif
+// dev ablation switches (scripts/micro/mlp_ablate.sh), 0 in the product build: 2 no GELU, 4 no MFMA, 8 no DMA,
+// 16 no LDS fragment reads, 32 no barriers, 64 no b1 loads, 512 per-step time stamps
+constexpr int DBG = MLP_DBG;
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_VMEM = 0x010, SG_DS_READ = 0x100;
 constexpr int BM = 96, E = 384, CHUNK = 128;
-constexpr int WAVES = 12, THREADS = 64 * WAVES;
-constexpr int ROW_BYTES = 128, BK = 64;
-constexpr int W1_STAGE = CHUNK * ROW_BYTES;       // 16 KiB: 128 hidden units x 64 k
-constexpr int W2_STAGE = E * ROW_BYTES;           // 48 KiB: 384 outputs x 64 hidden units
-constexpr int HS_TILE = BM * ROW_BYTES;           // 12 KiB per 64 hidden units
-constexpr int OFF_W1 = 0;
-constexpr int OFF_W2 = 2 * W1_STAGE;
-constexpr int OFF_HS = OFF_W2 + 2 * W2_STAGE;
-constexpr int OFF_STAT = OFF_HS + 2 * HS_TILE;
-constexpr int LDS = OFF_STAT + 4 * BM * 4;        // 155 136 B
-constexpr int KT1 = E / BK;                       // 6 K-steps in phase A
+constexpr int WAVES = 8, THREADS = 64 * WAVES;
+constexpr int ROW_BYTES = 128;
+constexpr int HS_KB = BM * ROW_BYTES;             // 12 KiB: 96 rows x 64 k
+constexpr int OFF_HS = 0;                         // [6][96][128 B]
+constexpr int OFF_GS = 6 * HS_KB;                 // [2][96][128 B]
+constexpr int OFF_RING = OFF_GS + 2 * HS_KB;
+constexpr int SLOT = 8192, NSLOT = 8;
+constexpr int LDS = OFF_RING + NSLOT * SLOT;      // 163 840 B
+constexpr int KT1 = 6, KT2 = 4;                   // steps of phase A (k 64) and phase B (k 32)
+constexpr int SLOTS_PER_CHUNK = 2 * KT1 + 3 * KT2;  // 24
+constexpr unsigned OOB = 0x7ffffff0u;
+static_assert(LDS == 160 * 1024, "LDS map");
+static_assert(SLOTS_PER_CHUNK % NSLOT == 0, "ring positions must repeat per chunk");
 
+extern unsigned long long* g_trace;
 struct Params {
     const __bf16* h;       // [M, 384] LayerNorm-ed block input
     const __bf16* W1;      // [F, 384]
@@ -53,207 +73,383 @@ struct Params {
     const float* beta;
     __bf16* h_out;         // [M, 384] LayerNorm(x_out)
     int M, F;
-    unsigned w1_bytes, w2_bytes;
+    unsigned h_bytes, w1_bytes, w2_bytes;
     float eps;
+    unsigned long long* trace;  // dev only (MLP_DBG & 512): per-step time stamps of block 0, waves 0 and 4
 };
-
-__device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
 
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
                                                    0, 0);
 }
 
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)), erf by A&S 7.1.26
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) = x (0.5 + t W(t^2)), t = clamp(x, -4.2, 4.2), where t W(t^2) is a degree-15 odd
+// minimax polynomial for 0.5 erf(t / sqrt 2), constrained to reach exactly 0.5 at |t| = 4.2 so that the function
+// saturates to x and to 0 outside. Absolute error < 1.8e-4 for every x, relative error < 6.2e-5 for x > 0.05 - a factor
+// 60 under bf16 resolution, which is what the result is rounded to. Twelve plain fp32 instructions and no
+// transcendental. Plain (unpacked) on purpose - this file is built with -fno-slp-vectorize: the GELU of the previous
+// chunk is issued between the MFMAs of the current one, and beside MFMAs a v_pk_fma_f32 costs about 22 cycles more
+// than the two v_fma_f32 it replaces.
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-    poly = __builtin_fmaf(t, poly, 1.421413741f);
-    poly = __builtin_fmaf(t, poly, -0.284496736f);
-    poly = __builtin_fmaf(t, poly, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = __builtin_fmaf(-poly, e, 1.0f);
-    const float erf = __builtin_copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf);
+    const float t = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f);
+    const float s = t * t;
+    float q = __builtin_fmaf(s, -1.141911177e-09f, 9.614189360e-08f);
+    q = __builtin_fmaf(s, q, -3.508876526e-06f);
+    q = __builtin_fmaf(s, q, 7.374335597e-05f);
+    q = __builtin_fmaf(s, q, -1.005266667e-03f);
+    q = __builtin_fmaf(s, q, 9.529921441e-03f);
+    q = __builtin_fmaf(s, q, -6.599143966e-02f);
+    q = __builtin_fmaf(s, q, 3.987765802e-01f);
+    return x * __builtin_fmaf(t, q, 0.5f);
+}
+__device__ __forceinline__ bf16x4 gelu4_bf16(f32x4 v) {
+    return bf16x4{(__bf16)gelu_fast(v[0]), (__bf16)gelu_fast(v[1]), (__bf16)gelu_fast(v[2]), (__bf16)gelu_fast(v[3])};
 }
 
-__global__ __launch_bounds__(THREADS, 3) void mlp_res_ln_kernel(const Params p) {
+// slots consumed by step s of a chunk (0..5 phase A, 6..9 phase B) and the first slot of step s
+__host__ __device__ constexpr int step_slots(int s) { return (s % 10) < KT1 ? 2 : 3; }
+__host__ __device__ constexpr int step_first(int s) { return s < KT1 ? 2 * s : 2 * KT1 + 3 * (s - KT1); }
+
+// wait until at most N of this wave's vector-memory operations are outstanding and every LDS read has returned,
+// then meet the other waves
+template <int N>
+__device__ __forceinline__ void wait_dma_and_barrier() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    __builtin_amdgcn_sched_barrier(0);  // nothing of the previous step may sink below, nothing of the next may rise above
+    if (!(DBG & 32)) {
+        // s_waitcnt vmcnt(N) lgkmcnt(0) as a builtin, not inline asm: the compiler's own wait-count bookkeeping sees it
+        // and does not re-wait for the fragment reads in front of the MFMAs that use them (gfx9 encoding:
+        // vmcnt [3:0] + [15:14], expcnt [6:4] = 7 (none), lgkmcnt [11:8])
+        __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rw = wv % 6, cw = wv / 6;
+    const int rg = wv >> 2, cg = wv & 3;
     const int f_row = lane & 15, f_kg = lane >> 4;
     const int m0 = blockIdx.x * BM;
-    const int m = m0 + rw * 16 + f_row;
-    const bool valid = m < p.M;
-    const size_t xrow = (size_t)m * E;
 
+    const __amdgpu_buffer_rsrc_t h_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.h), 0, p.h_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w1_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.W1), 0, p.w1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.W2), 0, p.w2_bytes, 0x00020000);
-    const int d_row = lane >> 3;
-    const unsigned d_chunk_bytes = (unsigned)(((lane & 7) ^ d_row) << 4);
 
-    // W1 tile (chunk c, K-step kt): rows 128 c + r, bytes [128 kt, +128) -> 16 DMA instructions, waves 0..7 two each
-    auto stage_w1 = [&](int c, int kt, int slot) {
-        if (wv < 8) {
-            char* dst = smem + OFF_W1 + slot * W1_STAGE + wv * 2048;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = (wv * 2 + j) * 8 + d_row;
-                const unsigned vo = (unsigned)(c * CHUNK + r) * (unsigned)(E * 2) + (unsigned)(kt * 128) + d_chunk_bytes;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rsrc, (lds_ptr_t)(dst + j * 1024), 16, vo, 0, 0, 0);
-            }
-        }
-    };
-    // W2 tile (chunk c, K-step k2): rows n = 0..383, bytes [(128 c + 64 k2) * 2, +128); `half` selects rows [192 half, +192):
-    // 24 DMA instructions per half, two per wave
-    auto stage_w2_half = [&](int c, int k2, int slot, int half) {
-        char* dst = smem + OFF_W2 + slot * W2_STAGE + half * (W2_STAGE / 2) + wv * 2048;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = half * 192 + (wv * 2 + j) * 8 + d_row;
-            const unsigned vo = (unsigned)n * (unsigned)(p.F * 2) + (unsigned)((c * CHUNK + k2 * BK) * 2) + d_chunk_bytes;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w2_rsrc, (lds_ptr_t)(dst + j * 1024), 16, vo, 0, 0, 0);
-        }
-    };
+    // ---- DMA addressing. One instruction moves 8 lines of 128 B; lane i lands at byte 16 i, so the XOR swizzle is
+    // applied to the SOURCE: lane (line l, physical chunk pc) fetches logical chunk pc ^ (l & 7).
+    const int d_line = wv * 8 + (lane >> 3);            // line inside a slot (0..63)
+    const int d_lc = (lane & 7) ^ (lane >> 3);          // logical 16-byte chunk (d_line & 7 == lane >> 3)
+    // W1 slot (kt, half): line l holds unit 64 half + l, k in [64 kt, +64)
+    const unsigned w1_lane = (unsigned)d_line * (E * 2) + (unsigned)(d_lc << 4);
+    // W2 slot (j, third): line l' = 64 third + l holds outputs l' (chunks 0..3) and l' + 192 (chunks 4..7), k in [32 j, +32)
+    const unsigned w2_row_bytes = (unsigned)p.F * 2u;
+    const unsigned w2_lane = (unsigned)(d_line + 192 * (d_lc >> 2)) * w2_row_bytes + (unsigned)((d_lc & 3) << 4);
 
+    const int nchunks = p.F / CHUNK;
     // Every workgroup walks the hidden chunks in a different rotation: all 256 CUs stream the SAME weights, and in
     // lockstep they would all hit the same L2 lines at the same moment.
-    const int nchunks = p.F / CHUNK;
     const int c_rot = blockIdx.x % nchunks;
     auto chunk_of = [&](int i) { const int c = i + c_rot; return c >= nchunks ? c - nchunks : c; };
 
-    // ---- prologue: first stages in flight, input rows into registers, accumulators = residual + b2
-    stage_w1(chunk_of(0), 0, 0);
-    stage_w2_half(chunk_of(0), 0, 0, 0);
-    stage_w2_half(chunk_of(0), 0, 0, 1);
-    u32x4 hf[KT1][2];
+    char* const ring = smem + OFF_RING;
+    // One slot of the phase-A tile sequence of the chunk visited ci-th (q = 2 kt + half) / of its phase-B tile
+    // sequence (q = 3 j + third) into ring position pos. Past the last chunk the DMA is issued out of bounds (it
+    // writes zeros) so that every wave's vmcnt arithmetic stays the same.
+    auto issue_w1 = [&](int ci, int q, int pos) {
+        if (DBG & 8) return;
+        const bool live = ci < nchunks;
+        const unsigned vo = (unsigned)(chunk_of(live ? ci : 0) * CHUNK + (q & 1) * 64) * (E * 2) + (unsigned)((q >> 1) * 128) + w1_lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w1_rsrc, (lds_ptr_t)(ring + pos * SLOT + wv * 1024), 16, live ? vo : OOB, 0, 0, 0);
+    };
+    auto issue_w2 = [&](int ci, int q, int pos) {
+        if (DBG & 8) return;
+        const bool live = ci < nchunks;
+        const unsigned vo = (unsigned)((q % 3) * 64) * w2_row_bytes + (unsigned)((chunk_of(live ? ci : 0) * CHUNK + 32 * (q / 3)) * 2) + w2_lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w2_rsrc, (lds_ptr_t)(ring + pos * SLOT + wv * 1024), 16, live ? vo : OOB, 0, 0, 0);
+    };
+    // The slot stream, in consumption order: A(0) | A(1) B(0) | A(2) B(1) | ... - twelve slots for the peeled first
+    // phase A, then 24 per loop iteration it (phase A of chunk it + 1, phase B of chunk it). g is the position in the
+    // stream relative to the start of iteration `it` (negative = the peeled phase); ring position = stream index & 7.
+    auto issue_rel = [&](int it, int g) {
+        const int pos = (g + 12 + 24) & (NSLOT - 1);  // 12 + 24 it + g, the multiples of 8 dropped
+        if (g < 0) issue_w1(0, g + 12, pos);
+        else if (g < 12) issue_w1(it + 1, g, pos);
+        else if (g < 24) issue_w2(it, g - 12, pos);
+        else issue_w1(it + 2, g - 24, pos);
+    };
+
+    // ---- fragment reads (ring positions as above)
+    const int frag_sw = f_row & 7;
+    const int rows0 = rg * 48 + f_row;
+    auto opaque = [](u32x4& v) { asm volatile("" : "=v"(v)); };  // dev only: a fragment that costs no LDS read
+    // phase A, step kt of a tile sequence starting at stream index g0: W1 fragments (2 units-of-16 x 2 k-halves) and
+    // h fragments (3 row blocks x 2 k-halves)
+    auto read_A = [&](int g0, int kt, u32x4 (&wf)[2][2], u32x4 (&hf)[3][2]) {
+        if (DBG & 16) {
+            for (int ks = 0; ks < 2; ++ks) { for (int nf = 0; nf < 2; ++nf) opaque(wf[nf][ks]); for (int rf = 0; rf < 3; ++rf) opaque(hf[rf][ks]); }
+            return;
+        }
+        const char* wbase = ring + ((g0 + 2 * kt + (cg >> 1)) & (NSLOT - 1)) * SLOT + ((cg & 1) * 32 + f_row) * ROW_BYTES;
+        const char* hbase = smem + OFF_HS + kt * HS_KB + rows0 * ROW_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((ks * 4 + f_kg) ^ frag_sw) << 4;
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) wf[nf][ks] = *reinterpret_cast<const u32x4*>(wbase + nf * 16 * ROW_BYTES + ch);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) hf[rf][ks] = *reinterpret_cast<const u32x4*>(hbase + rf * 16 * ROW_BYTES + ch);
+        }
+    };
+    // phase B, step j: W2 fragments (6 outputs-of-16) ...
+    auto read_Bw = [&](int g0, int j, u32x4 (&wf)[6]) {
+        if (DBG & 16) { for (int nf = 0; nf < 6; ++nf) opaque(wf[nf]); return; }
+        const int ch = (((cg >> 1) * 4 + f_kg) ^ frag_sw) << 4;
+#pragma unroll
+        for (int nf = 0; nf < 6; ++nf) {
+            const int line0 = (cg & 1) * 96 + nf * 16;
+            const int pos = (g0 + 3 * j + (line0 >> 6)) & (NSLOT - 1);
+            wf[nf] = *reinterpret_cast<const u32x4*>(ring + pos * SLOT + ((line0 & 63) + f_row) * ROW_BYTES + ch);
+        }
+    };
+    // ... and G fragments (3 row blocks)
+    auto read_Bg = [&](int j, u32x4 (&gf)[3]) {
+        if (DBG & 16) { for (int rf = 0; rf < 3; ++rf) opaque(gf[rf]); return; }
+        const char* gbase = smem + OFF_GS + (j >> 1) * HS_KB + rows0 * ROW_BYTES + ((((j & 1) * 4 + f_kg) ^ frag_sw) << 4);
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) gf[rf] = *reinterpret_cast<const u32x4*>(gbase + rf * 16 * ROW_BYTES);
+    };
+
+    // dev only: time stamp of step st of iteration it (block 0, waves 0 and 4)
+    auto stamp = [&](int it, int st) {
+        if (!(DBG & 512)) return;
+        if (blockIdx.x != 0 || (wv & 3) != 0) return;
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) p.trace[(wv >> 2) * 4096 + it * 10 + st] = t;
+    };
+
+    // ---- prologue: ring filled with the first eight slots, input rows into LDS, accumulators = residual + b2
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) issue_rel(0, q - 12);
     {
-        const __bf16* hrow = p.h + (size_t)(valid ? m : 0) * E;
+        // 72 DMA instructions, nine per wave: instruction i covers k-block i / 12, rows 8 (i % 12) .. +7
 #pragma unroll
-        for (int kt = 0; kt < KT1; ++kt)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                hf[kt][ks] = *reinterpret_cast<const u32x4*>(hrow + kt * BK + (ks * 4 + f_kg) * 8);
+        for (int jj = 0; jj < 9; ++jj) {
+            const int i = wv * 9 + jj;
+            const int kb = i / 12, row = (i % 12) * 8 + (lane >> 3);
+            const unsigned vo = (unsigned)(m0 + row) * (E * 2) + (unsigned)(kb * 128) + (unsigned)(d_lc << 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(h_rsrc, (lds_ptr_t)(smem + OFF_HS + i * 1024), 16,
+                                                     (m0 + row) < p.M ? vo : OOB, 0, 0, 0);
+        }
     }
-    f32x4 acc[12];
+    f32x4 acc[3][6];
+    bool valid[3];
 #pragma unroll
-    for (int nf = 0; nf < 12; ++nf) {
-        const int n = cw * 192 + nf * 16 + f_kg * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(p.b2 + n);
-        if (valid) v += *reinterpret_cast<const f32x4*>(p.residual + xrow + n);
-        acc[nf] = v;
+    for (int rf = 0; rf < 3; ++rf) {
+        const int m = m0 + rows0 + rf * 16;
+        valid[rf] = m < p.M;
+#pragma unroll
+        for (int nf = 0; nf < 6; ++nf) {
+            const int n = cg * 96 + nf * 16 + f_kg * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(p.b2 + n);
+            if (valid[rf]) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * E + n);
+            acc[rf][nf] = v;
+        }
     }
-    __syncthreads();
+    wait_dma_and_barrier<0>();
 
-    int a_it = 0;  // phase-A stage counter: W1 ring slot = a_it & 1
-    for (int ci = 0; ci < nchunks; ++ci) {
-        const int c = chunk_of(ci);
-        const int c_next = chunk_of(ci + 1 < nchunks ? ci + 1 : ci);
-        // ================= phase A: P[16 rows x 64 hidden] = h W1[chunk]^T
-        f32x4 pacc[4];
+    u32x4 wa[2][2][2], ha[2][3][2];  // phase-A fragments, double-buffered
+    u32x4 wb[2][6], gb[2][3];        // phase-B fragments, double-buffered
+    f32x4 pacc[3][2];                // P of the chunk in phase A
+    f32x4 pold[3][2];                // P of the previous chunk, on its way through GELU
+    f32x4 b1v[2];                    // b1 of the chunk in pold
+    auto load_b1 = [&](int ci) {
+        if (DBG & 64) return;
+        const int c = chunk_of(ci < nchunks ? ci : 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nf = 0; nf < 2; ++nf) b1v[nf] = *reinterpret_cast<const f32x4*>(p.b1 + c * CHUNK + cg * 32 + nf * 16 + f_kg * 4);
+    };
+    // GELU of one accumulator fragment of pold -> bf16 -> operand tile of phase B. Lane holds units
+    // 32 cg + 16 nf + 4 f_kg + (0..3) of its rows: k-block cg >> 1 of the chunk, 16-byte chunk
+    // 4 (cg & 1) + 2 nf + (f_kg >> 1), upper or lower 8 bytes.
+    auto gelu_frag = [&](int rf, int nf) {
+        char* gs = smem + OFF_GS + (cg >> 1) * HS_KB + rows0 * ROW_BYTES + (f_kg & 1) * 8;
+        const f32x4 v = pold[rf][nf] + b1v[nf];
+        const bf16x4 g = (DBG & 2) ? bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]} : gelu4_bf16(v);
+        const int ch = ((cg & 1) * 4 + 2 * nf + (f_kg >> 1)) ^ frag_sw;
+        *reinterpret_cast<bf16x4*>(gs + rf * 16 * ROW_BYTES + (ch << 4)) = g;
+    };
+    // One phase-A step: tile kt is in registers (wa/ha[kt & 1]); read the next tile (or the first phase-B tile),
+    // issue the DMA for the slots this step frees, run the MFMAs - and, in between, the GELU of one fragment of the
+    // PREVIOUS chunk, whose VALU work hides under this chunk's MFMAs.
+    // Issue order inside a step: the MFMAs only need fragments read one step ago, so they start at once and the next
+    // tile's LDS reads trickle in between them - a burst of reads from all eight waves would hold every wave in the
+    // LDS queue (in-order issue) while the matrix pipe idles.
+    auto step_A = [&](int it, int g0, int kt, bool with_gelu, bool last_of_peeled) {
+        const int cur = kt & 1;
+        stamp(it + (g0 < 0 ? 0 : 1), kt);
+        if (kt < KT1 - 1 || last_of_peeled) wait_dma_and_barrier<NSLOT - 2 - 2>();
+        else wait_dma_and_barrier<NSLOT - 2 - 3>();
+        issue_rel(it, g0 + 2 * kt + NSLOT);
+        issue_rel(it, g0 + 2 * kt + NSLOT + 1);
+        if (kt < KT1 - 1) read_A(g0 + 12, kt + 1, wa[cur ^ 1], ha[cur ^ 1]);
+        else if (last_of_peeled) read_A(g0 + 12 + 12, 0, wa[0], ha[0]);
+        else read_Bw(g0 + 12 + 12, 0, wb[0]);
 #pragma unroll
-        for (int kt = 0; kt < KT1; ++kt, ++a_it) {
-            const int slot = a_it & 1;
-            if (kt + 1 < KT1) stage_w1(c, kt + 1, slot ^ 1);
-            if (kt == KT1 - 2) stage_w2_half(c, 1, 1, 0);  // second W2 K-step of this chunk, spread over two A steps
-            if (kt == KT1 - 1) stage_w2_half(c, 1, 1, 1);
-            const char* wbase = smem + OFF_W1 + slot * W1_STAGE;
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf) {
-                    const u32x4 fw = *reinterpret_cast<const u32x4*>(wbase + swz(cw * 64 + nf * 16 + f_row, ks * 4 + f_kg));
-                    pacc[nf] = mma(fw, hf[kt][ks], pacc[nf]);
+                for (int nf = 0; nf < 2; ++nf) {
+                    if (!(DBG & 4)) pacc[rf][nf] = mma(wa[cur][nf][ks], ha[cur][rf][ks], pacc[rf][nf]);
                 }
-            if (kt + 1 < KT1) __syncthreads();
-        }
-        // GELU -> bf16 -> operand tile of phase B. Lane holds hidden units 64 cw + 16 nf + 4 f_kg + (0..3) of its row:
-        // K-step cw of the chunk, 16-byte chunk 2 nf + (f_kg >> 1), upper or lower 8 bytes.
-        {
-            char* hs = smem + OFF_HS + cw * HS_TILE;
-            const int r = rw * 16 + f_row;
+        if (with_gelu) gelu_frag(kt >> 1, kt & 1);
+        // issue order: one MFMA, a few VALU (GELU), one LDS read, ... - VALU and LDS work sits in the MFMA shadows
+        if (kt < KT1 - 1 || last_of_peeled) {
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b1 + c * CHUNK + cw * 64 + nf * 16 + f_kg * 4);
-                const f32x4 v = pacc[nf] + bv;
-                const bf16x4 g = {(__bf16)gelu_fast(v[0]), (__bf16)gelu_fast(v[1]), (__bf16)gelu_fast(v[2]),
-                                  (__bf16)gelu_fast(v[3])};
-                *reinterpret_cast<bf16x4*>(hs + swz(r, 2 * nf + (f_kg >> 1)) + (f_kg & 1) * 8) = g;
+            for (int i = 0; i < 12; ++i) {
+                SGB(SG_MFMA, 1);
+                if (with_gelu) SGB(SG_VALU, 4);
+                if (i < 10) SGB(SG_DS_READ, 1);
+                if (i == 1 || i == 5) SGB(SG_VMEM, 1);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                SGB(SG_MFMA, 1);
+                if (with_gelu) SGB(SG_VALU, 4);
+                if (i < 6) SGB(SG_DS_READ, 1);
+                if (i == 1 || i == 5) SGB(SG_VMEM, 1);
             }
         }
-        __syncthreads();  // G complete; W2 K-step 1 landed; W1 ring free
+    };
 
-        // ================= phase B: acc[16 rows x 192 cols] += G W2[:, chunk]^T
+    // ---- peeled phase A of the first chunk
+    read_A(0, 0, wa[0], ha[0]);
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            if (ci + 1 < nchunks) {
-                if (k2 == 0) stage_w1(c_next, 0, a_it & 1);                    // next chunk's first W1 tile
-                else { stage_w2_half(c_next, 0, 0, 0); stage_w2_half(c_next, 0, 0, 1); }  // and its first W2 tile
+    for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt) step_A(0, -12, kt, false, kt == KT1 - 1);
+    load_b1(0);
+
+    for (int it = 0; it < nchunks; ++it) {
+        // ================= phase A of chunk it + 1 (P = h W1[chunk]^T, 48 rows x 32 units) over GELU of chunk it
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                pold[rf][nf] = pacc[rf][nf];
+                pacc[rf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            const char* wbase = smem + OFF_W2 + k2 * W2_STAGE;
-            const char* hbase = smem + OFF_HS + k2 * HS_TILE;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const u32x4 fa = *reinterpret_cast<const u32x4*>(hbase + swz(rw * 16 + f_row, ks * 4 + f_kg));
+        for (int kt = 0; kt < KT1; ++kt) step_A(it, 0, kt, true, false);
+
+        // ================= phase B of chunk it: acc[48 rows x 96 outputs] += G W2[:, chunk]^T
 #pragma unroll
-                for (int nf = 0; nf < 12; ++nf) {
-                    const u32x4 fw = *reinterpret_cast<const u32x4*>(wbase + swz(cw * 192 + nf * 16 + f_row, ks * 4 + f_kg));
-                    acc[nf] = mma(fw, fa, acc[nf]);
+        for (int j = 0; j < KT2; ++j) {
+            const int cur = j & 1;
+            stamp(it + 1, KT1 + j);
+            if (j < KT2 - 1) wait_dma_and_barrier<NSLOT - 3 - 3>();
+            else wait_dma_and_barrier<NSLOT - 3 - 2>();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) issue_rel(it, 12 + 3 * j + NSLOT + i);
+            if (j == 0) read_Bg(0, gb[0]);  // G exists only after the barrier above
+            if (j < KT2 - 1) {
+                read_Bw(12 + 12, j + 1, wb[cur ^ 1]);
+                read_Bg(j + 1, gb[cur ^ 1]);
+            } else {
+                read_A(12 + 24, 0, wa[0], ha[0]);  // first phase-A tile of the next iteration
+                load_b1(it + 1);
+            }
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 6; ++nf) {
+                    if (!(DBG & 4)) acc[rf][nf] = mma(wb[cur][nf], gb[cur][rf], acc[rf][nf]);
                 }
+            if (j == 0) SGB(SG_DS_READ, 3);
+            if (j < KT2 - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { SGB(SG_MFMA, 2); SGB(SG_DS_READ, 1); if (i == 0 || i == 3 || i == 6) SGB(SG_VMEM, 1); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) { if (i < 2) SGB(SG_MFMA, 1); else SGB(SG_MFMA, 2); SGB(SG_DS_READ, 1); if (i == 0 || i == 3 || i == 6) SGB(SG_VMEM, 1); }
             }
-            __syncthreads();
         }
     }
 
-    // ---- LayerNorm epilogue (same as pp_gemm_ln.hip)
-    float s = 0.f;
+    // ---- LayerNorm epilogue: a row's 384 values sit in 4 lane groups x 4 column waves
+    wait_dma_and_barrier<0>();  // every wave is done with the ring; reuse it for the statistics exchange
+    float* stat = reinterpret_cast<float*>(ring);
+    float mean[3], rstd[3];
 #pragma unroll
-    for (int nf = 0; nf < 12; ++nf) {
-        const f32x4 v = acc[nf];
-        s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    float* stat = reinterpret_cast<float*>(smem + OFF_STAT);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (f_kg == 0) stat[cw * BM + rw * 16 + f_row] = s;
-    __syncthreads();
-    const float mean = (stat[rw * 16 + f_row] + stat[BM + rw * 16 + f_row]) * (1.0f / E);
-    float q = 0.f;
+    for (int rf = 0; rf < 3; ++rf) {
+        float s = 0.f;
 #pragma unroll
-    for (int nf = 0; nf < 12; ++nf)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float d = acc[nf][j] - mean;
-            q = __builtin_fmaf(d, d, q);
+        for (int nf = 0; nf < 6; ++nf) {
+            const f32x4 v = acc[rf][nf];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
         }
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    if (f_kg == 0) stat[2 * BM + cw * BM + rw * 16 + f_row] = q;
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (f_kg == 0) stat[cg * BM + rows0 + rf * 16] = s;
+    }
     __syncthreads();
-    const float var = (stat[2 * BM + rw * 16 + f_row] + stat[3 * BM + rw * 16 + f_row]) * (1.0f / E);
-    const float rstd = 1.0f / sqrtf(var + p.eps);
-    if (!valid) return;
 #pragma unroll
-    for (int nf = 0; nf < 12; ++nf) {
-        const int n = cw * 192 + nf * 16 + f_kg * 4;
-        const f32x4 v = acc[nf];
-        *reinterpret_cast<f32x4*>(p.x_out + xrow + n) = v;
+    for (int rf = 0; rf < 3; ++rf) {
+        const int r = rows0 + rf * 16;
+        mean[rf] = ((stat[r] + stat[BM + r]) + (stat[2 * BM + r] + stat[3 * BM + r])) * (1.0f / E);
+        float q = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < 6; ++nf)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = acc[rf][nf][k] - mean[rf];
+                q = __builtin_fmaf(d, d, q);
+            }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        if (f_kg == 0) stat[(4 + cg) * BM + r] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rf = 0; rf < 3; ++rf) {
+        const int r = rows0 + rf * 16;
+        const float var = ((stat[4 * BM + r] + stat[5 * BM + r]) + (stat[6 * BM + r] + stat[7 * BM + r])) * (1.0f / E);
+        rstd[rf] = 1.0f / sqrtf(var + p.eps);
+    }
+#pragma unroll
+    for (int nf = 0; nf < 6; ++nf) {
+        const int n = cg * 96 + nf * 16 + f_kg * 4;
         const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + n), b = *reinterpret_cast<const f32x4*>(p.beta + n);
-        const bf16x4 hv = {(__bf16)((v[0] - mean) * rstd * g[0] + b[0]), (__bf16)((v[1] - mean) * rstd * g[1] + b[1]),
-                           (__bf16)((v[2] - mean) * rstd * g[2] + b[2]), (__bf16)((v[3] - mean) * rstd * g[3] + b[3])};
-        *reinterpret_cast<bf16x4*>(p.h_out + xrow + n) = hv;
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            if (!valid[rf]) continue;
+            const size_t off = (size_t)(m0 + rows0 + rf * 16) * E + n;
+            const f32x4 v = acc[rf][nf];
+            *reinterpret_cast<f32x4*>(p.x_out + off) = v;
+            const float mu = mean[rf], rs = rstd[rf];
+            const bf16x4 hv = {(__bf16)((v[0] - mu) * rs * g[0] + b[0]), (__bf16)((v[1] - mu) * rs * g[1] + b[1]),
+                               (__bf16)((v[2] - mu) * rs * g[2] + b[2]), (__bf16)((v[3] - mu) * rs * g[3] + b[3])};
+            *reinterpret_cast<bf16x4*>(p.h_out + off) = hv;
+        }
     }
 }
 
+unsigned long long* g_trace = nullptr;
 }  // namespace mlp
 }  // namespace pp
+
+#if MLP_DBG & 512
+extern "C" void pp_mlp_set_trace(void* buf) { pp::mlp::g_trace = reinterpret_cast<unsigned long long*>(buf); }
+#endif
 
 extern "C" int pp_mlp_residual_layernorm(const void* h_in, const void* w1, const float* b1, const void* w2,
                                          const float* b2, const float* residual, float* x_out, const float* gamma,
@@ -264,7 +460,8 @@ extern "C" int pp_mlp_residual_layernorm(const void* h_in, const void* w1, const
     PP_REQUIRE(E == mlp::E, PP_ERR_UNSUPPORTED, "pp_mlp_residual_layernorm: built for embed dim 384 (ViT-S)");
     PP_REQUIRE(M > 0 && F > 0 && F % mlp::CHUNK == 0, PP_ERR_UNSUPPORTED,
                "pp_mlp_residual_layernorm: hidden width must be a positive multiple of 128");
-    PP_REQUIRE((size_t)F * E * 2 < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_mlp_residual_layernorm: weights exceed 2 GiB");
+    PP_REQUIRE((size_t)F * E * 2 < 0x7ffffff0u && (size_t)M * E * 2 < 0x7ffffff0u, PP_ERR_UNSUPPORTED,
+               "pp_mlp_residual_layernorm: operand exceeds 2 GiB");
     mlp::Params p{};
     p.h = reinterpret_cast<const __bf16*>(h_in);
     p.W1 = reinterpret_cast<const __bf16*>(w1);
@@ -278,9 +475,11 @@ extern "C" int pp_mlp_residual_layernorm(const void* h_in, const void* w1, const
     p.h_out = reinterpret_cast<__bf16*>(h_out);
     p.M = M;
     p.F = F;
+    p.h_bytes = (unsigned)((size_t)M * E * 2);
     p.w1_bytes = (unsigned)((size_t)F * E * 2);
     p.w2_bytes = (unsigned)((size_t)E * F * 2);
     p.eps = eps;
+    p.trace = mlp::g_trace;
     auto kern = mlp::mlp_res_ln_kernel;
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, mlp::LDS));
     hipLaunchKernelGGL(kern, dim3((M + mlp::BM - 1) / mlp::BM), dim3(mlp::THREADS), mlp::LDS,

@@ -2,7 +2,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from probpose_code_amd import _lib as L
-M, E, Fd = 24576, 384, 1536
+import os
+M, E, Fd = 24576, 384, int(os.environ.get("FD", "1536"))
 h = torch.randn(M, E, device="cuda").bfloat16(); w1 = (torch.randn(Fd, E, device="cuda") / E**0.5).bfloat16(); w2 = (torch.randn(E, Fd, device="cuda") / Fd**0.5).bfloat16()
 b1 = torch.randn(Fd, device="cuda"); b2 = torch.randn(E, device="cuda"); x = torch.randn(M, E, device="cuda"); g = torch.ones(E, device="cuda"); be = torch.zeros(E, device="cuda")
 ho = torch.empty_like(h)
