@@ -31,4 +31,8 @@ struct GemmParams {
 
 int gemm(const GemmParams& p, int prec, int groups, hipStream_t s);
 
+// pp_panel_gemm.hip: wide-tile bf16 kernel for the long-K convolutions (deconv N % 256 == 0, conv 3x3 N % 192 == 0)
+bool panel_gemm_supported(const GemmParams& p, int prec, int groups);
+int panel_gemm(const GemmParams& p, int groups, hipStream_t s);
+
 }  // namespace pp

@@ -1,0 +1,40 @@
+"""dev only: time the head convolutions at the bs64 shapes. LIB=path of an alternative library (scripts/micro/panel_ablate.sh)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from probpose_code_amd import _lib as L
+libpath = os.environ.get("LIB")
+if libpath:
+    lib = ctypes.CDLL(libpath)
+    fn = lib.pp_conv_gemm
+    fn.restype = ctypes.c_int
+    P, I, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
+    fn.argtypes = [I, I, P, P, P, P, I, I, I, I, I, I, I, I, LL, LL, LL, LL, I, I, I, P]
+    call = lambda *a: fn(*a)
+else:
+    call = lambda *a: L.call("pp_conv_gemm", *a)
+dt = torch.bfloat16
+B = 128
+cases = [("conv1 (4 towers)", 1, 16, 12, 384, 384, 4), ("deconv1", 2, 16, 12, 384, 256, 1), ("deconv2", 2, 32, 24, 256, 256, 1)]
+for name, kind, H, W, Cin, Cout, G in cases:
+    x = torch.randn(B, H, W, Cin, device="cuda").to(dt)
+    taps = 9 if kind == 1 else 4
+    ng = G if kind == 1 else 4
+    w = (torch.randn(ng, Cout, taps * Cin, device="cuda") / (taps * Cin) ** 0.5).to(dt)
+    b = torch.randn(ng, Cout, device="cuda")
+    if kind == 1:
+        out = torch.empty(G, B, H, W, Cout, device="cuda", dtype=dt)
+        args = (0, 1, x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, 0, 0, G, 0, Cout * taps * Cin, B * H * W * Cout, Cout, Cout, 0, 1, None)
+        flops = 2 * B * H * W * Cout * taps * Cin * G
+    else:
+        out = torch.empty(B, 2 * H, 2 * W, Cout, device="cuda", dtype=dt)
+        args = (0, 2, x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, -1, 0, 1, 0, 0, 0, 0, Cout, 2, 1, None)
+        flops = 2 * B * H * W * Cout * taps * Cin * 4
+    for _ in range(3): assert call(*args) in (0, None)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): call(*args)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f"{name:18s} {ms*1e3:8.1f} us  {flops/ms/1e9:7.0f} TF")

@@ -124,6 +124,50 @@ def test_deconv_phases_vs_torch(prec):
     torch.testing.assert_close(out.cpu().double().permute(0, 3, 1, 2), ref, **TOL[prec])
 
 
+def test_panel_deconv_all_phases_vs_torch():
+    """The wide-tile kernel (pp_panel_gemm.hip) takes bf16 deconvolutions with Cout % 256 == 0 once there are enough
+    tiles to fill the chip: ConvTranspose2d(k4, s2, p1) + bias + ReLU, four phases in one launch, batch not a
+    multiple of the 192-row tile so that tail rows and image borders are both exercised."""
+    L = _lib()
+    B, H, W, Cin, Cout = 51, 16, 12, 128, 256          # M = 9792 = 51 tiles of 192 rows, x 4 phases = 204 tiles
+    x = _rand(B, Cin, H, W, seed=31)
+    w = _rand(Cin, Cout, 4, 4, seed=32, scale=1 / math.sqrt(4 * Cin))
+    b = _rand(Cout, seed=33)
+    ref = F.relu(F.conv_transpose2d(_q(x, BF16), _q(w, BF16), b.double(), stride=2, padding=1))
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    ph = torch.empty((2, 2, Cout, 4 * Cin))
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    t = ty * 2 + tx
+                    ph[py, px, :, t * Cin:(t + 1) * Cin] = w[:, :, 3 - 2 * ty - py, 3 - 2 * tx - px].t()
+    pd = ph.bfloat16().cuda()
+    bd = b.cuda()
+    out = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.call("pp_conv_gemm", BF16, 2, xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout,
+           -1, 0, 1, 0, 0, 0, 0, Cout, 2, 1, None)
+    torch.testing.assert_close(out.cpu().double().permute(0, 3, 1, 2), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_panel_conv3x3_groups_vs_torch():
+    """Wide-tile path for the grouped 3x3 convolution (Cout % 192 == 0), shared input, bias, no activation."""
+    L = _lib()
+    G, B, H, W, C = 4, 124, 8, 6, 384    # M = 5952 -> 24 tiles of 256 rows (tail: 64) x 2 column tiles x 4 groups = 192
+    x = _rand(B, C, H, W, seed=34)
+    w = _rand(G, C, C, 3, 3, seed=35, scale=1 / math.sqrt(9 * C))
+    b = _rand(G, C, seed=36)
+    xq, wq = x.bfloat16().float(), w.bfloat16().float()  # fp32 reference on the bf16-rounded operands
+    ref = torch.stack([F.conv2d(xq, wq[g], b[g], padding=1) for g in range(G)]).double()
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    wd = w.permute(0, 1, 3, 4, 2).reshape(G, C, 9 * C).contiguous().bfloat16().cuda()
+    out = torch.full((G, B, H, W, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    bd = b.cuda()
+    L.call("pp_conv_gemm", BF16, 1, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, C, C,
+           0, 0, G, 0, C * 9 * C, B * H * W * C, C, C, 0, 1, None)
+    torch.testing.assert_close(out.cpu().double().permute(0, 1, 4, 2, 3), ref, rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("prec,hd,S", [(F32, 32, 192), (BF16, 32, 192), (BF16, 64, 192), (F32, 64, 192), (BF16, 64, 432)])
 def test_attention_vs_torch(prec, hd, S):
     L = _lib()
