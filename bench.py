@@ -61,15 +61,23 @@ def kernel_work_per_step(eng, B, passes, tag):
     esz = 4 if f32 else 2
     t = "f" if f32 else "DF16b"
     fused_ln = E == 384
-    fused_mlp = fused_ln and not f32 and eng.fuse_mlp
+    fused_mlp = fused_ln and not f32 and eng.fuse_mlp and Fd % 128 == 0
+    fused_proj = fused_mlp and eng.fuse_proj
     c_last = eng.w.deconv_channels[-1]
     final_fl, final_b = 2.0 * (B * passes * P) * eng.K * c_last, B * passes * P * (c_last * esz + eng.K * 4)
+    if tag == "proj_mlp_res_ln":  # proj + residual + ln2 + fc1 + GELU + fc2 + residual + LN per layer
+        return (L * (4.0 * M * E * Fd + 2.0 * M * E * E), L * (M * E * 2 + 2 * M * E * 4 + M * E * 2), L,
+                "_ZN2pp3mlp17mlp_res_ln_kernelILb1EEEvNS0_6ParamsE")
     if tag == "mlp_res_ln":  # fc1 + GELU + fc2 + residual + LN per layer
-        return L * 4.0 * M * E * Fd, L * (M * E * 2 + 2 * M * E * 4 + M * E * 2), L, "_ZN2pp3mlp17mlp_res_ln_kernelENS0_6ParamsE"
+        return L * 4.0 * M * E * Fd, L * (M * E * 2 + 2 * M * E * 4 + M * E * 2), L, "_ZN2pp3mlp17mlp_res_ln_kernelILb0EEEvNS0_6ParamsE"
     if tag == "gemm_res_ln":  # patch embed, proj (and fc2 when the FFN is not fused) + residual + LN
-        fl = 2.0 * M * E * 768 + L * 2.0 * M * E * E
-        by = M * 768 * esz + M * E * (4 + esz) + L * (M * E * esz + 2 * M * E * 4 + M * E * esz)
-        n = 1 + L
+        fl = 2.0 * M * E * 768
+        by = M * 768 * esz + M * E * (4 + esz)
+        n = 1
+        if not fused_proj:
+            fl += L * 2.0 * M * E * E
+            by += L * (M * E * esz + 2 * M * E * 4 + M * E * esz)
+            n += L
         if not fused_mlp:
             fl += L * 2.0 * M * E * Fd
             by += L * (M * Fd * esz + 2 * M * E * 4 + M * E * esz)
@@ -210,7 +218,7 @@ def main():
             "path_tflops": B * world * args.steps * GFLOP_PER_CROP_FLIP / dt / 1e3,
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_tag.items(), key=lambda kv: -kv[1][0])},
         }
-        if dom in ("mlp_res_ln", "gemm_res_ln", "gemm_bf16out", "gemm_f32out"):
+        if dom in ("proj_mlp_res_ln", "mlp_res_ln", "gemm_res_ln", "gemm_bf16out", "gemm_f32out"):
             fl, alg_bytes, n, mangled = kernel_work_per_step(eng, B, 2, dom)
             assert n == dom_n, (dom, n, dom_n)
             secs = dom_ms / n * 1e-3

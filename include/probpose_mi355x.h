@@ -145,6 +145,19 @@ int pp_mlp_residual_layernorm(const void* h_in, const void* w1, const float* b1,
                               const float* b2, const float* residual, float* x_out, const float* gamma,
                               const float* beta, float eps, void* h_out, int M, int E, int F, void* stream);
 
+/* Second half of a ViT layer in one launch (bf16 operands): attention output projection + residual, the LayerNorm
+ * in front of the FFN, the FFN + residual, and the LayerNorm that follows the layer
+ *   x1    = residual + attn Wp^T + bp ;          h  = LayerNorm(x1; gamma2, beta2, eps)
+ *   x_out = x1 + GELU(h W1^T + b1) W2^T + b2 ;   h_out = LayerNorm(x_out; gamma, beta, eps)
+ * (mmpretrain TransformerEncoderLayer.forward [3P]: x = x + attn(ln1(x)); x = ffn(ln2(x), identity=x), here from
+ * the point where the per-head attention outputs exist; ln1 of the NEXT layer / the final norm is the trailing
+ * LayerNorm). x1 and h never leave the CU. attn (M, E), wp (E, E), w1 (F, E), w2 (E, F), h_out are bf16; the
+ * rest fp32. E must be 384, F a multiple of 128. residual may alias x_out. */
+int pp_proj_mlp_residual_layernorm(const void* attn, const void* wp, const float* bp, const float* residual,
+                                   const float* gamma2, const float* beta2, const void* w1, const float* b1,
+                                   const void* w2, const float* b2, float* x_out, const float* gamma,
+                                   const float* beta, float eps, void* h_out, int M, int E, int F, void* stream);
+
 /* Convolutions of ProbMapHead as implicit GEMMs on NHWC activations (no im2col buffer):
  *   PP_CONV3X3     : Conv2d(Cin->Cout, k3, s1, p1) of the scalar towers
  *                    (mmpose/models/heads/hybrid_heads/probmap_head.py:261-410);

@@ -62,7 +62,11 @@ static_assert(SLOTS_PER_CHUNK % NSLOT == 0, "ring positions must repeat per chun
 
 extern unsigned long long* g_trace;
 struct Params {
-    const __bf16* h;       // [M, 384] LayerNorm-ed block input
+    const __bf16* h;       // [M, 384] LayerNorm-ed block input (PROJ: the attention output rows)
+    const __bf16* Wp;      // PROJ: [384, 384] attention output projection
+    const float* bp;       // PROJ: [384]
+    const float* gamma2;   // PROJ: LayerNorm in front of the FFN (ln2)
+    const float* beta2;
     const __bf16* W1;      // [F, 384]
     const float* b1;       // [F]
     const __bf16* W2;      // [384, F]
@@ -73,7 +77,7 @@ struct Params {
     const float* beta;
     __bf16* h_out;         // [M, 384] LayerNorm(x_out)
     int M, F;
-    unsigned h_bytes, w1_bytes, w2_bytes;
+    unsigned h_bytes, w1_bytes, w2_bytes, wp_bytes;
     float eps;
     unsigned long long* trace;  // dev only (MLP_DBG & 512): per-step time stamps of block 0, waves 0 and 4
 };
@@ -126,7 +130,13 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// PROJ = true puts the attention output projection in front:  x' = x + a Wp^T + bp ;  h = LayerNorm2(x')  and then the
+// block above on (x', h) - the 96 x 384 accumulators that end the projection ARE the residual the FFN accumulates on,
+// so x' and h never travel to HBM. The projection is 12 more steps of the phase-B kind (Wp tiles of 384 outputs x
+// 32 k = 3 ring slots) at the head of the same slot stream.
+template <bool PROJ>
 __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) {
+    constexpr int PRE = PROJ ? 36 : 0;  // ring slots streamed before the first phase A
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,6 +160,10 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     // W2 slot (j, third): line l' = 64 third + l holds outputs l' (chunks 0..3) and l' + 192 (chunks 4..7), k in [32 j, +32)
     const unsigned w2_row_bytes = (unsigned)p.F * 2u;
     const unsigned w2_lane = (unsigned)(d_line + 192 * (d_lc >> 2)) * w2_row_bytes + (unsigned)((d_lc & 3) << 4);
+    // Wp slot (j, third): the same two-rows-per-line image, row stride 384 elements
+    const unsigned wp_lane = (unsigned)(d_line + 192 * (d_lc >> 2)) * (E * 2) + (unsigned)((d_lc & 3) << 4);
+    const __amdgpu_buffer_rsrc_t wp_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(PROJ ? p.Wp : p.W1), 0, PROJ ? p.wp_bytes : p.w1_bytes, 0x00020000);
 
     const int nchunks = p.F / CHUNK;
     // Every workgroup walks the hidden chunks in a different rotation: all 256 CUs stream the SAME weights, and in
@@ -175,10 +189,17 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     };
     // The slot stream, in consumption order: A(0) | A(1) B(0) | A(2) B(1) | ... - twelve slots for the peeled first
     // phase A, then 24 per loop iteration it (phase A of chunk it + 1, phase B of chunk it). g is the position in the
-    // stream relative to the start of iteration `it` (negative = the peeled phase); ring position = stream index & 7.
+    // stream relative to the start of iteration `it` (negative = the peeled phase, below -12 = the projection);
+    // ring position = stream index & 7.
+    auto issue_wp = [&](int q, int pos) {
+        if (DBG & 8) return;
+        const unsigned vo = (unsigned)((q % 3) * 64) * (E * 2) + (unsigned)(32 * (q / 3) * 2) + wp_lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rsrc, (lds_ptr_t)(ring + pos * SLOT + wv * 1024), 16, vo, 0, 0, 0);
+    };
     auto issue_rel = [&](int it, int g) {
-        const int pos = (g + 12 + 24) & (NSLOT - 1);  // 12 + 24 it + g, the multiples of 8 dropped
-        if (g < 0) issue_w1(0, g + 12, pos);
+        const int pos = (g + 12 + 24 + 48 + PRE) & (NSLOT - 1);  // PRE + 12 + 24 it + g, multiples of 8 dropped
+        if (PROJ && g < -12) issue_wp(g + 48, pos);
+        else if (g < 0) issue_w1(0, g + 12, pos);
         else if (g < 12) issue_w1(it + 1, g, pos);
         else if (g < 24) issue_w2(it, g - 12, pos);
         else issue_w1(it + 2, g - 24, pos);
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
             for (int ks = 0; ks < 2; ++ks) { for (int nf = 0; nf < 2; ++nf) opaque(wf[nf][ks]); for (int rf = 0; rf < 3; ++rf) opaque(hf[rf][ks]); }
             return;
         }
-        const char* wbase = ring + ((g0 + 2 * kt + (cg >> 1)) & (NSLOT - 1)) * SLOT + ((cg & 1) * 32 + f_row) * ROW_BYTES;
+        const char* wbase = ring + ((g0 + PRE + 2 * kt + (cg >> 1)) & (NSLOT - 1)) * SLOT + ((cg & 1) * 32 + f_row) * ROW_BYTES;
         const char* hbase = smem + OFF_HS + kt * HS_KB + rows0 * ROW_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -213,14 +234,14 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 #pragma unroll
         for (int nf = 0; nf < 6; ++nf) {
             const int line0 = (cg & 1) * 96 + nf * 16;
-            const int pos = (g0 + 3 * j + (line0 >> 6)) & (NSLOT - 1);
+            const int pos = (g0 + PRE + 3 * j + (line0 >> 6)) & (NSLOT - 1);
             wf[nf] = *reinterpret_cast<const u32x4*>(ring + pos * SLOT + ((line0 & 63) + f_row) * ROW_BYTES + ch);
         }
     };
-    // ... and G fragments (3 row blocks)
-    auto read_Bg = [&](int j, u32x4 (&gf)[3]) {
+    // ... and row-operand fragments (3 row blocks) of k-step j (32 wide) of the G tile or of the input rows
+    auto read_rows = [&](int region, int j, u32x4 (&gf)[3]) {
         if (DBG & 16) { for (int rf = 0; rf < 3; ++rf) opaque(gf[rf]); return; }
-        const char* gbase = smem + OFF_GS + (j >> 1) * HS_KB + rows0 * ROW_BYTES + ((((j & 1) * 4 + f_kg) ^ frag_sw) << 4);
+        const char* gbase = smem + region + (j >> 1) * HS_KB + rows0 * ROW_BYTES + ((((j & 1) * 4 + f_kg) ^ frag_sw) << 4);
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) gf[rf] = *reinterpret_cast<const u32x4*>(gbase + rf * 16 * ROW_BYTES);
     };
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 
     // ---- prologue: ring filled with the first eight slots, input rows into LDS, accumulators = residual + b2
 #pragma unroll
-    for (int q = 0; q < NSLOT; ++q) issue_rel(0, q - 12);
+    for (int q = 0; q < NSLOT; ++q) issue_rel(0, q - 12 - PRE);
     {
         // 72 DMA instructions, nine per wave: instruction i covers k-block i / 12, rows 8 (i % 12) .. +7
 #pragma unroll
@@ -256,7 +277,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 #pragma unroll
         for (int nf = 0; nf < 6; ++nf) {
             const int n = cg * 96 + nf * 16 + f_kg * 4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(p.b2 + n);
+            f32x4 v = *reinterpret_cast<const f32x4*>((PROJ ? p.bp : p.b2) + n);
             if (valid[rf]) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * E + n);
             acc[rf][nf] = v;
         }
@@ -329,6 +350,96 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         }
     };
 
+    // LayerNorm statistics of the accumulator rows: a row's 384 values sit in 4 lane groups x 4 column waves; `stat` is
+    // 8 x 96 floats of LDS nobody else uses at that moment
+    auto row_stats = [&](float* stat, float (&mean)[3], float (&rstd)[3]) {
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            float sm = 0.f;
+#pragma unroll
+            for (int nf = 0; nf < 6; ++nf) {
+                const f32x4 v = acc[rf][nf];
+                sm += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            if (f_kg == 0) stat[cg * BM + rows0 + rf * 16] = sm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            const int r = rows0 + rf * 16;
+            mean[rf] = ((stat[r] + stat[BM + r]) + (stat[2 * BM + r] + stat[3 * BM + r])) * (1.0f / E);
+            float q = 0.f;
+#pragma unroll
+            for (int nf = 0; nf < 6; ++nf)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = acc[rf][nf][k] - mean[rf];
+                    q = __builtin_fmaf(d, d, q);
+                }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            if (f_kg == 0) stat[(4 + cg) * BM + r] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            const int r = rows0 + rf * 16;
+            const float var = ((stat[4 * BM + r] + stat[5 * BM + r]) + (stat[6 * BM + r] + stat[7 * BM + r])) * (1.0f / E);
+            rstd[rf] = 1.0f / sqrtf(var + p.eps);
+        }
+    };
+
+    if (PROJ) {
+        // ================= attention output projection: acc (= x + bp) += a Wp^T, twelve steps of k = 32 in the style
+        // of phase B with the input rows as the row operand; then h = LayerNorm2(acc) replaces the rows in LDS.
+        read_Bw(-PRE, 0, wb[0]);  // the projection tiles start the stream: ring position = slot index
+        read_rows(OFF_HS, 0, gb[0]);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int cur = j & 1;
+            if (j < 11) wait_dma_and_barrier<NSLOT - 3 - 3>();
+            else wait_dma_and_barrier<NSLOT - 3 - 2>();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) issue_rel(0, -48 + 3 * j + NSLOT + i);
+            if (j < 11) {
+                read_Bw(-PRE, j + 1, wb[cur ^ 1]);
+                read_rows(OFF_HS, j + 1, gb[cur ^ 1]);
+            }
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 6; ++nf) {
+                    if (!(DBG & 4)) acc[rf][nf] = mma(wb[cur][nf], gb[cur][rf], acc[rf][nf]);
+                }
+            if (j < 11) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { SGB(SG_MFMA, 2); SGB(SG_DS_READ, 1); if (i == 0 || i == 3 || i == 6) SGB(SG_VMEM, 1); }
+            }
+        }
+        // every wave has passed the barrier of step 11, so nobody reads the input rows any more; G is not in use yet
+        float mean2[3], rstd2[3];
+        row_stats(reinterpret_cast<float*>(smem + OFF_GS), mean2, rstd2);
+#pragma unroll
+        for (int nf = 0; nf < 6; ++nf) {
+            const int n = cg * 96 + nf * 16 + f_kg * 4;  // k-block n >> 6, 16-byte chunk (n & 63) >> 3, 8-byte half f_kg & 1
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma2 + n), b = *reinterpret_cast<const f32x4*>(p.beta2 + n);
+            const f32x4 b2v = *reinterpret_cast<const f32x4*>(p.b2 + n);
+            char* hs = smem + OFF_HS + (n >> 6) * HS_KB + rows0 * ROW_BYTES + (((((n & 63) >> 3)) ^ frag_sw) << 4) + (f_kg & 1) * 8;
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) {
+                const f32x4 v = acc[rf][nf];
+                const float mu = mean2[rf], rs = rstd2[rf];
+                const bf16x4 hv = {(__bf16)((v[0] - mu) * rs * g[0] + b[0]), (__bf16)((v[1] - mu) * rs * g[1] + b[1]),
+                                   (__bf16)((v[2] - mu) * rs * g[2] + b[2]), (__bf16)((v[3] - mu) * rs * g[3] + b[3])};
+                *reinterpret_cast<bf16x4*>(hs + rf * 16 * ROW_BYTES) = hv;
+                acc[rf][nf] = v + b2v;  // the FFN accumulates on x' + b2
+            }
+        }
+        wait_dma_and_barrier<0>();  // h complete, first phase-A tiles landed
+    }
+
     // ---- peeled phase A of the first chunk
     read_A(0, 0, wa[0], ha[0]);
 #pragma unroll
@@ -360,10 +471,10 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
             else wait_dma_and_barrier<NSLOT - 3 - 2>();
 #pragma unroll
             for (int i = 0; i < 3; ++i) issue_rel(it, 12 + 3 * j + NSLOT + i);
-            if (j == 0) read_Bg(0, gb[0]);  // G exists only after the barrier above
+            if (j == 0) read_rows(OFF_GS, 0, gb[0]);  // G exists only after the barrier above
             if (j < KT2 - 1) {
                 read_Bw(12 + 12, j + 1, wb[cur ^ 1]);
-                read_Bg(j + 1, gb[cur ^ 1]);
+                read_rows(OFF_GS, j + 1, gb[cur ^ 1]);
             } else {
                 read_A(12 + 24, 0, wa[0], ha[0]);  // first phase-A tile of the next iteration
                 load_b1(it + 1);
@@ -385,46 +496,10 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         }
     }
 
-    // ---- LayerNorm epilogue: a row's 384 values sit in 4 lane groups x 4 column waves
+    // ---- LayerNorm epilogue
     wait_dma_and_barrier<0>();  // every wave is done with the ring; reuse it for the statistics exchange
-    float* stat = reinterpret_cast<float*>(ring);
     float mean[3], rstd[3];
-#pragma unroll
-    for (int rf = 0; rf < 3; ++rf) {
-        float s = 0.f;
-#pragma unroll
-        for (int nf = 0; nf < 6; ++nf) {
-            const f32x4 v = acc[rf][nf];
-            s += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (f_kg == 0) stat[cg * BM + rows0 + rf * 16] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int rf = 0; rf < 3; ++rf) {
-        const int r = rows0 + rf * 16;
-        mean[rf] = ((stat[r] + stat[BM + r]) + (stat[2 * BM + r] + stat[3 * BM + r])) * (1.0f / E);
-        float q = 0.f;
-#pragma unroll
-        for (int nf = 0; nf < 6; ++nf)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float d = acc[rf][nf][k] - mean[rf];
-                q = __builtin_fmaf(d, d, q);
-            }
-        q += __shfl_xor(q, 16);
-        q += __shfl_xor(q, 32);
-        if (f_kg == 0) stat[(4 + cg) * BM + r] = q;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int rf = 0; rf < 3; ++rf) {
-        const int r = rows0 + rf * 16;
-        const float var = ((stat[4 * BM + r] + stat[5 * BM + r]) + (stat[6 * BM + r] + stat[7 * BM + r])) * (1.0f / E);
-        rstd[rf] = 1.0f / sqrtf(var + p.eps);
-    }
+    row_stats(reinterpret_cast<float*>(ring), mean, rstd);
 #pragma unroll
     for (int nf = 0; nf < 6; ++nf) {
         const int n = cg * 96 + nf * 16 + f_kg * 4;
@@ -450,6 +525,18 @@ unsigned long long* g_trace = nullptr;
 #if MLP_DBG & 512
 extern "C" void pp_mlp_set_trace(void* buf) { pp::mlp::g_trace = reinterpret_cast<unsigned long long*>(buf); }
 #endif
+
+namespace pp {
+namespace mlp {
+static int launch(const Params& p, bool proj, hipStream_t stream) {
+    auto kern = proj ? mlp_res_ln_kernel<true> : mlp_res_ln_kernel<false>;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    hipLaunchKernelGGL(kern, dim3((p.M + BM - 1) / BM), dim3(THREADS), LDS, stream, p);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+}  // namespace mlp
+}  // namespace pp
 
 extern "C" int pp_mlp_residual_layernorm(const void* h_in, const void* w1, const float* b1, const void* w2,
                                          const float* b2, const float* residual, float* x_out, const float* gamma,
@@ -480,10 +567,44 @@ extern "C" int pp_mlp_residual_layernorm(const void* h_in, const void* w1, const
     p.w2_bytes = (unsigned)((size_t)E * F * 2);
     p.eps = eps;
     p.trace = mlp::g_trace;
-    auto kern = mlp::mlp_res_ln_kernel;
-    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, mlp::LDS));
-    hipLaunchKernelGGL(kern, dim3((M + mlp::BM - 1) / mlp::BM), dim3(mlp::THREADS), mlp::LDS,
-                       reinterpret_cast<hipStream_t>(stream), p);
-    PP_LAUNCH_CHECK();
-    return PP_OK;
+    return mlp::launch(p, false, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pp_proj_mlp_residual_layernorm(const void* attn, const void* wp, const float* bp, const float* residual,
+                                              const float* gamma2, const float* beta2, const void* w1, const float* b1,
+                                              const void* w2, const float* b2, float* x_out, const float* gamma,
+                                              const float* beta, float eps, void* h_out, int M, int E, int F,
+                                              void* stream) {
+    using namespace pp;
+    PP_REQUIRE(attn && wp && bp && residual && gamma2 && beta2 && w1 && b1 && w2 && b2 && x_out && gamma && beta && h_out,
+               PP_ERR_INVALID_ARG, "pp_proj_mlp_residual_layernorm: NULL argument");
+    PP_REQUIRE(E == mlp::E, PP_ERR_UNSUPPORTED, "pp_proj_mlp_residual_layernorm: built for embed dim 384 (ViT-S)");
+    PP_REQUIRE(M > 0 && F > 0 && F % mlp::CHUNK == 0, PP_ERR_UNSUPPORTED,
+               "pp_proj_mlp_residual_layernorm: hidden width must be a positive multiple of 128");
+    PP_REQUIRE((size_t)F * E * 2 < 0x7ffffff0u && (size_t)M * E * 2 < 0x7ffffff0u, PP_ERR_UNSUPPORTED,
+               "pp_proj_mlp_residual_layernorm: operand exceeds 2 GiB");
+    mlp::Params p{};
+    p.h = reinterpret_cast<const __bf16*>(attn);
+    p.Wp = reinterpret_cast<const __bf16*>(wp);
+    p.bp = bp;
+    p.gamma2 = gamma2;
+    p.beta2 = beta2;
+    p.W1 = reinterpret_cast<const __bf16*>(w1);
+    p.b1 = b1;
+    p.W2 = reinterpret_cast<const __bf16*>(w2);
+    p.b2 = b2;
+    p.residual = residual;
+    p.x_out = x_out;
+    p.gamma = gamma;
+    p.beta = beta;
+    p.h_out = reinterpret_cast<__bf16*>(h_out);
+    p.M = M;
+    p.F = F;
+    p.h_bytes = (unsigned)((size_t)M * E * 2);
+    p.w1_bytes = (unsigned)((size_t)F * E * 2);
+    p.w2_bytes = (unsigned)((size_t)E * F * 2);
+    p.wp_bytes = (unsigned)((size_t)E * E * 2);
+    p.eps = eps;
+    p.trace = mlp::g_trace;
+    return mlp::launch(p, true, reinterpret_cast<hipStream_t>(stream));
 }

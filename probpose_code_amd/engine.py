@@ -73,6 +73,7 @@ class ProbPoseEngine:
         self._flip: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
         self.fuse_mlp = os.environ.get("PP_FUSE_MLP", "1") != "0"
+        self.fuse_proj = os.environ.get("PP_FUSE_PROJ", "1") != "0"
         self.profile: Optional[Dict[str, list]] = None
         # tower pooling schedule (probmap_head.py:264) and the spatial sizes it produces
         self.pools = ((4, 3), (2, 2), (2, 2))
@@ -173,11 +174,21 @@ class ProbPoseEngine:
             self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], ws["qkv"], M, 3 * E, E)
             self._call("attention", "pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), B * passes,
                        self.Np, self.heads, self.hd, scale, st)
-            res_ln(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])
             last = i + 1 == L
             gn, bn = (w["ln_f.w"], w["ln_f.b"]) if last else (w[f"l{i + 1}.ln1.w"], w[f"l{i + 1}.ln1.b"])
             h_next = ws["feat"] if last else ws["h"]
-            if fused and self.precision == "bf16" and Fd % 128 == 0 and self.fuse_mlp:
+            fuse_ffn = fused and self.precision == "bf16" and Fd % 128 == 0 and self.fuse_mlp
+            if fuse_ffn and self.fuse_proj:
+                # second half of the layer in one kernel: projection + residual, ln2, FFN + residual, next LayerNorm;
+                # the intermediate residual stream and ln2 output stay on the CU
+                self._call("proj_mlp_res_ln", "pp_proj_mlp_residual_layernorm", ws["h"].data_ptr(),
+                           w[f"l{i}.proj.w"].data_ptr(), w[f"l{i}.proj.b"].data_ptr(), ws["x"].data_ptr(),
+                           w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(), w[f"l{i}.fc1.w"].data_ptr(),
+                           w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.w"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(),
+                           ws["x"].data_ptr(), gn.data_ptr(), bn.data_ptr(), self.ln_eps, h_next.data_ptr(), M, E, Fd, st)
+                continue
+            res_ln(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])
+            if fuse_ffn:
                 # whole FFN + residual + next LayerNorm in one kernel: the 4x-wide hidden activation stays on the CU
                 self._call("mlp_res_ln", "pp_mlp_residual_layernorm", ws["h"].data_ptr(), w[f"l{i}.fc1.w"].data_ptr(),
                            w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.w"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(),
