@@ -152,11 +152,14 @@ int pp_mlp_residual_layernorm(const void* h_in, const void* w1, const float* b1,
  * (mmpretrain TransformerEncoderLayer.forward [3P]: x = x + attn(ln1(x)); x = ffn(ln2(x), identity=x), here from
  * the point where the per-head attention outputs exist; ln1 of the NEXT layer / the final norm is the trailing
  * LayerNorm). x1 and h never leave the CU. attn (M, E), wp (E, E), w1 (F, E), w2 (E, F), h_out are bf16; the
- * rest fp32. E must be 384, F a multiple of 128. residual may alias x_out. */
+ * rest fp32. E must be 384, F a multiple of 128. residual may alias x_out.
+ * With wqkv != NULL the next layer's qkv Linear (nn.Linear(E, 3E), weight (3E, E) bf16, bias fp32) is applied to
+ * h_out in the same launch:  qkv_out (M, 3E) bf16 = h_out wqkv^T + bqkv ; h_out may then be NULL (not stored). */
 int pp_proj_mlp_residual_layernorm(const void* attn, const void* wp, const float* bp, const float* residual,
                                    const float* gamma2, const float* beta2, const void* w1, const float* b1,
                                    const void* w2, const float* b2, float* x_out, const float* gamma,
-                                   const float* beta, float eps, void* h_out, int M, int E, int F, void* stream);
+                                   const float* beta, float eps, void* h_out, const void* wqkv, const float* bqkv,
+                                   void* qkv_out, int M, int E, int F, void* stream);
 
 /* Convolutions of ProbMapHead as implicit GEMMs on NHWC activations (no im2col buffer):
  *   PP_CONV3X3     : Conv2d(Cin->Cout, k3, s1, p1) of the scalar towers

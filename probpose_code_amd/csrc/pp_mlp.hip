@@ -41,7 +41,7 @@ namespace mlp {
 #define MLP_DBG 0
 #endif
 // dev ablation switches (scripts/micro/mlp_ablate.sh), 0 in the product build: 2 no GELU, 4 no MFMA, 8 no DMA,
-// 16 no LDS fragment reads, 32 no barriers, 64 no b1 loads, 512 per-step time stamps
+// 16 no LDS fragment reads, 32 no barriers, 64 no b1 loads, 512 per-step time stamps, 1024 no qkv stores
 constexpr int DBG = MLP_DBG;
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_VMEM = 0x010, SG_DS_READ = 0x100;
@@ -67,6 +67,9 @@ struct Params {
     const float* bp;       // PROJ: [384]
     const float* gamma2;   // PROJ: LayerNorm in front of the FFN (ln2)
     const float* beta2;
+    const __bf16* Wq;      // QKV: [1152, 384] qkv projection of the NEXT layer
+    const float* bq;       // QKV: [1152]
+    __bf16* qkv;           // QKV: [M, 1152] output
     const __bf16* W1;      // [F, 384]
     const float* b1;       // [F]
     const __bf16* W2;      // [384, F]
@@ -77,7 +80,7 @@ struct Params {
     const float* beta;
     __bf16* h_out;         // [M, 384] LayerNorm(x_out)
     int M, F;
-    unsigned h_bytes, w1_bytes, w2_bytes, wp_bytes;
+    unsigned h_bytes, w1_bytes, w2_bytes, wp_bytes, wq_bytes;
     float eps;
     unsigned long long* trace;  // dev only (MLP_DBG & 512): per-step time stamps of block 0, waves 0 and 4
 };
@@ -130,11 +133,22 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// qkv slot q (step q / 3 = 12 column-block + k-step, third q % 3): rows of Wq block-wise in the image of a Wp tile; past
+// the last slot the DMA is issued out of bounds (a plain function: a value-returning lambda for this inside the kernel
+// template made the host pass drop the kernel stubs without a diagnostic)
+__device__ __forceinline__ unsigned wq_slot_offset(int q, unsigned wp_lane) {
+    const int t = q / 3;
+    return q < 108 ? (unsigned)((t / 12) * 384 + (q % 3) * 64) * (unsigned)(E * 2) + (unsigned)(32 * (t % 12) * 2) + wp_lane : OOB;
+}
+
 // PROJ = true puts the attention output projection in front:  x' = x + a Wp^T + bp ;  h = LayerNorm2(x')  and then the
 // block above on (x', h) - the 96 x 384 accumulators that end the projection ARE the residual the FFN accumulates on,
 // so x' and h never travel to HBM. The projection is 12 more steps of the phase-B kind (Wp tiles of 384 outputs x
 // 32 k = 3 ring slots) at the head of the same slot stream.
-template <bool PROJ>
+// QKV = true appends the next layer's qkv projection:  qkv = h_out Wq^T + bq  for the 96 rows, three column blocks of
+// 384 with the block's accumulators reused, 36 more steps of the phase-B kind at the tail of the slot stream; h_out then
+// goes to LDS instead of HBM (p.h_out may be NULL).
+template <bool PROJ, bool QKV>
 __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) {
     constexpr int PRE = PROJ ? 36 : 0;  // ring slots streamed before the first phase A
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -164,6 +178,8 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     const unsigned wp_lane = (unsigned)(d_line + 192 * (d_lc >> 2)) * (E * 2) + (unsigned)((d_lc & 3) << 4);
     const __amdgpu_buffer_rsrc_t wp_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(PROJ ? p.Wp : p.W1), 0, PROJ ? p.wp_bytes : p.w1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wq_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(QKV ? p.Wq : p.W1), 0, QKV ? p.wq_bytes : p.w1_bytes, 0x00020000);
 
     const int nchunks = p.F / CHUNK;
     // Every workgroup walks the hidden chunks in a different rotation: all 256 CUs stream the SAME weights, and in
@@ -195,6 +211,10 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         if (DBG & 8) return;
         const unsigned vo = (unsigned)((q % 3) * 64) * (E * 2) + (unsigned)(32 * (q / 3) * 2) + wp_lane;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rsrc, (lds_ptr_t)(ring + pos * SLOT + wv * 1024), 16, vo, 0, 0, 0);
+    };
+    auto issue_wq = [&](int q, int pos, unsigned lane_off) {
+        if (DBG & 8) return;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wq_rsrc, (lds_ptr_t)(ring + pos * SLOT + wv * 1024), 16, wq_slot_offset(q, lane_off), 0, 0, 0);
     };
     auto issue_rel = [&](int it, int g) {
         const int pos = (g + 12 + 24 + 48 + PRE) & (NSLOT - 1);  // PRE + 12 + 24 it + g, multiples of 8 dropped
@@ -496,26 +516,115 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         }
     }
 
-    // ---- LayerNorm epilogue
-    wait_dma_and_barrier<0>();  // every wave is done with the ring; reuse it for the statistics exchange
+    // ---- LayerNorm epilogue (G is out of use: its region carries the statistics exchange while the ring may already
+    // hold qkv tiles)
+    wait_dma_and_barrier<63>();
     float mean[3], rstd[3];
-    row_stats(reinterpret_cast<float*>(ring), mean, rstd);
+    row_stats(reinterpret_cast<float*>(smem + OFF_GS), mean, rstd);
+    // Everything lane-dependent below is recomputed from a laundered lane id: these addresses are loop-invariant, the
+    // compiler would hoist them above the FFN loop, and that loop has no register to spare (the same trick as in the
+    // epilogue of pp_gemm.hip).
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int e_row = lane_e & 15, e_kg = lane_e >> 4, e_rows0 = rg * 48 + e_row, e_sw = e_row & 7;
+    unsigned wq_lane = 0;
+    if (QKV) {
+        const int lc = (lane_e & 7) ^ (lane_e >> 3);
+        wq_lane = (unsigned)(wv * 8 + (lane_e >> 3) + 192 * (lc >> 2)) * (E * 2) + (unsigned)((lc & 3) << 4);
+        // the statistics exchange ended with every DMA of the FFN landed (the last ones were out-of-bounds fillers), so
+        // the ring restarts at slot 0 with the first qkv tiles; they fly under the stores below
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) issue_wq(q, q, wq_lane);
+    }
 #pragma unroll
     for (int nf = 0; nf < 6; ++nf) {
-        const int n = cg * 96 + nf * 16 + f_kg * 4;
+        const int n = cg * 96 + nf * 16 + e_kg * 4;
         const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + n), b = *reinterpret_cast<const f32x4*>(p.beta + n);
+        char* hs = smem + OFF_HS + (n >> 6) * HS_KB + e_rows0 * ROW_BYTES + (((((n & 63) >> 3)) ^ e_sw) << 4) + (e_kg & 1) * 8;
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
-            if (!valid[rf]) continue;
-            const size_t off = (size_t)(m0 + rows0 + rf * 16) * E + n;
+            const int m = m0 + e_rows0 + rf * 16;
+            const size_t off = (size_t)m * E + n;
             const f32x4 v = acc[rf][nf];
-            *reinterpret_cast<f32x4*>(p.x_out + off) = v;
             const float mu = mean[rf], rs = rstd[rf];
             const bf16x4 hv = {(__bf16)((v[0] - mu) * rs * g[0] + b[0]), (__bf16)((v[1] - mu) * rs * g[1] + b[1]),
                                (__bf16)((v[2] - mu) * rs * g[2] + b[2]), (__bf16)((v[3] - mu) * rs * g[3] + b[3])};
-            *reinterpret_cast<bf16x4*>(p.h_out + off) = hv;
+            if (QKV) *reinterpret_cast<bf16x4*>(hs + rf * 16 * ROW_BYTES) = hv;  // the row operand of the qkv steps
+            if (m >= p.M) continue;
+            *reinterpret_cast<f32x4*>(p.x_out + off) = v;
+            if (p.h_out) *reinterpret_cast<bf16x4*>(p.h_out + off) = hv;
         }
     }
+    if (!QKV) {
+        wait_dma_and_barrier<0>();  // the out-of-bounds DMAs past the last chunk must not outlive the workgroup
+        return;
+    }
+
+    // ================= qkv of the next layer: three column blocks x twelve k-steps, accumulators reused per block.
+    // Global stores share vmcnt with the DMA stream and may retire out of order with it, so the step after any store
+    // waits for everything (vmcnt 0) before the counted waits resume.
+    wait_dma_and_barrier<0>();
+    constexpr int QBASE = -PRE;  // ring position of qkv slot q is q & 7
+    read_Bw(QBASE, 0, wb[0]);
+    read_rows(OFF_HS, 0, gb[0]);
+    for (int cb = 0; cb < 3; ++cb) {  // column block: q, k, v
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 6; ++nf) acc[rf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {  // (unrolled: the fragment buffers must be indexed statically)
+            const int cur = j & 1, t = cb * 12 + j;
+            if (j == 0) wait_dma_and_barrier<0>();
+            else wait_dma_and_barrier<NSLOT - 3 - 3>();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) issue_wq(3 * t + NSLOT + i, (3 * t + NSLOT + i) & (NSLOT - 1), wq_lane);
+            read_Bw(QBASE, t + 1, wb[cur ^ 1]);  // (past the last step: a harmless read of the zero filler)
+            read_rows(OFF_HS, (j + 1) % 12, gb[cur ^ 1]);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 6; ++nf) {
+                    if (!(DBG & 4)) acc[rf][nf] = mma(wb[cur][nf], gb[cur][rf], acc[rf][nf]);
+                }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { SGB(SG_MFMA, 2); SGB(SG_DS_READ, 1); if (i == 0 || i == 3 || i == 6) SGB(SG_VMEM, 1); }
+        }
+        // Output block (96 rows x 384 columns, bf16) in three passes of 128 columns through the G region (96 rows x
+        // 256 B, 16-byte chunks XOR-swizzled by row & 7), so that every row leaves as 256 contiguous bytes: stored
+        // straight from the accumulator layout (8 bytes per lane, 32-byte runs) the same data takes twice as long.
+        __builtin_amdgcn_sched_barrier(0);
+        char* gst = smem + OFF_GS;
+#pragma unroll
+        for (int ps = 0; ps < 3; ++ps) {
+#pragma unroll
+            for (int nf = 0; nf < 6; ++nf) {
+                const int col = cg * 96 + nf * 16;  // first column of this fragment inside the block (wave-uniform)
+                if ((col >> 7) != ps) continue;
+                const int n = col + e_kg * 4;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bq + cb * 384 + n);
+                const int byte = (n & 127) * 2;
+#pragma unroll
+                for (int rf = 0; rf < 3; ++rf) {
+                    const f32x4 v = acc[rf][nf] + bv;
+                    const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    const int row = e_rows0 + rf * 16;
+                    *reinterpret_cast<bf16x4*>(gst + row * 256 + ((((byte >> 4) ^ (row & 7)) << 4) | (byte & 15))) = ov;
+                }
+            }
+            wait_dma_and_barrier<63>();  // LDS only: the DMA of the next tiles stays in flight
+#pragma unroll
+            for (int r0 = 0; r0 < BM; r0 += THREADS / 16) {
+                const int row = r0 + (tid >> 4), ch = tid & 15;  // (tid is lane-dependent: fine, used only here)
+                const int m = m0 + row;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(gst + row * 256 + ((ch ^ (row & 7)) << 4));
+                if (m < p.M && !(DBG & 1024))
+                    *reinterpret_cast<u32x4*>(p.qkv + (size_t)m * (3 * E) + cb * 384 + ps * 128 + ch * 8) = raw;
+            }
+            wait_dma_and_barrier<63>();  // the staging rows are rewritten by the next pass
+        }
+    }
+    wait_dma_and_barrier<0>();  // the out-of-bounds DMAs past the last tile must not outlive the workgroup
 }
 
 unsigned long long* g_trace = nullptr;
@@ -528,8 +637,11 @@ extern "C" void pp_mlp_set_trace(void* buf) { pp::mlp::g_trace = reinterpret_cas
 
 namespace pp {
 namespace mlp {
-static int launch(const Params& p, bool proj, hipStream_t stream) {
-    auto kern = proj ? mlp_res_ln_kernel<true> : mlp_res_ln_kernel<false>;
+static int launch(const Params& p, bool proj, bool qkv, hipStream_t stream) {
+    typedef void (*kern_t)(const Params);
+    kern_t kern = static_cast<kern_t>(mlp_res_ln_kernel<false, false>);
+    if (proj && qkv) kern = static_cast<kern_t>(mlp_res_ln_kernel<true, true>);
+    else if (proj) kern = static_cast<kern_t>(mlp_res_ln_kernel<true, false>);
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     hipLaunchKernelGGL(kern, dim3((p.M + BM - 1) / BM), dim3(THREADS), LDS, stream, p);
     PP_LAUNCH_CHECK();
@@ -567,17 +679,20 @@ extern "C" int pp_mlp_residual_layernorm(const void* h_in, const void* w1, const
     p.w2_bytes = (unsigned)((size_t)E * F * 2);
     p.eps = eps;
     p.trace = mlp::g_trace;
-    return mlp::launch(p, false, reinterpret_cast<hipStream_t>(stream));
+    return mlp::launch(p, false, false, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pp_proj_mlp_residual_layernorm(const void* attn, const void* wp, const float* bp, const float* residual,
                                               const float* gamma2, const float* beta2, const void* w1, const float* b1,
                                               const void* w2, const float* b2, float* x_out, const float* gamma,
-                                              const float* beta, float eps, void* h_out, int M, int E, int F,
-                                              void* stream) {
+                                              const float* beta, float eps, void* h_out, const void* wqkv,
+                                              const float* bqkv, void* qkv_out, int M, int E, int F, void* stream) {
     using namespace pp;
-    PP_REQUIRE(attn && wp && bp && residual && gamma2 && beta2 && w1 && b1 && w2 && b2 && x_out && gamma && beta && h_out,
+    PP_REQUIRE(attn && wp && bp && residual && gamma2 && beta2 && w1 && b1 && w2 && b2 && x_out && gamma && beta,
                PP_ERR_INVALID_ARG, "pp_proj_mlp_residual_layernorm: NULL argument");
+    const bool qkv = wqkv != nullptr;
+    PP_REQUIRE(qkv ? (bqkv && qkv_out) : (h_out != nullptr), PP_ERR_INVALID_ARG,
+               "pp_proj_mlp_residual_layernorm: needs h_out, or wqkv + bqkv + qkv_out");
     PP_REQUIRE(E == mlp::E, PP_ERR_UNSUPPORTED, "pp_proj_mlp_residual_layernorm: built for embed dim 384 (ViT-S)");
     PP_REQUIRE(M > 0 && F > 0 && F % mlp::CHUNK == 0, PP_ERR_UNSUPPORTED,
                "pp_proj_mlp_residual_layernorm: hidden width must be a positive multiple of 128");
@@ -604,7 +719,11 @@ extern "C" int pp_proj_mlp_residual_layernorm(const void* attn, const void* wp, 
     p.w1_bytes = (unsigned)((size_t)F * E * 2);
     p.w2_bytes = (unsigned)((size_t)E * F * 2);
     p.wp_bytes = (unsigned)((size_t)E * E * 2);
+    p.Wq = reinterpret_cast<const __bf16*>(wqkv);
+    p.bq = bqkv;
+    p.qkv = reinterpret_cast<__bf16*>(qkv_out);
+    p.wq_bytes = (unsigned)((size_t)3 * E * E * 2);
     p.eps = eps;
     p.trace = mlp::g_trace;
-    return mlp::launch(p, true, reinterpret_cast<hipStream_t>(stream));
+    return mlp::launch(p, true, qkv, reinterpret_cast<hipStream_t>(stream));
 }

@@ -74,6 +74,7 @@ class ProbPoseEngine:
         self._graphs: Dict[tuple, tuple] = {}
         self.fuse_mlp = os.environ.get("PP_FUSE_MLP", "1") != "0"
         self.fuse_proj = os.environ.get("PP_FUSE_PROJ", "1") != "0"
+        self.fuse_qkv = os.environ.get("PP_FUSE_QKV", "1") != "0"
         self.profile: Optional[Dict[str, list]] = None
         # tower pooling schedule (probmap_head.py:264) and the spatial sizes it produces
         self.pools = ((4, 3), (2, 2), (2, 2))
@@ -170,8 +171,11 @@ class ProbPoseEngine:
 
         res_ln(ws["patches"], w["patch_w"], w["patch_b"], Kp, w["l0.ln1.w"], w["l0.ln1.b"], ws["h"],
                residual=w["pos_embed"], res_mod=self.Np)
+        qkv_done = False  # the fused layer kernel has already produced this layer's qkv
         for i in range(L):
-            self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], ws["qkv"], M, 3 * E, E)
+            if not qkv_done:
+                self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], ws["qkv"], M, 3 * E, E)
+            qkv_done = False
             self._call("attention", "pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), B * passes,
                        self.Np, self.heads, self.hd, scale, st)
             last = i + 1 == L
@@ -181,11 +185,16 @@ class ProbPoseEngine:
             if fuse_ffn and self.fuse_proj:
                 # second half of the layer in one kernel: projection + residual, ln2, FFN + residual, next LayerNorm;
                 # the intermediate residual stream and ln2 output stay on the CU
+                # ... and, except after the last layer, the next layer's qkv Linear on that LayerNorm output
+                nq = None if (last or not self.fuse_qkv) else (w[f"l{i + 1}.qkv.w"], w[f"l{i + 1}.qkv.b"])
                 self._call("proj_mlp_res_ln", "pp_proj_mlp_residual_layernorm", ws["h"].data_ptr(),
                            w[f"l{i}.proj.w"].data_ptr(), w[f"l{i}.proj.b"].data_ptr(), ws["x"].data_ptr(),
                            w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(), w[f"l{i}.fc1.w"].data_ptr(),
                            w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.w"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(),
-                           ws["x"].data_ptr(), gn.data_ptr(), bn.data_ptr(), self.ln_eps, h_next.data_ptr(), M, E, Fd, st)
+                           ws["x"].data_ptr(), gn.data_ptr(), bn.data_ptr(), self.ln_eps,
+                           None if nq else h_next.data_ptr(), nq[0].data_ptr() if nq else None,
+                           nq[1].data_ptr() if nq else None, ws["qkv"].data_ptr() if nq else None, M, E, Fd, st)
+                qkv_done = nq is not None
                 continue
             res_ln(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])
             if fuse_ffn:

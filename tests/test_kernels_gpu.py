@@ -341,15 +341,17 @@ def test_fused_mlp_residual_layernorm(M):
     torch.testing.assert_close(hd.cpu().double(), href, rtol=3e-2, atol=3e-2)
 
 
-@pytest.mark.parametrize("M", [96, 480])
-def test_fused_proj_mlp_residual_layernorm(M):
-    """Second half of a ViT layer in one launch: x1 = x + a Wp^T + bp; h = LN2(x1); x2 = x1 + FFN(h); h' = LN(x2).
-    Reference in fp64 on the bf16-rounded operands, with h and the hidden activation rounded to bf16 as the kernel does."""
+@pytest.mark.parametrize("M,with_qkv", [(96, False), (480, False), (96, True), (480, True)])
+def test_fused_proj_mlp_residual_layernorm(M, with_qkv):
+    """Second half of a ViT layer in one launch: x1 = x + a Wp^T + bp; h = LN2(x1); x2 = x1 + FFN(h); h' = LN(x2),
+    optionally followed by the next layer's qkv = h' Wq^T + bq. Reference in fp64 on the bf16-rounded operands, with h,
+    h' and the hidden activation rounded to bf16 as the kernel does."""
     L = _lib()
     E, Fd = 384, 1536
     a, wp, bp = _rand(M, E, seed=61), _rand(E, E, seed=62, scale=1 / math.sqrt(E)), _rand(E, seed=63, scale=0.3)
     w1, b1 = _rand(Fd, E, seed=64, scale=1 / math.sqrt(E)), _rand(Fd, seed=65, scale=0.3)
     w2, b2 = _rand(E, Fd, seed=66, scale=1 / math.sqrt(Fd)), _rand(E, seed=67, scale=0.3)
+    wq, bq = _rand(3 * E, E, seed=73, scale=1 / math.sqrt(E)), _rand(3 * E, seed=74, scale=0.3)
     x0 = _rand(M, E, seed=68, scale=2.0)
     g2, be2 = 1 + 0.1 * _rand(E, seed=69), _rand(E, seed=70)
     g, be = 1 + 0.1 * _rand(E, seed=71), _rand(E, seed=72)
@@ -358,12 +360,18 @@ def test_fused_proj_mlp_residual_layernorm(M):
     hid = F.gelu(_q(h.float(), BF16) @ _q(w1, BF16).t() + b1.double())
     xref = x1 + _q(hid.float(), BF16) @ _q(w2, BF16).t() + b2.double()
     href = F.layer_norm(xref, (E,), g.double(), be.double(), 1e-6)
+    qref = _q(href.float(), BF16) @ _q(wq, BF16).t() + bq.double()
     ad, wpd, w1d, w2d = a.bfloat16().cuda(), wp.bfloat16().cuda(), w1.bfloat16().cuda(), w2.bfloat16().cuda()
+    wqd, bqd = wq.bfloat16().cuda(), bq.cuda()
     bpd, b1d, b2d, g2d, be2d, gd, bed = bp.cuda(), b1.cuda(), b2.cuda(), g2.cuda(), be2.cuda(), g.cuda(), be.cuda()
     x = x0.clone().cuda()
     hout = torch.empty(M, E, dtype=torch.bfloat16, device="cuda")
+    qout = torch.full((M, 3 * E), float("nan"), dtype=torch.bfloat16, device="cuda")
     L.call("pp_proj_mlp_residual_layernorm", ad.data_ptr(), wpd.data_ptr(), bpd.data_ptr(), x.data_ptr(), g2d.data_ptr(),
            be2d.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), x.data_ptr(), gd.data_ptr(),
-           bed.data_ptr(), 1e-6, hout.data_ptr(), M, E, Fd, None)
+           bed.data_ptr(), 1e-6, hout.data_ptr(), wqd.data_ptr() if with_qkv else None, bqd.data_ptr() if with_qkv else None,
+           qout.data_ptr() if with_qkv else None, M, E, Fd, None)
     torch.testing.assert_close(x.cpu().double(), xref, rtol=2e-2, atol=3e-2)
     torch.testing.assert_close(hout.cpu().double(), href, rtol=3e-2, atol=3e-2)
+    if with_qkv:
+        torch.testing.assert_close(qout.cpu().double(), qref, rtol=3e-2, atol=6e-2)
