@@ -218,6 +218,17 @@ int pp_tower_final(const void* feat, int feat_bf16, const float* w, const float*
                    const int32_t* flip_indices, float* out, int B, int passes, int C, int K, float err_div,
                    void* stream);
 
+/* Ex-OKS similarity of one (image, category) cell (COCOeval.computeExtendedOks,
+ * mmpose/evaluation/metrics/_cocoeval.py:540-707, iouType "keypoints"; window from fix_bbox_aspect_ratio,
+ * mmpose/structures/keypoint/keypoints_min_padding.py:68-133). float64 device arrays: gt_kpts (G, K, 3) = x, y, v with
+ * v = 3 for keypoints outside the activation window; gt_bbox (G, 4) xywh; gt_area (G); dt_kpts (D, K, 3) = x, y, presence
+ * probability, ALREADY in evaluation order (stable descending score, at most maxDets = 20); sigmas (K);
+ * gt_visibilities (n_vis) int32 = the visibility value of levels 1..n_vis (level 0 is v > 0).
+ * confidence_thr = NaN stands for the reference's None. out (n_vis + 1, D, G) float64. */
+int pp_extended_oks(const double* gt_kpts, const double* gt_bbox, const double* gt_area, const double* dt_kpts,
+                    const double* sigmas, const int* gt_visibilities, int G, int D, int K, int n_vis,
+                    double confidence_thr, double padding, int use_area, int original, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,10 @@ Pinning status (DESIGN.md §Oracle has the full table):
   ``mmpose/codecs/probmap.py:170-220``, ``mmpose/models/utils/tta.py:35-39``) -- PINNED:
   checked bit-for-bit against outputs of the reference's own functions imported in
   isolation in the build container (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``).
+* Ex-OKS similarity (``exoks_ref``; reference ``mmpose/evaluation/metrics/_cocoeval.py:540-707``,
+  ``mmpose/structures/keypoint/keypoints_min_padding.py:68-133``) -- PINNED: 60 synthetic cells scored by the
+  reference's own ``COCOeval.computeExtendedOks`` (``tests/golden/make_golden_exoks.py`` ->
+  ``tests/golden/exoks_cases.npz``, ``exoks_chain.npz``), matched to 1e-12.
 * Sparsemax (PyPI ``sparsemax``, un-vendored, unpinned in ``requirements/build.txt:4``),
   ViT backbone (``mmpretrain==1.2.0`` ``VisionTransformer``, un-vendored), ``ProbMapHead``
   network (needs mmcv/mmengine, not importable) -- PARITY UNPINNED: restated from the

@@ -83,3 +83,25 @@ def load_reference():
     ns.tta = _load("_ref_tta", "mmpose/models/utils/tta.py")
     ns.KEYPOINT_CODECS = reg.KEYPOINT_CODECS
     return ns
+
+
+def load_reference_eval():
+    """The reference's Ex-OKS evaluator (mmpose/evaluation/metrics/_cocoeval.py) and its bbox helper, behind stubs for
+    ``xtcocotools._mask`` (mask IoU only) and the ``mmpose.structures.keypoint`` package (re-exports the real
+    ``fix_bbox_aspect_ratio``). Returns a namespace with ``COCOeval`` and ``fix_bbox_aspect_ratio``."""
+    if not os.path.isdir(REF):
+        raise RuntimeError(f"reference tree not found at {REF}")
+    if "mmpose" not in sys.modules:
+        _shell("mmpose", os.path.join(REF, "mmpose"))
+    _shell("mmpose.structures")
+    kp = _shell("mmpose.structures.keypoint")
+    minpad = _load("_ref_keypoints_min_padding", "mmpose/structures/keypoint/keypoints_min_padding.py")
+    kp.fix_bbox_aspect_ratio = minpad.fix_bbox_aspect_ratio
+    _shell("mmpose.evaluation")
+    _shell("mmpose.evaluation.metrics", os.path.join(REF, "mmpose/evaluation/metrics"))
+    _shell("mmpose.evaluation.metrics._mask")
+    ce = _load("mmpose.evaluation.metrics._cocoeval", "mmpose/evaluation/metrics/_cocoeval.py")
+    ns = types.SimpleNamespace()
+    ns.COCOeval = ce.COCOeval
+    ns.fix_bbox_aspect_ratio = minpad.fix_bbox_aspect_ratio
+    return ns
