@@ -2,9 +2,9 @@
 already-cropped inputs into the ``{inputs, data_samples}`` batch that ``model.test_step`` consumes
 (what ``inference_topdown`` :133-200 builds through the val pipeline + ``pseudo_collate``).
 
-The crop pipeline itself (LoadImage / GetBBoxCenterScale / TopdownAffine with cv2.warpAffine) is the
-"next" row of SURVEY.md 8f and not part of this round: callers hand over 256x192 uint8 crops plus the
-``input_center`` / ``input_scale`` that ``TopdownAffine`` recorded for them.
+``inference_topdown`` (:133-200) runs the val pipeline of the config on the device: GetBBoxCenterScale and the
+TopdownAffine box arithmetic on the host (``transforms.py``), the image warp as one HIP launch for all boxes
+(``pp_warp_affine_u8``), then ``test_step``. Callers that already hold 256x192 uint8 crops use ``pack_crops``.
 """
 from typing import Optional, Sequence, Union
 
@@ -15,6 +15,7 @@ from .config import Config
 from .pose_estimators import build_pose_estimator
 from .structures import InstanceData, PoseDataSample
 from .synthetic import COCO_FLIP_INDICES
+from . import transforms as T
 
 
 def coco_dataset_meta() -> dict:
@@ -74,3 +75,36 @@ def pack_crops(crops_u8: torch.Tensor, input_center: np.ndarray, input_scale: np
         ))
         samples.append(ds)
     return dict(inputs=[crops_u8[b] for b in range(B)], data_samples=samples)
+
+
+def inference_topdown(model, img: Union[np.ndarray, torch.Tensor], bboxes=None, bbox_format: str = "xyxy"):
+    """apis/inference.py:133-200 for an image already in memory: ``img`` is (H, W, 3) uint8 BGR (what LoadImage /
+    cv2.imread produce), host array or device tensor; ``bboxes`` (N, 4) in ``bbox_format``, None or empty = the whole
+    image as one box. Returns list[PoseDataSample], one per box, keypoints in image coordinates."""
+    if isinstance(img, str):
+        raise TypeError("inference_topdown: image decoding is not part of this package - pass the loaded (H, W, 3) uint8 array")
+    h, w = img.shape[:2]
+    if bboxes is None or len(bboxes) == 0:
+        bboxes = np.array([[0, 0, w, h]], dtype=np.float32)
+    else:
+        bboxes = np.array(bboxes) if isinstance(bboxes, list) else np.asarray(bboxes)
+        assert bbox_format in {"xyxy", "xywh"}, f'Invalid bbox_format "{bbox_format}".'
+        if bbox_format == "xywh":
+            bboxes = T.bbox_xywh2xyxy(bboxes)
+    bboxes = np.asarray(bboxes, np.float32)[:, :4]
+    input_size = tuple(model.head.decoder.input_size)  # (w, h)
+    pipeline = model.cfg.get("val_pipeline", None) if hasattr(model, "cfg") else None
+    pad = 1.25
+    if pipeline:
+        for t in pipeline:
+            if t.get("type") == "TopdownAffine":
+                pad = float(t.get("input_padding", pad))
+    centers, scales, mats = T.topdown_affine_params(bboxes, input_size, input_padding=pad)
+    dev = next(model.parameters()).device
+    img_t = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
+    crops = T.warp_affine_crops(img_t.to(dev), mats, input_size)
+    batch = pack_crops(crops, centers, scales, model.dataset_meta, bboxes=bboxes)
+    for ds in batch["data_samples"]:
+        ds.set_metainfo(dict(ori_shape=(h, w), img_shape=(h, w)))
+    with torch.no_grad():
+        return model.test_step(batch)

@@ -105,3 +105,11 @@ def load_reference_eval():
     ns.COCOeval = ce.COCOeval
     ns.fix_bbox_aspect_ratio = minpad.fix_bbox_aspect_ratio
     return ns
+
+
+def load_reference_bbox():
+    """mmpose/structures/bbox/transforms.py behind the empty ``cv2`` stub (cv2 is only used by get_warp_matrix's
+    callers, not by the functions the fixtures need)."""
+    if "cv2" not in sys.modules:
+        _shell("cv2")
+    return _load("_ref_bbox_transforms", "mmpose/structures/bbox/transforms.py")

@@ -1,0 +1,106 @@
+"""Crop pipeline in front of the hot path: box arithmetic against the reference's own outputs
+(CPU), the HIP warp against the oracle restatement of cv2.warpAffine (GPU, bit-exact; the oracle itself is unpinned - no
+cv2 here), inference_topdown end to end."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "warp_boxes.npz"))
+
+
+def test_box_arithmetic_matches_reference_outputs():
+    from probpose_code_amd import transforms as T
+
+    assert np.array_equal(T.bbox_xywh2xyxy(G["boxes_xywh"]), G["xywh2xyxy"])
+    for pad in (1.0, 1.25):
+        c, s = T.bbox_xyxy2cs(G["boxes_xyxy"], padding=pad)
+        assert np.array_equal(c, G[f"center_p{pad}"]) and np.array_equal(s, G[f"scale_p{pad}"])
+    c, s = T.bbox_xyxy2cs(G["boxes_xyxy"], padding=1.25)
+    fixed = T.fix_aspect_ratio(s, aspect_ratio=192 / 256)
+    assert np.allclose(fixed, G["fixed_scale"], rtol=0, atol=0)
+    for i in range(len(c)):
+        m = T.get_udp_warp_matrix(c[i], G["fixed_scale"][i], float(G["rot"][i]), (192, 256))
+        assert m.dtype == np.float32 and np.array_equal(m, G["udp_mats"][i]), i
+
+
+def test_udp_warp_maps_box_corners_onto_the_input_grid():
+    """UDP: the padded, aspect-fixed box maps onto [0, w-1] x [0, h-1] exactly."""
+    from probpose_code_amd import transforms as T
+
+    c, s, mats = T.topdown_affine_params(G["boxes_xyxy"][:5], (192, 256))
+    for i in range(5):
+        tl = mats[i] @ np.array([c[i, 0] - s[i, 0] / 2, c[i, 1] - s[i, 1] / 2, 1.0])
+        br = mats[i] @ np.array([c[i, 0] + s[i, 0] / 2, c[i, 1] + s[i, 1] / 2, 1.0])
+        assert np.allclose(tl, [0, 0], atol=2e-3) and np.allclose(br, [191, 255], atol=2e-3)
+        assert np.allclose(T.invert_affine(mats[i]) @ np.append(mats[i] @ np.array([10.0, 20.0, 1.0]), 1.0), [10, 20], atol=1e-3)
+
+
+def test_oracle_warp_identity_and_shift():
+    """Known answers for the restated cv2 arithmetic: identity copies, an integer shift moves and zero-fills, a half-pixel
+    shift averages neighbours with round-half-up."""
+    from oracle import warp_ref
+
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    eye = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
+    assert np.array_equal(warp_ref.warp_affine_u8(img, eye, (30, 20)), img)
+    sh = warp_ref.warp_affine_u8(img, np.array([[1, 0, 3], [0, 1, 2]], np.float32), (30, 20))
+    assert np.array_equal(sh[2:, 3:], img[:-2, :-3]) and not sh[:2].any() and not sh[:, :3].any()
+    half = warp_ref.warp_affine_u8(img, np.array([[1, 0, 0.5], [0, 1, 0]], np.float32), (30, 20))
+    exp = (img[:, :-1].astype(np.int64) * 16384 + img[:, 1:].astype(np.int64) * 16384 + 16384) >> 15
+    assert np.array_equal(half[:, 1:], exp.astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_hip_warp_bit_exact_vs_oracle():
+    import torch
+
+    from oracle import warp_ref
+    from probpose_code_amd import transforms as T
+
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    boxes = np.array([[0, 0, 640, 480], [100.3, 50.7, 220.9, 400.2], [-30, -20, 90, 200], [500, 300, 700, 520], [300, 200, 310, 215]],
+                     np.float32)
+    c, s, mats = T.topdown_affine_params(boxes, (192, 256))
+    mats[2] = T.get_udp_warp_matrix(c[2], s[2], 25.0, (192, 256))  # one rotated box
+    crops = T.warp_affine_crops(torch.from_numpy(img).cuda(), mats, (192, 256)).cpu().numpy()
+    assert crops.shape == (5, 3, 256, 192) and crops.dtype == np.uint8
+    for i in range(5):
+        ref = warp_ref.warp_affine_u8(img, mats[i], (192, 256)).transpose(2, 0, 1)
+        assert np.array_equal(crops[i], ref), i
+
+
+@pytest.mark.gpu
+def test_inference_topdown_end_to_end():
+    """image + boxes -> PoseDataSamples; equals pack_crops + test_step on the same crops; keypoints land inside the
+    padded box in image coordinates; default box = whole image."""
+    import torch
+
+    from probpose_code_amd import apis, synthetic as S
+    from probpose_code_amd import transforms as T
+
+    cfg = os.path.join(os.path.dirname(HERE), "configs", "td-pm_ProbPose-small_mi355x_coco-256x192.py")
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
+    model = apis.init_model(cfg, dict(state_dict=sd), device="cuda:0", cfg_options={"model.precision": "f32"})
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    boxes = np.array([[100, 50, 220, 400], [300, 100, 520, 460], [10, 10, 60, 90]], np.float32)
+    res = apis.inference_topdown(model, img, boxes)
+    assert len(res) == 3
+    c, s, mats = T.topdown_affine_params(boxes, (192, 256))
+    crops = T.warp_affine_crops(torch.from_numpy(img).cuda(), mats, (192, 256))
+    ref = model.test_step(apis.pack_crops(crops, c, s, model.dataset_meta, bboxes=boxes))
+    for i in range(3):
+        kp = res[i].pred_instances.keypoints
+        assert kp.shape == (1, 17, 2) and np.array_equal(kp, ref[i].pred_instances.keypoints)
+        assert np.allclose(res[i].pred_instances.bboxes, boxes[i][None])
+        lo, hi = c[i] - 0.5 * s[i] - 1, c[i] + 0.5 * s[i] + 1
+        assert (kp[0] >= lo).all() and (kp[0] <= hi).all()
+    whole = apis.inference_topdown(model, img)
+    assert len(whole) == 1 and np.allclose(whole[0].pred_instances.bboxes, [[0, 0, 640, 480]])
+    xywh = apis.inference_topdown(model, img, np.array([[100, 50, 120, 350]], np.float32), bbox_format="xywh")
+    # (not bit-identical: the residual GEMM rotates its K order per workgroup, so the last bit depends on the batch position)
+    assert np.allclose(xywh[0].pred_instances.keypoints, res[0].pred_instances.keypoints, atol=1e-3)
