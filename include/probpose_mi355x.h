@@ -209,6 +209,17 @@ int pp_layernorm(const float* x, const float* gamma, const float* beta, void* y,
 int pp_maxpool_relu_nhwc(const void* in, int in_bf16, void* out, int out_bf16, int N, int H, int W, int C,
                          int ph, int pw, void* stream);
 
+/* Split-K form of the towers' 3x3 convolution for stages with few output pixels: the nine taps are cut into ksplit
+ * (1, 3 or 9) slices, every (slice, group) pair is its own set of output tiles, and the fp32 partial sums go to
+ * partials (ksplit, groups, B*H*W, Cout) WITHOUT bias. Weight layout as PP_CONV3X3 of pp_conv_gemm. Followed by
+ * pp_sum_maxpool_relu_nhwc, which reduces the slices, adds the (folded BatchNorm) bias, pools and applies ReLU
+ * (probmap_head.py:261-294). */
+int pp_conv3x3_splitk(int prec, const void* act_nhwc, const void* weight, float* partials, int B, int H, int W, int Cin,
+                      int Cout, int groups, long long stride_act_g, long long stride_w_g, int ksplit, void* stream);
+int pp_sum_maxpool_relu_nhwc(const float* partials, int nsplit, long long split_stride, const float* bias,
+                             int images_per_group, void* out, int out_bf16, int N, int H, int W, int C, int ph, int pw,
+                             void* stream);
+
 /* Last layer of the four scalar towers (Conv1x1 -> Sigmoid; ReLU for the error tower,
  * probmap_head.py:280-290,405) on the 1x1 pooled feature, fused with the flip-test average of the
  * scalars (probmap_head.py:766-774). feat: (4, passes * B, C); w: (4, K, C) fp32; bias: (4, K);

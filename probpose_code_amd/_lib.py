@@ -66,6 +66,8 @@ SIGNATURES = {
     "pp_mlp_residual_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, _P]),
     "pp_proj_mlp_residual_layernorm": (
         c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "pp_conv3x3_splitk": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_int, _P]),
+    "pp_sum_maxpool_relu_nhwc": (c_int, [_P, c_int, c_longlong, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pp_warp_affine_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "pp_extended_oks": (
         c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int, _P, _P]),

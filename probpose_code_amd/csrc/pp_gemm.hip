@@ -112,13 +112,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
     const unsigned d_chunk_bytes = (unsigned)(((lane & 7) ^ d_row) << 4);
     StageRows sr;
     int st_py = p.py, st_px = p.px;  // deconv phase of the tile being staged (all-phases launch: group index)
+    int st_tap0 = 0;                 // split-K conv: first tap of the K slice being staged
+    const int problems = p.ksplit > 1 ? p.groups / p.ksplit : p.groups;
     auto setup_stage = [&](int z, int m0, int n0) {
         if (GATHER == G_DECONV && p.py < 0) {
             st_py = z >> 1;
             st_px = z & 1;
         }
-        const char* Act = reinterpret_cast<const char*>(p.A) + (size_t)z * p.strideA_z * ESZ;
-        const char* Wt = reinterpret_cast<const char*>(p.W) + (size_t)z * p.strideW_z * ESZ;
+        const int zp = p.ksplit > 1 ? z % problems : z, zs = p.ksplit > 1 ? z / problems : 0;
+        if (GATHER != G_LINEAR) st_tap0 = zs * (p.K / p.Cin);
+        const char* Act = reinterpret_cast<const char*>(p.A) + (size_t)zp * p.strideA_z * ESZ;
+        const char* Wt = reinterpret_cast<const char*>(p.W) + ((size_t)zp * p.strideW_z + (size_t)zs * p.K) * ESZ;
         sr.a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Act), 0, p.a_bytes, 0x00020000);
         sr.w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wt), 0, p.w_bytes, 0x00020000);
 #pragma unroll
@@ -144,8 +148,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
         char* adst = wdst + TILE_BYTES;
         int dy = 0, dx = 0, c0 = k0;
         if (GATHER != G_LINEAR) {
-            const int tap = k0 / p.Cin;
-            c0 = k0 - tap * p.Cin;
+            const int tap_local = k0 / p.Cin;
+            const int tap = st_tap0 + tap_local;
+            c0 = k0 - tap_local * p.Cin;
             if (GATHER == G_CONV3) {  // 3x3, pad 1: tap = ky*3 + kx reads (y + ky - 1, x + kx - 1)
                 dy = tap / 3 - 1;
                 dx = tap - (tap / 3) * 3 - 1;
@@ -389,6 +394,8 @@ static int launch_gemm(const GemmParams& p_in, int groups, hipStream_t s) {
     static const int dbg = getenv("PP_GEMM_DBG") ? atoi(getenv("PP_GEMM_DBG")) : 0;
     p.dbg = dbg;
     p.groups = groups;
+    if (p.ksplit < 1) p.ksplit = 1;
+    PP_REQUIRE(groups % p.ksplit == 0, PP_ERR_INVALID_ARG, "pp gemm: groups must be a multiple of ksplit");
     constexpr int BK = Prec<T>::BK;
     PP_REQUIRE(p.K > 0 && p.K % BK == 0, PP_ERR_UNSUPPORTED, "pp gemm: K must be a positive multiple of the K-tile");
     PP_REQUIRE(p.M > 0 && p.N > 0, PP_ERR_INVALID_ARG, "pp gemm: M and N must be positive");
@@ -483,4 +490,27 @@ extern "C" int pp_conv_gemm(int prec, int kind, const void* act_nhwc, const void
     static const bool use_panel = !(getenv("PP_PANEL") && atoi(getenv("PP_PANEL")) == 0);  // dev switch for A/B timing
     if (use_panel && panel_gemm_supported(p, prec, groups)) return panel_gemm(p, groups, reinterpret_cast<hipStream_t>(stream));
     return gemm(p, prec, groups, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pp_conv3x3_splitk(int prec, const void* act_nhwc, const void* weight, float* partials, int B, int H, int W,
+                                 int Cin, int Cout, int groups, long long stride_act_g, long long stride_w_g, int ksplit,
+                                 void* stream) {
+    using namespace pp;
+    PP_REQUIRE(act_nhwc && weight && partials, PP_ERR_INVALID_ARG, "pp_conv3x3_splitk: NULL argument");
+    PP_REQUIRE(groups >= 1 && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PP_ERR_INVALID_ARG, "pp_conv3x3_splitk: bad shape");
+    PP_REQUIRE(ksplit == 1 || ksplit == 3 || ksplit == 9, PP_ERR_UNSUPPORTED, "pp_conv3x3_splitk: ksplit must be 1, 3 or 9 (whole taps)");
+    GemmParams p{};
+    p.A = act_nhwc; p.W = weight; p.C = partials; p.bias = nullptr; p.residual = nullptr;
+    p.M = B * H * W; p.N = Cout;
+    p.K = 9 * Cin / ksplit;
+    p.lda = Cin; p.ldw = 9 * Cin; p.ldc = Cout;
+    p.H = H; p.Wd = W; p.Cin = Cin;
+    p.act = ACT_NONE; p.out_bf16 = 0; p.gather = G_CONV3; p.ldres = Cout;
+    p.ksplit = ksplit;
+    const size_t esz = prec == PP_PREC_BF16 ? 2 : 4;
+    const size_t ab = (size_t)B * H * W * Cin * esz, wb = (size_t)Cout * 9 * Cin * esz;
+    PP_REQUIRE(ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_conv3x3_splitk: operands must be smaller than 2 GiB");
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    p.strideA_z = stride_act_g; p.strideW_z = stride_w_g; p.strideC_z = (long long)p.M * Cout; p.strideBias_z = 0;
+    return gemm(p, prec, groups * ksplit, reinterpret_cast<hipStream_t>(stream));
 }

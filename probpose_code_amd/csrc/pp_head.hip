@@ -46,6 +46,39 @@ __global__ __launch_bounds__(256) void maxpool_relu_kernel(const TI* __restrict_
     store4(out + (((size_t)n * Ho + yo) * Wo + xo) * C + c, m);
 }
 
+// The same pooling on split-K partial sums: in = sum over `nsplit` fp32 slices (slice stride `split_stride` elements)
+// + bias[n / images_per_group][c]; the 3x3 convolutions of the later tower stages have so few output rows that one
+// workgroup per output tile leaves most of the chip idle, so their K loop is cut in three (pp_conv3x3_splitk) and the
+// reduction is folded in here.
+template <typename TO>
+__global__ __launch_bounds__(256) void sum_maxpool_relu_kernel(const float* __restrict__ in, int nsplit, long long split_stride,
+                                                               const float* __restrict__ bias, int images_per_group,
+                                                               TO* __restrict__ out, int N, int H, int W, int C, int ph,
+                                                               int pw) {
+    const int Ho = H / ph, Wo = W / pw, C4 = C / 4;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)N * Ho * Wo * C4) return;
+    const int c = (int)(gid % C4) * 4;
+    long long r = gid / C4;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    f32x4 m = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = 0; i < ph; ++i)
+        for (int j = 0; j < pw; ++j) {
+            const float* src = in + (((size_t)n * H + yo * ph + i) * W + xo * pw + j) * C + c;
+            f32x4 v = *reinterpret_cast<const f32x4*>(src);
+            for (int sp = 1; sp < nsplit; ++sp) v += *reinterpret_cast<const f32x4*>(src + sp * split_stride);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], v[q]);
+        }
+    const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + (size_t)(n / images_per_group) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q] + b[q], 0.f);  // max(x) + b == max(x + b): the bias is per channel
+    store4(out + (((size_t)n * Ho + yo) * Wo + xo) * C + c, m);
+}
+
 // Final layer of the four towers + flip-test average (probmap_head.py:766-774).
 //   feat [4][passes*B][C] (1x1 spatial), w [4][K][C] fp32, bias [4][K] fp32
 //   out  [4][B][K] fp32:  act(w.f + b) for the un-flipped crop, averaged with the flipped
@@ -122,6 +155,27 @@ extern "C" int pp_tower_final(const void* feat, int feat_bf16, const float* w, c
     else
         hipLaunchKernelGGL(tower_final_kernel<float>, grid, block, 0, s, reinterpret_cast<const float*>(feat), w, bias,
                            flip_indices, out, B, passes, C, K, err_div);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+extern "C" int pp_sum_maxpool_relu_nhwc(const float* partials, int nsplit, long long split_stride, const float* bias,
+                                        int images_per_group, void* out, int out_bf16, int N, int H, int W, int C, int ph,
+                                        int pw, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(partials && out, PP_ERR_INVALID_ARG, "pp_sum_maxpool_relu_nhwc: NULL argument");
+    PP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ph > 0 && pw > 0 && H >= ph && W >= pw && nsplit >= 1 &&
+                   images_per_group >= 1,
+               PP_ERR_INVALID_ARG, "pp_sum_maxpool_relu_nhwc: bad shape");
+    const long long total = (long long)N * (H / ph) * (W / pw) * (C / 4);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (out_bf16)
+        hipLaunchKernelGGL(sum_maxpool_relu_kernel<__bf16>, grid, block, 0, s, partials, nsplit, split_stride, bias,
+                           images_per_group, reinterpret_cast<__bf16*>(out), N, H, W, C, ph, pw);
+    else
+        hipLaunchKernelGGL(sum_maxpool_relu_kernel<float>, grid, block, 0, s, partials, nsplit, split_stride, bias,
+                           images_per_group, reinterpret_cast<float*>(out), N, H, W, C, ph, pw);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

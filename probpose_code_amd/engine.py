@@ -75,6 +75,7 @@ class ProbPoseEngine:
         self.fuse_mlp = os.environ.get("PP_FUSE_MLP", "1") != "0"
         self.fuse_proj = os.environ.get("PP_FUSE_PROJ", "1") != "0"
         self.fuse_qkv = os.environ.get("PP_FUSE_QKV", "1") != "0"
+        self.split_k = os.environ.get("PP_SPLIT_K", "1") != "0"
         self.profile: Optional[Dict[str, list]] = None
         # tower pooling schedule (probmap_head.py:264) and the spatial sizes it produces
         self.pools = ((4, 3), (2, 2), (2, 2))
@@ -113,6 +114,8 @@ class ProbPoseEngine:
         for j, (th, tw) in enumerate(self.tower_hw):
             ph, pw_ = self.pools[j]
             ws[f"t{j}"] = e(4, nb, th, tw, E)
+            if nb * th * tw * 4 < 128 * 128:
+                ws[f"tp{j}"] = e(3, 4, nb, th, tw, E, dt=f32)  # split-K partial sums of the small tower stages
             ws[f"p{j}"] = e(4, nb, th // ph, tw // pw_, E)
         self._ws[key] = ws
         return ws
@@ -234,6 +237,18 @@ class ProbPoseEngine:
         for j, (th, tw) in enumerate(self.tower_hw):
             ph, pw_ = self.pools[j]
             out = ws[f"t{j}"]
+            rows = nb * th * tw
+            if self.split_k and f"tp{j}" in ws:
+                # few output rows: one workgroup per 128 x 128 tile would leave most CUs idle for a 54-step K loop;
+                # cut K in three (one kernel row of taps each), reduce + bias in the pooling kernel
+                part = ws[f"tp{j}"]
+                self._call("conv3x3_splitk", "pp_conv3x3_splitk", self.prec, src.data_ptr(), w[f"tower{j}.w"].data_ptr(),
+                           part.data_ptr(), nb, th, tw, E, E, 4, stride_src, E * 9 * E, 3, st)
+                self._call("maxpool", "pp_sum_maxpool_relu_nhwc", part.data_ptr(), 3, 4 * rows * E, w[f"tower{j}.b"].data_ptr(),
+                           nb, ws[f"p{j}"].data_ptr(), ob, 4 * nb, th, tw, E, ph, pw_, st)
+                src = ws[f"p{j}"]
+                stride_src = nb * (th // ph) * (tw // pw_) * E
+                continue
             self._call("conv3x3", "pp_conv_gemm", self.prec, CONV3X3, src.data_ptr(), w[f"tower{j}.w"].data_ptr(),
                       w[f"tower{j}.b"].data_ptr(), out.data_ptr(), nb, th, tw, E, E, 0, 0, 4, stride_src,
                       E * 9 * E, nb * th * tw * E, E, E, ACT_NONE, ob, st)

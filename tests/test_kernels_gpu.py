@@ -375,3 +375,25 @@ def test_fused_proj_mlp_residual_layernorm(M, with_qkv):
     torch.testing.assert_close(hout.cpu().double(), href, rtol=3e-2, atol=3e-2)
     if with_qkv:
         torch.testing.assert_close(qout.cpu().double(), qref, rtol=3e-2, atol=6e-2)
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_conv3x3_splitk_sum_maxpool_vs_torch(prec):
+    """Split-K tower convolution + (reduce, bias, MaxPool, ReLU) against torch."""
+    L = _lib()
+    G, B, H, W, C = 4, 3, 4, 4, 128
+    x = _rand(G, B, C, H, W, seed=81)
+    w = _rand(G, C, C, 3, 3, seed=82, scale=1 / math.sqrt(9 * C))
+    b = _rand(G, C, seed=83)
+    ref = torch.stack([F.relu(F.max_pool2d(F.conv2d(_q(x[g], prec), _q(w[g], prec), b[g].double(), padding=1), (2, 2)))
+                       for g in range(G)])
+    xd = x.permute(0, 1, 3, 4, 2).contiguous().to(_dt(prec)).cuda()
+    wd = w.permute(0, 1, 3, 4, 2).reshape(G, C, 9 * C).contiguous().to(_dt(prec)).cuda()
+    for ks in (3, 9):
+        part = torch.full((ks, G, B, H, W, C), float("nan"), device="cuda")
+        L.call("pp_conv3x3_splitk", prec, xd.data_ptr(), wd.data_ptr(), part.data_ptr(), B, H, W, C, C, G, B * H * W * C, C * 9 * C, ks,
+               None)
+        out = torch.empty((G, B, H // 2, W // 2, C), device="cuda")
+        L.call("pp_sum_maxpool_relu_nhwc", part.data_ptr(), ks, G * B * H * W * C, b.cuda().data_ptr(), B, out.data_ptr(), 0, G * B, H, W, C,
+               2, 2, None)
+        torch.testing.assert_close(out.cpu().double().permute(0, 1, 4, 2, 3), ref, **TOL[prec])
