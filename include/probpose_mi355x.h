@@ -209,6 +209,21 @@ int pp_layernorm(const float* x, const float* gamma, const float* beta, void* y,
 int pp_maxpool_relu_nhwc(const void* in, int in_bf16, void* out, int out_bf16, int N, int H, int W, int C,
                          int ph, int pw, void* stream);
 
+/* Last deconvolution of the heatmap branch fused with the 1x1 convolution that follows it (bf16 operands):
+ *   ConvTranspose2d(Cin -> 256, k4, s2, p1) + BN + ReLU  ->  Conv2d(256 -> K, k1)
+ * (probmap_head.py:435-472 and :244-249; reshaped to (B, K, H'W') at :627-648). weight / bias as PP_DECONV4X4S2 of
+ * pp_conv_gemm with py < 0 (four phase matrices, folded BatchNorm); head_w (32, 256) bf16 = the 1x1 kernel, rows >= K
+ * zero; head_b (K) fp32. The 256-channel feature map is never stored. logits_phased (B, K, 4, H*W) fp32: output pixel
+ * (2y + py, 2x + px) of map (b, k) sits at [b, k, 2 py + px, y W + x] - the layout pp_probmap_head_decode_phased reads. */
+int pp_deconv_head(const void* act_nhwc, const void* weight, const float* bias, const void* head_w, const float* head_b,
+                   float* logits_phased, int B, int H, int W, int Cin, int Cout, int K, void* stream);
+
+/* pp_probmap_head_decode for logits in the phase-separated layout of pp_deconv_head (H, W = the heatmap size). */
+int pp_probmap_head_decode_phased(const float* logits, const float* logits_flip, const int32_t* flip_indices,
+                                  const double* taps, const int32_t* radius, int B, int K, int H, int W, double in_w,
+                                  double in_h, float temperature, float normalize, float* avg_out, float* conv_out,
+                                  float* locs, double* keypoints, float* scores, void* stream);
+
 /* Split-K form of the towers' 3x3 convolution for stages with few output pixels: the nine taps are cut into ksplit
  * (1, 3 or 9) slices, every (slice, group) pair is its own set of output tiles, and the fp32 partial sums go to
  * partials (ksplit, groups, B*H*W, Cout) WITHOUT bias. Weight layout as PP_CONV3X3 of pp_conv_gemm. Followed by

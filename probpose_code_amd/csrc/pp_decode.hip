@@ -149,7 +149,7 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     const float* __restrict__ hm, const float* __restrict__ hm_flip, const int32_t* __restrict__ flip_indices,
     const double* __restrict__ taps, const int32_t* __restrict__ radius, int K, int H, int W, double in_w,
     double in_h, float temperature, float normalize, float* __restrict__ avg_out, float* __restrict__ conv_out,
-    float* __restrict__ locs, double* __restrict__ keypoints, float* __restrict__ scores) {
+    float* __restrict__ locs, double* __restrict__ keypoints, float* __restrict__ scores, int phased) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int bk = blockIdx.x;
@@ -247,10 +247,18 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         for (int e = 0; e < NV; ++e) {
             const int i4 = tid + e * DEC_THREADS;
             if (i4 < HW4) {
-                const int y = i4 / W4, x = (i4 - y * W4) * 4;
-                float* d = mapf + y * Wp + RM + x;
+                // memory order of the four values -> pixel (y, x0 + j * dx): row-major, or (logits written by the fused
+                // deconvolution head) the four 2x2 output phases one after the other, each a (H/2, W/2) row-major block
+                int y = i4 / W4, x0 = (i4 - y * W4) * 4, dx = 1;
+                if (phased) {
+                    const int e0 = i4 * 4, q = HW >> 2, z = e0 / q, rr = e0 - z * q, yy = rr / (W >> 1);
+                    y = 2 * yy + (z >> 1);
+                    x0 = 2 * (rr - yy * (W >> 1)) + (z & 1);
+                    dx = 2;
+                }
+                float* d = mapf + y * Wp + RM + x0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[j] = clamp01(fmaxf(z0[e][j] - tau0, 0.0f) * normalize);
+                for (int j = 0; j < 4; ++j) d[j * dx] = clamp01(fmaxf(z0[e][j] - tau0, 0.0f) * normalize);
             }
         }
         if (HAS_FLIP) {
@@ -259,12 +267,18 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
             for (int e = 0; e < NV; ++e) {
                 const int i4 = tid + e * DEC_THREADS;
                 if (i4 < HW4) {
-                    const int y = i4 / W4, xf = (i4 - y * W4) * 4;
-                    float* d = mapf + y * Wp + RM + (W - 1 - xf);  // pixel xf + j of the flipped pass lands at W-1-xf-j
+                    int y = i4 / W4, xf = (i4 - y * W4) * 4, dx = 1;
+                    if (phased) {
+                        const int e0 = i4 * 4, q = HW >> 2, z = e0 / q, rr = e0 - z * q, yy = rr / (W >> 1);
+                        y = 2 * yy + (z >> 1);
+                        xf = 2 * (rr - yy * (W >> 1)) + (z & 1);
+                        dx = 2;
+                    }
+                    float* d = mapf + y * Wp + RM + (W - 1 - xf);  // pixel xf + j dx of the flipped pass lands at W-1-xf-j dx
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {                // exactly one thread owns each cell
                         const float p = clamp01(fmaxf(z1[e][j] - tau1, 0.0f) * normalize);
-                        d[-j] = (d[-j] + p) * 0.5f;
+                        d[-j * dx] = (d[-j * dx] + p) * 0.5f;
                     }
                 }
             }
@@ -374,7 +388,7 @@ static size_t decode_lds_bytes(int H, int W) {
 }
 
 typedef void (*DecodeKernel)(const float*, const float*, const int32_t*, const double*, const int32_t*, int, int, int,
-                             double, double, float, float, float*, float*, float*, double*, float*);
+                             double, double, float, float, float*, float*, float*, double*, float*, int);
 
 template <int NV>
 static DecodeKernel pick_kernel(bool from_logits, bool flip) {
@@ -387,9 +401,11 @@ static DecodeKernel pick_kernel(bool from_logits, bool flip) {
 static int decode_launch(bool from_logits, const float* hm, const float* hm_flip, const int32_t* flip_indices,
                          const double* taps, const int32_t* radius, int B, int K, int H, int W, double in_w,
                          double in_h, float temperature, float normalize, float* avg_out, float* conv_out, float* locs,
-                         double* keypoints, float* scores, void* stream) {
+                         double* keypoints, float* scores, void* stream, int phased = 0) {
     using namespace pp;
     PP_REQUIRE(B >= 0 && K > 0 && H > 0 && W > 0, PP_ERR_INVALID_ARG, "pp_probmap_(head_)decode: bad B/K/H/W");
+    PP_REQUIRE(!phased || (from_logits && H % 2 == 0 && W % 8 == 0), PP_ERR_UNSUPPORTED,
+               "pp_probmap_head_decode_phased: needs an even height and a width that is a multiple of 8");
     if (B == 0) return PP_OK;  // empty batch: nothing to read or write (buffers may be NULL)
     PP_REQUIRE(hm && taps && radius && locs && keypoints && scores, PP_ERR_INVALID_ARG,
                "pp_probmap_decode: hm, taps, radius, locs, keypoints and scores must be non-NULL");
@@ -412,7 +428,7 @@ static int decode_launch(bool from_logits, const float* hm, const float* hm_flip
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * K), dim3(DEC_THREADS), lds, s, hm, hm_flip, flip_indices, taps, radius, K, H,
-                       W, in_w, in_h, temperature, normalize, avg_out, conv_out, locs, keypoints, scores);
+                       W, in_w, in_h, temperature, normalize, avg_out, conv_out, locs, keypoints, scores, phased);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
@@ -431,4 +447,13 @@ extern "C" int pp_probmap_head_decode(const float* logits, const float* logits_f
                                       float* conv_out, float* locs, double* keypoints, float* scores, void* stream) {
     return decode_launch(true, logits, logits_flip, flip_indices, taps, radius, B, K, H, W, in_w, in_h, temperature,
                          normalize, avg_out, conv_out, locs, keypoints, scores, stream);
+}
+
+extern "C" int pp_probmap_head_decode_phased(const float* logits, const float* logits_flip, const int32_t* flip_indices,
+                                             const double* taps, const int32_t* radius, int B, int K, int H, int W,
+                                             double in_w, double in_h, float temperature, float normalize,
+                                             float* avg_out, float* conv_out, float* locs, double* keypoints,
+                                             float* scores, void* stream) {
+    return decode_launch(true, logits, logits_flip, flip_indices, taps, radius, B, K, H, W, in_w, in_h, temperature,
+                         normalize, avg_out, conv_out, locs, keypoints, scores, stream, 1);
 }

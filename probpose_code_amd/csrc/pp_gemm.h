@@ -22,6 +22,10 @@ struct GemmParams {
     int gather;             // G_*
     int res_mod;            // >0: residual row = m % res_mod (broadcast over the batch, e.g. pos_embed)
     int ldres;              // row stride of residual (elements); 0 -> ldc
+    const void* head_w;     // wide-tile deconvolution only: [32, N] bf16 (rows >= head_n zero) of a 1x1 convolution applied to the
+    const float* head_b;    // ReLU'd tile in the epilogue instead of storing it: logits (B, head_n, 4 phases, H * W) fp32 to head_out
+    float* head_out;
+    int head_n;
     int ksplit;             // >1: split-K launch - `groups` counts (K slice, problem) pairs, z = slice * (groups / ksplit) + problem;
                             // K is the length of one slice, ldw the full row; conv gathers start at tap slice * K / Cin
     int groups;             // independent problems in one launch (the four towers); tiles of all groups share the persistent grid

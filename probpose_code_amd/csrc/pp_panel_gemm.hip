@@ -260,6 +260,11 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         // ---- epilogue. Accumulator layout: lane holds n = 4 f_kg + (0..3) of fragment column cf for row f_row of
         // fragment row rf. One row half (one rg) at a time through the staging region, 16-byte chunks XOR-swizzled by
         // (row & 7); then every thread stores 16-byte pieces of whole output rows.
+        // (lane-dependent addresses from a laundered lane id: they are loop-invariant, hoisted above the K loop they would
+        // cost the registers that loop does not have)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int e_row = lane_e & 15, e_kg = lane_e >> 4, tid_e = (tid & ~63) | lane_e;
         int z, m0, n0;
         decode_tile(tile, z, m0, n0);
         const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias_z : nullptr;
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
             if (rg == h) {
 #pragma unroll
                 for (int cf = 0; cf < CF; ++cf) {
-                    const int nl = cg * (BN / 4) + cf * 16 + f_kg * 4;
+                    const int nl = cg * (BN / 4) + cf * 16 + e_kg * 4;
                     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n0 + nl);
 #pragma unroll
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
                             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                         }
                         const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                        const int ml = rf * 16 + f_row;
+                        const int ml = rf * 16 + e_row;
                         const int byte = nl * 2;
                         *reinterpret_cast<bf16x4*>(cst + ml * ROWB + ((((byte >> 4) ^ (ml & 7)) << 4) | (byte & 15))) = ov;
                     }
@@ -292,7 +297,41 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
             }
             wait_vm_lgkm<63>();  // LDS writes only: the DMA of the next tile stays in flight
             __builtin_amdgcn_s_barrier();
-            const int cl = tid % LPR, rl = tid / LPR;
+            if (GATHER == G_DECONV && p.head_w) {
+                // Fused 1x1 convolution (the heatmap head's final layer, probmap_head.py:244-249): the staged half tile
+                // holds ALL BN = N channels of 96 pixels, so logits[pixel, n] = sum_c tile[pixel, c] Wf[n, c] + bf[n] is
+                // 6 x 2 x 8 more MFMAs (waves 0-5, one row fragment each) and the 201 MB feature map never reaches HBM.
+                // Activations are the MFMA "A" operand here: a lane ends up with 4 consecutive pixels of one channel,
+                // which is contiguous in the phase-separated logits layout (B, n, phase, y * W + x).
+                if (wv < 6) {
+                    const int rf = wv, ml = rf * 16 + e_row;
+                    f32x4 hacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                    const __bf16* hw_ = reinterpret_cast<const __bf16*>(p.head_w);
+#pragma unroll
+                    for (int ks = 0; ks < BN / 32; ++ks) {
+                        const u32x4 a = *reinterpret_cast<const u32x4*>(cst + ml * ROWB + (((4 * ks + e_kg) ^ (ml & 7)) << 4));
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) {
+                            const u32x4 b = *reinterpret_cast<const u32x4*>(hw_ + (size_t)(nf * 16 + e_row) * BN + ks * 32 + e_kg * 8);
+                            hacc[nf] = mma(a, b, hacc[nf]);
+                        }
+                    }
+                    const int hw = p.H * p.Wd;
+                    const int m = m0 + h * (BM / 2) + rf * 16 + e_kg * 4;  // first of the lane's four pixels
+                    if (m < p.M) {
+                        const int b_img = m / hw, r = m - b_img * hw;
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) {
+                            const int n = nf * 16 + e_row;
+                            if (n < p.head_n) {
+                                const f32x4 v = hacc[nf] + p.head_b[n];
+                                *reinterpret_cast<f32x4*>(p.head_out + (((size_t)b_img * p.head_n + n) * 4 + z) * hw + r) = v;
+                            }
+                        }
+                    }
+                }
+            } else {
+            const int cl = tid_e % LPR, rl = tid_e / LPR;
             if (rl < RPP) {
                 for (int r0 = 0; r0 < BM / 2; r0 += RPP) {
                     const int ml = r0 + rl;
@@ -309,6 +348,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
                     const u32x4 raw = *reinterpret_cast<const u32x4*>(cst + ml * ROWB + ((cl ^ (ml & 7)) << 4));
                     *reinterpret_cast<u32x4*>(Cb + orow * p.ldc + n0 + cl * 8) = raw;
                 }
+            }
             }
             wait_vm_lgkm<63>();
             __builtin_amdgcn_s_barrier();  // the staging region is reused by the other row half / the next tile

@@ -76,6 +76,8 @@ class ProbPoseEngine:
         self.fuse_proj = os.environ.get("PP_FUSE_PROJ", "1") != "0"
         self.fuse_qkv = os.environ.get("PP_FUSE_QKV", "1") != "0"
         self.split_k = os.environ.get("PP_SPLIT_K", "1") != "0"
+        self.fuse_head = os.environ.get("PP_FUSE_HEAD", "1") != "0"
+        self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
         # tower pooling schedule (probmap_head.py:264) and the spatial sizes it produces
         self.pools = ((4, 3), (2, 2), (2, 2))
@@ -216,9 +218,20 @@ class ProbPoseEngine:
         w = self.w
         ob = int(self.dtype == torch.bfloat16)
         src, cin, hh, ww = feat, self.E, self.Hp, self.Wp
+        self._logits_phased = False
+        nd = len(w.deconv_channels)
         for j, cout in enumerate(w.deconv_channels):
             dst = ws[f"d{j}"]
             wj = w[f"deconv{j}.w"]
+            if (j == nd - 1 and self.fuse_head and ob and cout == 256 and w.has("final.w_pad") and cin % 32 == 0
+                    and (hh * ww) % 4 == 0):
+                # last deconvolution + the 1x1 conv behind it in one kernel; the 256-channel map is never stored and the
+                # logits come out phase-separated (the decode kernel reads that layout directly)
+                self._call("deconv_head", "pp_deconv_head", src.data_ptr(), wj.data_ptr(), w[f"deconv{j}.b"].data_ptr(),
+                           w["final.w_pad"].data_ptr(), w["final.b"].data_ptr(), ws["logits"].data_ptr(), nb, hh, ww, cin, cout,
+                           self.K, st)
+                self._logits_phased = True
+                return ws["logits"]
             # all four output phases of the transposed conv in one persistent launch
             self._call("deconv", "pp_conv_gemm", self.prec, DECONV, src.data_ptr(), wj.data_ptr(),
                        w[f"deconv{j}.b"].data_ptr(), dst.data_ptr(), nb, hh, ww, cin, cout, -1, -1, 1, 0, 0, 0, 0, cout,
@@ -299,13 +312,13 @@ class ProbPoseEngine:
             logits = self.heatmap_logits(feat_nhwc, nb, ws, st)
             fi = self._flip_indices(flip_indices) if flip_test else None
             lf = logits[B:] if flip_test else None
-            self._call("head_decode", "pp_probmap_head_decode", logits.data_ptr(), _lib.ptr(lf), _lib.ptr(fi), self.taps.data_ptr(),
+            self._call("head_decode", "pp_probmap_head_decode_phased" if self._logits_phased else "pp_probmap_head_decode", logits.data_ptr(), _lib.ptr(lf), _lib.ptr(fi), self.taps.data_ptr(),
                       self.radius.data_ptr(), B, self.K, self.Hh, self.Wh, float(self.input_size[0]),
                       float(self.input_size[1]), self.temperature, float(self.normalize),
                       ws["heatmaps"].data_ptr() if return_heatmaps else None, None, ws["locs"].data_ptr(),
                       ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), st)
             scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, st)
-        out = dict(keypoints=ws["keypoints"], scores=ws["scores"], locs=ws["locs"], scalars=scalars, logits=logits)
+        out = dict(keypoints=ws["keypoints"], scores=ws["scores"], locs=ws["locs"], scalars=scalars)
         if return_heatmaps:
             out["heatmaps"] = ws["heatmaps"]
         return out

@@ -49,6 +49,9 @@ class PackedWeights:
     def __getitem__(self, k):
         return self.t[k]
 
+    def has(self, k) -> bool:
+        return k in self.t
+
 
 def _bn_fold(sd, name):
     scale = sd[name + ".weight"].float() / torch.sqrt(sd[name + ".running_var"].float() + BN_EPS)
@@ -108,6 +111,10 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device) -> PackedWeigh
         j += 1
     t["final.w"] = op(sd["head.final_layer.weight"].reshape(K, -1))
     t["final.b"] = f32(sd["head.final_layer.bias"])
+    if K <= 32:  # zero-padded to 32 rows: the MFMA operand of the 1x1 conv fused into the last deconvolution (pp_deconv_head)
+        wpad = torch.zeros((32, t["final.w"].shape[1]), dtype=torch.float32)
+        wpad[:K] = sd["head.final_layer.weight"].reshape(K, -1).float()
+        t["final.w_pad"] = op(wpad)
 
     # ---- scalar towers
     for c in range(3):

@@ -28,8 +28,6 @@ for prec in ("f32", "bf16"):
     torch.cuda.synchronize()
     feat = out["features"].float().cpu()[:B].permute(0, 3, 1, 2)
     print(f"[{prec}] feat max|d| {(feat - f0).abs().max():.3e}  (ref std {f0.std():.3f})")
-    lg = out["logits"].cpu()[:B].reshape(lg0.shape)
-    print(f"[{prec}] logits max|d| {(lg - lg0).abs().max():.3e} (ref std {lg0.std():.3f})")
     hm = out["heatmaps"].cpu().numpy()
     print(f"[{prec}] heatmap max|d| {np.abs(hm - ref['heatmaps']).max():.3e}  nnz/map {np.mean((ref['heatmaps']>0).reshape(B,17,-1).sum(-1)):.1f}")
     kp = out["keypoints"].cpu().numpy()[:, None]

@@ -397,3 +397,50 @@ def test_conv3x3_splitk_sum_maxpool_vs_torch(prec):
         L.call("pp_sum_maxpool_relu_nhwc", part.data_ptr(), ks, G * B * H * W * C, b.cuda().data_ptr(), B, out.data_ptr(), 0, G * B, H, W, C,
                2, 2, None)
         torch.testing.assert_close(out.cpu().double().permute(0, 1, 4, 2, 3), ref, **TOL[prec])
+
+
+def test_deconv_head_and_phased_decode_vs_unfused():
+    """Last deconvolution fused with the 1x1 conv (pp_deconv_head) -> phase-separated logits; decoding them with
+    pp_probmap_head_decode_phased gives bit-identical results to decoding the same logits rearranged to planar layout, and
+    the logits match ConvTranspose2d + ReLU + Conv1x1 in torch."""
+    L = _lib()
+    B, H, W, Cin, Cout, K = 6, 32, 24, 128, 256, 17
+    x = _rand(B, Cin, H, W, seed=91)
+    w = _rand(Cin, Cout, 4, 4, seed=92, scale=1 / math.sqrt(4 * Cin))
+    b = _rand(Cout, seed=93, scale=0.2)
+    wf, bf = _rand(K, Cout, seed=94, scale=4 / math.sqrt(Cout)), _rand(K, seed=95)
+    mid = F.relu(F.conv_transpose2d(_q(x, BF16), _q(w, BF16), b.double(), stride=2, padding=1))
+    ref = F.conv2d(_q(mid.float(), BF16), _q(wf, BF16)[:, :, None, None], bf.double())     # (B, K, 2H, 2W)
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    ph = torch.empty((2, 2, Cout, 4 * Cin))
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    t = ty * 2 + tx
+                    ph[py, px, :, t * Cin:(t + 1) * Cin] = w[:, :, 3 - 2 * ty - py, 3 - 2 * tx - px].t()
+    wpad = torch.zeros(32, Cout)
+    wpad[:K] = wf
+    lg = torch.full((B, K, 4, H * W), float("nan"), device="cuda")
+    phd, bd, wpd, bfd = ph.bfloat16().cuda(), b.cuda(), wpad.bfloat16().cuda(), bf.cuda()  # (held: the launch is asynchronous)
+    L.call("pp_deconv_head", xd.data_ptr(), phd.data_ptr(), bd.data_ptr(), wpd.data_ptr(), bfd.data_ptr(), lg.data_ptr(), B, H, W, Cin,
+           Cout, K, None)
+    planar = lg.reshape(B, K, 2, 2, H, W).permute(0, 1, 4, 2, 5, 3).reshape(B, K, 2 * H, 2 * W).contiguous()
+    torch.testing.assert_close(planar.cpu().double(), ref, rtol=3e-2, atol=5e-2)
+    # decode both layouts (first half of the batch un-flipped, second half as its flip partner)
+    from probpose_code_amd.codecs import oks_kernel_taps
+
+    taps, radius = oks_kernel_taps(K, 2 * H, 2 * W)
+    td, rd = torch.from_numpy(taps).cuda(), torch.from_numpy(radius).cuda()
+    fi = torch.tensor([0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15], dtype=torch.int32, device="cuda")
+    outs = []
+    for name, src in (("pp_probmap_head_decode_phased", lg), ("pp_probmap_head_decode", planar)):
+        hm = torch.empty((3, K, 2 * H, 2 * W), device="cuda")
+        locs = torch.empty((3, K, 2), device="cuda")
+        kp = torch.empty((3, K, 2), dtype=torch.float64, device="cuda")
+        sc = torch.empty((3, K), device="cuda")
+        L.call(name, src.data_ptr(), src[3:].data_ptr(), fi.data_ptr(), td.data_ptr(), rd.data_ptr(), 3, K, 2 * H, 2 * W, 192.0, 256.0,
+               0.5, 1.0, hm.data_ptr(), None, locs.data_ptr(), kp.data_ptr(), sc.data_ptr(), None)
+        outs.append((hm.cpu(), locs.cpu(), kp.cpu(), sc.cpu()))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
