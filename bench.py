@@ -65,6 +65,16 @@ def kernel_work_per_step(eng, B, passes, tag):
     fused_proj = fused_mlp and eng.fuse_proj
     c_last = eng.w.deconv_channels[-1]
     final_fl, final_b = 2.0 * (B * passes * P) * eng.K * c_last, B * passes * P * (c_last * esz + eng.K * 4)
+    if tag == "vit_layer":  # attention + proj + residual + ln2 + fc1 + GELU + fc2 + residual + LN (+ the next layer's qkv)
+        att_fl = 4.0 * (B * passes) * eng.heads * eng.Np * eng.Np * eng.hd  # QK^T + PV
+        fl = L * (att_fl + 4.0 * M * E * Fd + 2.0 * M * E * E)
+        by = L * (M * 3 * E * 2 + 2 * M * E * 4) + M * E * 2  # qkv in, residual stream in + out; features out once
+        if eng.fuse_qkv:
+            fl += (L - 1) * 2.0 * M * E * 3 * E
+            by += (L - 1) * M * 3 * E * 2
+        else:
+            by += (L - 1) * M * E * 2
+        return fl, by, L, "_ZN2pp3mlp17mlp_res_ln_kernelILb1ELb%dELb1EEEvNS0_6ParamsE" % int(eng.fuse_qkv)
     if tag == "proj_mlp_res_ln":  # proj + residual + ln2 + fc1 + GELU + fc2 + residual + LN (+ the next layer's qkv)
         fl = L * (4.0 * M * E * Fd + 2.0 * M * E * E)
         by = L * (M * E * 2 + 2 * M * E * 4) + M * E * 2  # attention rows in, residual stream in + out; features out once
@@ -73,9 +83,9 @@ def kernel_work_per_step(eng, B, passes, tag):
             by += (L - 1) * M * 3 * E * 2
         else:
             by += (L - 1) * M * E * 2
-        return fl, by, L, "_ZN2pp3mlp17mlp_res_ln_kernelILb1ELb%dEEEvNS0_6ParamsE" % int(eng.fuse_qkv)
+        return fl, by, L, "_ZN2pp3mlp17mlp_res_ln_kernelILb1ELb%dELb0EEEvNS0_6ParamsE" % int(eng.fuse_qkv)
     if tag == "mlp_res_ln":  # fc1 + GELU + fc2 + residual + LN per layer
-        return L * 4.0 * M * E * Fd, L * (M * E * 2 + 2 * M * E * 4 + M * E * 2), L, "_ZN2pp3mlp17mlp_res_ln_kernelILb0ELb0EEEvNS0_6ParamsE"
+        return L * 4.0 * M * E * Fd, L * (M * E * 2 + 2 * M * E * 4 + M * E * 2), L, "_ZN2pp3mlp17mlp_res_ln_kernelILb0ELb0ELb0EEEvNS0_6ParamsE"
     if tag == "gemm_res_ln":  # patch embed, proj (and fc2 when the FFN is not fused) + residual + LN
         fl = 2.0 * M * E * 768
         by = M * 768 * esz + M * E * (4 + esz)
@@ -118,7 +128,9 @@ def pmc_traffic(kernel_mangled):
             return ks[kernel_mangled]["hbm_bytes_per_launch"]
         # rocprofv3 reports some names demangled: match on the template arguments of the fused layer kernel
         if "mlp_res_ln_kernel" in kernel_mangled:
-            want = "<true, true>" if "ILb1ELb1E" in kernel_mangled else ("<true, false>" if "ILb1ELb0E" in kernel_mangled else "<false, false>")
+            import re as _re
+            bits = _re.search(r"ILb(\d)ELb(\d)ELb(\d)E", kernel_mangled)
+            want = "<" + ", ".join("true" if b == "1" else "false" for b in bits.groups()) + ">" if bits else "<"
             for k, v in ks.items():
                 if "mlp_res_ln_kernel" in k and want in k:
                     return v["hbm_bytes_per_launch"]
@@ -234,7 +246,7 @@ def main():
             "path_tflops": B * world * args.steps * GFLOP_PER_CROP_FLIP / dt / 1e3,
             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_tag.items(), key=lambda kv: -kv[1][0])},
         }
-        if dom in ("proj_mlp_res_ln", "mlp_res_ln", "gemm_res_ln", "gemm_bf16out", "gemm_f32out"):
+        if dom in ("vit_layer", "proj_mlp_res_ln", "mlp_res_ln", "gemm_res_ln", "gemm_bf16out", "gemm_f32out"):
             fl, alg_bytes, n, mangled = kernel_work_per_step(eng, B, 2, dom)
             assert n == dom_n, (dom, n, dom_n)
             secs = dom_ms / n * 1e-3

@@ -209,6 +209,20 @@ int pp_layernorm(const float* x, const float* gamma, const float* beta, void* y,
 int pp_maxpool_relu_nhwc(const void* in, int in_bf16, void* out, int out_bf16, int N, int H, int W, int C,
                          int ph, int pw, void* stream);
 
+/* A whole ViT-S encoder layer in one launch (bf16 operands), from the qkv of this layer to the qkv of the next:
+ *   a     = softmax(q k^T * scale) v per head                  (mmpretrain MultiheadAttention [3P], as pp_attention)
+ *   x1    = residual + a Wp^T + bp ;          h  = LayerNorm(x1; gamma2, beta2, eps)
+ *   x_out = x1 + GELU(h W1^T + b1) W2^T + b2 ;   h_out = LayerNorm(x_out; gamma, beta, eps)
+ *   qkv_out = h_out wqkv^T + bqkv                               (when wqkv != NULL; h_out may then be NULL)
+ * i.e. pp_attention followed by pp_proj_mlp_residual_layernorm with neither the attention output nor anything between
+ * the two residual adds leaving the CU. qkv_in (M, 3E) bf16 row-major [q | k | v] as the qkv Linear emits it; rows
+ * [s * seq_len, (s + 1) * seq_len) are sequence s. Built for E = 384, heads * 32 = E, seq_len = 192 (256x192 input);
+ * other shapes take the separate entry points. qkv_out must not alias qkv_in. */
+int pp_vit_layer(const void* qkv_in, int seq_len, int heads, float scale, const void* wp, const float* bp,
+                 const float* residual, const float* gamma2, const float* beta2, const void* w1, const float* b1,
+                 const void* w2, const float* b2, float* x_out, const float* gamma, const float* beta, float eps,
+                 void* h_out, const void* wqkv, const float* bqkv, void* qkv_out, int M, int E, int F, void* stream);
+
 /* Last deconvolution of the heatmap branch fused with the 1x1 convolution that follows it (bf16 operands):
  *   ConvTranspose2d(Cin -> 256, k4, s2, p1) + BN + ReLU  ->  Conv2d(256 -> K, k1)
  * (probmap_head.py:435-472 and :244-249; reshaped to (B, K, H'W') at :627-648). weight / bias as PP_DECONV4X4S2 of

@@ -33,6 +33,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 namespace mlp {
@@ -67,6 +68,8 @@ struct Params {
     const float* bp;       // PROJ: [384]
     const float* gamma2;   // PROJ: LayerNorm in front of the FFN (ln2)
     const float* beta2;
+    const __bf16* qkv_in;  // ATT: [M, 1152] q | k | v of THIS layer (row-major, as the qkv Linear / the previous launch wrote it)
+    float scale_log2e;     // ATT: head_dim^-0.5 * log2(e)
     const __bf16* Wq;      // QKV: [1152, 384] qkv projection of the NEXT layer
     const float* bq;       // QKV: [1152]
     __bf16* qkv;           // QKV: [M, 1152] output
@@ -148,8 +151,14 @@ __device__ __forceinline__ unsigned wq_slot_offset(int q, unsigned wp_lane) {
 // QKV = true appends the next layer's qkv projection:  qkv = h_out Wq^T + bq  for the 96 rows, three column blocks of
 // 384 with the block's accumulators reused, 36 more steps of the phase-B kind at the tail of the slot stream; h_out then
 // goes to LDS instead of HBM (p.h_out may be NULL).
-template <bool PROJ, bool QKV>
+// ATT = true puts the attention itself in front of the projection: the 96 rows are half of a 192-token sequence; for
+// each of the 12 heads K and V^T of the whole sequence are staged in LDS (double-buffered, in the ring's region, which
+// the weight stream only needs afterwards), S^T = K Q^T, softmax in registers, O^T = V^T P^T exactly as in
+// pp_attention.hip, and the normalised output rows go straight into the LDS image the projection reads - the attention
+// output never exists in HBM and a ViT layer is ONE launch.
+template <bool PROJ, bool QKV, bool ATT>
 __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) {
+    static_assert(!ATT || PROJ, "the attention phase feeds the projection");
     constexpr int PRE = PROJ ? 36 : 0;  // ring slots streamed before the first phase A
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -274,10 +283,121 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         if (lane == 0) p.trace[(wv >> 2) * 4096 + it * 10 + st] = t;
     };
 
+    if (ATT) {
+        // ================= attention of this workgroup's 96 query rows (waves 0-5: one 16-query tile each; all eight waves
+        // stage K / V). Sequence = 192 tokens = this workgroup's rows and its neighbour's.
+        constexpr int SEQ = 192, NKT = SEQ / 16, HEADS = E / 32, RS = 3 * E;
+        constexpr int SPV = SEQ + 8;                     // V^T row pitch (elements): 8 * odd -> conflict-free reads
+        constexpr int KBYTES = SEQ * 64, HBYTES = KBYTES + 32 * SPV * 2;  // one head: K [192][32] + V^T [32][200]
+        static_assert(2 * HBYTES <= NSLOT * SLOT, "two heads of K/V fit in the ring region");
+        const __bf16* qkv = p.qkv_in;
+        const int srow0 = (m0 / SEQ) * SEQ;
+        u32x4 qf[HEADS];
+        if (wv < 6) {
+            const int qm = m0 + wv * 16 + f_row;
+            const __bf16* qrow = qkv + (size_t)(qm < p.M ? qm : p.M - 1) * RS + f_kg * 8;
+#pragma unroll
+            for (int hd = 0; hd < HEADS; ++hd) qf[hd] = *reinterpret_cast<const u32x4*>(qrow + hd * 32);
+        }
+        // Roles: waves 0-5 compute (one 16-query tile each), waves 6-7 stage the NEXT head's K / V^T meanwhile - global
+        // loads, the K copy and the 16-bit transposing scatter of V all run beside the other waves' MFMAs and softmax.
+        auto stage_head = [&](int hd, int buf, int t0, int nthreads) {
+            char* kb = ring + buf * HBYTES;
+            __bf16* vt = reinterpret_cast<__bf16*>(kb + KBYTES);
+            constexpr int NCH = SEQ * 4;  // 16-byte chunks per operand
+            for (int base = 0; base < NCH; base += 4 * nthreads) {
+                u32x4 kr[4], vr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = base + u * nthreads + t0;
+                    if (i < NCH) {
+                        const int r = srow0 + (i >> 2);
+                        const __bf16* src = qkv + (size_t)(r < p.M ? r : p.M - 1) * RS + E + hd * 32 + (i & 3) * 8;
+                        kr[u] = *reinterpret_cast<const u32x4*>(src);
+                        vr[u] = *reinterpret_cast<const u32x4*>(src + E);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = base + u * nthreads + t0;
+                    if (i < NCH) {
+                        const int r = i >> 2, c = i & 3;
+                        *reinterpret_cast<u32x4*>(kb + r * 64 + c * 16) = kr[u];
+                        const bf16x8 ve = __builtin_bit_cast(bf16x8, vr[u]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) vt[(c * 8 + j) * SPV + r] = ve[j];
+                    }
+                }
+            }
+        };
+        stage_head(0, 0, tid, THREADS);  // first head: everybody
+        __syncthreads();
+        for (int hd = 0; hd < HEADS; ++hd) {
+            if (wv >= 6) {
+                if (hd + 1 < HEADS) stage_head(hd + 1, (hd + 1) & 1, tid - 384, 128);
+            } else {
+                const char* Ks = ring + (hd & 1) * HBYTES;
+                const __bf16* Vt = reinterpret_cast<const __bf16*>(Ks + KBYTES);
+                u32x4 qh = qf[0];
+#pragma unroll
+                for (int k = 1; k < HEADS; ++k) qh = hd == k ? qf[k] : qh;  // (register array: select, no dynamic index)
+                f32x4 sc[NKT];
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)  // S^T: lane holds keys 16 kt + 4 f_kg + (0..3) of query f_row
+                    sc[kt] = mma(*reinterpret_cast<const u32x4*>(Ks + (kt * 16 + f_row) * 64 + f_kg * 16), qh, f32x4{0.f, 0.f, 0.f, 0.f});
+                float mx = -__builtin_inff();
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sc[kt][i]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mb = mx * p.scale_log2e;
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], p.scale_log2e, -mb));  // arg <= 0
+                        sc[kt][i] = pe;
+                        sum += pe;
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int blk = 0; blk < NKT / 2; ++blk) {  // O^T = V^T P^T; the key order inside a 32-key block is a
+                    const f32x4 p0 = sc[2 * blk], p1 = sc[2 * blk + 1];  // permutation shared by both operands
+                    const bf16x8 pf = {(__bf16)p0[0], (__bf16)p0[1], (__bf16)p0[2], (__bf16)p0[3],
+                                       (__bf16)p1[0], (__bf16)p1[1], (__bf16)p1[2], (__bf16)p1[3]};
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const __bf16* vrow = Vt + (dt * 16 + f_row) * SPV + blk * 32 + 4 * f_kg;
+                        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow), hi = *reinterpret_cast<const u32x2*>(vrow + 16);
+                        const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
+                    }
+                }
+                // lane holds d = 16 dt + 4 f_kg + (0..3) of query f_row: 8 bytes into the row-operand image of the projection
+                const float inv = 1.0f / sum;
+                const int row = wv * 16 + f_row;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int n = hd * 32 + dt * 16 + f_kg * 4;
+                    const f32x4 v = o[dt] * inv;
+                    const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(smem + OFF_HS + (n >> 6) * HS_KB + row * ROW_BYTES + (((((n & 63) >> 3)) ^ (row & 7)) << 4) +
+                                               (f_kg & 1) * 8) = ov;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
     // ---- prologue: ring filled with the first eight slots, input rows into LDS, accumulators = residual + b2
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) issue_rel(0, q - 12 - PRE);
-    {
+    if (!ATT) {
         // 72 DMA instructions, nine per wave: instruction i covers k-block i / 12, rows 8 (i % 12) .. +7
 #pragma unroll
         for (int jj = 0; jj < 9; ++jj) {
@@ -637,11 +757,13 @@ extern "C" void pp_mlp_set_trace(void* buf) { pp::mlp::g_trace = reinterpret_cas
 
 namespace pp {
 namespace mlp {
-static int launch(const Params& p, bool proj, bool qkv, hipStream_t stream) {
+static int launch(const Params& p, bool proj, bool qkv, bool att, hipStream_t stream) {
     typedef void (*kern_t)(const Params);
-    kern_t kern = static_cast<kern_t>(mlp_res_ln_kernel<false, false>);
-    if (proj && qkv) kern = static_cast<kern_t>(mlp_res_ln_kernel<true, true>);
-    else if (proj) kern = static_cast<kern_t>(mlp_res_ln_kernel<true, false>);
+    kern_t kern = static_cast<kern_t>(mlp_res_ln_kernel<false, false, false>);
+    if (att && qkv) kern = static_cast<kern_t>(mlp_res_ln_kernel<true, true, true>);
+    else if (att) kern = static_cast<kern_t>(mlp_res_ln_kernel<true, false, true>);
+    else if (proj && qkv) kern = static_cast<kern_t>(mlp_res_ln_kernel<true, true, false>);
+    else if (proj) kern = static_cast<kern_t>(mlp_res_ln_kernel<true, false, false>);
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     hipLaunchKernelGGL(kern, dim3((p.M + BM - 1) / BM), dim3(THREADS), LDS, stream, p);
     PP_LAUNCH_CHECK();
@@ -679,7 +801,7 @@ extern "C" int pp_mlp_residual_layernorm(const void* h_in, const void* w1, const
     p.w2_bytes = (unsigned)((size_t)E * F * 2);
     p.eps = eps;
     p.trace = mlp::g_trace;
-    return mlp::launch(p, false, false, reinterpret_cast<hipStream_t>(stream));
+    return mlp::launch(p, false, false, false, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pp_proj_mlp_residual_layernorm(const void* attn, const void* wp, const float* bp, const float* residual,
@@ -725,5 +847,54 @@ extern "C" int pp_proj_mlp_residual_layernorm(const void* attn, const void* wp, 
     p.wq_bytes = (unsigned)((size_t)3 * E * E * 2);
     p.eps = eps;
     p.trace = mlp::g_trace;
-    return mlp::launch(p, true, qkv, reinterpret_cast<hipStream_t>(stream));
+    return mlp::launch(p, true, qkv, false, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pp_vit_layer(const void* qkv_in, int seq_len, int heads, float scale, const void* wp, const float* bp,
+                            const float* residual, const float* gamma2, const float* beta2, const void* w1,
+                            const float* b1, const void* w2, const float* b2, float* x_out, const float* gamma,
+                            const float* beta, float eps, void* h_out, const void* wqkv, const float* bqkv,
+                            void* qkv_out, int M, int E, int F, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(qkv_in && wp && bp && residual && gamma2 && beta2 && w1 && b1 && w2 && b2 && x_out && gamma && beta,
+               PP_ERR_INVALID_ARG, "pp_vit_layer: NULL argument");
+    const bool qkv = wqkv != nullptr;
+    PP_REQUIRE(qkv ? (bqkv && qkv_out) : (h_out != nullptr), PP_ERR_INVALID_ARG, "pp_vit_layer: needs h_out, or wqkv + bqkv + qkv_out");
+    PP_REQUIRE(qkv_out != qkv_in, PP_ERR_INVALID_ARG, "pp_vit_layer: qkv_out must not alias qkv_in (other workgroups still read it)");
+    PP_REQUIRE(E == mlp::E && heads * 32 == E && seq_len == 192, PP_ERR_UNSUPPORTED,
+               "pp_vit_layer: built for ViT-S at 256x192 (embed dim 384, 12 heads x 32, 192 tokens)");
+    PP_REQUIRE(M > 0 && M % seq_len == 0 && F > 0 && F % mlp::CHUNK == 0, PP_ERR_UNSUPPORTED,
+               "pp_vit_layer: M must be a multiple of the sequence length, the hidden width a multiple of 128");
+    PP_REQUIRE((size_t)F * E * 2 < 0x7ffffff0u && (size_t)M * 3 * E * 2 < 0x7ffffff0u, PP_ERR_UNSUPPORTED,
+               "pp_vit_layer: operand exceeds 2 GiB");
+    mlp::Params p{};
+    p.qkv_in = reinterpret_cast<const __bf16*>(qkv_in);
+    p.scale_log2e = scale * 1.44269504088896340736f;
+    p.h = reinterpret_cast<const __bf16*>(qkv_in);  // (unused: no row DMA in this mode)
+    p.Wp = reinterpret_cast<const __bf16*>(wp);
+    p.bp = bp;
+    p.gamma2 = gamma2;
+    p.beta2 = beta2;
+    p.W1 = reinterpret_cast<const __bf16*>(w1);
+    p.b1 = b1;
+    p.W2 = reinterpret_cast<const __bf16*>(w2);
+    p.b2 = b2;
+    p.residual = residual;
+    p.x_out = x_out;
+    p.gamma = gamma;
+    p.beta = beta;
+    p.h_out = reinterpret_cast<__bf16*>(h_out);
+    p.M = M;
+    p.F = F;
+    p.h_bytes = (unsigned)((size_t)M * E * 2);
+    p.w1_bytes = (unsigned)((size_t)F * E * 2);
+    p.w2_bytes = (unsigned)((size_t)E * F * 2);
+    p.wp_bytes = (unsigned)((size_t)E * E * 2);
+    p.Wq = reinterpret_cast<const __bf16*>(wqkv);
+    p.bq = bqkv;
+    p.qkv = reinterpret_cast<__bf16*>(qkv_out);
+    p.wq_bytes = (unsigned)((size_t)3 * E * E * 2);
+    p.eps = eps;
+    p.trace = mlp::g_trace;
+    return mlp::launch(p, true, qkv, true, reinterpret_cast<hipStream_t>(stream));
 }

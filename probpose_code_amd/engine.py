@@ -76,6 +76,9 @@ class ProbPoseEngine:
         self.fuse_proj = os.environ.get("PP_FUSE_PROJ", "1") != "0"
         self.fuse_qkv = os.environ.get("PP_FUSE_QKV", "1") != "0"
         self.split_k = os.environ.get("PP_SPLIT_K", "1") != "0"
+        # attention inside the layer kernel (pp_vit_layer, one launch per layer): correct and tested, but measured break-even
+        # with pp_attention + the fused rest (its K/V staging is latency-bound with one workgroup per CU) - off by default
+        self.fuse_attn = os.environ.get("PP_FUSE_ATTN", "0") != "0"
         self.fuse_head = os.environ.get("PP_FUSE_HEAD", "1") != "0"
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
@@ -103,7 +106,7 @@ class ProbPoseEngine:
         E, Fd = self.E, self.w.ffn_dims
         e = lambda *s, dt=T: torch.empty(s, dtype=dt, device=dev)  # noqa: E731
         ws = dict(
-            patches=e(M, 3 * self.P * self.P), x=e(M, E, dt=f32), h=e(M, E), qkv=e(M, 3 * E), f=e(M, Fd),
+            patches=e(M, 3 * self.P * self.P), x=e(M, E, dt=f32), h=e(M, E), qkv=e(M, 3 * E), qkv2=e(M, 3 * E), f=e(M, Fd),
             feat=e(M, E), logits=e(nb, self.K, self.Hh * self.Wh, dt=f32),
             scalars=e(4, B, self.K, dt=f32), locs=e(B, self.K, 2, dt=f32),
             keypoints=e(B, self.K, 2, dt=torch.float64), scores=e(B, self.K, dt=f32),
@@ -177,11 +180,29 @@ class ProbPoseEngine:
         res_ln(ws["patches"], w["patch_w"], w["patch_b"], Kp, w["l0.ln1.w"], w["l0.ln1.b"], ws["h"],
                residual=w["pos_embed"], res_mod=self.Np)
         qkv_done = False  # the fused layer kernel has already produced this layer's qkv
+        one_launch = (fused and self.precision == "bf16" and Fd % 128 == 0 and self.fuse_mlp and self.fuse_proj and self.fuse_attn
+                      and self.Np == 192 and self.hd == 32)
+        qcur, qnext = ws["qkv"], ws["qkv2"]
         for i in range(L):
             if not qkv_done:
-                self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], ws["qkv"], M, 3 * E, E)
+                self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], qcur, M, 3 * E, E)
+            if one_launch:
+                # a ViT layer in ONE launch: attention, projection, ln2, FFN, next LayerNorm and the next layer's qkv
+                last = i + 1 == L
+                gn, bn = (w["ln_f.w"], w["ln_f.b"]) if last else (w[f"l{i + 1}.ln1.w"], w[f"l{i + 1}.ln1.b"])
+                nq = None if (last or not self.fuse_qkv) else (w[f"l{i + 1}.qkv.w"], w[f"l{i + 1}.qkv.b"])
+                h_next = ws["feat"] if last else ws["h"]
+                self._call("vit_layer", "pp_vit_layer", qcur.data_ptr(), self.Np, self.heads, scale, w[f"l{i}.proj.w"].data_ptr(),
+                           w[f"l{i}.proj.b"].data_ptr(), ws["x"].data_ptr(), w[f"l{i}.ln2.w"].data_ptr(),
+                           w[f"l{i}.ln2.b"].data_ptr(), w[f"l{i}.fc1.w"].data_ptr(), w[f"l{i}.fc1.b"].data_ptr(),
+                           w[f"l{i}.fc2.w"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(), ws["x"].data_ptr(), gn.data_ptr(),
+                           bn.data_ptr(), self.ln_eps, None if nq else h_next.data_ptr(), nq[0].data_ptr() if nq else None,
+                           nq[1].data_ptr() if nq else None, qnext.data_ptr() if nq else None, M, E, Fd, st)
+                qkv_done = nq is not None
+                qcur, qnext = qnext, qcur
+                continue
             qkv_done = False
-            self._call("attention", "pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), B * passes,
+            self._call("attention", "pp_attention", self.prec, qcur.data_ptr(), ws["h"].data_ptr(), B * passes,
                        self.Np, self.heads, self.hd, scale, st)
             last = i + 1 == L
             gn, bn = (w["ln_f.w"], w["ln_f.b"]) if last else (w[f"l{i + 1}.ln1.w"], w[f"l{i + 1}.ln1.b"])
@@ -198,7 +219,7 @@ class ProbPoseEngine:
                            w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.w"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(),
                            ws["x"].data_ptr(), gn.data_ptr(), bn.data_ptr(), self.ln_eps,
                            None if nq else h_next.data_ptr(), nq[0].data_ptr() if nq else None,
-                           nq[1].data_ptr() if nq else None, ws["qkv"].data_ptr() if nq else None, M, E, Fd, st)
+                           nq[1].data_ptr() if nq else None, qcur.data_ptr() if nq else None, M, E, Fd, st)
                 qkv_done = nq is not None
                 continue
             res_ln(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])

@@ -444,3 +444,43 @@ def test_deconv_head_and_phased_decode_vs_unfused():
         outs.append((hm.cpu(), locs.cpu(), kp.cpu(), sc.cpu()))
     for a, c in zip(*outs):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("n_seq,with_qkv", [(1, True), (3, False), (3, True)])
+def test_vit_layer_one_launch(n_seq, with_qkv):
+    """pp_vit_layer = attention + projection + ln2 + FFN + LayerNorm (+ next qkv) in one launch, against the chain of the
+    separate kernels' torch reference (fp64 on bf16-rounded operands, intermediates rounded to bf16 where the kernel does)."""
+    L = _lib()
+    E, Fd, S, heads, hd = 384, 1536, 192, 12, 32
+    M = n_seq * S
+    qkv = _rand(M, 3 * E, seed=101, scale=1.2)
+    wp, bp = _rand(E, E, seed=102, scale=1 / math.sqrt(E)), _rand(E, seed=103, scale=0.3)
+    w1, b1 = _rand(Fd, E, seed=104, scale=1 / math.sqrt(E)), _rand(Fd, seed=105, scale=0.3)
+    w2, b2 = _rand(E, Fd, seed=106, scale=1 / math.sqrt(Fd)), _rand(E, seed=107, scale=0.3)
+    wq, bq = _rand(3 * E, E, seed=108, scale=1 / math.sqrt(E)), _rand(3 * E, seed=109, scale=0.3)
+    x0 = _rand(M, E, seed=110, scale=2.0)
+    g2, be2 = 1 + 0.1 * _rand(E, seed=111), _rand(E, seed=112)
+    g, be = 1 + 0.1 * _rand(E, seed=113), _rand(E, seed=114)
+    t = _q(qkv, BF16).reshape(n_seq, S, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    att = ((t[0] @ t[1].transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    a = (att @ t[2]).transpose(1, 2).reshape(M, E)
+    x1 = x0.double() + _q(a.float(), BF16) @ _q(wp, BF16).t() + bp.double()
+    h = F.layer_norm(x1, (E,), g2.double(), be2.double(), 1e-6)
+    hid = F.gelu(_q(h.float(), BF16) @ _q(w1, BF16).t() + b1.double())
+    xref = x1 + _q(hid.float(), BF16) @ _q(w2, BF16).t() + b2.double()
+    href = F.layer_norm(xref, (E,), g.double(), be.double(), 1e-6)
+    qref = _q(href.float(), BF16) @ _q(wq, BF16).t() + bq.double()
+    d = lambda v, bf=False: (v.bfloat16() if bf else v).cuda()  # noqa: E731
+    qd, wpd, w1d, w2d, wqd = d(qkv, True), d(wp, True), d(w1, True), d(w2, True), d(wq, True)
+    bpd, b1d, b2d, bqd, g2d, be2d, gd, bed = d(bp), d(b1), d(b2), d(bq), d(g2), d(be2), d(g), d(be)
+    x = x0.clone().cuda()
+    hout = torch.empty(M, E, dtype=torch.bfloat16, device="cuda")
+    qout = torch.full((M, 3 * E), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.call("pp_vit_layer", qd.data_ptr(), S, heads, hd ** -0.5, wpd.data_ptr(), bpd.data_ptr(), x.data_ptr(), g2d.data_ptr(),
+           be2d.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), x.data_ptr(), gd.data_ptr(), bed.data_ptr(),
+           1e-6, hout.data_ptr(), wqd.data_ptr() if with_qkv else None, bqd.data_ptr() if with_qkv else None,
+           qout.data_ptr() if with_qkv else None, M, E, Fd, None)
+    torch.testing.assert_close(x.cpu().double(), xref, rtol=2e-2, atol=4e-2)
+    torch.testing.assert_close(hout.cpu().double(), href, rtol=3e-2, atol=4e-2)
+    if with_qkv:
+        torch.testing.assert_close(qout.cpu().double(), qref, rtol=3e-2, atol=8e-2)
