@@ -681,13 +681,12 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     }
 
     // ================= qkv of the next layer: three column blocks x twelve k-steps, accumulators reused per block.
-    // Global stores share vmcnt with the DMA stream and may retire out of order with it, so the step after any store
-    // waits for everything (vmcnt 0) before the counted waits resume.
     wait_dma_and_barrier<0>();
     constexpr int QBASE = -PRE;  // ring position of qkv slot q is q & 7
     read_Bw(QBASE, 0, wb[0]);
     read_rows(OFF_HS, 0, gb[0]);
-    for (int cb = 0; cb < 3; ++cb) {  // column block: q, k, v
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb) {  // column block: q, k, v (unrolled: ring positions and LDS offsets become immediates)
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
@@ -695,8 +694,10 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 #pragma unroll
         for (int j = 0; j < 12; ++j) {  // (unrolled: the fragment buffers must be indexed statically)
             const int cur = j & 1, t = cb * 12 + j;
-            if (j == 0) wait_dma_and_barrier<0>();
-            else wait_dma_and_barrier<NSLOT - 3 - 3>();
+            // (a counted wait is safe right after the previous block's stores too: the DMA loads retire in order among
+            // themselves, so "at most two of my operations outstanding" implies the tile has landed - outstanding stores
+            // can only make the wait longer, never let it pass early)
+            wait_dma_and_barrier<NSLOT - 3 - 3>();
 #pragma unroll
             for (int i = 0; i < 3; ++i) issue_wq(3 * t + NSLOT + i, (3 * t + NSLOT + i) & (NSLOT - 1), wq_lane);
             read_Bw(QBASE, t + 1, wb[cur ^ 1]);  // (past the last step: a harmless read of the zero filler)
