@@ -19,8 +19,6 @@
 //     rows) land on the same XCD / L2.
 #include "pp_common.h"
 
-#include <cstdlib>
-
 namespace pp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -64,7 +62,7 @@ __device__ __forceinline__ int kswz(int row, int chunk) {
 
 template <typename T, int HD, int NT>
 __global__ __launch_bounds__(ATT_THREADS, (NT <= 12 ? 3 : 1)) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                                int n_seq, int heads, float scale_log2e, int dbg) {
+                                                                int n_seq, int heads, float scale_log2e) {
     using C = AttCfg<T, HD, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                        // [SP][HD], chunk-swizzled
@@ -93,7 +91,6 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 12 ? 3 : 1)) void attention_ker
     }
 
     // ---- stage K (row-major, swizzled) and V (transposed); zero the padded key rows
-    if (!(dbg & 1))
     for (int i = tid; i < C::SP * C::RC; i += ATT_THREADS) {
         const int r = i / C::RC, c = i - r * C::RC;
         u32x4 kv = u32x4{0, 0, 0, 0}, vv = u32x4{0, 0, 0, 0};
@@ -112,7 +109,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 12 ? 3 : 1)) void attention_ker
 #pragma unroll
     for (int t = 0; t < QPW; ++t) {
         const int qt = wave + t * (ATT_THREADS / 64);
-        if (qt >= NT || (dbg & 2)) break;
+        if (qt >= NT) break;
         u32x4 qf[C::NG];
 #pragma unroll
         for (int g = 0; g < C::NG; ++g) qf[g] = qf_all[t][g];
@@ -206,8 +203,7 @@ static int launch_attention(const void* qkv, void* out, int n_seq, int heads, fl
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)C::LDS));
     hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(ATT_THREADS), C::LDS, s, reinterpret_cast<const T*>(qkv),
-                       reinterpret_cast<T*>(out), n_seq, heads, scale * 1.44269504088896340736f,
-                       getenv("PP_ATT_DBG") ? atoi(getenv("PP_ATT_DBG")) : 0);
+                       reinterpret_cast<T*>(out), n_seq, heads, scale * 1.44269504088896340736f);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

@@ -29,7 +29,6 @@ struct GemmParams {
     int ksplit;             // >1: split-K launch - `groups` counts (K slice, problem) pairs, z = slice * (groups / ksplit) + problem;
                             // K is the length of one slice, ldw the full row; conv gathers start at tap slice * K / Cin
     int groups;             // independent problems in one launch (the four towers); tiles of all groups share the persistent grid
-    int dbg;                // development knobs (PP_GEMM_DBG): 1 skip stores, 2 skip re-staging, 4 single K-tile
     int planar_P;           // >0: store planar, out[((m / P) * N + n) * P + m % P]  (NHWC rows -> (B, N, P) planes)
     unsigned a_bytes, w_bytes;  // extent of the activation / weight tensor of ONE group (buffer-descriptor bound)
     long long strideA_z, strideW_z, strideC_z, strideBias_z;  // grouped launch (blockIdx.z), in elements

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
 
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     const int tiles_per_group = ntn * ntm, ntiles = tiles_per_group * p.groups;
-    const int nk = (p.dbg & 4) ? 1 : p.K / BK;
+    const int nk = p.K / BK;
 
     // XCD-aware order: block b runs on XCD b % 8 and visits b, b + G, ... (G % 8 == 0 keeps it there);
     // logical tile = (t % 8) * (ntiles / 8) + t / 8 gives each XCD a contiguous run of the tile list.
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
         for (int kt = 0; kt < nk; ++kt, ++it) {
             const int buf = it & 1;
             // next K-tile's DMA flies under this tile's MFMAs -- across the seam it is the next OUTPUT tile's first
-            if (!(p.dbg & 2)) {
+            {
                 if (kt + 1 < nk) {
                     stage(kt + 1, buf ^ 1);
                 } else if (next_tile < ntiles) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
                     }
                 }
             }
-        } else if (!((p.dbg & 1) && acc[0][0][0] != 12345.678f)) {
+        } else {
             // Row-major output through LDS: 16-byte chunks of a row XOR-swizzled by (row & 15) -> the fragment
             // writes and the row reads are both bank-conflict free. bf16: whole 128 x 256 B tile at once;
             // fp32: two 64-row halves (64 x 512 B = one 32 KiB buffer each).
@@ -391,8 +391,6 @@ static int device_cus() {
 template <typename T>
 static int launch_gemm(const GemmParams& p_in, int groups, hipStream_t s) {
     GemmParams p = p_in;
-    static const int dbg = getenv("PP_GEMM_DBG") ? atoi(getenv("PP_GEMM_DBG")) : 0;
-    p.dbg = dbg;
     p.groups = groups;
     if (p.ksplit < 1) p.ksplit = 1;
     PP_REQUIRE(groups % p.ksplit == 0, PP_ERR_INVALID_ARG, "pp gemm: groups must be a multiple of ksplit");
