@@ -8,6 +8,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_void_p
 
+# torch BEFORE the dlopen below: PyTorch-ROCm ships its own libamdhip64.so; if this library were loaded first it would
+# bind /opt/rocm's copy and the process would hold two HIP runtimes - device pointers handed over from torch tensors
+# are then unknown to ours ("no ROCm-capable device is detected" at the first launch).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libprobpose_mi355x.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)

@@ -77,12 +77,23 @@ def pack_crops(crops_u8: torch.Tensor, input_center: np.ndarray, input_scale: np
     return dict(inputs=[crops_u8[b] for b in range(B)], data_samples=samples)
 
 
+def load_image_bgr(path: str) -> np.ndarray:
+    """LoadImage for a file path (mmpose/datasets/transforms/loading.py:47-107 -> mmcv.imread, BGR uint8). mmcv decodes
+    with cv2; this build has Pillow only, whose JPEG decoder may differ from cv2's by one grey level in a few pixels."""
+    from PIL import Image
+
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
 def inference_topdown(model, img: Union[np.ndarray, torch.Tensor], bboxes=None, bbox_format: str = "xyxy"):
     """apis/inference.py:133-200 for an image already in memory: ``img`` is (H, W, 3) uint8 BGR (what LoadImage /
     cv2.imread produce), host array or device tensor; ``bboxes`` (N, 4) in ``bbox_format``, None or empty = the whole
-    image as one box. Returns list[PoseDataSample], one per box, keypoints in image coordinates."""
+    image as one box; ``img`` may also be a file path. Returns list[PoseDataSample], one per box, keypoints in image
+    coordinates."""
     if isinstance(img, str):
-        raise TypeError("inference_topdown: image decoding is not part of this package - pass the loaded (H, W, 3) uint8 array")
+        img = load_image_bgr(img)
     h, w = img.shape[:2]
     if bboxes is None or len(bboxes) == 0:
         bboxes = np.array([[0, 0, w, h]], dtype=np.float32)

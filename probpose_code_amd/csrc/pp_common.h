@@ -18,8 +18,12 @@ inline int fail(int code, const char* what) {
     return code;
 }
 
+// Argument check at the head of every entry point. It also drops whatever error an EARLIER runtime call of this
+// thread (the caller's, e.g. a device probe of the framework around us) left in HIP's sticky per-thread slot, so that
+// PP_LAUNCH_CHECK reports this entry point's own launches only.
 #define PP_REQUIRE(cond, code, msg)          \
     do {                                     \
+        (void)hipGetLastError();             \
         if (!(cond)) {                       \
             ::pp::set_error("%s", (msg));    \
             return (code);                   \

@@ -104,6 +104,30 @@ except Exception:  # noqa: BLE001
             vals = self.values()
             return len(vals[0]) if vals else 0
 
+        @staticmethod
+        def cat(instances_list):
+            """mmengine InstanceData.cat: concatenate every data field along the first dimension."""
+            import numpy as np
+            import torch
+
+            assert len(instances_list) > 0 and all(isinstance(i, InstanceData) for i in instances_list)
+            if len(instances_list) == 1:
+                return instances_list[0]
+            out = InstanceData(metainfo=instances_list[0].metainfo)
+            for k in instances_list[0].keys():
+                vals = [getattr(i, k) for i in instances_list]
+                v0 = vals[0]
+                if isinstance(v0, torch.Tensor):
+                    merged = torch.cat(vals, dim=0)
+                elif isinstance(v0, np.ndarray):
+                    merged = np.concatenate(vals, axis=0)
+                elif isinstance(v0, (str, list, tuple)):
+                    merged = [x for v in vals for x in (v if isinstance(v, (list, tuple)) else [v])]
+                else:
+                    raise ValueError(f"The type of `{k}` is `{type(v0)}` which has no concatenation rule")
+                setattr(out, k, merged)
+            return out
+
     class PixelData(BaseDataElement):
         """Pixel-level fields of shape (C, H, W)."""
 
@@ -151,4 +175,30 @@ except Exception:  # noqa: BLE001
             return super().__contains__(priv)
 
 
-__all__ = ["BaseDataElement", "InstanceData", "PixelData", "PoseDataSample", "USING_MMENGINE"]
+
+
+def merge_data_samples(data_samples):
+    """mmpose/structures/utils.py:16-47 without the heatmap re-projection (:48-...): the top-down predictions of one
+    image - one PoseDataSample per box - merged into a single sample with all instances; metainfo of the first sample,
+    ``input_center`` / ``input_scale`` stacked."""
+    import warnings
+
+    import numpy as np
+
+    if not isinstance(data_samples, (list, tuple)) or not all(isinstance(d, PoseDataSample) for d in data_samples):
+        raise ValueError("Invalid input type, should be a list of :obj:`PoseDataSample`")
+    if len(data_samples) == 0:
+        warnings.warn("Try to merge an empty list of data samples.")
+        return PoseDataSample()
+    metadata = dict(data_samples[0].metainfo)
+    metadata["input_center"] = np.array([ds.input_center for ds in data_samples])
+    metadata["input_scale"] = np.array([ds.input_scale for ds in data_samples])
+    merged = PoseDataSample(metainfo=metadata)
+    if "gt_instances" in data_samples[0]:
+        merged.gt_instances = InstanceData.cat([d.gt_instances for d in data_samples])
+    if "pred_instances" in data_samples[0]:
+        merged.pred_instances = InstanceData.cat([d.pred_instances for d in data_samples])
+    return merged
+
+
+__all__ = ["BaseDataElement", "InstanceData", "PixelData", "PoseDataSample", "USING_MMENGINE", "merge_data_samples"]

@@ -104,3 +104,32 @@ def test_inference_topdown_end_to_end():
     xywh = apis.inference_topdown(model, img, np.array([[100, 50, 120, 350]], np.float32), bbox_format="xywh")
     # (not bit-identical: the residual GEMM rotates its K order per workgroup, so the last bit depends on the batch position)
     assert np.allclose(xywh[0].pred_instances.keypoints, res[0].pred_instances.keypoints, atol=1e-3)
+
+
+def test_merge_data_samples_and_image_loading(tmp_path):
+    """merge_data_samples (structures/utils.py:16-47) on the shim containers; load_image_bgr returns cv2-order channels."""
+    from PIL import Image
+
+    from probpose_code_amd import apis
+    from probpose_code_amd.structures import InstanceData, PoseDataSample, merge_data_samples
+
+    samples = []
+    for i in range(3):
+        ds = PoseDataSample(metainfo=dict(input_center=np.array([i, i], np.float32), input_scale=np.array([2 * i, 3 * i], np.float32),
+                                          ori_shape=(10, 20)))
+        pi = InstanceData()
+        pi.keypoints = np.full((1, 17, 2), float(i))
+        pi.keypoint_scores = np.full((1, 17), float(i), np.float32)
+        ds.pred_instances = pi
+        samples.append(ds)
+    m = merge_data_samples(samples)
+    assert m.pred_instances.keypoints.shape == (3, 17, 2) and m.pred_instances.keypoints[2, 0, 0] == 2.0
+    assert m.input_center.shape == (3, 2) and m.ori_shape == (10, 20)
+    with pytest.raises(ValueError):
+        merge_data_samples([1, 2])
+    rgb = np.zeros((4, 5, 3), np.uint8)
+    rgb[..., 0] = 200  # red
+    path = str(tmp_path / "red.png")
+    Image.fromarray(rgb).save(path)
+    bgr = apis.load_image_bgr(path)
+    assert bgr.shape == (4, 5, 3) and bgr[0, 0].tolist() == [0, 0, 200]
