@@ -283,6 +283,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         if (lane == 0) p.trace[(wv >> 2) * 4096 + it * 10 + st] = t;
     };
 
+    stamp(20, 0);  // kernel start
     if (ATT) {
         // ================= attention of this workgroup's 96 query rows (waves 0-5: one 16-query tile each; all eight waves
         // stage K / V). Sequence = 192 tokens = this workgroup's rows and its neighbour's.
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         }
     };
 
+    stamp(20, 1);  // prologue done (rows, residual, first tiles)
     if (PROJ) {
         // ================= attention output projection: acc (= x + bp) += a Wp^T, twelve steps of k = 32 in the style
         // of phase B with the input rows as the row operand; then h = LayerNorm2(acc) replaces the rows in LDS.
@@ -580,6 +582,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         wait_dma_and_barrier<0>();  // h complete, first phase-A tiles landed
     }
 
+    stamp(20, 2);  // projection + ln2 done
     // ---- peeled phase A of the first chunk
     read_A(0, 0, wa[0], ha[0]);
 #pragma unroll
@@ -636,6 +639,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         }
     }
 
+    stamp(20, 3);  // FFN loop done
     // ---- LayerNorm epilogue (G is out of use: its region carries the statistics exchange while the ring may already
     // hold qkv tiles)
     wait_dma_and_barrier<63>();
@@ -675,6 +679,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
             if (p.h_out) *reinterpret_cast<bf16x4*>(p.h_out + off) = hv;
         }
     }
+    stamp(20, 4);  // LayerNorm + x_out / h stores issued
     if (!QKV) {
         wait_dma_and_barrier<0>();  // the out-of-bounds DMAs past the last chunk must not outlive the workgroup
         return;
@@ -694,6 +699,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 #pragma unroll
         for (int j = 0; j < 12; ++j) {  // (unrolled: the fragment buffers must be indexed statically)
             const int cur = j & 1, t = cb * 12 + j;
+            stamp(22 + 2 * cb, j);
             // (a counted wait is safe right after the previous block's stores too: the DMA loads retire in order among
             // themselves, so "at most two of my operations outstanding" implies the tile has landed - outstanding stores
             // can only make the wait longer, never let it pass early)
@@ -715,6 +721,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         // 256 B, 16-byte chunks XOR-swizzled by row & 7), so that every row leaves as 256 contiguous bytes: stored
         // straight from the accumulator layout (8 bytes per lane, 32-byte runs) the same data takes twice as long.
         __builtin_amdgcn_sched_barrier(0);
+        stamp(22 + 2 * cb, 12);  // block's MFMAs issued
         char* gst = smem + OFF_GS;
 #pragma unroll
         for (int ps = 0; ps < 3; ++ps) {
@@ -745,7 +752,9 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
             wait_dma_and_barrier<63>();  // the staging rows are rewritten by the next pass
         }
     }
+    stamp(20, 5);  // qkv tail done
     wait_dma_and_barrier<0>();  // the out-of-bounds DMAs past the last tile must not outlive the workgroup
+    stamp(20, 6);
 }
 
 unsigned long long* g_trace = nullptr;
