@@ -136,12 +136,13 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// qkv slot q (step q / 3 = 12 column-block + k-step, third q % 3): rows of Wq block-wise in the image of a Wp tile; past
-// the last slot the DMA is issued out of bounds (a plain function: a value-returning lambda for this inside the kernel
-// template made the host pass drop the kernel stubs without a diagnostic)
-__device__ __forceinline__ unsigned wq_slot_offset(int q, unsigned wp_lane) {
+// qkv tile stream of the tail: step t = 6 b + kt (column block b of 192 outputs, k-step kt of 64), three slots of 64
+// weight rows each: slot q = 3 t + third holds rows 192 b + 64 third + (0..63), k in [64 kt, +64), plain 128-byte lines
+// like a W1 slot. Past the last slot the DMA is issued out of bounds (a plain function: a value-returning lambda for this
+// inside the kernel template made the host pass drop the kernel stubs without a diagnostic).
+__device__ __forceinline__ unsigned wq_slot_offset(int q, unsigned lane_off) {
     const int t = q / 3;
-    return q < 108 ? (unsigned)((t / 12) * 384 + (q % 3) * 64) * (unsigned)(E * 2) + (unsigned)(32 * (t % 12) * 2) + wp_lane : OOB;
+    return q < 108 ? (unsigned)((t / 6) * 192 + (q % 3) * 64) * (unsigned)(E * 2) + (unsigned)((t % 6) * 128) + lane_off : OOB;
 }
 
 // PROJ = true puts the attention output projection in front:  x' = x + a Wp^T + bp ;  h = LayerNorm2(x')  and then the
@@ -221,9 +222,13 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         const unsigned vo = (unsigned)((q % 3) * 64) * (E * 2) + (unsigned)(32 * (q / 3) * 2) + wp_lane;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rsrc, (lds_ptr_t)(ring + pos * SLOT + wv * 1024), 16, vo, 0, 0, 0);
     };
+    // (in the qkv tail only waves 0-3 issue DMA, two of the eight 1 KiB pieces of a slot each: lines 16 w .. 16 w + 15)
     auto issue_wq = [&](int q, int pos, unsigned lane_off) {
         if (DBG & 8) return;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wq_rsrc, (lds_ptr_t)(ring + pos * SLOT + wv * 1024), 16, wq_slot_offset(q, lane_off), 0, 0, 0);
+        const unsigned vo = wq_slot_offset(q, lane_off);
+        char* dst = ring + pos * SLOT + (wv & 3) * 2048;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wq_rsrc, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wq_rsrc, (lds_ptr_t)(dst + 1024), 16, vo == OOB ? OOB : vo + 8 * (E * 2), 0, 0, 0);
     };
     auto issue_rel = [&](int it, int g) {
         const int pos = (g + 12 + 24 + 48 + PRE) & (NSLOT - 1);  // PRE + 12 + 24 it + g, multiples of 8 dropped
@@ -654,11 +659,13 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     unsigned wq_lane = 0;
     if (QKV) {
         const int lc = (lane_e & 7) ^ (lane_e >> 3);
-        wq_lane = (unsigned)(wv * 8 + (lane_e >> 3) + 192 * (lc >> 2)) * (E * 2) + (unsigned)((lc & 3) << 4);
+        wq_lane = (unsigned)((wv & 3) * 16 + (lane_e >> 3)) * (E * 2) + (unsigned)(lc << 4);  // W1-style lines, two pieces per wave
         // the statistics exchange ended with every DMA of the FFN landed (the last ones were out-of-bounds fillers), so
         // the ring restarts at slot 0 with the first qkv tiles; they fly under the stores below
+        if (rg == 0) {
 #pragma unroll
-        for (int q = 0; q < NSLOT; ++q) issue_wq(q, q, wq_lane);
+            for (int q = 0; q < NSLOT; ++q) issue_wq(q, q, wq_lane);
+        }
     }
 #pragma unroll
     for (int nf = 0; nf < 6; ++nf) {
@@ -685,71 +692,119 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         return;
     }
 
-    // ================= qkv of the next layer: three column blocks x twelve k-steps, accumulators reused per block.
+    // ================= qkv of the next layer: six column blocks of 192 outputs x six k-steps of 64 (18 MFMAs per wave
+    // and step, wave tile 48 rows x 48 outputs). Two accumulator sets: while block b+1 accumulates, block b leaves -
+    // bias, bf16, one 48-row half at a time through the G region (512 B pitch, chunks XOR-swizzled by row & 7) so that
+    // every row goes out as three whole cache lines - spread over four of the next block's steps instead of
+    // one burst per block that stalls the whole chip on the HBM write queue. Roles by wave, because global stores share
+    // vmcnt with the DMA stream and a counted wait would sit behind them: waves 0-3 issue all the DMA (and count it),
+    // waves 4-7 do all the stores (and never wait for them before the end).
     wait_dma_and_barrier<0>();
-    constexpr int QBASE = -PRE;  // ring position of qkv slot q is q & 7
-    read_Bw(QBASE, 0, wb[0]);
-    read_rows(OFF_HS, 0, gb[0]);
+    u32x4 wq_f[2][3][2], hq_f[2][3][2];  // fragments of the qkv steps, double-buffered: [buffer][fragment][k-half]
+    auto read_Q = [&](int t, u32x4 (&wf)[3][2], u32x4 (&hf)[3][2]) {
+        if (DBG & 16) {
+            for (int ks = 0; ks < 2; ++ks) for (int f = 0; f < 3; ++f) { opaque(wf[f][ks]); opaque(hf[f][ks]); }
+            return;
+        }
+        const char* hbase = smem + OFF_HS + (t % 6) * HS_KB + rows0 * ROW_BYTES;
 #pragma unroll
-    for (int cb = 0; cb < 3; ++cb) {  // column block: q, k, v (unrolled: ring positions and LDS offsets become immediates)
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((ks * 4 + f_kg) ^ frag_sw) << 4;
 #pragma unroll
-        for (int rf = 0; rf < 3; ++rf)
+            for (int nfr = 0; nfr < 3; ++nfr) {
+                const int line = cg * 48 + nfr * 16;  // first weight row of the fragment inside the 192-row tile (wave-uniform)
+                const int pos = (3 * t + (line >> 6)) & (NSLOT - 1);
+                wf[nfr][ks] = *reinterpret_cast<const u32x4*>(ring + pos * SLOT + ((line & 63) + f_row) * ROW_BYTES + ch);
+            }
 #pragma unroll
-            for (int nf = 0; nf < 6; ++nf) acc[rf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rf = 0; rf < 3; ++rf) hf[rf][ks] = *reinterpret_cast<const u32x4*>(hbase + rf * 16 * ROW_BYTES + ch);
+        }
+    };
+    char* gst = smem + OFF_GS;
+    // Row half `ps` (48 rows x 192 columns = three whole 128-byte lines per row) of the block held in accumulator set
+    // `set` into the staging rows (512-byte pitch): the four waves that own those rows. The bias of the block was loaded
+    // during the block itself (see the step loop for where, relative to the counted DMA waits).
+    f32x4 bq_f[3];
+    auto load_bias = [&](int bb) {
 #pragma unroll
-        for (int j = 0; j < 12; ++j) {  // (unrolled: the fragment buffers must be indexed statically)
-            const int cur = j & 1, t = cb * 12 + j;
-            stamp(22 + 2 * cb, j);
-            // (a counted wait is safe right after the previous block's stores too: the DMA loads retire in order among
-            // themselves, so "at most two of my operations outstanding" implies the tile has landed - outstanding stores
-            // can only make the wait longer, never let it pass early)
-            wait_dma_and_barrier<NSLOT - 3 - 3>();
+        for (int nfr = 0; nfr < 3; ++nfr) bq_f[nfr] = *reinterpret_cast<const f32x4*>(p.bq + bb * 192 + cg * 48 + nfr * 16 + e_kg * 4);
+    };
+    auto stage_half = [&](int ps, int set) {
+        if (rg != ps) return;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) issue_wq(3 * t + NSLOT + i, (3 * t + NSLOT + i) & (NSLOT - 1), wq_lane);
-            read_Bw(QBASE, t + 1, wb[cur ^ 1]);  // (past the last step: a harmless read of the zero filler)
-            read_rows(OFF_HS, (j + 1) % 12, gb[cur ^ 1]);
+        for (int nfr = 0; nfr < 3; ++nfr) {
+            const int byte = (cg * 48 + nfr * 16 + e_kg * 4) * 2;
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) {
+                const f32x4 v = acc[rf][set * 3 + nfr] + bq_f[nfr];
+                const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                const int row = rf * 16 + e_row;  // row inside the half
+                *reinterpret_cast<bf16x4*>(gst + row * 512 + ((((byte >> 4) ^ (row & 7)) << 4) | (byte & 15))) = ov;
+            }
+        }
+    };
+    // the staged half to HBM: waves 4-7, 48 rows x 24 chunks of 16 bytes
+    auto store_half = [&](int bb, int ps, int i_lo, int i_hi) {
+        if (rg == 0) return;
+#pragma unroll
+        for (int i5 = i_lo; i5 < i_hi; ++i5) {
+            const int idx = i5 * 256 + (tid - 256);  // (tid is lane-dependent: fine, used only here)
+            const int row = idx / 24, ch = idx - row * 24;
+            if (idx < 48 * 24) {
+                const int m = m0 + ps * 48 + row;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(gst + row * 512 + ((ch ^ (row & 7)) << 4));
+                if (m < p.M && !(DBG & 1024))
+                    *reinterpret_cast<u32x4*>(p.qkv + (size_t)m * (3 * E) + bb * 192 + ch * 8) = raw;
+            }
+        }
+    };
+    read_Q(0, wq_f[0], hq_f[0]);
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {  // block 6 is the drain: no MFMAs, only block 5 leaving
+        const int set = b & 1;
+        if (b < 6) {
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
-                for (int nf = 0; nf < 6; ++nf) {
-                    if (!(DBG & 4)) acc[rf][nf] = mma(wb[cur][nf], gb[cur][rf], acc[rf][nf]);
-                }
-#pragma unroll
-            for (int i = 0; i < 9; ++i) { SGB(SG_MFMA, 2); SGB(SG_DS_READ, 1); if (i == 0 || i == 3 || i == 6) SGB(SG_VMEM, 1); }
+                for (int nfr = 0; nfr < 3; ++nfr) acc[rf][set * 3 + nfr] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // Output block (96 rows x 384 columns, bf16) in three passes of 128 columns through the G region (96 rows x
-        // 256 B, 16-byte chunks XOR-swizzled by row & 7), so that every row leaves as 256 contiguous bytes: stored
-        // straight from the accumulator layout (8 bytes per lane, 32-byte runs) the same data takes twice as long.
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(22 + 2 * cb, 12);  // block's MFMAs issued
-        char* gst = smem + OFF_GS;
 #pragma unroll
-        for (int ps = 0; ps < 3; ++ps) {
+        for (int kt = 0; kt < (b < 6 ? 6 : 5); ++kt) {
+            const int t = b * 6 + kt, cur = t & 1;
+            stamp(22 + 2 * (b >> 1), (b & 1) * 6 + kt);
+            if (rg == 0) wait_dma_and_barrier<2 * (NSLOT - 3 - 3)>();
+            else wait_dma_and_barrier<63>();
+            // this block's bias, for its own departure during the next block (the previous block's was last used at step
+            // 3). Issued between the counted wait and the DMA of this step: older than that DMA, so the next counted
+            // wait covers it for free.
+            if (b < 6 && kt == 4) load_bias(b);
+            if (rg == 0) {
 #pragma unroll
-            for (int nf = 0; nf < 6; ++nf) {
-                const int col = cg * 96 + nf * 16;  // first column of this fragment inside the block (wave-uniform)
-                if ((col >> 7) != ps) continue;
-                const int n = col + e_kg * 4;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bq + cb * 384 + n);
-                const int byte = (n & 127) * 2;
-#pragma unroll
-                for (int rf = 0; rf < 3; ++rf) {
-                    const f32x4 v = acc[rf][nf] + bv;
-                    const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    const int row = e_rows0 + rf * 16;
-                    *reinterpret_cast<bf16x4*>(gst + row * 256 + ((((byte >> 4) ^ (row & 7)) << 4) | (byte & 15))) = ov;
-                }
+                for (int i = 0; i < 3; ++i) issue_wq(3 * t + NSLOT + i, (3 * t + NSLOT + i) & (NSLOT - 1), wq_lane);
             }
-            wait_dma_and_barrier<63>();  // LDS only: the DMA of the next tiles stays in flight
+            __builtin_amdgcn_sched_barrier(0);
+            if (b < 6) {
+                read_Q(t + 1, wq_f[cur ^ 1], hq_f[cur ^ 1]);  // (past the last step: a harmless read of the zero filler)
 #pragma unroll
-            for (int r0 = 0; r0 < BM; r0 += THREADS / 16) {
-                const int row = r0 + (tid >> 4), ch = tid & 15;  // (tid is lane-dependent: fine, used only here)
-                const int m = m0 + row;
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(gst + row * 256 + ((ch ^ (row & 7)) << 4));
-                if (m < p.M && !(DBG & 1024))
-                    *reinterpret_cast<u32x4*>(p.qkv + (size_t)m * (3 * E) + cb * 384 + ps * 128 + ch * 8) = raw;
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                        for (int nfr = 0; nfr < 3; ++nfr) {
+                            if (!(DBG & 4)) acc[rf][set * 3 + nfr] = mma(wq_f[cur][nfr][ks], hq_f[cur][rf][ks], acc[rf][set * 3 + nfr]);
+                        }
             }
-            wait_dma_and_barrier<63>();  // the staging rows are rewritten by the next pass
+            // The previous block leaves in the shadow of this block's MFMAs (which were issued first): rows 0-47 are
+            // staged at step 0 and stored over steps 1-2, rows 48-95 staged at step 3 and stored over steps 4-5 (the
+            // drain block has five steps: its second half goes out in one piece).
+            if (b > 0) {
+                if (kt == 0) stage_half(0, set ^ 1);
+                if (kt == 1) store_half(b - 1, 0, 0, 3);
+                if (kt == 2) store_half(b - 1, 0, 3, 5);
+                if (kt == 3) stage_half(1, set ^ 1);
+                if (kt == 4) store_half(b - 1, 1, 0, b < 6 ? 3 : 5);
+                if (kt == 5) store_half(b - 1, 1, 3, 5);
+            }
         }
     }
     stamp(20, 5);  // qkv tail done

@@ -27,7 +27,6 @@ for w in (0, 1):
     for i, n in enumerate(names):
         print(f"   {n:30s} {ph[i+1]-ph[i]:7d}")
 for w in (0, 1):
-    for cb in range(3):
-        q = t[w * 4096 + (22 + 2 * cb) * 10: w * 4096 + (22 + 2 * cb) * 10 + 13]
-        nxt = t[w * 4096 + (22 + 2 * (cb + 1)) * 10] if cb < 2 else t[w * 4096 + 205]
-        print(f"wave {4*w} block {cb}: steps {[int(q[i+1]-q[i]) for i in range(12)]}  output staging + stores {int(nxt - q[12])}")
+    for pair in range(4):
+        q = t[w * 4096 + (22 + 2 * pair) * 10: w * 4096 + (22 + 2 * pair) * 10 + 13]
+        print(f"wave {4*w} blocks {2*pair},{2*pair+1}: step durations {[int(q[i+1]-q[i]) for i in range(11) if q[i+1] > 0 and q[i] > 0]}")
