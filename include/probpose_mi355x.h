@@ -269,6 +269,38 @@ int pp_extended_oks(const double* gt_kpts, const double* gt_bbox, const double* 
                     const double* sigmas, const int* gt_visibilities, int G, int D, int K, int n_vis,
                     double confidence_thr, double padding, int use_area, int original, double* out, void* stream);
 
+/* pp_extended_oks for every (image, category) cell of a dataset in one launch. Instances / detections of cell c are rows
+ * [cell_gt_off[c], cell_gt_off[c + 1]) / [cell_dt_off[c], cell_dt_off[c + 1]) of the flat arrays (detections of a cell in
+ * evaluation order, at most maxDets); its (n_vis + 1, Dc, Gc) float64 block is written at out + cell_out_off[c]. */
+int pp_exoks_cells(const double* gt_kpts, const double* gt_bbox, const double* gt_area, const double* dt_kpts,
+                   const double* sigmas, const int* gt_visibilities, const int* cell_gt_off, const int* cell_dt_off,
+                   const long long* cell_out_off, int n_cells, int K, int n_vis, double confidence_thr, double padding,
+                   int use_area, int original, double* out, void* stream);
+
+/* Greedy detection <-> instance matching of every (cell, visibility level, area range) at every similarity threshold
+ * (COCOeval.evaluateImg, mmpose/evaluation/metrics/_cocoeval.py:709-887, the return_matching=False branch: by similarity,
+ * or by nearest box centre when match_by_bbox). ious / offsets as written by pp_exoks_cells; gt_ignore (N_gt, L) uint8 =
+ * gt["ignore"][level]; gt_area (N_gt) = the area of the range test (:729-733); boxes xywh float64; area_rng (A, 2);
+ * iou_thrs (T <= 64). max_gt_per_cell sizes the LDS. Outputs: dt_match (L, A, T, N_dt) int32 = row of the matched instance
+ * or -1; dt_ignore (L, A, T, N_dt) uint8; gt_match (L, A, T, N_gt) int32 = row of the matching detection or -1;
+ * gt_ignore_out (L, A, N_gt) uint8 = the cell's _ignore flag; sim_sum / sim_cnt (L, A, n_cells) = sum / number of the
+ * similarities of the matches made over all thresholds (COCOeval.loc_similarities, :857). */
+int pp_exoks_match(const double* ious, const int* cell_gt_off, const int* cell_dt_off, const long long* cell_iou_off,
+                   const unsigned char* gt_ignore, const unsigned char* gt_iscrowd, const double* gt_area,
+                   const double* gt_bbox, const double* dt_area, const double* dt_bbox, const double* area_rng,
+                   const double* iou_thrs, int n_cells, int max_gt_per_cell, int N_gt, int N_dt, int L, int A, int T,
+                   int match_by_bbox, int* dt_match, unsigned char* dt_ignore, int* gt_match,
+                   unsigned char* gt_ignore_out, double* sim_sum, int* sim_cnt, void* stream);
+
+/* Precision / recall / score tables of the dataset (COCOeval.accumulate, _cocoeval.py:889-1009; one category, one maxDets).
+ * order (N_dt) int32 = np.argsort(-score, kind="mergesort") over all detections in cell order; rec_thrs (R <= 128);
+ * chunk_scratch: int32 (L * A * T, ceil(N_dt / 256), 2). precision / scores (T, L, R, A) and recall (T, L, A) float64 must be
+ * pre-filled with -1 by the caller: entries of rows without a counted instance are left untouched (:941-943, :955-956). */
+int pp_exmap_accumulate(const int* dt_match, const unsigned char* dt_ignore, const unsigned char* gt_ignore,
+                        const int* order, const double* dt_score, const double* rec_thrs, int n_cells, int N_gt, int N_dt,
+                        int L, int A, int T, int R, int* chunk_scratch, double* precision, double* recall, double* scores,
+                        void* stream);
+
 /* Person crops of the top-down pipeline: n times cv2.warpAffine(img, M_i, (out_w, out_h), flags=INTER_LINEAR), zero border
  * (TopdownAffine.transform, mmpose/datasets/transforms/topdown_transforms.py:118-126), written as the CHW uint8 tensors
  * PackPoseInputs emits (mmpose/datasets/transforms/formatting.py:14-36,195). img_hwc: (img_h, img_w, channels) uint8 on

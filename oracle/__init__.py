@@ -17,6 +17,10 @@ Pinning status (DESIGN.md §Oracle has the full table):
   ``mmpose/structures/keypoint/keypoints_min_padding.py:68-133``) -- PINNED: 60 synthetic cells scored by the
   reference's own ``COCOeval.computeExtendedOks`` (``tests/golden/make_golden_exoks.py`` ->
   ``tests/golden/exoks_cases.npz``, ``exoks_chain.npz``), matched to 1e-12.
+* Ex-mAP evaluator (``exmap_ref``; reference ``mmpose/evaluation/metrics/_cocoeval.py:161-503,709-1190``:
+  ``_prepare``, ``evaluateImg``, ``accumulate``, ``summarize``) -- PINNED: five synthetic datasets run through the
+  reference's own ``COCOeval.evaluate(); accumulate(); summarize()`` (``tests/golden/make_golden_exmap.py`` ->
+  ``tests/golden/exmap_cases.npz``); precision / recall / scores / stats and every per-image match reproduced exactly.
 * Sparsemax (PyPI ``sparsemax``, un-vendored, unpinned in ``requirements/build.txt:4``),
   ViT backbone (``mmpretrain==1.2.0`` ``VisionTransformer``, un-vendored), ``ProbMapHead``
   network (needs mmcv/mmengine, not importable) -- PARITY UNPINNED: restated from the

@@ -84,6 +84,12 @@ SIGNATURES = {
     "pp_warp_affine_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "pp_extended_oks": (
         c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int, _P, _P]),
+    "pp_exoks_cells": (
+        c_int, [_P] * 9 + [c_int, c_int, c_int, c_double, c_double, c_int, c_int, _P, _P]),
+    "pp_exoks_match": (
+        c_int, [_P] * 12 + [c_int] * 8 + [_P] * 7),
+    "pp_exmap_accumulate": (
+        c_int, [_P] * 6 + [c_int] * 7 + [_P] * 5),
     "pp_conv_gemm": (
         c_int,
         [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

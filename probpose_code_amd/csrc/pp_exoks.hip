@@ -3,6 +3,7 @@
 // fix_bbox_aspect_ratio, mmpose/structures/keypoint/keypoints_min_padding.py:68-133). float64 like the numpy original.
 // One thread per (visibility level, detection, instance); K (17) keypoints are a serial loop - the cell is tiny, the
 // kernel exists so that keypoints and presence probabilities can stay on the device through evaluation.
+// pp_exoks_cells is the same arithmetic for every cell of a dataset in one launch (one workgroup per cell, CSR offsets).
 #include "pp_common.h"
 
 namespace pp {
@@ -19,13 +20,15 @@ struct ExOksParams {
     double confidence_thr;   // NaN: presence probabilities are used clipped to [0, 1] but not binarised
     double padding;
     int use_area, original;
+    // dataset form (pp_exoks_cells): instances / detections of cell c are [cell_gt_off[c], cell_gt_off[c + 1]) and
+    // [cell_dt_off[c], cell_dt_off[c + 1]); its (n_vis + 1, Dc, Gc) block starts at out + cell_out_off[c]
+    const int* cell_gt_off;
+    const int* cell_dt_off;
+    const long long* cell_out_off;
 };
 
-__global__ void extended_oks_kernel(const ExOksParams p) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int L = p.n_vis + 1;
-    if (idx >= L * p.D * p.G) return;
-    const int g = idx % p.G, d = (idx / p.G) % p.D, lvl = idx / (p.G * p.D);
+// similarity of detection d (global index) to instance g (global index) at visibility level lvl
+__device__ double exoks_pair(const ExOksParams& p, int g, int d, int lvl) {
     const double* gk = p.gt_kpts + (size_t)g * p.K * 3;
     const double* dk = p.dt_kpts + (size_t)d * p.K * 3;
     const double bx = p.gt_bbox[4 * g], by = p.gt_bbox[4 * g + 1], bw = p.gt_bbox[4 * g + 2], bh = p.gt_bbox[4 * g + 3];
@@ -90,7 +93,22 @@ __global__ void extended_oks_kernel(const ExOksParams p) {
         }
         sum += exp(-(dist / var / area / 2));
     }
-    p.out[idx] = sum / (double)(k1 > 0 ? k1 : p.K);
+    return sum / (double)(k1 > 0 ? k1 : p.K);
+}
+
+__global__ void extended_oks_kernel(const ExOksParams p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = p.n_vis + 1;
+    if (idx >= L * p.D * p.G) return;
+    p.out[idx] = exoks_pair(p, idx % p.G, (idx / p.G) % p.D, idx / (p.G * p.D));
+}
+
+__global__ void extended_oks_cells_kernel(const ExOksParams p) {
+    const int c = blockIdx.x;
+    const int g0 = p.cell_gt_off[c], G = p.cell_gt_off[c + 1] - g0, d0 = p.cell_dt_off[c], D = p.cell_dt_off[c + 1] - d0;
+    double* out = p.out + p.cell_out_off[c];
+    for (int idx = threadIdx.x; idx < (p.n_vis + 1) * D * G; idx += blockDim.x)
+        out[idx] = exoks_pair(p, g0 + idx % G, d0 + (idx / G) % D, idx / (G * D));
 }
 
 }  // namespace pp
@@ -106,9 +124,26 @@ extern "C" int pp_extended_oks(const double* gt_kpts, const double* gt_bbox, con
                "pp_extended_oks: bad shape");
     PP_REQUIRE(padding >= 1.0, PP_ERR_INVALID_ARG, "pp_extended_oks: padding must be >= 1.0");  // _cocoeval.py:560
     ExOksParams p{gt_kpts, gt_bbox, gt_area, dt_kpts, sigmas, gt_visibilities, out, G, D, K, n_vis, confidence_thr, padding,
-                  use_area, original};
+                  use_area, original, nullptr, nullptr, nullptr};
     const int total = (n_vis + 1) * D * G;
     hipLaunchKernelGGL(extended_oks_kernel, dim3((total + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), p);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+extern "C" int pp_exoks_cells(const double* gt_kpts, const double* gt_bbox, const double* gt_area, const double* dt_kpts,
+                              const double* sigmas, const int* gt_visibilities, const int* cell_gt_off, const int* cell_dt_off,
+                              const long long* cell_out_off, int n_cells, int K, int n_vis, double confidence_thr,
+                              double padding, int use_area, int original, double* out, void* stream) {
+    using namespace pp;
+    if (n_cells == 0) return PP_OK;
+    PP_REQUIRE(gt_kpts && gt_bbox && gt_area && dt_kpts && sigmas && cell_gt_off && cell_dt_off && cell_out_off && out,
+               PP_ERR_INVALID_ARG, "pp_exoks_cells: NULL argument");
+    PP_REQUIRE(n_cells > 0 && K > 0 && n_vis >= 0 && (n_vis == 0 || gt_visibilities), PP_ERR_INVALID_ARG, "pp_exoks_cells: bad shape");
+    PP_REQUIRE(padding >= 1.0, PP_ERR_INVALID_ARG, "pp_exoks_cells: padding must be >= 1.0");  // _cocoeval.py:560
+    ExOksParams p{gt_kpts, gt_bbox, gt_area, dt_kpts, sigmas, gt_visibilities, out, 0, 0, K, n_vis, confidence_thr, padding,
+                  use_area, original, cell_gt_off, cell_dt_off, cell_out_off};
+    hipLaunchKernelGGL(extended_oks_cells_kernel, dim3(n_cells), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), p);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

@@ -113,3 +113,15 @@ def load_reference_bbox():
     if "cv2" not in sys.modules:
         _shell("cv2")
     return _load("_ref_bbox_transforms", "mmpose/structures/bbox/transforms.py")
+
+
+def load_reference_nms():
+    """mmpose/evaluation/functional/nms.py (oks_iou / oks_nms) behind a stub for ``mmpose.structures.bbox.bbox_overlaps``
+    (used only by the box NMS variants)."""
+    if "mmpose" not in sys.modules:
+        _shell("mmpose", os.path.join(REF, "mmpose"))
+    if "mmpose.structures" not in sys.modules:
+        _shell("mmpose.structures")
+    b = _shell("mmpose.structures.bbox")
+    b.bbox_overlaps = None
+    return _load("_ref_nms", "mmpose/evaluation/functional/nms.py")
