@@ -269,6 +269,18 @@ int pp_extended_oks(const double* gt_kpts, const double* gt_bbox, const double* 
                     const double* sigmas, const int* gt_visibilities, int G, int D, int K, int n_vis,
                     double confidence_thr, double padding, int use_area, int original, double* out, void* stream);
 
+/* Person heatmaps back on the image, merged: out[k, y, x] = max over the n persons of cv2.warpAffine(heatmap_n[k], M_n,
+ * (img_w, img_h), INTER_LINEAR) with zero border (revert_heatmap + the np.max of merge_data_samples,
+ * mmpose/structures/utils.py:105-123, 146-175) in one launch. heatmaps (n, K <= 32, hm_h, hm_w) float32; inverse_maps
+ * (n, 2, 3) float64 = the image -> heatmap maps (warpAffine inverts M itself); out (K, img_h, img_w) float32. */
+int pp_revert_heatmaps_max(const float* heatmaps, const double* inverse_maps, float* out, int n, int K, int hm_h, int hm_w,
+                           int img_h, int img_w, void* stream);
+
+/* In place heatmaps[k] = heatmaps[k] / sum(heatmaps[k]) * presence[k] - the posterior the visualiser draws
+ * (mmpose/visualization/local_visualizer.py:827-837). heatmaps (K, H, W) float32, presence (K) float32, scratch: K * 64
+ * float64. */
+int pp_heatmap_posterior(float* heatmaps, const float* presence, double* scratch, int K, int H, int W, void* stream);
+
 /* pp_extended_oks for every (image, category) cell of a dataset in one launch. Instances / detections of cell c are rows
  * [cell_gt_off[c], cell_gt_off[c + 1]) / [cell_dt_off[c], cell_dt_off[c + 1]) of the flat arrays (detections of a cell in
  * evaluation order, at most maxDets); its (n_vis + 1, Dc, Gc) float64 block is written at out + cell_out_off[c]. */

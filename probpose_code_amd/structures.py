@@ -177,10 +177,64 @@ except Exception:  # noqa: BLE001
 
 
 
+def _image_padding(centers, scales, ori_shape):
+    """[left, top, right, bottom] padding that keeps every activation window (+10 px) inside (structures/utils.py:70-87)."""
+    import numpy as np
+
+    pad = np.zeros(4, np.int64)
+    for c, s in zip(centers, scales):
+        pad = np.maximum(pad, [int(max(s[0] / 2 - c[0] + 10, 0)), int(max(s[1] / 2 - c[1] + 10, 0)),
+                               int(max(c[0] + s[0] / 2 - ori_shape[1] + 10, 0)), int(max(c[1] + s[1] / 2 - ori_shape[0] + 10, 0))])
+    return pad
+
+
+def revert_heatmaps_max(heatmaps, input_centers, input_scales, img_shape, device="cuda"):
+    """The (K, h, w) maps of n persons back on an image of ``img_shape`` = (H, W), merged by maximum - what
+    ``np.max([revert_heatmap(...) for ...], axis=0)`` gives in the reference (structures/utils.py:105-123), in one launch
+    (pp_revert_heatmaps_max). ``heatmaps``: (n, K, h, w) array / tensor or a list of (K, h, w). Returns a float32 device
+    tensor (K, H, W)."""
+    import numpy as np
+    import torch
+
+    from . import _lib
+    from .transforms import get_warp_matrix, invert_affine
+
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("revert_heatmaps_max runs on the GPU only (no CPU fallback)")
+    if isinstance(heatmaps, (list, tuple)):
+        heatmaps = torch.stack([torch.as_tensor(h) for h in heatmaps])
+    hm = torch.as_tensor(heatmaps).to(device=device, dtype=torch.float32).contiguous()
+    if hm.dim() == 3:
+        hm = hm[None]
+    n, K, h, w = hm.shape
+    centers = np.asarray(input_centers, np.float64).reshape(n, 2)
+    scales = np.asarray(input_scales, np.float64).reshape(n, 2)
+    inv = np.stack([invert_affine(get_warp_matrix(centers[i], scales[i], 0, (w, h), inv=True)) for i in range(n)])
+    inv_d = torch.from_numpy(inv).to(device)
+    out = torch.empty((K, int(img_shape[0]), int(img_shape[1])), dtype=torch.float32, device=device)
+    _lib.call("pp_revert_heatmaps_max", hm.data_ptr(), inv_d.data_ptr(), out.data_ptr(), n, K, h, w, int(img_shape[0]),
+              int(img_shape[1]), torch.cuda.current_stream(device).cuda_stream)
+    return out
+
+
+def revert_heatmap(heatmap, input_center, input_scale, img_shape):
+    """structures/utils.py:146-175: one (K, h, w) or (h, w) map back on the image; returns a numpy array like the
+    reference."""
+    import torch
+
+    hm = torch.as_tensor(heatmap)
+    out = revert_heatmaps_max(hm[None] if hm.dim() == 3 else hm[None, None], [input_center], [input_scale], img_shape)
+    out = out.cpu().numpy()
+    return out if hm.dim() == 3 else out[0]
+
+
 def merge_data_samples(data_samples):
-    """mmpose/structures/utils.py:16-47 without the heatmap re-projection (:48-...): the top-down predictions of one
-    image - one PoseDataSample per box - merged into a single sample with all instances; metainfo of the first sample,
-    ``input_center`` / ``input_scale`` stacked."""
+    """mmpose/structures/utils.py:16-143: the top-down predictions of one image - one PoseDataSample per box - merged
+    into a single sample with all instances; metainfo of the first sample, ``input_center`` / ``input_scale`` stacked.
+    Predicted heatmaps (``pred_fields.heatmaps``, present with ``test_cfg.output_heatmaps``) are put back on the image
+    padded so that every activation window fits, and merged by maximum (:48-128); ground-truth heatmaps on the
+    un-padded image (:130-141)."""
     import warnings
 
     import numpy as np
@@ -198,7 +252,41 @@ def merge_data_samples(data_samples):
         merged.gt_instances = InstanceData.cat([d.gt_instances for d in data_samples])
     if "pred_instances" in data_samples[0]:
         merged.pred_instances = InstanceData.cat([d.pred_instances for d in data_samples])
+    centers = [np.asarray(ds.input_center, np.float64).reshape(2) for ds in data_samples]
+    scales = [np.asarray(ds.input_scale, np.float64).reshape(2) for ds in data_samples]
+    ori_shape = data_samples[0].metainfo.get("ori_shape")
+    if "pred_fields" in data_samples[0] and "heatmaps" in data_samples[0].pred_fields:
+        pad = _image_padding(centers, scales, ori_shape)
+        padded_shape = (ori_shape[0] + pad[1] + pad[3], ori_shape[1] + pad[0] + pad[2])
+        maps = revert_heatmaps_max([ds.pred_fields.heatmaps for ds in data_samples], [c + pad[:2] for c in centers], scales,
+                                   padded_shape)
+        merged.pred_fields = PixelData(heatmaps=maps.cpu().numpy())
+        merged.set_metainfo(dict(image_pad=pad))
+    if "gt_fields" in data_samples[0] and "heatmaps" in data_samples[0].gt_fields:
+        maps = revert_heatmaps_max([ds.gt_fields.heatmaps for ds in data_samples], centers, scales, ori_shape)
+        merged.gt_fields = PixelData(heatmaps=maps.cpu().numpy())
     return merged
 
 
-__all__ = ["BaseDataElement", "InstanceData", "PixelData", "PoseDataSample", "USING_MMENGINE", "merge_data_samples"]
+def posterior_heatmaps(heatmaps, keypoints_probs, device="cuda"):
+    """What ``--draw-heatmap`` shows (mmpose/visualization/local_visualizer.py:827-837): every map normalised to sum 1,
+    times the presence probability of its keypoint averaged over the instances. ``heatmaps`` (K, H, W), ``keypoints_probs``
+    (n, K). Returns a float32 device tensor (pp_heatmap_posterior)."""
+    import torch
+
+    from . import _lib
+
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("posterior_heatmaps runs on the GPU only (no CPU fallback)")
+    hm = torch.as_tensor(heatmaps).to(device=device, dtype=torch.float32).contiguous().clone()
+    K, H, W = hm.shape
+    pr = torch.as_tensor(keypoints_probs).to(device=device, dtype=torch.float32).reshape(-1, K).mean(dim=0).contiguous()
+    scratch = torch.empty(K * 64, dtype=torch.float64, device=device)
+    _lib.call("pp_heatmap_posterior", hm.data_ptr(), pr.data_ptr(), scratch.data_ptr(), K, H, W,
+              torch.cuda.current_stream(device).cuda_stream)
+    return hm
+
+
+__all__ = ["BaseDataElement", "InstanceData", "PixelData", "PoseDataSample", "USING_MMENGINE", "merge_data_samples",
+           "revert_heatmap", "revert_heatmaps_max", "posterior_heatmaps"]

@@ -72,6 +72,25 @@ def invert_affine(m: np.ndarray) -> np.ndarray:
     return M
 
 
+def get_warp_matrix(center, scale, rot, output_size, inv=False):
+    """mmpose/structures/bbox/transforms.py:362-426 (shift 0, fix_aspect_ratio=True): the box of size ``scale`` around
+    ``center``, rotated by ``rot`` degrees, onto ``output_size`` = (w, h). Three point pairs held in float32 like the
+    reference's (centre; the point half a box width to its left, rotated; the third perpendicular to those two, computed
+    in float32), then the affine map through them - cv2.getAffineTransform in the reference, here the 3x3 solve
+    [x y 1] A = [x' y'] in float64."""
+    center, scale = np.asarray(center, np.float64).reshape(2), np.asarray(scale, np.float64).reshape(2)
+    rad = np.deg2rad(rot)
+    sn, cs = np.sin(rad), np.cos(rad)
+    half = scale[0] * -0.5
+    src, dst = np.ones((3, 3), np.float32), np.ones((3, 3), np.float32)  # homogeneous rows
+    src[0, :2], src[1, :2] = center, center + np.array([cs * half - sn * 0.0, sn * half + cs * 0.0])
+    dst[0, :2], dst[1, :2] = [output_size[0] * 0.5, output_size[1] * 0.5], [0.0, output_size[1] * 0.5]
+    for p in (src, dst):
+        p[2, 0], p[2, 1] = p[1, 0] - (p[0, 1] - p[1, 1]), p[1, 1] + (p[0, 0] - p[1, 0])
+    a, b = (dst, src) if inv else (src, dst)
+    return np.linalg.solve(a.astype(np.float64), b[:, :2].astype(np.float64)).T
+
+
 def topdown_affine_params(bboxes_xyxy: np.ndarray, input_size: Tuple[int, int], padding: float = 1.25, input_padding: float = 1.25):
     """What GetBBoxCenterScale + TopdownAffine compute per box before the warp (common_transforms.py:57-85,
     topdown_transforms.py:83-117): returns (centers (n,2), scales (n,2), warp matrices (n,2,3) float32). As in the
