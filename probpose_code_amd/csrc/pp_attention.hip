@@ -28,6 +28,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int ATT_THREADS = 256;
+#ifndef ATT_ABL  // dev (scripts/micro/att_ablate.sh): 1 no V transpose, 2 no math, 3 no K / V loads - timing only, wrong results
+#define ATT_ABL 0
+#endif
 
 __device__ __forceinline__ f32x4 att_mma(const u32x4& a, const u32x4& b, f32x4 c, __bf16) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
@@ -94,11 +97,15 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 12 ? 3 : 1)) void attention_ker
     for (int i = tid; i < C::SP * C::RC; i += ATT_THREADS) {
         const int r = i / C::RC, c = i - r * C::RC;
         u32x4 kv = u32x4{0, 0, 0, 0}, vv = u32x4{0, 0, 0, 0};
-        if (r < C::S) {
+        if (r < C::S && ATT_ABL != 3) {
             kv = *reinterpret_cast<const u32x4*>(base + (size_t)r * row_stride + E + c * C::CH);
             vv = *reinterpret_cast<const u32x4*>(base + (size_t)r * row_stride + 2 * E + c * C::CH);
         }
         *reinterpret_cast<u32x4*>(Ks + ((size_t)r * C::RC + kswz<C::RC>(r, c)) * 16) = kv;
+        if (ATT_ABL == 1) {
+            *reinterpret_cast<u32x4*>(Vt + (size_t)i * C::CH) = vv;
+            continue;
+        }
         T ve[C::CH];
         *reinterpret_cast<u32x4*>(ve) = vv;
 #pragma unroll
@@ -110,6 +117,11 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 12 ? 3 : 1)) void attention_ker
     for (int t = 0; t < QPW; ++t) {
         const int qt = wave + t * (ATT_THREADS / 64);
         if (qt >= NT) break;
+        if (ATT_ABL == 2) {
+            T* orow0 = out + ((size_t)seq * C::S + qt * 16 + fr) * E + head * HD;
+            for (int dt = 0; dt < C::DT; ++dt) *reinterpret_cast<u32x2*>(orow0 + dt * 16 + 4 * fg) = u32x2{qf_all[t][0][0], (unsigned)Ks[lane * 4]};
+            continue;
+        }
         u32x4 qf[C::NG];
 #pragma unroll
         for (int g = 0; g < C::NG; ++g) qf[g] = qf_all[t][g];

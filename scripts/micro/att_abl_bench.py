@@ -6,7 +6,7 @@ E = heads * hd
 qkv = torch.randn(n_seq * S, 3 * E, device="cuda").to(torch.bfloat16)
 out = torch.empty(n_seq * S, E, device="cuda", dtype=torch.bfloat16)
 P = ctypes.c_void_p
-for name in ("probpose_code_amd/libprobpose_mi355x.so", "scripts/micro/build/libatt_abl2.so", "scripts/micro/build/libatt_abl3.so"):
+for name in ("probpose_code_amd/libprobpose_mi355x.so", "scripts/micro/build/libatt_abl1.so", "scripts/micro/build/libatt_abl2.so", "scripts/micro/build/libatt_abl3.so"):
     lib = ctypes.CDLL(os.path.join("/root/repo", name))
     fn = lib.pp_attention; fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_int, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, P]
