@@ -168,7 +168,8 @@ def test_panel_conv3x3_groups_vs_torch():
     torch.testing.assert_close(out.cpu().double().permute(0, 1, 4, 2, 3), ref, rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("prec,hd,S", [(F32, 32, 192), (BF16, 32, 192), (BF16, 64, 192), (F32, 64, 192), (BF16, 64, 432)])
+@pytest.mark.parametrize("prec,hd,S", [(F32, 32, 192), (BF16, 32, 192), (BF16, 64, 192), (F32, 64, 192), (BF16, 64, 432), (BF16, 32, 432),
+                                       (F32, 32, 432)])
 def test_attention_vs_torch(prec, hd, S):
     L = _lib()
     n_seq, heads = 3, 4
