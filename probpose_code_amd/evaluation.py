@@ -132,41 +132,44 @@ class COCOeval:
     def _prepare(self):
         p = self.params
         K = len(self.sigmas)
-        gts = [dict(g) for g in _annotations(self.cocoGt, p.imgIds)]
-        dts = [dict(d) for d in _annotations(self.cocoDt, p.imgIds)]
-        levels = set()
-        vis_all = []
-        for g in gts:
-            kp = np.array(g["keypoints"])
-            vis = kp[2::3]
-            if self.ignore_near_bbox:  # keypoints within 5 % of the box edge are not evaluated (:228-246)
-                x0, y0, w, h = g["bbox"]
-                x1, y1, tx, ty = x0 + w, y0 + h, 0.05 * w, 0.05 * h
-                x, y = kp[0::3], kp[1::3]
-                in_y, in_x = (y > y0 - ty) & (y < y1 + ty), (x > x0 - tx) & (x < x1 + tx)
-                vis[((np.abs(x - x0) < tx) | (np.abs(x - x1) < tx)) & in_y | ((np.abs(y - y0) < ty) | (np.abs(y - y1) < ty)) & in_x] = 0
-            if not self.extended_oks:  # the classic metric knows only v in {1, 2} (:248-257)
-                vis[~((vis == 1) | (vis == 2))] = 0
-            elif "pad_to_contain" in g:  # v = 3 <=> the keypoint needs more padding than the activation window has (:262-271)
-                ptc = np.array(g["pad_to_contain"], dtype=np.float64)
-                ptc[vis <= 0] = -1.0
+        gts = list(_annotations(self.cocoGt, p.imgIds))  # (read only: edited visibilities / flags live in arrays)
+        dts = list(_annotations(self.cocoDt, p.imgIds))
+        # instances: all keypoints as one array, the visibility edits of the reference vectorised over the instances
+        gkp = np.array([g["keypoints"] for g in gts], np.float64).reshape(len(gts), K, 3)
+        gbb = np.array([g["bbox"] for g in gts], np.float64).reshape(len(gts), 4)
+        vis = gkp[:, :, 2].copy()
+        if self.ignore_near_bbox:  # keypoints within 5 % of the box edge are not evaluated (:228-246)
+            x0, y0, w, h = (gbb[:, i:i + 1] for i in range(4))
+            x1, y1, tx, ty = x0 + w, y0 + h, 0.05 * w, 0.05 * h
+            x, y = gkp[:, :, 0], gkp[:, :, 1]
+            in_y, in_x = (y > y0 - ty) & (y < y1 + ty), (x > x0 - tx) & (x < x1 + tx)
+            vis[((np.abs(x - x0) < tx) | (np.abs(x - x1) < tx)) & in_y | ((np.abs(y - y0) < ty) | (np.abs(y - y1) < ty)) & in_x] = 0
+        if not self.extended_oks:  # the classic metric knows only v in {1, 2} (:248-257)
+            vis[~((vis == 1) | (vis == 2))] = 0
+        else:  # v = 3 <=> the keypoint needs more padding than the activation window has (:262-271)
+            has = np.array(["pad_to_contain" in g for g in gts], bool)
+            if has.any():
+                ptc = np.array([g["pad_to_contain"] for g, hh in zip(gts, has) if hh], np.float64).reshape(-1, K)
+                v = vis[has]
+                ptc[v <= 0] = -1.0
                 out = ptc > self.padding
-                vis[(vis > 2) & (~out)] = 1
-                vis[out] = 3
-            vis = vis.astype(int)
-            levels.update(np.unique(vis).tolist())
-            vis_all.append(vis)
-            g["_kp"] = np.asarray(kp, np.float64).reshape(K, 3).copy()
-            g["_kp"][:, 2] = vis
-        self.gt_visibilities = [v for v in sorted(levels) if v > 0]
+                v[(v > 2) & (~out)] = 1
+                v[out] = 3
+                vis[has] = v
+        vis = vis.astype(int)  # (:273: truncation, as the reference's astype)
+        gkp[:, :, 2] = vis
+        self.gt_visibilities = [int(v) for v in np.unique(vis) if v > 0]
         L = len(self.gt_visibilities) + 1
-        for g, vis in zip(gts, vis_all):  # per-level ignore flags (:303-362): indexed by the visibility VALUE (:358)
-            present = np.unique(vis[vis > 0])
-            ign = np.ones(L, bool)
-            ign[present] = False
-            ign[0] = len(present) <= 0
-            g["_ignore"] = ign
-        dts = [d for d in dts if np.count_nonzero(np.array(d["keypoints"])[2::3] > 0) > 0]  # (:412-416)
+        # per-level ignore flags (:303-362): level index = the visibility VALUE (:358); level 0 = no annotated keypoint
+        g_ignore = np.ones((len(gts), L), bool)
+        if len(gts):
+            for v in np.unique(vis[vis > 0]):
+                g_ignore[(vis == v).any(1), v] = False  # (IndexError for a value beyond the level count, as in the reference)
+            g_ignore[:, 0] = ~(vis > 0).any(1)
+        dkp = np.array([d["keypoints"] for d in dts], np.float64).reshape(len(dts), K, 3)
+        keep = (dkp[:, :, 2] > 0).any(1)  # detections without a positive confidence are dropped (:412-416)
+        dts = [d for d, k in zip(dts, keep) if k]
+        dkp = dkp[keep]
 
         # cells = images with at least one instance or detection, in image order; detections of a cell in evaluation order
         img_ids = list(np.unique(p.imgIds))
@@ -184,6 +187,7 @@ class COCOeval:
             d_order = d_order[rank < p.maxDets[-1]]  # at most maxDets per image (:548-550, :741)
         gts = [gts[i] for i in g_order]
         dts = [dts[i] for i in d_order]
+        gkp, gbb, g_ignore, dkp = gkp[g_order], gbb[g_order], g_ignore[g_order], dkp[d_order]
         g_img, d_img, d_score = g_img[g_order], d_img[d_order], d_score[d_order]
         cells = np.unique(np.r_[g_img, d_img]).astype(np.int64)
         cell_gt_off = np.searchsorted(g_img, np.r_[cells, len(img_ids)], side="left").astype(np.int32)
@@ -197,12 +201,12 @@ class COCOeval:
         N_gt, N_dt = len(gts), len(dts)
         f64 = lambda rows, width: np.array(rows, np.float64).reshape(len(rows), *width)  # noqa: E731
         h = dict(
-            gt_kpts=f64([g["_kp"] for g in gts], (K, 3)), gt_bbox=f64([g["bbox"] for g in gts], (4,)),
+            gt_kpts=gkp, gt_bbox=gbb,
             gt_area_oks=f64([g.get("area", 0.0) for g in gts], ()),
             gt_area_rng=f64([g["area"] if ("area" in g and self.use_area) else g["bbox"][2] * g["bbox"][3] * 0.53 for g in gts], ()),
-            gt_ignore=np.array([g["_ignore"] for g in gts], np.uint8).reshape(N_gt, L),
+            gt_ignore=g_ignore.astype(np.uint8).reshape(N_gt, L),
             gt_iscrowd=np.array([int(g["iscrowd"]) for g in gts], np.uint8),
-            dt_kpts=f64([d["keypoints"] for d in dts], (K, 3)), dt_bbox=f64([d["bbox"] for d in dts], (4,)),
+            dt_kpts=dkp, dt_bbox=f64([d["bbox"] for d in dts], (4,)),
             dt_area=f64([d["area"] for d in dts], ()), dt_score=d_score,
             order=np.argsort(-d_score, kind="mergesort").astype(np.int32),  # over the concatenation of the cells (:946-952)
             cell_gt_off=cell_gt_off, cell_dt_off=cell_dt_off, cell_iou_off=cell_iou_off[:-1].copy(),
