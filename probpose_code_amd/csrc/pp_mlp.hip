@@ -35,6 +35,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
 namespace mlp {
 
@@ -290,67 +293,66 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 
     stamp(20, 0);  // kernel start
     if (ATT) {
-        // ================= attention of this workgroup's 96 query rows (waves 0-5: one 16-query tile each; all eight waves
-        // stage K / V). Sequence = 192 tokens = this workgroup's rows and its neighbour's.
+        // ================= attention of this workgroup's 96 query rows (waves 0-5: one 16-query tile each). Sequence = 192
+        // tokens = this workgroup's rows and its neighbour's. K and V of one head (192 x 32 each, 24 KiB together) arrive by
+        // LDS-DMA, all eight waves issuing, three heads in rotation (two thirds of the ring region + the G region, which
+        // the FFN only needs later) so that a head has two heads' worth of math to land. Both stay row-major by key:
+        //   * K chunk (key, c) sits at 16-byte position 4 key + (c ^ ((key >> 2) & 3)) - the 16 keys x one chunk a
+        //     ds_read_b128 of the S^T = K Q^T operand touches then hit 16 different bank groups;
+        //   * V chunk (key, c) at 4 key + (c ^ 2 ((key >> 2) & 1)); the O^T = V^T P^T operand - eight keys of one head
+        //     dimension per lane - comes out of two ds_read_b64_tr_b16, the gfx950 transposing read: within 16 lanes, lane
+        //     4 r + q supplies the address of four consecutive 16-bit elements M[r][4 q ..], lane i receives M[0..3][i]
+        //     (scripts/micro/tr_probe.hip). No register staging, no 16-bit scatter.
         constexpr int SEQ = 192, NKT = SEQ / 16, HEADS = E / 32, RS = 3 * E;
-        constexpr int SPV = SEQ + 8;                     // V^T row pitch (elements): 8 * odd -> conflict-free reads
-        constexpr int KBYTES = SEQ * 64, HBYTES = KBYTES + 32 * SPV * 2;  // one head: K [192][32] + V^T [32][200]
-        static_assert(2 * HBYTES <= NSLOT * SLOT, "two heads of K/V fit in the ring region");
-        const __bf16* qkv = p.qkv_in;
+        constexpr int KBYTES = SEQ * 64, HBYTES = 2 * KBYTES;  // one head: K [192][64 B] + V [192][64 B]
+        static_assert(2 * HBYTES <= NSLOT * SLOT && HBYTES <= 2 * HS_KB, "two heads in the ring region, one in the G region");
         const int srow0 = (m0 / SEQ) * SEQ;
+        const __amdgpu_buffer_rsrc_t qkv_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.qkv_in), 0, (unsigned)p.M * (unsigned)(RS * 2), 0x00020000);
         u32x4 qf[HEADS];
         if (wv < 6) {
             const int qm = m0 + wv * 16 + f_row;
-            const __bf16* qrow = qkv + (size_t)(qm < p.M ? qm : p.M - 1) * RS + f_kg * 8;
+            const __bf16* qrow = p.qkv_in + (size_t)(qm < p.M ? qm : p.M - 1) * RS + f_kg * 8;
 #pragma unroll
             for (int hd = 0; hd < HEADS; ++hd) qf[hd] = *reinterpret_cast<const u32x4*>(qrow + hd * 32);
         }
-        // Roles: waves 0-5 compute (one 16-query tile each), waves 6-7 stage the NEXT head's K / V^T meanwhile - global
-        // loads, the K copy and the 16-bit transposing scatter of V all run beside the other waves' MFMAs and softmax.
-        auto stage_head = [&](int hd, int buf, int t0, int nthreads) {
-            char* kb = ring + buf * HBYTES;
-            __bf16* vt = reinterpret_cast<__bf16*>(kb + KBYTES);
-            constexpr int NCH = SEQ * 4;  // 16-byte chunks per operand
-            for (int base = 0; base < NCH; base += 4 * nthreads) {
-                u32x4 kr[4], vr[4];
+        auto head_buf = [&](int hd) -> char* { return hd % 3 == 2 ? smem + OFF_GS : ring + (hd % 3) * HBYTES; };
+        // instruction i of a head (24 of 1 KiB): i < 12 K keys 16 i .., else V keys 16 (i - 12) ..; lane = (key, position)
+        const int a_key = lane >> 2, a_pos = lane & 3;
+        auto issue_head = [&](int hd) {
+            char* dst = head_buf(hd);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = base + u * nthreads + t0;
-                    if (i < NCH) {
-                        const int r = srow0 + (i >> 2);
-                        const __bf16* src = qkv + (size_t)(r < p.M ? r : p.M - 1) * RS + E + hd * 32 + (i & 3) * 8;
-                        kr[u] = *reinterpret_cast<const u32x4*>(src);
-                        vr[u] = *reinterpret_cast<const u32x4*>(src + E);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = base + u * nthreads + t0;
-                    if (i < NCH) {
-                        const int r = i >> 2, c = i & 3;
-                        *reinterpret_cast<u32x4*>(kb + r * 64 + c * 16) = kr[u];
-                        const bf16x8 ve = __builtin_bit_cast(bf16x8, vr[u]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) vt[(c * 8 + j) * SPV + r] = ve[j];
-                    }
-                }
+            for (int u = 0; u < 3; ++u) {
+                const int i = wv + 8 * u;
+                const bool isv = i >= 12;
+                const int key = 16 * (isv ? i - 12 : i) + a_key;
+                const int c = isv ? (a_pos ^ (2 * ((key >> 2) & 1))) : (a_pos ^ ((key >> 2) & 3));
+                const unsigned vo = (unsigned)(srow0 + key) * (unsigned)(RS * 2) + (unsigned)((isv ? 2 * E : E) * 2 + hd * 64 + c * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qkv_rsrc, (lds_ptr_t)(dst + i * 1024), 16, vo, 0, 0, 0);  // rows past M: out of bounds = zeros
             }
         };
-        stage_head(0, 0, tid, THREADS);  // first head: everybody
-        __syncthreads();
-        for (int hd = 0; hd < HEADS; ++hd) {
-            if (wv >= 6) {
-                if (hd + 1 < HEADS) stage_head(hd + 1, (hd + 1) & 1, tid - 384, 128);
-            } else {
-                const char* Ks = ring + (hd & 1) * HBYTES;
-                const __bf16* Vt = reinterpret_cast<const __bf16*>(Ks + KBYTES);
-                u32x4 qh = qf[0];
+        issue_head(0);
+        issue_head(1);
+        const int k_frag_off = f_row * 64 + ((f_kg ^ ((f_row >> 2) & 3)) << 4);  // + kt * 1024
+        // transposing V read: lane supplies key 4 f_kg + (f_row >> 2) of the 16-key tile, elements 4 (f_row & 3) .. + 3 of the
+        // 16-dimension tile dt: chunk 2 dt + ((f_row & 3) >> 1), swizzled by 2 (f_kg & 1), upper or lower half
+        // (chunk (2 dt + q) ^ 2 (f_kg & 1) = 2 (dt ^ (f_kg & 1)) + q)
+        const int v_frag_off = KBYTES + (4 * f_kg + (f_row >> 2)) * 64 + (((f_row & 3) >> 1) << 4) + (f_row & 1) * 8;
+        const int v_dt_off[2] = {(f_kg & 1) * 32, ((f_kg & 1) ^ 1) * 32};
 #pragma unroll
-                for (int k = 1; k < HEADS; ++k) qh = hd == k ? qf[k] : qh;  // (register array: select, no dynamic index)
+        for (int hd = 0; hd < HEADS; ++hd) {
+            stamp(30, hd);
+            if (hd + 1 < HEADS) wait_dma_and_barrier<3>();  // head hd has landed (head hd + 1 may still fly); head hd - 1 is done with
+            else wait_dma_and_barrier<0>();
+            stamp(32, hd);
+            if (hd + 2 < HEADS) issue_head(hd + 2);
+            if (wv < 6) {
+                const char* Ks = head_buf(hd);
+                const u32x4 qh = qf[hd];
                 f32x4 sc[NKT];
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)  // S^T: lane holds keys 16 kt + 4 f_kg + (0..3) of query f_row
-                    sc[kt] = mma(*reinterpret_cast<const u32x4*>(Ks + (kt * 16 + f_row) * 64 + f_kg * 16), qh, f32x4{0.f, 0.f, 0.f, 0.f});
+                    sc[kt] = mma(*reinterpret_cast<const u32x4*>(Ks + kt * 1024 + k_frag_off), qh, f32x4{0.f, 0.f, 0.f, 0.f});
                 float mx = -__builtin_inff();
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
@@ -378,9 +380,10 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                                        (__bf16)p1[0], (__bf16)p1[1], (__bf16)p1[2], (__bf16)p1[3]};
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        const __bf16* vrow = Vt + (dt * 16 + f_row) * SPV + blk * 32 + 4 * f_kg;
-                        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow), hi = *reinterpret_cast<const u32x2*>(vrow + 16);
-                        const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+                        const char* vsrc = Ks + v_frag_off + blk * 2048 + v_dt_off[dt];  // keys 32 blk + .., chunks 2 dt, 2 dt + 1 (swizzled)
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vsrc));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vsrc + 1024));
+                        const s16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
                     }
                 }
@@ -396,8 +399,9 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                                                (f_kg & 1) * 8) = ov;
                 }
             }
-            __syncthreads();
         }
+        stamp(30, HEADS);
+        __syncthreads();  // the last head's math is done: the ring and the G region are free, the rows are in place
     }
 
     // ---- prologue: ring filled with the first eight slots, input rows into LDS, accumulators = residual + b2

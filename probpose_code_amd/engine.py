@@ -77,7 +77,7 @@ class ProbPoseEngine:
         self.fuse_qkv = os.environ.get("PP_FUSE_QKV", "1") != "0"
         self.split_k = os.environ.get("PP_SPLIT_K", "1") != "0"
         # attention inside the layer kernel (pp_vit_layer, one launch per layer): correct and tested, but measured break-even
-        # with pp_attention + the fused rest (its K/V staging is latency-bound with one workgroup per CU) - off by default
+        # with pp_attention + the fused rest ("what did not help") - off by default
         self.fuse_attn = os.environ.get("PP_FUSE_ATTN", "0") != "0"
         self.fuse_head = os.environ.get("PP_FUSE_HEAD", "1") != "0"
         self._logits_phased = False

@@ -26,6 +26,24 @@ for w in (0, 1):
     print(f"wave {4*w}: total {ph[6]-ph[0]} ticks")
     for i, n in enumerate(names):
         print(f"   {n:30s} {ph[i+1]-ph[i]:7d}")
+if os.environ.get("VIT"):  # the same through pp_vit_layer (attention phase in front): stamps of its twelve heads
+    fv = lib.pp_vit_layer
+    fv.restype = ctypes.c_int
+    fv.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_float] + [P] * 12 + [ctypes.c_float] + [P] * 4 + [ctypes.c_int] * 3 + [P]
+    qi = torch.randn(M, 3 * E, device="cuda").bfloat16()
+    for _ in range(3):
+        assert fv(qi.data_ptr(), 192, 12, 32 ** -0.5, wp.data_ptr(), bp.data_ptr(), x.data_ptr(), g2.data_ptr(), be2.data_ptr(), w1.data_ptr(),
+                  b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(), g.data_ptr(), be.data_ptr(), 1e-6, ho.data_ptr(), wq.data_ptr(),
+                  bq.data_ptr(), qo.data_ptr(), M, E, Fd, None) == 0
+    torch.cuda.synchronize()
+    t = trace.cpu().numpy()
+    for w in (0, 1):
+        ph = t[w * 4096 + 200: w * 4096 + 207]
+        hd = t[w * 4096 + 300: w * 4096 + 313]
+        aw = t[w * 4096 + 320: w * 4096 + 332]
+        print(f"   wait + barrier per head {[int(aw[i]-hd[i]) for i in range(12)]}")
+        print(f"vit_layer wave {4*w}: total {ph[6]-ph[0]} ticks; prologue incl. attention {ph[1]-ph[0]}; start -> head 0 {hd[0]-ph[0]}; heads {[int(hd[i+1]-hd[i]) for i in range(12)]}")
+    sys.exit(0)
 for w in (0, 1):
     for pair in range(4):
         q = t[w * 4096 + (22 + 2 * pair) * 10: w * 4096 + (22 + 2 * pair) * 10 + 13]
