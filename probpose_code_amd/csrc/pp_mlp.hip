@@ -345,6 +345,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
             if (hd + 1 < HEADS) wait_dma_and_barrier<3>();  // head hd has landed (head hd + 1 may still fly); head hd - 1 is done with
             else wait_dma_and_barrier<0>();
             stamp(32, hd);
+            stamp(32, hd);
             if (hd + 2 < HEADS) issue_head(hd + 2);
             if (wv < 6) {
                 const char* Ks = head_buf(hd);
