@@ -269,6 +269,11 @@ int pp_extended_oks(const double* gt_kpts, const double* gt_bbox, const double* 
                     const double* sigmas, const int* gt_visibilities, int G, int D, int K, int n_vis,
                     double confidence_thr, double padding, int use_area, int original, double* out, void* stream);
 
+/* Result record of the multi-GPU exchange: records[i] = [x, y, conf, prob, vis, oks, err] (float64 x 7) for the n =
+ * crops x keypoints outputs - keypoints (n, 2) float64, scores (n) float32 from the decode, scalars (4, n) float32 from
+ * pp_tower_final. One fixed-layout all_gather of this replaces mmengine's pickled collect_results. */
+int pp_pack_records(const double* keypoints, const float* scores, const float* scalars, double* records, int n, void* stream);
+
 /* Person heatmaps back on the image, merged: out[k, y, x] = max over the n persons of cv2.warpAffine(heatmap_n[k], M_n,
  * (img_w, img_h), INTER_LINEAR) with zero border (revert_heatmap + the np.max of merge_data_samples,
  * mmpose/structures/utils.py:105-123, 146-175) in one launch. heatmaps (n, K <= 32, hm_h, hm_w) float32; inverse_maps

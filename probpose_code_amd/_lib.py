@@ -84,6 +84,7 @@ SIGNATURES = {
     "pp_warp_affine_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "pp_extended_oks": (
         c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int, _P, _P]),
+    "pp_pack_records": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "pp_revert_heatmaps_max": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
     "pp_heatmap_posterior": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "pp_exoks_cells": (

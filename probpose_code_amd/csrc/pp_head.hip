@@ -179,3 +179,31 @@ extern "C" int pp_sum_maxpool_relu_nhwc(const float* partials, int nsplit, long 
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
+
+// The fixed-layout result record of the multi-GPU exchange (probpose_code_amd/dist.py): per (crop, keypoint) seven float64
+// [x, y, conf, prob, vis, oks, err] from the decode outputs (keypoints f64, scores f32) and the four tower scalars
+// (tower-major f32) - what collect_results carries as pickled dicts in the reference.
+namespace pp {
+__global__ void pack_records_kernel(const double* __restrict__ kpts, const float* __restrict__ scores,
+                                    const float* __restrict__ scalars, double* __restrict__ rec, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double* r = rec + (size_t)i * 7;
+    r[0] = kpts[2 * i];
+    r[1] = kpts[2 * i + 1];
+    r[2] = (double)scores[i];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r[3 + t] = (double)scalars[(size_t)t * n + i];
+}
+}  // namespace pp
+
+extern "C" int pp_pack_records(const double* keypoints, const float* scores, const float* scalars, double* records, int n,
+                               void* stream) {
+    using namespace pp;
+    if (n == 0) return PP_OK;
+    PP_REQUIRE(keypoints && scores && scalars && records && n > 0, PP_ERR_INVALID_ARG, "pp_pack_records: NULL argument or negative count");
+    hipLaunchKernelGGL(pack_records_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keypoints,
+                       scores, scalars, records, n);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}

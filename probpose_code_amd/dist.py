@@ -28,11 +28,25 @@ def interleave(gathered: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
     return out if n is None else out[:n]
 
 
-def pack_records(out: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """Engine outputs -> (B, K, 7) float64 records [x, y, conf, prob, vis, oks, err(raw)]."""
-    kp = out["keypoints"]
-    sc = out["scalars"].to(torch.float64)
-    return torch.cat([kp, out["scores"].to(torch.float64)[..., None], sc.permute(1, 2, 0)], dim=-1)
+def pack_records(out: Dict[str, torch.Tensor], into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Engine outputs -> (B, K, 7) float64 records [x, y, conf, prob, vis, oks, err(raw)]; on a GPU one launch of
+    pp_pack_records, straight into ``into`` when given."""
+    kp, scores, sc = out["keypoints"], out["scores"], out["scalars"]
+    if kp.is_cuda:
+        from . import _lib
+
+        kp, scores, sc = kp.contiguous(), scores.contiguous(), sc.contiguous()
+        rec = into if into is not None else torch.empty(kp.shape[:2] + (len(RECORD_FIELDS),), dtype=torch.float64, device=kp.device)
+        assert rec.is_contiguous() and rec.dtype == torch.float64 and kp.dtype == torch.float64 and scores.dtype == torch.float32 \
+            and sc.dtype == torch.float32 and sc.shape[0] == 4
+        _lib.call("pp_pack_records", kp.data_ptr(), scores.data_ptr(), sc.data_ptr(), rec.data_ptr(), kp.shape[0] * kp.shape[1],
+                  torch.cuda.current_stream(kp.device).cuda_stream)
+        return rec
+    rec = torch.cat([kp, scores.to(torch.float64)[..., None], sc.to(torch.float64).permute(1, 2, 0)], dim=-1)
+    if into is not None:
+        into.copy_(rec)
+        return into
+    return rec
 
 
 class ResultGather:
@@ -48,10 +62,10 @@ class ResultGather:
         self.host = torch.empty(shape, dtype=torch.float64, pin_memory=pin)
 
     def __call__(self, out: Dict[str, torch.Tensor]) -> torch.Tensor:
-        rec = pack_records(out)
         if self.world > 1:
+            rec = pack_records(out)
             dist.all_gather_into_tensor(self.gathered.flatten(0, 1), rec.contiguous(), group=self.group)
         else:
-            self.gathered[0].copy_(rec)
+            pack_records(out, into=self.gathered[0])
         self.host.copy_(self.gathered, non_blocking=True)
         return self.host

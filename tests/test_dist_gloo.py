@@ -2,6 +2,8 @@
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -51,3 +53,20 @@ def test_shard_indices_match_default_sampler():
 
     assert shard_indices(10, 0, 4) == [0, 4, 8] and shard_indices(10, 3, 4) == [3, 7]
     assert sorted(sum((shard_indices(513, r, 8) for r in range(8)), [])) == list(range(513))
+
+
+@pytest.mark.gpu
+def test_pack_records_kernel_matches_the_torch_form():
+    """pp_pack_records (one launch) against the cat / permute / cast form the CPU path uses."""
+    from probpose_code_amd.dist import ResultGather, pack_records
+
+    B, K = 5, 17
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    out = dict(keypoints=torch.rand(B, K, 2, dtype=torch.float64, device="cuda", generator=gen),
+               scores=torch.rand(B, K, device="cuda", generator=gen), scalars=torch.rand(4, B, K, device="cuda", generator=gen))
+    ref = pack_records({k: v.cpu() for k, v in out.items()})
+    assert torch.equal(pack_records(out).cpu(), ref)
+    g = ResultGather(B, K, "cuda", 1)
+    host = g(out)
+    torch.cuda.synchronize()
+    assert torch.equal(host[0], ref)
