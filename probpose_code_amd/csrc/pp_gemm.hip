@@ -434,6 +434,11 @@ int gemm(const GemmParams& p, int prec, int groups, hipStream_t s) {
 
 }  // namespace pp
 
+static bool panel_enabled() {
+    static const bool use_panel = !(getenv("PP_PANEL") && atoi(getenv("PP_PANEL")) == 0);  // dev switch for A/B timing
+    return use_panel;
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" int pp_gemm(int prec, const void* act, const void* weight, const float* bias, const float* residual,
                        int res_mod, void* out, int M, int N, int K, int lda, int ldw, int ldc, int act_fn,
@@ -485,8 +490,7 @@ extern "C" int pp_conv_gemm(int prec, int kind, const void* act_nhwc, const void
     PP_REQUIRE(ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_conv_gemm: operands must be smaller than 2 GiB");
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     p.strideA_z = stride_act_g; p.strideW_z = stride_w_g; p.strideC_z = stride_out_g; p.strideBias_z = stride_bias_g;
-    static const bool use_panel = !(getenv("PP_PANEL") && atoi(getenv("PP_PANEL")) == 0);  // dev switch for A/B timing
-    if (use_panel && panel_gemm_supported(p, prec, groups)) return panel_gemm(p, groups, reinterpret_cast<hipStream_t>(stream));
+    if (panel_enabled() && panel_gemm_supported(p, prec, groups)) return panel_gemm(p, groups, reinterpret_cast<hipStream_t>(stream));
     return gemm(p, prec, groups, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -510,6 +514,8 @@ extern "C" int pp_conv3x3_splitk(int prec, const void* act_nhwc, const void* wei
     PP_REQUIRE(ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_conv3x3_splitk: operands must be smaller than 2 GiB");
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     p.strideA_z = stride_act_g; p.strideW_z = stride_w_g; p.strideC_z = (long long)p.M * Cout; p.strideBias_z = 0;
+    if (panel_enabled() && panel_gemm_supported(p, prec, groups * ksplit))  // enough 256 x 192 tiles to fill the chip
+        return panel_gemm(p, groups * ksplit, reinterpret_cast<hipStream_t>(stream));
     return gemm(p, prec, groups * ksplit, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -114,6 +114,12 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         int z = 0, m0 = 0, n0 = 0;
         i_live = i_tile < ntiles;
         if (i_live) decode_tile(i_tile, z, m0, n0);
+        int tap0 = 0;
+        if (GATHER == G_CONV3 && p.ksplit > 1) {  // split-K over whole taps: group index = slice * problems + problem
+            const int problems = p.groups / p.ksplit;
+            tap0 = (z / problems) * (9 / p.ksplit);
+            z = z % problems;
+        }
         if (GATHER == G_DECONV) {
             i_py = p.py < 0 ? (z >> 1) : p.py;
             i_px = p.py < 0 ? (z & 1) : p.px;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         }
         w_voff = (unsigned)(n0 + 8 * (wv + 8 * JA - NA) + d_l) * (unsigned)(p.ldw * 2) + d_kbytes;  // n < N: N % BN == 0
         i_step = 0;
-        i_tap = 0;
+        i_tap = tap0;
         i_c0 = 0;
     };
     // issue instruction j of the stage at the cursor into ring buffer `buf`
@@ -267,6 +273,21 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         const int e_row = lane_e & 15, e_kg = lane_e >> 4, tid_e = (tid & ~63) | lane_e;
         int z, m0, n0;
         decode_tile(tile, z, m0, n0);
+        if (GATHER == G_CONV3 && p.ksplit > 1) {
+            // split-K partial sums: fp32, no bias / activation, straight from the accumulators (16 bytes per lane, the four
+            // lane groups of a row fragment make 64 contiguous bytes); slice-major [group index][M][N]
+            float* __restrict__ Cp = reinterpret_cast<float*>(p.C) + (size_t)z * p.strideC_z;
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf) {
+                const int m = m0 + rg * (BM / 2) + rf * 16 + e_row;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf)
+                    *reinterpret_cast<f32x4*>(Cp + (size_t)m * p.ldc + n0 + cg * (BN / 4) + cf * 16 + e_kg * 4) = acc[cf][rf];
+            }
+            wait_vm_lgkm<0>();  // (stores share vmcnt with the DMA of the next tile: drain, as below)
+            continue;
+        }
         const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias_z : nullptr;
         __bf16* __restrict__ Cb = reinterpret_cast<__bf16*>(p.C) + (size_t)z * p.strideC_z;
         char* cst = smem + OFF_CST;
@@ -374,7 +395,9 @@ static int device_cus() {
 }  // namespace panel
 
 bool panel_gemm_supported(const GemmParams& p, int prec, int groups) {
-    if (prec != PP_PREC_BF16 || !p.out_bf16 || p.residual || p.planar_P > 0) return false;
+    const bool partials = p.gather == G_CONV3 && p.ksplit > 1 && !p.out_bf16 && !p.bias;  // fp32 split-K partial sums
+    if (prec != PP_PREC_BF16 || (!p.out_bf16 && !partials) || p.residual || p.planar_P > 0) return false;
+    if (p.ksplit > 1 && !partials) return false;
     if (p.act != ACT_NONE && p.act != ACT_RELU) return false;
     if (p.Cin % 32 != 0 || p.K % 128 != 0 || p.ldc % 8 != 0) return false;
     int BM, BN;

@@ -400,6 +400,29 @@ def test_conv3x3_splitk_sum_maxpool_vs_torch(prec):
         torch.testing.assert_close(out.cpu().double().permute(0, 1, 4, 2, 3), ref, **TOL[prec])
 
 
+def test_conv3x3_splitk_wide_tiles_vs_torch():
+    """The tower stage shape of the bs64 path (4 towers x 128 images x 4 x 4 pixels x 384 channels, three K slices):
+    192 tiles of 256 x 192 -> the persistent wide-tile kernel writes the fp32 partial sums; ragged variant (100 images)
+    stays on the 128 x 128 kernel. Both against torch."""
+    L = _lib()
+    G, H, W, C, ks = 4, 4, 4, 384, 3
+    for B in (128, 100):
+        x = _rand(G, B, C, H, W, seed=84)
+        w = _rand(G, C, C, 3, 3, seed=85, scale=1 / math.sqrt(9 * C))
+        b = _rand(G, C, seed=86)
+        ref = torch.stack([F.relu(F.max_pool2d(F.conv2d(_q(x[g], BF16), _q(w[g], BF16), b[g].double(), padding=1), (2, 2)))
+                           for g in range(G)])
+        xd = x.permute(0, 1, 3, 4, 2).contiguous().bfloat16().cuda()
+        wd = w.permute(0, 1, 3, 4, 2).reshape(G, C, 9 * C).contiguous().bfloat16().cuda()
+        part = torch.full((ks, G, B, H, W, C), float("nan"), device="cuda")
+        L.call("pp_conv3x3_splitk", BF16, xd.data_ptr(), wd.data_ptr(), part.data_ptr(), B, H, W, C, C, G, B * H * W * C, C * 9 * C, ks, None)
+        assert not torch.isnan(part).any()
+        bd = b.cuda()
+        out = torch.empty((G, B, H // 2, W // 2, C), device="cuda")
+        L.call("pp_sum_maxpool_relu_nhwc", part.data_ptr(), ks, G * B * H * W * C, bd.data_ptr(), B, out.data_ptr(), 0, G * B, H, W, C, 2, 2, None)
+        torch.testing.assert_close(out.cpu().double().permute(0, 1, 4, 2, 3), ref, **TOL[BF16])
+
+
 def test_deconv_head_and_phased_decode_vs_unfused():
     """Last deconvolution fused with the 1x1 conv (pp_deconv_head) -> phase-separated logits; decoding them with
     pp_probmap_head_decode_phased gives bit-identical results to decoding the same logits rearranged to planar layout, and
