@@ -161,7 +161,10 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     ArgBest* red = reinterpret_cast<ArgBest*>(smem);                                         // [4] cross-wave argmax
     float* mapf = reinterpret_cast<float*>(smem + RED_BYTES);                                // [H][Wp] (+ slack) averaged map, x-padded
     double* rowd = reinterpret_cast<double*>(smem + RED_BYTES + (((H * Wp + 32) * 4 + 15) & ~15));  // [H+2RM][W] row pass, y-padded
-    float* convf = reinterpret_cast<float*>(rowd + (H + 2 * RM) * W);                        // [H][W] convolved map (f32)
+    // [H][W] convolved map (f32): it takes the place of the averaged map, which is dead once the row pass is through - except
+    // for the one value at the final argmax (the score), so every thread parks its share of the map (4 NV values) in
+    // registers first. 49 KiB instead of 61 at 64 x 48: three workgroups per CU.
+    float* convf = mapf;
 
     const f32x4* src = reinterpret_cast<const f32x4*>(hm + (size_t)bk * HW);
     const f32x4* srcf = nullptr;
@@ -326,7 +329,14 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         else
             rowd[(RM + H + (p - RM)) * W + x] = rowd[(RM + H - 1 - (p - RM)) * W + x];
     }
-    __syncthreads();
+    float mine[4 * NV];  // averaged map at pixels tid + 256 i
+#pragma unroll
+    for (int i = 0; i < 4 * NV; ++i) {
+        const int px = tid + i * DEC_THREADS;
+        const int y = px / W, x = px - y * W;
+        mine[i] = px < HW ? mapf[y * Wp + RM + x] : 0.f;
+    }
+    __syncthreads();  // (also: every thread has its copy before the column pass overwrites the map)
 
     // ---- column pass + running argmax
     ArgBest best;
@@ -350,6 +360,18 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         if (better(ov, oi, best.v, best.idx)) best = ArgBest{ov, oi};
     }
     if (lane_id() == 0) red[wave_id()] = best;
+    __syncthreads();
+    {  // every thread finds the winner; the owner of that pixel hands its parked map value over
+        ArgBest bb = red[0];
+        for (int w = 1; w < DEC_THREADS / WAVE; ++w)
+            if (better(red[w].v, red[w].idx, bb.v, bb.idx)) bb = red[w];
+        if ((bb.idx & (DEC_THREADS - 1)) == tid) {
+            float sv = mine[0];
+#pragma unroll
+            for (int i = 1; i < 4 * NV; ++i) sv = (bb.idx / DEC_THREADS) == i ? mine[i] : sv;
+            reinterpret_cast<float*>(red + DEC_THREADS / WAVE)[0] = sv;
+        }
+    }
     __syncthreads();
     if (conv_out)
         for (int i = tid; i < HW; i += DEC_THREADS) conv_out[(size_t)bk * HW + i] = convf[i];
@@ -378,13 +400,13 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         // probmap.py:218 -- f32 locs promoted to f64 by the division
         keypoints[2 * bk + 0] = (double)lx / (double)(W - 1) * in_w;
         keypoints[2 * bk + 1] = (double)ly / (double)(H - 1) * in_h;
-        scores[bk] = mapf[yi * Wp + RM + xi];  // raw (un-convolved) averaged map at the integer argmax
+        scores[bk] = reinterpret_cast<const float*>(red + DEC_THREADS / WAVE)[0];  // raw (un-convolved) averaged map at the integer argmax
     }
 }
 
 static size_t decode_lds_bytes(int H, int W) {
     const size_t mapf = (((size_t)H * (W + 2 * RM) + 32) * 4 + 15) & ~(size_t)15;
-    return RED_BYTES + mapf + (size_t)(H + 2 * RM) * W * 8 + (size_t)H * W * 4;
+    return RED_BYTES + mapf + (size_t)(H + 2 * RM) * W * 8;  // (the convolved map reuses the averaged map's region)
 }
 
 typedef void (*DecodeKernel)(const float*, const float*, const int32_t*, const double*, const int32_t*, int, int, int,
