@@ -292,6 +292,10 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     };
 
     stamp(20, 0);  // kernel start
+    f32x4 acc[3][6];  // the 96 x 384 block this workgroup owns: residual + bias, then the projection / FFN accumulate on it
+    bool valid[3];
+#pragma unroll
+    for (int rf = 0; rf < 3; ++rf) valid[rf] = m0 + rg * 48 + f_row + rf * 16 < p.M;
     if (ATT) {
         // ================= attention of this workgroup's 96 query rows (waves 0-5: one 16-query tile each). Sequence = 192
         // tokens = this workgroup's rows and its neighbour's. K and V of one head (192 x 32 each, 24 KiB together) arrive by
@@ -342,11 +346,27 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 #pragma unroll
         for (int hd = 0; hd < HEADS; ++hd) {
             stamp(30, hd);
-            if (hd + 1 < HEADS) wait_dma_and_barrier<3>();  // head hd has landed (head hd + 1 may still fly); head hd - 1 is done with
-            else wait_dma_and_barrier<0>();
+            // head hd has landed; younger than its DMA and allowed to fly on: the residual loads of iterations hd - 2 and
+            // hd - 1 (three per iteration 1..6, see below) and the DMA of head hd + 1. Past the barrier head hd - 1 is done with.
+            // (heads 0, 1: 3 - 2: 6 - 3..7: 9 - 8: 6 - 9, 10: 3 - 11: 0)
+            if (hd + 1 == HEADS) wait_dma_and_barrier<0>();
+            else if (hd >= 3 && hd <= 7) wait_dma_and_barrier<9>();
+            else if (hd == 2 || hd == 8) wait_dma_and_barrier<6>();
+            else wait_dma_and_barrier<3>();
             stamp(32, hd);
             stamp(32, hd);
             if (hd + 2 < HEADS) issue_head(hd + 2);
+            if (hd >= 1 && hd <= 6) {
+                // The residual rows (147 KB per workgroup, fp32) trickle in under the attention math, three loads per head
+                // once the first heads are through: plain loads into the accumulators - the bias is added after the phase,
+                // an add (or a select: rows past M read row M - 1, nothing of them is ever stored) here would wait for them.
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int i = (hd - 1) * 3 + u, rf = i / 6, nf = i % 6;
+                    const int m = m0 + rg * 48 + f_row + rf * 16;
+                    acc[rf][nf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(m < p.M ? m : p.M - 1) * E + cg * 96 + nf * 16 + f_kg * 4);
+                }
+            }
             if (wv < 6) {
                 const char* Ks = head_buf(hd);
                 const u32x4 qh = qf[hd];
@@ -419,17 +439,15 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                                                      (m0 + row) < p.M ? vo : OOB, 0, 0, 0);
         }
     }
-    f32x4 acc[3][6];
-    bool valid[3];
 #pragma unroll
     for (int rf = 0; rf < 3; ++rf) {
         const int m = m0 + rows0 + rf * 16;
-        valid[rf] = m < p.M;
 #pragma unroll
         for (int nf = 0; nf < 6; ++nf) {
             const int n = cg * 96 + nf * 16 + f_kg * 4;
             f32x4 v = *reinterpret_cast<const f32x4*>((PROJ ? p.bp : p.b2) + n);
-            if (valid[rf]) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * E + n);
+            if (ATT) v += acc[rf][nf];  // (the residual came in under the attention phase)
+            else if (valid[rf]) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * E + n);
             acc[rf][nf] = v;
         }
     }

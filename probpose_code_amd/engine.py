@@ -76,9 +76,10 @@ class ProbPoseEngine:
         self.fuse_proj = os.environ.get("PP_FUSE_PROJ", "1") != "0"
         self.fuse_qkv = os.environ.get("PP_FUSE_QKV", "1") != "0"
         self.split_k = os.environ.get("PP_SPLIT_K", "1") != "0"
-        # attention inside the layer kernel (pp_vit_layer, one launch per layer): correct and tested, but measured break-even
-        # with pp_attention + the fused rest ("what did not help") - off by default
-        self.fuse_attn = os.environ.get("PP_FUSE_ATTN", "0") != "0"
+        # attention inside the layer kernel (pp_vit_layer, one launch per layer; 192-token sequences, head dim 32): about 2 %
+        # faster per step than pp_attention + the fused rest since the residual rows load under its attention phase
+        # (DESIGN.md 4); PP_FUSE_ATTN=0 switches back to two launches per layer
+        self.fuse_attn = os.environ.get("PP_FUSE_ATTN", "1") != "0"
         self.fuse_head = os.environ.get("PP_FUSE_HEAD", "1") != "0"
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
