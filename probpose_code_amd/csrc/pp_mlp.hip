@@ -310,6 +310,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         constexpr int SEQ = 192, NKT = SEQ / 16, HEADS = E / 32, RS = 3 * E;
         constexpr int KBYTES = SEQ * 64, HBYTES = 2 * KBYTES;  // one head: K [192][64 B] + V [192][64 B]
         static_assert(2 * HBYTES <= NSLOT * SLOT && HBYTES <= 2 * HS_KB, "two heads in the ring region, one in the G region");
+        static_assert((HEADS - 1) % 3 == 2, "the last head sits in the G region (the weight stream starts under it)");
         const int srow0 = (m0 / SEQ) * SEQ;
         const __amdgpu_buffer_rsrc_t qkv_rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.qkv_in), 0, (unsigned)p.M * (unsigned)(RS * 2), 0x00020000);
@@ -356,6 +357,12 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
             stamp(32, hd);
             stamp(32, hd);
             if (hd + 2 < HEADS) issue_head(hd + 2);
+            if (hd + 1 == HEADS) {
+                // the last head sits in the G region: the ring is free, the first eight slots of the weight stream fly
+                // under its math
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) issue_rel(0, q - 12 - PRE);
+            }
             if (hd >= 1 && hd <= 6) {
                 // The residual rows (147 KB per workgroup, fp32) trickle in under the attention math, three loads per head
                 // once the first heads are through: plain loads into the accumulators - the bias is added after the phase,
@@ -426,8 +433,10 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     }
 
     // ---- prologue: ring filled with the first eight slots, input rows into LDS, accumulators = residual + b2
+    if (!ATT) {
 #pragma unroll
-    for (int q = 0; q < NSLOT; ++q) issue_rel(0, q - 12 - PRE);
+        for (int q = 0; q < NSLOT; ++q) issue_rel(0, q - 12 - PRE);
+    }
     if (!ATT) {
         // 72 DMA instructions, nine per wave: instruction i covers k-block i / 12, rows 8 (i % 12) .. +7
 #pragma unroll
