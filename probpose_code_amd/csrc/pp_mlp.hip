@@ -315,12 +315,6 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         const __amdgpu_buffer_rsrc_t qkv_rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.qkv_in), 0, (unsigned)p.M * (unsigned)(RS * 2), 0x00020000);
         u32x4 qf[HEADS];
-        if (wv < 6) {
-            const int qm = m0 + wv * 16 + f_row;
-            const __bf16* qrow = p.qkv_in + (size_t)(qm < p.M ? qm : p.M - 1) * RS + f_kg * 8;
-#pragma unroll
-            for (int hd = 0; hd < HEADS; ++hd) qf[hd] = *reinterpret_cast<const u32x4*>(qrow + hd * 32);
-        }
         auto head_buf = [&](int hd) -> char* { return hd % 3 == 2 ? smem + OFF_GS : ring + (hd % 3) * HBYTES; };
         // instruction i of a head (24 of 1 KiB): i < 12 K keys 16 i .., else V keys 16 (i - 12) ..; lane = (key, position)
         const int a_key = lane >> 2, a_pos = lane & 3;
@@ -336,7 +330,15 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(qkv_rsrc, (lds_ptr_t)(dst + i * 1024), 16, vo, 0, 0, 0);  // rows past M: out of bounds = zeros
             }
         };
+        // order of the first requests: K / V of head 0, the Q fragments (all eight waves, so that every wave's count is the
+        // same; waves 6, 7 never use theirs), K / V of head 1 - the first head does not wait for 74 KB of Q behind it
         issue_head(0);
+        {
+            const int qm = m0 + (wv < 6 ? wv : 0) * 16 + f_row;
+            const __bf16* qrow = p.qkv_in + (size_t)(qm < p.M ? qm : p.M - 1) * RS + f_kg * 8;
+#pragma unroll
+            for (int hd = 0; hd < HEADS; ++hd) qf[hd] = *reinterpret_cast<const u32x4*>(qrow + hd * 32);
+        }
         issue_head(1);
         const int k_frag_off = f_row * 64 + ((f_kg ^ ((f_row >> 2) & 3)) << 4);  // + kt * 1024
         // transposing V read: lane supplies key 4 f_kg + (f_row >> 2) of the 16-key tile, elements 4 (f_row & 3) .. + 3 of the
@@ -349,10 +351,12 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
             stamp(30, hd);
             // head hd has landed; younger than its DMA and allowed to fly on: the residual loads of iterations hd - 2 and
             // hd - 1 (three per iteration 1..6, see below) and the DMA of head hd + 1. Past the barrier head hd - 1 is done with.
-            // (heads 0, 1: 3 - 2: 6 - 3..7: 9 - 8: 6 - 9, 10: 3 - 11: 0)
+            // (head 0: 12 Q loads + 3 - 1: 3 - then 2 residual loads per iteration 1..9: heads 2: 5 - 3..10: 7 - 11: 0;
+            // "at most as many outstanding as there are younger requests" is always a safe count)
             if (hd + 1 == HEADS) wait_dma_and_barrier<0>();
-            else if (hd >= 3 && hd <= 7) wait_dma_and_barrier<9>();
-            else if (hd == 2 || hd == 8) wait_dma_and_barrier<6>();
+            else if (hd == 0) wait_dma_and_barrier<HEADS + 3>();
+            else if (hd >= 3) wait_dma_and_barrier<7>();
+            else if (hd == 2) wait_dma_and_barrier<5>();
             else wait_dma_and_barrier<3>();
             stamp(32, hd);
             stamp(32, hd);
@@ -363,13 +367,13 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 #pragma unroll
                 for (int q = 0; q < NSLOT; ++q) issue_rel(0, q - 12 - PRE);
             }
-            if (hd >= 1 && hd <= 6) {
-                // The residual rows (147 KB per workgroup, fp32) trickle in under the attention math, three loads per head
-                // once the first heads are through: plain loads into the accumulators - the bias is added after the phase,
+            if (hd >= 1 && hd <= 9) {
+                // The residual rows (147 KB per workgroup, fp32) trickle in under the attention math, two loads per head
+                // once the first head is through: plain loads into the accumulators - the bias is added after the phase,
                 // an add (or a select: rows past M read row M - 1, nothing of them is ever stored) here would wait for them.
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int i = (hd - 1) * 3 + u, rf = i / 6, nf = i % 6;
+                for (int u = 0; u < 2; ++u) {
+                    const int i = (hd - 1) * 2 + u, rf = i / 6, nf = i % 6;
                     const int m = m0 + rg * 48 + f_row + rf * 16;
                     acc[rf][nf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(m < p.M ? m : p.M - 1) * E + cg * 96 + nf * 16 + f_kg * 4);
                 }
