@@ -152,14 +152,15 @@ __device__ __forceinline__ unsigned wq_slot_offset(int q, unsigned lane_off) {
 // block above on (x', h) - the 96 x 384 accumulators that end the projection ARE the residual the FFN accumulates on,
 // so x' and h never travel to HBM. The projection is 12 more steps of the phase-B kind (Wp tiles of 384 outputs x
 // 32 k = 3 ring slots) at the head of the same slot stream.
-// QKV = true appends the next layer's qkv projection:  qkv = h_out Wq^T + bq  for the 96 rows, three column blocks of
-// 384 with the block's accumulators reused, 36 more steps of the phase-B kind at the tail of the slot stream; h_out then
-// goes to LDS instead of HBM (p.h_out may be NULL).
+// QKV = true appends the next layer's qkv projection:  qkv = h_out Wq^T + bq  for the 96 rows, six column blocks of
+// 192 in two accumulator sets (the block's accumulators reused), 36 steps of k = 64 at the tail of the slot stream; h_out
+// then goes to LDS instead of HBM (p.h_out may be NULL).
 // ATT = true puts the attention itself in front of the projection: the 96 rows are half of a 192-token sequence; for
-// each of the 12 heads K and V^T of the whole sequence are staged in LDS (double-buffered, in the ring's region, which
-// the weight stream only needs afterwards), S^T = K Q^T, softmax in registers, O^T = V^T P^T exactly as in
-// pp_attention.hip, and the normalised output rows go straight into the LDS image the projection reads - the attention
-// output never exists in HBM and a ViT layer is ONE launch.
+// each of the 12 heads K and V of the whole sequence come in by LDS-DMA (three heads in rotation: two in the ring's
+// region, which the weight stream only needs afterwards, one in the G region), S^T = K Q^T, softmax in registers,
+// O^T = V^T P^T with V read through the transposing ds_read_b64_tr_b16, and the normalised output rows go straight into
+// the LDS image the projection reads - the attention output never exists in HBM and a ViT layer is ONE launch. The
+// residual rows load under this phase, the first weight slots under its last head.
 template <bool PROJ, bool QKV, bool ATT>
 __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) {
     static_assert(!ATT || PROJ, "the attention phase feeds the projection");
