@@ -100,9 +100,18 @@ int pp_probmap_head_decode(const float* logits, const float* logits_flip, const 
  * Operand precision of the MFMA kernels.
  *   PP_PREC_BF16: bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) -- throughput mode.
  *   PP_PREC_F32 : fp32 operands, fp32 accumulate (v_mfma_f32_16x16x4_f32, exact fp32
- *                 products) -- the mode whose results are compared with the fp32 reference.
+ *                 products) -- bit-for-bit an fp32 fmaf chain, at 1/16 of the bf16 MFMA rate.
+ *   PP_PREC_F16X3: split-fp16 operands (x = hi + lo, both fp16; a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
+ *                 v_mfma_f32_16x16x32_f16, fp32 accumulate): operand error ~2^-23, fp32's own rounding step --
+ *                 the mode that meets the reference's 1e-3 tolerance at MFMA fp16 rate. Operand tensors are 4 bytes
+ *                 per element in blocks of 32 elements along the contiguous axis: 32 hi halves (64 B) then 32 lo
+ *                 halves (64 B); every row pitch / channel count must be a multiple of 32. Host-side packing:
+ *                 probpose_code_amd/weights.py::to_split.
+ * Output-format flags (`out_bf16`, `h_bf16`, `in_bf16`, `feat_bf16` arguments below): PP_OUT_F32 = fp32,
+ * PP_OUT_BF16 = bf16 (with PP_PREC_BF16), PP_OUT_SPLIT = split fp16 (with PP_PREC_F16X3).
  * ---------------------------------------------------------------------------------- */
-enum { PP_PREC_BF16 = 0, PP_PREC_F32 = 1 };
+enum { PP_PREC_BF16 = 0, PP_PREC_F32 = 1, PP_PREC_F16X3 = 2 };
+enum { PP_OUT_F32 = 0, PP_OUT_BF16 = 1, PP_OUT_SPLIT = 2 };
 enum { PP_ACT_NONE = 0, PP_ACT_GELU = 1, PP_ACT_RELU = 2 };
 enum { PP_CONV3X3 = 1, PP_DECONV4X4S2 = 2 };
 

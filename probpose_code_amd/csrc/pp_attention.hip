@@ -18,6 +18,7 @@
 //   * blockIdx is remapped so that the heads of one crop (adjacent columns of the same qkv
 //     rows) land on the same XCD / L2.
 #include "pp_common.h"
+#include "pp_split.h"
 
 namespace pp {
 
@@ -423,6 +424,334 @@ static int launch_attention(const void* qkv, void* out, int n_seq, int heads, fl
     return PP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// PP_PREC_F16X3: the same single-pass attention on split-fp16 operands (pp_split.h). qkv rows are 3 E elements of
+// 4 bytes in 128-byte blocks (32 hi halves | 32 lo halves), so a head of 32 dims is exactly one block. K is staged as
+// the raw blocks (chunk-swizzled), V transposed into a hi and a lo plane; every contraction is three fp16 MFMAs
+// (lo*hi + hi*lo + hi*hi); the softmax probabilities are split in registers (p in [0, 1]: a subnormal low half is
+// an absolute error below 2^-25). Output rows are written in the split format.
+template <int HD, int NT>
+struct AttSplitCfg {
+    static constexpr int S = NT * 16;
+    static constexpr int NTP = (NT + 1) & ~1;
+    static constexpr int SP = NTP * 16;
+    static constexpr int SPV = SP + 8;          // V^T row pitch in halves
+    static constexpr int NB = HD / 32;          // 128-byte blocks per head row
+    static constexpr int RC = NB * 8;           // 16-byte chunks per head row
+    static constexpr int DT = HD / 16;
+    static constexpr size_t K_BYTES = (size_t)SP * HD * 4;
+    static constexpr size_t V_BYTES = (size_t)2 * HD * SPV * 2;
+    static constexpr size_t LDS = K_BYTES + V_BYTES;
+};
+
+template <int HD, int NT>
+__global__ __launch_bounds__(ATT_THREADS, (HD == 32 ? 3 : 1)) void attention_split_kernel(const char* __restrict__ qkv, char* __restrict__ out,
+                                                                      int n_seq, int heads, float scale_log2e) {
+    using C = AttSplitCfg<HD, NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                                                         // [SP][RC chunks], chunk-swizzled
+    _Float16* Vh = reinterpret_cast<_Float16*>(smem + C::K_BYTES);           // [HD][SPV] hi halves of V^T
+    _Float16* Vl = Vh + HD * C::SPV;                                         // [HD][SPV] lo halves
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    int id = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);  // XCD-aware remap (as above)
+    const int seq = id / heads, head = id - seq * heads;
+    const int E = heads * HD;
+    const size_t row_bytes = (size_t)3 * E * 4;
+    const char* base = qkv + (size_t)seq * C::S * row_bytes + (size_t)head * HD * 4;
+
+    constexpr int QPW = (NT + ATT_THREADS / 64 - 1) / (ATT_THREADS / 64);
+    f16x8 qh_all[QPW][C::NB], ql_all[QPW][C::NB];
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+        const int qt = wave + t * (ATT_THREADS / 64);
+        const char* qrow = base + (size_t)((qt < NT ? qt : 0) * 16 + fr) * row_bytes;
+#pragma unroll
+        for (int g = 0; g < C::NB; ++g) {
+            qh_all[t][g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + fg * 16);
+            ql_all[t][g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + 64 + fg * 16);
+        }
+    }
+
+    // ---- stage K (raw blocks, swizzled) and V^T (hi / lo planes); zero the padded key rows
+    for (int i = tid; i < C::SP * C::RC; i += ATT_THREADS) {
+        const int r = i / C::RC, c = i - r * C::RC;
+        u32x4 kv = u32x4{0, 0, 0, 0}, vv = u32x4{0, 0, 0, 0};
+        if (r < C::S) {
+            kv = *reinterpret_cast<const u32x4*>(base + (size_t)r * row_bytes + (size_t)E * 4 + c * 16);
+            vv = *reinterpret_cast<const u32x4*>(base + (size_t)r * row_bytes + (size_t)2 * E * 4 + c * 16);
+        }
+        *reinterpret_cast<u32x4*>(Ks + ((size_t)r * C::RC + (c ^ (r & 7))) * 16) = kv;
+        const f16x8 ve = __builtin_bit_cast(f16x8, vv);
+        const int d0 = (c >> 3) * 32 + (c & 3) * 8;
+        _Float16* plane = (c & 4) ? Vl : Vh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) plane[(d0 + j) * C::SPV + r] = ve[j];
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+        const int qt = wave + t * (ATT_THREADS / 64);
+        if (qt >= NT) break;
+        // ---- scores: s[kt][i] = q . k for key 16 kt + 4 fg + i
+        f32x4 s[C::NTP];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int r = kt * 16 + fr;
+#pragma unroll
+            for (int g = 0; g < C::NB; ++g) {
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(Ks + ((size_t)r * C::RC + ((g * 8 + fg) ^ (r & 7))) * 16);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(Ks + ((size_t)r * C::RC + ((g * 8 + 4 + fg) ^ (r & 7))) * 16);
+                acc = split_mma(kh, kl, qh_all[t][g], ql_all[t][g], acc);
+            }
+            s[kt] = acc;
+        }
+        // ---- softmax over the 16 NT keys of this lane's query (fp32)
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[kt][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mb = mx * scale_log2e;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p = exp2f(__builtin_fmaf(s[kt][i], scale_log2e, -mb));  // full-precision exp2 (the parity mode)
+                s[kt][i] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (C::NTP > NT) s[C::NTP - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- O^T = V^T P^T
+        f32x4 o[C::DT];
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < C::NTP / 2; ++blk) {
+            const f32x4 p0 = s[2 * blk], p1 = s[2 * blk + 1];
+            f16x8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ph[j] = split_hi(p0[j]);
+                pl[j] = split_lo(p0[j], ph[j]);
+                ph[4 + j] = split_hi(p1[j]);
+                pl[4 + j] = split_lo(p1[j], ph[4 + j]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                const int off = (dt * 16 + fr) * C::SPV + blk * 32 + 4 * fg;
+                const u32x2 h0 = *reinterpret_cast<const u32x2*>(Vh + off), h1 = *reinterpret_cast<const u32x2*>(Vh + off + 16);
+                const u32x2 l0 = *reinterpret_cast<const u32x2*>(Vl + off), l1 = *reinterpret_cast<const u32x2*>(Vl + off + 16);
+                const u32x4 vh = {h0[0], h0[1], h1[0], h1[1]}, vl = {l0[0], l0[1], l1[0], l1[1]};
+                o[dt] = split_mma(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, vl), ph, pl, o[dt]);
+            }
+        }
+        // ---- normalise and store: lane holds d = 16 dt + 4 fg + (0..3) of query 16 qt + fr
+        const float inv = 1.0f / sum;
+        const size_t oidx = ((size_t)seq * C::S + qt * 16 + fr) * E + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) split_store4(out, oidx + dt * 16 + 4 * fg, o[dt] * inv);
+    }
+}
+
+template <int HD, int NT>
+static int launch_attention_split(const void* qkv, void* out, int n_seq, int heads, float scale, hipStream_t s) {
+    using C = AttSplitCfg<HD, NT>;
+    static_assert(C::LDS <= 160 * 1024, "K/V of one head must fit in one CU's LDS");
+    auto kern = attention_split_kernel<HD, NT>;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+    hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(ATT_THREADS), C::LDS, s, reinterpret_cast<const char*>(qkv),
+                       reinterpret_cast<char*>(out), n_seq, heads, scale * 1.44269504088896340736f);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+// Long sequences in the split format (432 tokens @384x288; head dim 64 does not fit K and V^T of all keys in one CU's
+// LDS - 229 KiB): the keys are walked in NSTAGE stages of KS key tiles. Per stage the workgroup stages that slice of K
+// and V^T, then every wave runs its query tiles over it with the online softmax (running maximum m, running sum l, O
+// rescaled when the maximum moves); the per-tile state lives in registers across the stages, so a wave owns ONE query
+// tile (several per wave spilled: 283 scratch registers at head dim 64): the query tiles of a (sequence, head) are cut
+// into QSPLIT workgroups of 7 waves, each of which stages the K / V slices for itself (L2-resident re-reads).
+template <int HD, int NT, int NSTAGE>
+struct AttSplitStreamCfg {
+    static constexpr int NTP = ((NT + 2 * NSTAGE - 1) / (2 * NSTAGE)) * (2 * NSTAGE);  // key tiles padded to whole stages of pairs
+    static constexpr int KS = NTP / NSTAGE;     // key tiles per stage (even)
+    static constexpr int SS = KS * 16;          // keys per stage
+    static constexpr int SPV = SS + 8;
+    static constexpr int NB = HD / 32, RC = NB * 8, DT = HD / 16;
+    static constexpr size_t K_BYTES = (size_t)SS * HD * 4;
+    static constexpr size_t V_BYTES = (size_t)2 * HD * SPV * 2;
+    static constexpr size_t LDS = K_BYTES + V_BYTES;
+};
+
+template <int HD, int NT, int NSTAGE, int THREADS, int QSPLIT>
+__global__ __launch_bounds__(THREADS, 1) void attention_split_stream_kernel(const char* __restrict__ qkv, char* __restrict__ out,
+                                                                          int n_seq, int heads, float scale_log2e) {
+    using C = AttSplitStreamCfg<HD, NT, NSTAGE>;
+    constexpr int S = NT * 16, NW = THREADS / 64, TPW = (NT + QSPLIT - 1) / QSPLIT, QPW = (TPW + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    _Float16* Vh = reinterpret_cast<_Float16*>(smem + C::K_BYTES);
+    _Float16* Vl = Vh + HD * C::SPV;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    int id = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
+    const int qs = id % QSPLIT;  // the QSPLIT workgroups of a (sequence, head) are neighbours: same XCD, same L2 lines
+    id /= QSPLIT;
+    const int seq = id / heads, head = id - seq * heads;
+    const int E = heads * HD;
+    const size_t row_bytes = (size_t)3 * E * 4;
+    const char* base = qkv + (size_t)seq * S * row_bytes + (size_t)head * HD * 4;
+
+    f32x4 o[QPW][C::DT];
+    float m_run[QPW], l_run[QPW];
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+        m_run[t] = -__builtin_inff();
+        l_run[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll
+    for (int st = 0; st < NSTAGE; ++st) {
+        if (st > 0) __syncthreads();  // every wave is done with the previous slice
+        for (int i = tid; i < C::SS * C::RC; i += THREADS) {
+            const int r = i / C::RC, c = i - r * C::RC;
+            const int key = st * C::SS + r;
+            u32x4 kv = u32x4{0, 0, 0, 0}, vv = u32x4{0, 0, 0, 0};
+            if (key < S) {
+                kv = *reinterpret_cast<const u32x4*>(base + (size_t)key * row_bytes + (size_t)E * 4 + c * 16);
+                vv = *reinterpret_cast<const u32x4*>(base + (size_t)key * row_bytes + (size_t)2 * E * 4 + c * 16);
+            }
+            *reinterpret_cast<u32x4*>(Ks + ((size_t)r * C::RC + (c ^ (r & 7))) * 16) = kv;
+            const f16x8 ve = __builtin_bit_cast(f16x8, vv);
+            const int d0 = (c >> 3) * 32 + (c & 3) * 8;
+            _Float16* plane = (c & 4) ? Vl : Vh;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) plane[(d0 + j) * C::SPV + r] = ve[j];
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int t = 0; t < QPW; ++t) {
+            const int qt = qs * TPW + wave + t * NW;
+            if (wave + t * NW < TPW && qt < NT) {
+                const char* qrow = base + (size_t)(qt * 16 + fr) * row_bytes;
+                f16x8 qh[C::NB], ql[C::NB];
+#pragma unroll
+                for (int g = 0; g < C::NB; ++g) {
+                    qh[g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + fg * 16);
+                    ql[g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + 64 + fg * 16);
+                }
+                f32x4 sc[C::KS];
+                float mx = m_run[t];
+#pragma unroll
+                for (int kt = 0; kt < C::KS; ++kt) {
+                    if (st * C::KS + kt >= NT) continue;  // padded key tile (compile-time)
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const int r = kt * 16 + fr;
+#pragma unroll
+                    for (int g = 0; g < C::NB; ++g) {
+                        const f16x8 kh = *reinterpret_cast<const f16x8*>(Ks + ((size_t)r * C::RC + ((g * 8 + fg) ^ (r & 7))) * 16);
+                        const f16x8 kl = *reinterpret_cast<const f16x8*>(Ks + ((size_t)r * C::RC + ((g * 8 + 4 + fg) ^ (r & 7))) * 16);
+                        acc = split_mma(kh, kl, qh[g], ql[g], acc);
+                    }
+                    sc[kt] = acc;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[i]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (st > 0) {  // rescale what the earlier stages accumulated (exp2(-inf) = 0 never occurs: st 0 set m_run)
+                    const float alpha = exp2f((m_run[t] - mx) * scale_log2e);
+                    l_run[t] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; ++dt) o[t][dt] *= alpha;
+                }
+                m_run[t] = mx;
+                const float mb = mx * scale_log2e;
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < C::KS; ++kt) {
+                    if (st * C::KS + kt >= NT) {
+                        sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};  // padded keys weigh nothing
+                        continue;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float p = exp2f(__builtin_fmaf(sc[kt][i], scale_log2e, -mb));
+                        sc[kt][i] = p;
+                        sum += p;
+                    }
+                }
+                l_run[t] += sum;  // this lane's keys only; the four lanes of a query are added up at the end
+#pragma unroll
+                for (int blk = 0; blk < C::KS / 2; ++blk) {
+                    if (st * C::KS + 2 * blk >= NT) continue;
+                    const f32x4 p0 = sc[2 * blk], p1 = sc[2 * blk + 1];
+                    f16x8 ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ph[j] = split_hi(p0[j]);
+                        pl[j] = split_lo(p0[j], ph[j]);
+                        ph[4 + j] = split_hi(p1[j]);
+                        pl[4 + j] = split_lo(p1[j], ph[4 + j]);
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; ++dt) {
+                        const int off = (dt * 16 + fr) * C::SPV + blk * 32 + 4 * fg;
+                        const u32x2 h0 = *reinterpret_cast<const u32x2*>(Vh + off), h1 = *reinterpret_cast<const u32x2*>(Vh + off + 16);
+                        const u32x2 l0 = *reinterpret_cast<const u32x2*>(Vl + off), l1 = *reinterpret_cast<const u32x2*>(Vl + off + 16);
+                        const u32x4 vh = {h0[0], h0[1], h1[0], h1[1]}, vl = {l0[0], l0[1], l1[0], l1[1]};
+                        o[t][dt] = split_mma(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, vl), ph, pl, o[t][dt]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one tile's score fragments at a time (registers)
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < QPW; ++t) {
+        const int qt = qs * TPW + wave + t * NW;
+        if (wave + t * NW < TPW && qt < NT) {
+            float sum = l_run[t];
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            const size_t oidx = ((size_t)seq * S + qt * 16 + fr) * E + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) split_store4(out, oidx + dt * 16 + 4 * fg, o[t][dt] * inv);
+        }
+    }
+}
+
+template <int HD, int NT, int NSTAGE>
+static int launch_attention_split_stream(const void* qkv, void* out, int n_seq, int heads, float scale, hipStream_t s) {
+    using C = AttSplitStreamCfg<HD, NT, NSTAGE>;
+    static_assert(C::LDS <= 160 * 1024, "one stage of K/V must fit in one CU's LDS");
+    constexpr int QSPLIT = 4, THREADS = 64 * ((NT + QSPLIT - 1) / QSPLIT);  // 27 query tiles: 4 workgroups of 7 waves
+    auto kern = attention_split_stream_kernel<HD, NT, NSTAGE, THREADS, QSPLIT>;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+    hipLaunchKernelGGL(kern, dim3(n_seq * heads * QSPLIT), dim3(THREADS), C::LDS, s, reinterpret_cast<const char*>(qkv),
+                       reinterpret_cast<char*>(out), n_seq, heads, scale * 1.44269504088896340736f);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
 }  // namespace pp
 
 extern "C" int pp_attention(int prec, const void* qkv, void* out, int n_seq, int seq_len, int heads, int head_dim,
@@ -442,11 +771,16 @@ extern "C" int pp_attention(int prec, const void* qkv, void* out, int n_seq, int
         PP_ATT_CASE(float, 32, 12)
         PP_ATT_CASE(float, 64, 12)
         PP_ATT_CASE(float, 32, 27)
+    } else if (prec == PP_PREC_F16X3) {
+        if (head_dim == 32 && seq_len == 192) return launch_attention_split<32, 12>(qkv, out, n_seq, heads, scale, s);
+        if (head_dim == 64 && seq_len == 192) return launch_attention_split<64, 12>(qkv, out, n_seq, heads, scale, s);
+        if (head_dim == 32 && seq_len == 432) return launch_attention_split_stream<32, 27, 2>(qkv, out, n_seq, heads, scale, s);
+        if (head_dim == 64 && seq_len == 432) return launch_attention_split_stream<64, 27, 2>(qkv, out, n_seq, heads, scale, s);
     } else {
         return fail(PP_ERR_INVALID_ARG, "pp_attention: unknown precision");
     }
 #undef PP_ATT_CASE
     return fail(PP_ERR_UNSUPPORTED,
                 "pp_attention: (seq_len, head_dim) not instantiated: supported 192/432 tokens x 32/64 "
-                "(fp32 at 432 x 64 exceeds one CU's LDS)");
+                "(fp32 at 432 x 64 exceeds one CU's LDS; PP_PREC_F16X3 covers it in two key stages)");
 }

@@ -13,7 +13,9 @@
 //   * 256 threads = 4 waves as 2(n) x 2(m), each wave 64x64 = 4x4 MFMA 16x16 fragments, fp32
 //     accumulators; operand precision is a template parameter:
 //       bf16 -> v_mfma_f32_16x16x32_bf16, BK = 64;  f32 -> v_mfma_f32_16x16x4_f32 (exact fp32
-//     products), BK = 32. Both have the same 128-byte-per-row LDS image and C/D layout;
+//     products), BK = 32;  split fp16 (pp_split.h: x = hi + lo, 32 hi halves | 32 lo halves per 128-byte block)
+//     -> three v_mfma_f32_16x16x32_f16 per fragment pair (lo*hi + hi*lo + hi*hi), BK = 32. All have the same
+//     128-byte-per-row LDS image and C/D layout;
 //   * staging by LDS-DMA (`buffer_load_dwordx4 ... lds`): no VGPR round trip, no ds_write pass.
 //     The DMA destination is lane-linear, so the bank-conflict swizzle (16-byte chunk index
 //     XOR row & 7) is applied on the per-lane SOURCE address; out-of-range rows / conv padding
@@ -30,6 +32,7 @@
 //     n-tiles that share one activation panel hit the same L2.
 #include "pp_common.h"
 #include "pp_gemm.h"
+#include "pp_split.h"
 
 #include <cstdlib>
 
@@ -58,6 +61,11 @@ template <>
 struct Prec<float> {
     static constexpr int BK = 32;
 };
+template <>
+struct Prec<SplitH> {
+    static constexpr int BK = 32;  // one 128-byte block: 32 hi halves | 32 lo halves
+};
+enum { FMT_F32 = 0, FMT_BF16 = 1, FMT_SPLIT = 2 };  // GemmParams::out_bf16 carries this code (PP_OUT_*)
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
 
@@ -82,7 +90,7 @@ struct StageRows {
     __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
 };
 
-template <typename T, int GATHER, bool OUT_BF16>
+template <typename T, int GATHER, int OUT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams p) {
     constexpr int BK = Prec<T>::BK;
     constexpr int ESZ = (int)sizeof(T);
@@ -209,18 +217,36 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
             }
             const char* wbase = smem + buf * BUF_BYTES;
             const char* abase = wbase + TILE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {  // two 4-chunk groups per 128-byte row
-                u32x4 fw[4], fa[4];
+            if constexpr (sizeof(T) == 4 && !__is_same(T, float)) {
+                // split fp16: chunk f_kg = this lane's eight hi halves of the K = 32 block, chunk 4 + f_kg the lo halves
+                u32x4 fwh[4], fwl[4], fah[4], fal[4];
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
-                    fw[f] = *reinterpret_cast<const u32x4*>(wbase + swz(wy * 64 + f * 16 + f_row, ks * 4 + f_kg));
-                    fa[f] = *reinterpret_cast<const u32x4*>(abase + swz(wx * 64 + f * 16 + f_row, ks * 4 + f_kg));
+                    fwh[f] = *reinterpret_cast<const u32x4*>(wbase + swz(wy * 64 + f * 16 + f_row, f_kg));
+                    fwl[f] = *reinterpret_cast<const u32x4*>(wbase + swz(wy * 64 + f * 16 + f_row, 4 + f_kg));
+                    fah[f] = *reinterpret_cast<const u32x4*>(abase + swz(wx * 64 + f * 16 + f_row, f_kg));
+                    fal[f] = *reinterpret_cast<const u32x4*>(abase + swz(wx * 64 + f * 16 + f_row, 4 + f_kg));
                 }
 #pragma unroll
                 for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-                    for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mma(fw[nf], fa[mf], acc[nf][mf], T{});
+                    for (int mf = 0; mf < 4; ++mf)
+                        acc[nf][mf] = split_mma(__builtin_bit_cast(f16x8, fwh[nf]), __builtin_bit_cast(f16x8, fwl[nf]),
+                                                __builtin_bit_cast(f16x8, fah[mf]), __builtin_bit_cast(f16x8, fal[mf]), acc[nf][mf]);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {  // two 4-chunk groups per 128-byte row
+                    u32x4 fw[4], fa[4];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        fw[f] = *reinterpret_cast<const u32x4*>(wbase + swz(wy * 64 + f * 16 + f_row, ks * 4 + f_kg));
+                        fa[f] = *reinterpret_cast<const u32x4*>(abase + swz(wx * 64 + f * 16 + f_row, ks * 4 + f_kg));
+                    }
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                        for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mma(fw[nf], fa[mf], acc[nf][mf], T{});
+                }
             }
             __syncthreads();
         }
@@ -283,10 +309,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
         } else {
             // Row-major output through LDS: 16-byte chunks of a row XOR-swizzled by (row & 15) -> the fragment
             // writes and the row reads are both bank-conflict free. bf16: whole 128 x 256 B tile at once;
-            // fp32: two 64-row halves (64 x 512 B = one 32 KiB buffer each).
+            // fp32 / split fp16: two 64-row halves staged as fp32 (64 x 512 B = one 32 KiB buffer each); a split row
+            // leaves as 8 elements per lane = 16 bytes of hi halves + 16 bytes of lo halves.
+            constexpr bool OUT_BF16 = OUT == FMT_BF16, OUT_SPLIT = OUT == FMT_SPLIT;
             constexpr int halves = OUT_BF16 ? 1 : 2;
-            constexpr int lpr = OUT_BF16 ? 16 : 32;  // 16-byte lanes per output row
-            constexpr int epl = OUT_BF16 ? 8 : 4;    // elements per lane
+            constexpr int lpr = OUT == FMT_F32 ? 32 : 16;  // lanes per output row
+            constexpr int epl = OUT == FMT_F32 ? 4 : 8;    // elements per lane
             constexpr int rows_per_pass = GEMM_THREADS / lpr;
             const int cl = tid_e % lpr, rl = tid_e / lpr;
             const int n = n0 + cl * epl;
@@ -346,6 +374,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
                             for (int j = 0; j < 8; ++j)
                                 if (n + j < p.N) o[j] = cv[j];
                         }
+                    } else if constexpr (OUT_SPLIT) {
+                        f32x4 v0 = *reinterpret_cast<const f32x4*>(cst + ml * 512 + (((2 * cl) ^ (ml & 15)) << 4));
+                        f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + ml * 512 + (((2 * cl + 1) ^ (ml & 15)) << 4));
+                        if (p.residual) {
+                            v0 += *reinterpret_cast<const f32x4*>(p.residual + roff);
+                            v1 += *reinterpret_cast<const f32x4*>(p.residual + roff + 4);
+                        }
+                        f16x8 hv, lv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            hv[j] = split_hi(v0[j]);
+                            lv[j] = split_lo(v0[j], hv[j]);
+                            hv[4 + j] = split_hi(v1[j]);
+                            lv[4 + j] = split_lo(v1[j], hv[4 + j]);
+                        }
+                        char* o = split_addr(Cb, eoff);  // N % 32 == 0 and ldc % 32 == 0 (checked at launch): always a full 8
+                        *reinterpret_cast<f16x8*>(o) = hv;
+                        *reinterpret_cast<f16x8*>(o + 64) = lv;
                     } else {
                         f32x4 v = *reinterpret_cast<const f32x4*>(cst + ml * 512 + ((cl ^ (ml & 15)) << 4));
                         float* o = reinterpret_cast<float*>(Cb) + eoff;
@@ -397,8 +443,17 @@ static int launch_gemm(const GemmParams& p_in, int groups, hipStream_t s) {
     constexpr int BK = Prec<T>::BK;
     PP_REQUIRE(p.K > 0 && p.K % BK == 0, PP_ERR_UNSUPPORTED, "pp gemm: K must be a positive multiple of the K-tile");
     PP_REQUIRE(p.M > 0 && p.N > 0, PP_ERR_INVALID_ARG, "pp gemm: M and N must be positive");
+    PP_REQUIRE(p.out_bf16 >= FMT_F32 && p.out_bf16 <= FMT_SPLIT, PP_ERR_INVALID_ARG, "pp gemm: unknown output format");
+    constexpr bool is_split = !__is_same(T, float) && sizeof(T) == 4;
+    PP_REQUIRE(p.out_bf16 == FMT_F32 || (p.out_bf16 == FMT_SPLIT) == is_split, PP_ERR_UNSUPPORTED,
+               "pp gemm: the output is fp32 or the operand format of the precision mode (bf16 / split fp16)");
     PP_REQUIRE(p.planar_P > 0 || p.ldc % (p.out_bf16 ? 8 : 4) == 0, PP_ERR_UNSUPPORTED,
                "pp gemm: ldc must be a multiple of 8 (bf16 out) / 4 (fp32 out) elements");
+    PP_REQUIRE(p.out_bf16 != FMT_SPLIT || (p.ldc % 32 == 0 && p.N % 32 == 0 && p.strideC_z % 32 == 0), PP_ERR_UNSUPPORTED,
+               "pp gemm: split-fp16 output needs N, ldc and the group stride to be multiples of 32 elements");
+    if (is_split)
+        PP_REQUIRE(p.lda % 32 == 0 && p.ldw % 32 == 0 && p.strideA_z % 32 == 0 && p.strideW_z % 32 == 0, PP_ERR_UNSUPPORTED,
+                   "pp gemm: split-fp16 operands need row pitches and group strides that are multiples of 32 elements");
     PP_REQUIRE(!(p.planar_P > 0 && p.out_bf16), PP_ERR_UNSUPPORTED, "pp gemm: planar output is fp32 only");
     if (p.gather != G_LINEAR)
         PP_REQUIRE(p.Cin % BK == 0 && p.H > 0 && p.Wd > 0, PP_ERR_UNSUPPORTED,
@@ -413,10 +468,11 @@ static int launch_gemm(const GemmParams& p_in, int groups, hipStream_t s) {
     const int grid = (int)(ntiles < slots ? ntiles : slots);
     void (*kern)(const GemmParams) = nullptr;
     const bool ob = p.out_bf16 != 0;
+    constexpr int OP = __is_same(T, float) ? FMT_F32 : (is_split ? FMT_SPLIT : FMT_BF16);  // operand-format output of T
     switch (p.gather) {
-        case G_LINEAR: kern = ob ? gemm_kernel<T, G_LINEAR, true> : gemm_kernel<T, G_LINEAR, false>; break;
-        case G_CONV3: kern = ob ? gemm_kernel<T, G_CONV3, true> : gemm_kernel<T, G_CONV3, false>; break;
-        case G_DECONV: kern = ob ? gemm_kernel<T, G_DECONV, true> : gemm_kernel<T, G_DECONV, false>; break;
+        case G_LINEAR: kern = ob ? gemm_kernel<T, G_LINEAR, OP> : gemm_kernel<T, G_LINEAR, FMT_F32>; break;
+        case G_CONV3: kern = ob ? gemm_kernel<T, G_CONV3, OP> : gemm_kernel<T, G_CONV3, FMT_F32>; break;
+        case G_DECONV: kern = ob ? gemm_kernel<T, G_DECONV, OP> : gemm_kernel<T, G_DECONV, FMT_F32>; break;
         default: return fail(PP_ERR_INVALID_ARG, "pp gemm: unknown gather mode");
     }
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -429,6 +485,7 @@ static int launch_gemm(const GemmParams& p_in, int groups, hipStream_t s) {
 int gemm(const GemmParams& p, int prec, int groups, hipStream_t s) {
     if (prec == PP_PREC_BF16) return launch_gemm<__bf16>(p, groups, s);
     if (prec == PP_PREC_F32) return launch_gemm<float>(p, groups, s);
+    if (prec == PP_PREC_F16X3) return launch_gemm<SplitH>(p, groups, s);
     return fail(PP_ERR_INVALID_ARG, "pp gemm: unknown precision");
 }
 

@@ -16,6 +16,7 @@
 //     centred variance by two 2-hop DPP reductions + one LDS exchange between the two column halves, then the fp32
 //     stream and the normalised operand (bf16 or fp32) are both written out.
 #include "pp_common.h"
+#include "pp_split.h"
 
 namespace pp {
 
@@ -62,6 +63,10 @@ struct Prec<__bf16> {
 template <>
 struct Prec<float> {
     static constexpr int BK = 32;
+};
+template <>
+struct Prec<SplitH> {
+    static constexpr int BK = 32;  // split fp16 (pp_split.h): one 128-byte block = 32 hi halves | 32 lo halves
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
@@ -148,13 +153,24 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_res_ln_kernel(const Params p)
         if (kt + 1 < nk) stage(kstep(kt + 1), buf ^ 1);
         const char* wbase = smem + buf * STAGE;
         const char* abase = wbase + W_TILE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const u32x4 fa = *reinterpret_cast<const u32x4*>(abase + swz(rw * 16 + f_row, ks * 4 + f_kg));
+        if constexpr (__is_same(T, SplitH)) {
+            const f16x8 fah = *reinterpret_cast<const f16x8*>(abase + swz(rw * 16 + f_row, f_kg));
+            const f16x8 fal = *reinterpret_cast<const f16x8*>(abase + swz(rw * 16 + f_row, 4 + f_kg));
 #pragma unroll
             for (int nf = 0; nf < 12; ++nf) {
-                const u32x4 fw = *reinterpret_cast<const u32x4*>(wbase + swz(cw * 192 + nf * 16 + f_row, ks * 4 + f_kg));
-                acc[nf] = mma(fw, fa, acc[nf], T{});
+                const f16x8 fwh = *reinterpret_cast<const f16x8*>(wbase + swz(cw * 192 + nf * 16 + f_row, f_kg));
+                const f16x8 fwl = *reinterpret_cast<const f16x8*>(wbase + swz(cw * 192 + nf * 16 + f_row, 4 + f_kg));
+                acc[nf] = split_mma(fwh, fwl, fah, fal, acc[nf]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const u32x4 fa = *reinterpret_cast<const u32x4*>(abase + swz(rw * 16 + f_row, ks * 4 + f_kg));
+#pragma unroll
+                for (int nf = 0; nf < 12; ++nf) {
+                    const u32x4 fw = *reinterpret_cast<const u32x4*>(wbase + swz(cw * 192 + nf * 16 + f_row, ks * 4 + f_kg));
+                    acc[nf] = mma(fw, fa, acc[nf], T{});
+                }
             }
         }
         __syncthreads();
@@ -197,7 +213,9 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_res_ln_kernel(const Params p)
         f32x4 h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) h[j] = (v[j] - mean) * rstd * g[j] + b[j];
-        if (p.h_bf16) {
+        if (p.h_bf16 == 2) {  // PP_OUT_SPLIT
+            split_store4(p.h_out, xrow + n, h);
+        } else if (p.h_bf16) {
             const bf16x4 hv = {(__bf16)h[0], (__bf16)h[1], (__bf16)h[2], (__bf16)h[3]};
             *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.h_out) + xrow + n) = hv;
         } else {
@@ -220,7 +238,12 @@ extern "C" int pp_gemm_residual_layernorm(int prec, const void* act, const void*
     PP_REQUIRE(M > 0 && K > 0, PP_ERR_INVALID_ARG, "pp_gemm_residual_layernorm: M and K must be positive");
     const int bk = prec == PP_PREC_BF16 ? 64 : 32;
     const size_t esz = prec == PP_PREC_BF16 ? 2 : 4;
-    PP_REQUIRE(prec == PP_PREC_BF16 || prec == PP_PREC_F32, PP_ERR_INVALID_ARG, "pp_gemm_residual_layernorm: unknown precision");
+    PP_REQUIRE(prec == PP_PREC_BF16 || prec == PP_PREC_F32 || prec == PP_PREC_F16X3, PP_ERR_INVALID_ARG,
+               "pp_gemm_residual_layernorm: unknown precision");
+    PP_REQUIRE(h_bf16 == PP_OUT_F32 || h_bf16 == (prec == PP_PREC_BF16 ? PP_OUT_BF16 : (prec == PP_PREC_F16X3 ? PP_OUT_SPLIT : PP_OUT_F32)),
+               PP_ERR_UNSUPPORTED, "pp_gemm_residual_layernorm: h_out is fp32 or the operand format of the precision mode");
+    PP_REQUIRE(prec != PP_PREC_F16X3 || (lda % 32 == 0 && ldw % 32 == 0), PP_ERR_UNSUPPORTED,
+               "pp_gemm_residual_layernorm: split-fp16 operands need row pitches that are multiples of 32 elements");
     PP_REQUIRE(K % bk == 0 && lda % 8 == 0 && ldw % 8 == 0, PP_ERR_UNSUPPORTED,
                "pp_gemm_residual_layernorm: K must be a multiple of the K-tile, lda/ldw multiples of 8");
     const size_t ab = ((size_t)(M - 1) * lda + K) * esz, wb = ((size_t)(N - 1) * ldw + K) * esz;
@@ -234,6 +257,10 @@ extern "C" int pp_gemm_residual_layernorm(int prec, const void* act, const void*
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (prec == PP_PREC_BF16) {
         auto kern = rl::gemm_res_ln_kernel<__bf16>;
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, rl::LDS));
+        hipLaunchKernelGGL(kern, grid, block, rl::LDS, s, p);
+    } else if (prec == PP_PREC_F16X3) {
+        auto kern = rl::gemm_res_ln_kernel<SplitH>;
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, rl::LDS));
         hipLaunchKernelGGL(kern, grid, block, rl::LDS, s, p);
     } else {

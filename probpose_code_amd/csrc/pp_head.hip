@@ -4,21 +4,25 @@
 // NHWC activations; what is left is MaxPool + ReLU between them and the final
 // Conv1x1 -> Sigmoid/ReLU -> flip-test average on the 1x1 feature.
 #include "pp_common.h"
+#include "pp_split.h"
 
 namespace pp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ f32x4 load4(const __bf16* p) {
-    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+// four consecutive elements at element index idx (idx % 4 == 0) of a tensor in one of the three activation formats
+__device__ __forceinline__ f32x4 load4(const float* base, size_t idx) { return *reinterpret_cast<const f32x4*>(base + idx); }
+__device__ __forceinline__ f32x4 load4(const __bf16* base, size_t idx) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(base + idx);
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
-__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-__device__ __forceinline__ void store4(__bf16* p, f32x4 v) {
-    *reinterpret_cast<bf16x4*>(p) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+__device__ __forceinline__ f32x4 load4(const SplitH* base, size_t idx) { return split_load4(base, idx); }
+__device__ __forceinline__ void store4(float* base, size_t idx, f32x4 v) { *reinterpret_cast<f32x4*>(base + idx) = v; }
+__device__ __forceinline__ void store4(__bf16* base, size_t idx, f32x4 v) {
+    *reinterpret_cast<bf16x4*>(base + idx) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
 }
+__device__ __forceinline__ void store4(SplitH* base, size_t idx, f32x4 v) { split_store4(base, idx, v); }
 
 // MaxPool2d(kernel = stride = (ph, pw), no padding, floor) followed by ReLU on NHWC tensors.
 // in  [N, H, W, C] -> out [N, H/ph, W/pw, C]; one thread per 4 output channels.
@@ -37,13 +41,13 @@ __global__ __launch_bounds__(256) void maxpool_relu_kernel(const TI* __restrict_
     f32x4 m = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     for (int i = 0; i < ph; ++i)
         for (int j = 0; j < pw; ++j) {
-            const f32x4 v = load4(in + (((size_t)n * H + yo * ph + i) * W + xo * pw + j) * C + c);
+            const f32x4 v = load4(in, (((size_t)n * H + yo * ph + i) * W + xo * pw + j) * C + c);
 #pragma unroll
             for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], v[q]);
         }
 #pragma unroll
     for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], 0.f);
-    store4(out + (((size_t)n * Ho + yo) * Wo + xo) * C + c, m);
+    store4(out, (((size_t)n * Ho + yo) * Wo + xo) * C + c, m);
 }
 
 // The same pooling on split-K partial sums: in = sum over `nsplit` fp32 slices (slice stride `split_stride` elements)
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void sum_maxpool_relu_kernel(const float* __re
     const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + (size_t)(n / images_per_group) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q] + b[q], 0.f);  // max(x) + b == max(x + b): the bias is per channel
-    store4(out + (((size_t)n * Ho + yo) * Wo + xo) * C + c, m);
+    store4(out, (((size_t)n * Ho + yo) * Wo + xo) * C + c, m);
 }
 
 // Final layer of the four towers + flip-test average (probmap_head.py:766-774).
@@ -98,11 +102,11 @@ __global__ __launch_bounds__(256) void tower_final_kernel(const TI* __restrict__
     float res = 0.f;
     for (int pass = 0; pass < passes; ++pass) {
         const int kk = pass ? flip_indices[k] : k;
-        const TI* f = feat + ((size_t)t * passes * B + (size_t)pass * B + b) * C;
+        const size_t f = ((size_t)t * passes * B + (size_t)pass * B + b) * C;
         const float* wr = w + ((size_t)t * K + kk) * C;
         float acc = 0.f;
         for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 fv = load4(f + c), wv = load4(wr + c);
+            const f32x4 fv = load4(feat, f + c), wv = load4(wr, c);
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(fv[q], wv[q], acc);
         }
@@ -130,7 +134,13 @@ extern "C" int pp_maxpool_relu_nhwc(const void* in, int in_bf16, void* out, int 
 #define PP_MP(TI, TO)                                                                                             \
     hipLaunchKernelGGL((maxpool_relu_kernel<TI, TO>), grid, block, 0, s, reinterpret_cast<const TI*>(in),         \
                        reinterpret_cast<TO*>(out), N, H, W, C, ph, pw)
-    if (in_bf16 && out_bf16) PP_MP(__bf16, __bf16);
+    PP_REQUIRE(in_bf16 >= 0 && in_bf16 <= 2 && out_bf16 >= 0 && out_bf16 <= 2 && (in_bf16 != 2 || out_bf16 != 1) &&
+                   (in_bf16 != 1 || out_bf16 != 2) && ((in_bf16 != 2 && out_bf16 != 2) || C % 32 == 0),
+               PP_ERR_UNSUPPORTED, "pp_maxpool_relu_nhwc: formats are PP_OUT_F32 / _BF16 / _SPLIT (bf16 and split do not mix; split needs C % 32 == 0)");
+    if (in_bf16 == 2 && out_bf16 == 2) PP_MP(SplitH, SplitH);
+    else if (in_bf16 == 2) PP_MP(SplitH, float);
+    else if (out_bf16 == 2) PP_MP(float, SplitH);
+    else if (in_bf16 && out_bf16) PP_MP(__bf16, __bf16);
     else if (in_bf16) PP_MP(__bf16, float);
     else if (out_bf16) PP_MP(float, __bf16);
     else PP_MP(float, float);
@@ -149,7 +159,11 @@ extern "C" int pp_tower_final(const void* feat, int feat_bf16, const float* w, c
     PP_REQUIRE(B > 0 && K > 0 && C % 4 == 0, PP_ERR_INVALID_ARG, "pp_tower_final: bad shape");
     const dim3 grid((4 * B * K + 3) / 4), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (feat_bf16)
+    if (feat_bf16 == 2) {
+        PP_REQUIRE(C % 32 == 0, PP_ERR_UNSUPPORTED, "pp_tower_final: split-fp16 features need C % 32 == 0");
+        hipLaunchKernelGGL(tower_final_kernel<SplitH>, grid, block, 0, s, reinterpret_cast<const SplitH*>(feat), w, bias,
+                           flip_indices, out, B, passes, C, K, err_div);
+    } else if (feat_bf16)
         hipLaunchKernelGGL(tower_final_kernel<__bf16>, grid, block, 0, s, reinterpret_cast<const __bf16*>(feat), w, bias,
                            flip_indices, out, B, passes, C, K, err_div);
     else
@@ -170,7 +184,11 @@ extern "C" int pp_sum_maxpool_relu_nhwc(const float* partials, int nsplit, long 
     const long long total = (long long)N * (H / ph) * (W / pw) * (C / 4);
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (out_bf16)
+    if (out_bf16 == 2) {
+        PP_REQUIRE(C % 32 == 0, PP_ERR_UNSUPPORTED, "pp_sum_maxpool_relu_nhwc: split-fp16 output needs C % 32 == 0");
+        hipLaunchKernelGGL(sum_maxpool_relu_kernel<SplitH>, grid, block, 0, s, partials, nsplit, split_stride, bias,
+                           images_per_group, reinterpret_cast<SplitH*>(out), N, H, W, C, ph, pw);
+    } else if (out_bf16)
         hipLaunchKernelGGL(sum_maxpool_relu_kernel<__bf16>, grid, block, 0, s, partials, nsplit, split_stride, bias,
                            images_per_group, reinterpret_cast<__bf16*>(out), N, H, W, C, ph, pw);
     else

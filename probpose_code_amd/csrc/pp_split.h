@@ -1,0 +1,64 @@
+// Split-fp16 operand format of PP_PREC_F16X3 (the precision mode that meets the path's 1e-3 tolerance at MFMA
+// fp16 rate instead of the 16x slower fp32 MFMA).
+//
+// A value x (fp32) is carried as  hi = fp16(x),  lo = fp16(x - hi):  hi + lo represents x to ~2^-23 relative - fp32's
+// own rounding step - and a product is  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  (three v_mfma_f32_16x16x32_f16 with
+// fp32 accumulation; the dropped lo*lo term is 2^-24 relative). The MFMA keeps fp16 subnormals (probed on gfx950,
+// scripts/micro/f16_denorm_probe.hip), so small weights' low halves need no scaling.
+//
+// Memory layout: 4 bytes per element like fp32, in BLOCKS OF 32 ELEMENTS along the contiguous (K) axis:
+//     bytes [0, 64)   32 hi halves   | bytes [64, 128)   32 lo halves
+// A 128-byte block is one LDS row of a K-tile; the 16-byte chunk c (0..3) holds the eight hi halves that ONE lane
+// feeds to the K = 32 MFMA (k = 8 c .. 8 c + 7) and chunk 4 + c the matching lo halves. Every row length is a
+// multiple of 32 elements, so element index -> block is global: block = idx >> 5, position = idx & 31.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pp {
+
+struct SplitH {
+    unsigned raw;  // container only (sizeof == 4); never interpreted as a number
+};
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float split_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ _Float16 split_hi(float x) { return (_Float16)x; }
+__device__ __forceinline__ _Float16 split_lo(float x, _Float16 hi) { return (_Float16)(x - (float)hi); }
+
+// address of the hi half of element `idx` of a split tensor (the lo half lives 64 bytes further)
+__device__ __forceinline__ char* split_addr(void* base, size_t idx) {
+    return reinterpret_cast<char*>(base) + (idx >> 5) * 128 + (idx & 31) * 2;
+}
+__device__ __forceinline__ const char* split_addr(const void* base, size_t idx) {
+    return reinterpret_cast<const char*>(base) + (idx >> 5) * 128 + (idx & 31) * 2;
+}
+
+// four consecutive elements (idx % 4 == 0): two 8-byte accesses
+__device__ __forceinline__ void split_store4(void* base, size_t idx, split_f32x4 v) {
+    f16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = split_hi(v[j]);
+        l[j] = split_lo(v[j], h[j]);
+    }
+    char* p = split_addr(base, idx);
+    *reinterpret_cast<f16x4*>(p) = h;
+    *reinterpret_cast<f16x4*>(p + 64) = l;
+}
+__device__ __forceinline__ split_f32x4 split_load4(const void* base, size_t idx) {
+    const char* p = split_addr(base, idx);
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p), l = *reinterpret_cast<const f16x4*>(p + 64);
+    return split_f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+}
+
+// acc += a * b for one K = 32 block given the hi / lo fragments of both operands (small terms first)
+__device__ __forceinline__ split_f32x4 split_mma(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, split_f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+
+}  // namespace pp

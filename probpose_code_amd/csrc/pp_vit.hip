@@ -1,6 +1,7 @@
 // Memory-bound pieces of the ViT backbone for gfx950: input preprocessing fused with the
 // patch-embed im2col, and LayerNorm as a wavefront reduction.
 #include "pp_common.h"
+#include "pp_split.h"
 
 namespace pp {
 
@@ -74,7 +75,21 @@ __global__ __launch_bounds__(256) void preproc_im2col_kernel(const TIn* __restri
         }
     }
     T* dst = A + (size_t)m * (3 * P * P) + c * P * P + i * P;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (__is_same(T, SplitH)) {  // 16 consecutive k = half a 32-element block: 32 B of hi halves, 32 B of lo halves
+        f16x8 h0, h1, l0, l1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h0[j] = split_hi(v[j]);
+            l0[j] = split_lo(v[j], h0[j]);
+            h1[j] = split_hi(v[8 + j]);
+            l1[j] = split_lo(v[8 + j], h1[j]);
+        }
+        char* o = split_addr(A, (size_t)m * (3 * P * P) + c * P * P + i * P);
+        reinterpret_cast<f16x8*>(o)[0] = h0;
+        reinterpret_cast<f16x8*>(o)[1] = h1;
+        reinterpret_cast<f16x8*>(o + 64)[0] = l0;
+        reinterpret_cast<f16x8*>(o + 64)[1] = l1;
+    } else if constexpr (sizeof(T) == 2) {
         bf16x8 o0, o1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -128,7 +143,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const f32x2 g = g2[lane + 64 * i], b = b2[lane + 64 * i];
         const float o0 = (v[i][0] - mean) * rstd * g[0] + b[0];
         const float o1 = (v[i][1] - mean) * rstd * g[1] + b[1];
-        if constexpr (sizeof(TO) == 2) {
+        if constexpr (__is_same(TO, SplitH)) {
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const _Float16 h0 = split_hi(o0), h1 = split_hi(o1);
+            char* o = split_addr(y, (size_t)row * E + 2 * (lane + 64 * i));
+            *reinterpret_cast<f16x2*>(o) = f16x2{h0, h1};
+            *reinterpret_cast<f16x2*>(o + 64) = f16x2{split_lo(o0, h0), split_lo(o1, h1)};
+        } else if constexpr (sizeof(TO) == 2) {
             reinterpret_cast<bf16x2*>(y + (size_t)row * E)[lane + 64 * i] = bf16x2{(__bf16)o0, (__bf16)o1};
         } else {
             reinterpret_cast<f32x2*>(y + (size_t)row * E)[lane + 64 * i] = f32x2{o0, o1};
@@ -179,6 +200,8 @@ extern "C" int pp_preproc_im2col(int prec, const void* img, int img_is_f32, void
         if (img_is_f32) PP_IM2COL(__bf16, float); else PP_IM2COL(__bf16, uint8_t);
     } else if (prec == PP_PREC_F32) {
         if (img_is_f32) PP_IM2COL(float, float); else PP_IM2COL(float, uint8_t);
+    } else if (prec == PP_PREC_F16X3) {
+        if (img_is_f32) PP_IM2COL(SplitH, float); else PP_IM2COL(SplitH, uint8_t);
     } else
         return fail(PP_ERR_INVALID_ARG, "pp_preproc_im2col: unknown precision");
 #undef PP_IM2COL
@@ -192,5 +215,6 @@ extern "C" int pp_layernorm(const float* x, const float* gamma, const float* bet
     PP_REQUIRE(x && gamma && beta && y, PP_ERR_INVALID_ARG, "pp_layernorm: NULL argument");
     PP_REQUIRE(M > 0, PP_ERR_INVALID_ARG, "pp_layernorm: M must be positive");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (out_bf16 == PP_OUT_SPLIT) return launch_ln<SplitH>(x, gamma, beta, y, M, E, eps, s);
     return out_bf16 ? launch_ln<__bf16>(x, gamma, beta, y, M, E, eps, s) : launch_ln<float>(x, gamma, beta, y, M, E, eps, s);
 }

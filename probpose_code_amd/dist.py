@@ -51,21 +51,55 @@ def pack_records(out: Dict[str, torch.Tensor], into: Optional[torch.Tensor] = No
 
 class ResultGather:
     """Per-step: pack the batch's result record, all_gather it over RCCL when world > 1 and start the copy
-    into pinned host memory. Buffers are allocated once."""
+    into pinned host memory. Buffers are allocated once, for ``batch`` rows per rank.
+
+    A rank may hold FEWER than ``batch`` rows (the tail batch of a ``round_up=False`` shard): its record is padded to
+    ``batch`` rows inside, the row counts travel with the records (one extra row), and ``counts`` says how many rows of
+    every rank's block are valid. ``__call__`` returns the pinned host tensor (world, batch, K, 7) right after ENQUEUING
+    the device-to-host copy: ``wait()`` (or a device synchronize) must come before the host reads it."""
 
     def __init__(self, batch: int, num_keypoints: int, device, world: int = 1, group=None):
-        self.world, self.group = world, group
+        self.world, self.group, self.batch = world, group, batch
         self.device = torch.device(device)
-        shape = (world, batch, num_keypoints, len(RECORD_FIELDS))
-        self.gathered = torch.empty(shape, dtype=torch.float64, device=self.device)
+        K, F = num_keypoints, len(RECORD_FIELDS)
+        # one extra row per rank carries the rank's valid-row count, so sizes and records are ONE collective
+        self._send = torch.zeros((batch + 1, K, F), dtype=torch.float64, device=self.device)
+        self._recv = torch.empty((world, batch + 1, K, F), dtype=torch.float64, device=self.device)
+        self.gathered = self._recv[:, :batch]
         pin = self.device.type == "cuda"
-        self.host = torch.empty(shape, dtype=torch.float64, pin_memory=pin)
+        self._host = torch.empty((world, batch + 1, K, F), dtype=torch.float64, pin_memory=pin)
+        self.host = self._host[:, :batch]
+        self._event = torch.cuda.Event() if pin else None
 
     def __call__(self, out: Dict[str, torch.Tensor]) -> torch.Tensor:
+        n = int(out["keypoints"].shape[0])
+        if n > self.batch:
+            raise ValueError(f"ResultGather was built for at most {self.batch} rows per rank, got {n}")
+        dst = self._send if self.world > 1 else self._recv[0]
+        pack_records(out, into=dst[:n])
+        if n < self.batch:
+            dst[n:self.batch].zero_()  # no stale rows from an earlier, fuller batch
+        dst[self.batch].fill_(float(n))
         if self.world > 1:
-            rec = pack_records(out)
-            dist.all_gather_into_tensor(self.gathered.flatten(0, 1), rec.contiguous(), group=self.group)
-        else:
-            pack_records(out, into=self.gathered[0])
-        self.host.copy_(self.gathered, non_blocking=True)
+            dist.all_gather_into_tensor(self._recv.flatten(0, 1), self._send, group=self.group)
+        self._host.copy_(self._recv, non_blocking=True)
+        if self._event is not None:
+            self._event.record(torch.cuda.current_stream(self.device))
         return self.host
+
+    def wait(self) -> torch.Tensor:
+        """Block the host until the last step's device-to-host copy has landed; returns the host tensor."""
+        if self._event is not None:
+            self._event.synchronize()
+        return self.host
+
+    @property
+    def counts(self) -> List[int]:
+        """Valid rows per rank of the last gathered step (after ``wait()``)."""
+        return [int(self._host[r, self.batch, 0, 0].item()) for r in range(self.world)]
+
+    def ordered(self) -> torch.Tensor:
+        """Last step's records in dataset order (``collect_results``): rank-major blocks interleaved, padding rows of
+        short ranks dropped. Strided shards put the short ranks last, so the valid rows are a prefix."""
+        self.wait()
+        return interleave(self.host, sum(self.counts))

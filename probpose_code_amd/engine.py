@@ -24,10 +24,12 @@ import torch
 
 from . import _lib
 from .codecs import oks_kernel_taps
-from .weights import PackedWeights, pack
+from .weights import PackedWeights, from_split, pack, to_split
 
-PREC = {"bf16": 0, "f32": 1}
-_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32}
+PREC = {"bf16": 0, "f32": 1, "f16x3": 2}  # PP_PREC_*
+# torch dtype of the operand buffers; "f16x3" = split fp16 (x = hi + lo, csrc/pp_split.h) in a 4-byte-per-element container
+_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32, "f16x3": torch.float32}
+_FMT = {"bf16": 1, "f32": 0, "f16x3": 2}  # PP_OUT_*: format code of an operand-precision output
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 CONV3X3, DECONV = 1, 2
 
@@ -46,7 +48,8 @@ class ProbPoseEngine:
         self.precision = precision
         self.prec = PREC[precision]
         self.dtype = _DTYPE[precision]
-        self.w: PackedWeights = pack(state_dict, self.dtype, self.device)
+        self.fmt = _FMT[precision]
+        self.w: PackedWeights = pack(state_dict, self.dtype, self.device, split=precision == "f16x3")
         self.heads = num_heads
         self.H, self.W = img_size
         self.P, self.pad = patch_size, patch_padding
@@ -148,7 +151,8 @@ class ProbPoseEngine:
 
     def _gemm(self, st, a, w, bias, out, M, N, K, act=ACT_NONE, residual=None, res_mod=0, out_bf16=None, planar=0,
               ldc=None):
-        ob = int(out.dtype == torch.bfloat16) if out_bf16 is None else out_bf16
+        """``out_bf16``: PP_OUT_* format of ``out``; default = the operand format of the precision mode."""
+        ob = self.fmt if out_bf16 is None else out_bf16
         self._call("gemm_bf16out" if ob else "gemm_f32out", "pp_gemm", self.prec, a.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(residual),
                    res_mod, out.data_ptr(), M, N, K, K, K, N if ldc is None else ldc, act, ob, planar, st)
 
@@ -157,7 +161,7 @@ class ProbPoseEngine:
         B = imgs_u8.shape[0]
         M = B * passes * self.Np
         E, Fd, w = self.E, self.w.ffn_dims, self.w
-        ob = int(self.dtype == torch.bfloat16)
+        ob = self.fmt
         self._call("im2col", "pp_preproc_im2col", self.prec, imgs_u8.data_ptr(), int(imgs_u8.dtype == torch.float32),
                   ws["patches"].data_ptr(), B, passes, self.H, self.W, self.P, self.pad, self.mean.ctypes.data,
                   self.std.ctypes.data, int(self.bgr_to_rgb), st)
@@ -174,7 +178,7 @@ class ProbPoseEngine:
                            bk.data_ptr(), residual.data_ptr(), res_mod, ws["x"].data_ptr(), gamma.data_ptr(),
                            beta.data_ptr(), self.ln_eps, h_out.data_ptr(), ob, M, E, K, K, K, st)
             else:
-                self._gemm(st, a, wk, bk, ws["x"], M, E, K, residual=residual, res_mod=res_mod)
+                self._gemm(st, a, wk, bk, ws["x"], M, E, K, residual=residual, res_mod=res_mod, out_bf16=0)
                 self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                            h_out.data_ptr(), M, E, self.ln_eps, ob, st)
 
@@ -238,15 +242,15 @@ class ProbPoseEngine:
     def heatmap_logits(self, feat: torch.Tensor, nb: int, ws, st) -> torch.Tensor:
         """NHWC features -> planar logits (nb, K, Hh*Wh) fp32 (deconv x n + BN + ReLU, final 1x1 conv)."""
         w = self.w
-        ob = int(self.dtype == torch.bfloat16)
+        ob = self.fmt
         src, cin, hh, ww = feat, self.E, self.Hp, self.Wp
         self._logits_phased = False
         nd = len(w.deconv_channels)
         for j, cout in enumerate(w.deconv_channels):
             dst = ws[f"d{j}"]
             wj = w[f"deconv{j}.w"]
-            if (j == nd - 1 and self.fuse_head and ob and cout == 256 and w.has("final.w_pad") and cin % 32 == 0
-                    and (hh * ww) % 4 == 0):
+            if (j == nd - 1 and self.fuse_head and ob == 1 and cout == 256 and w.has("final.w_pad") and cin % 32 == 0
+                    and ww % 4 == 0):
                 # last deconvolution + the 1x1 conv behind it in one kernel; the 256-channel map is never stored and the
                 # logits come out phase-separated (the decode kernel reads that layout directly)
                 self._call("deconv_head", "pp_deconv_head", src.data_ptr(), wj.data_ptr(), w[f"deconv{j}.b"].data_ptr(),
@@ -267,7 +271,7 @@ class ProbPoseEngine:
         """NHWC features -> (4, B, K) fp32: probability, visibility, oks, error (error NOT yet / diagonal)."""
         w, E = self.w, self.E
         nb = B * passes
-        ob = int(self.dtype == torch.bfloat16)
+        ob = self.fmt
         src, stride_src = feat, 0  # the four towers share the backbone features
         for j, (th, tw) in enumerate(self.tower_hw):
             ph, pw_ = self.pools[j]
@@ -313,6 +317,21 @@ class ProbPoseEngine:
         with torch.cuda.device(self.device):
             feat = self.backbone(imgs, passes, ws, _lib.stream_ptr(self.device))
         return feat.view(B * passes, self.Hp, self.Wp, self.E)
+
+    # features cross the module-level interfaces (backbone(x) -> head.forward(feats)) as ordinary tensors: bf16 / fp32
+    # as they are, split fp16 decoded to fp32 on the way out and re-encoded on the way in (host-side plumbing, not on the
+    # fused predict path)
+    def export_features(self, feat: torch.Tensor) -> torch.Tensor:
+        """Engine feature buffer -> the caller's own tensor (a copy: the workspace is reused by the next call)."""
+        return from_split(feat) if self.precision == "f16x3" else feat.clone()
+
+    def import_features(self, x_nhwc: torch.Tensor) -> torch.Tensor:
+        """NHWC feature tensor of any float dtype -> contiguous buffer in the engine's operand format."""
+        if self.precision == "f16x3":
+            return to_split(x_nhwc.float().contiguous())
+        if x_nhwc.dtype != self.dtype or not x_nhwc.is_contiguous():
+            x_nhwc = x_nhwc.to(self.dtype).contiguous()
+        return x_nhwc
 
     @torch.no_grad()
     def run_head(self, feat_nhwc: torch.Tensor, flip_test: bool, flip_indices=None,

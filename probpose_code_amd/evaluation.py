@@ -134,6 +134,15 @@ class COCOeval:
         K = len(self.sigmas)
         gts = list(_annotations(self.cocoGt, p.imgIds))  # (read only: edited visibilities / flags live in arrays)
         dts = list(_annotations(self.cocoDt, p.imgIds))
+        # the reference forms (image, category) cells and loads annotations by catIds (:170-176, :415-422); this evaluator
+        # forms cells by image only, which is the same thing for ONE category (COCO person) and nothing else
+        cats = {a.get("category_id", 1) for a in gts} | {a.get("category_id", 1) for a in dts}
+        if len(cats) > 1:
+            raise NotImplementedError(f"COCOeval (MI355X) evaluates one category at a time; annotations carry {sorted(cats)}")
+        if self.use_area:  # `tmparea = gt["area"]` raises KeyError in the reference (:696-697); never guess an area
+            for g in gts:
+                if "area" not in g:
+                    raise KeyError("area")
         # instances: all keypoints as one array, the visibility edits of the reference vectorised over the instances
         gkp = np.array([g["keypoints"] for g in gts], np.float64).reshape(len(gts), K, 3)
         gbb = np.array([g["bbox"] for g in gts], np.float64).reshape(len(gts), 4)

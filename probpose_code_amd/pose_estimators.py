@@ -155,11 +155,14 @@ class VisionTransformer(nn.Module):
 
     def forward(self, x: Tensor) -> Tuple[Tensor]:
         """(B, 3, H, W) float32 preprocessed (reference contract) or uint8 raw crops -> ``(feat,)`` with
-        feat of logical shape (B, E, Hp, Wp) (a channels-last view of the engine's NHWC buffer)."""
+        feat of logical shape (B, E, Hp, Wp), channels-last in memory. The result is the caller's own copy (the
+        engine's workspace is reused by the next call with the same batch size: the reference's flip-test call pattern,
+        ``feats = extract_feat(x); feats_flip = extract_feat(x.flip(-1))``, topdown.py:109-112, must see two tensors)."""
         if self._owner is None:
             raise RuntimeError("VisionTransformer (MI355X) must be built inside a TopdownPoseEstimator: "
                                "the HIP engine is owned by the estimator")
-        feat = self._owner().engine.run_backbone(x, flip_test=False)
+        eng = self._owner().engine
+        feat = eng.export_features(eng.run_backbone(x, flip_test=False))
         return (feat.permute(0, 3, 1, 2),)
 
 
@@ -259,10 +262,7 @@ class ProbMapHead(nn.Module):
     def _to_nhwc(self, feats) -> Tensor:
         x = feats[-1] if isinstance(feats, (tuple, list)) else feats
         eng = self._engine
-        x = x.permute(0, 2, 3, 1)
-        if x.dtype != eng.dtype or not x.is_contiguous():
-            x = x.to(eng.dtype).contiguous()  # layout/dtype plumbing for foreign feature maps
-        return x
+        return eng.import_features(x.permute(0, 2, 3, 1))  # layout/format plumbing for feature maps handed in from outside
 
     def forward(self, feats: Tuple[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
         """probmap_head.py:600-625 -> heatmaps (B,K,H,W), probability, visibility, oks, error (B,K,1,1)."""
@@ -328,8 +328,9 @@ class ProbMapHead(nn.Module):
 # =================================================================================================
 @register(MODELS, reference_name="TopdownPoseEstimator", mi355x_name="TopdownPoseEstimatorMI355X")
 class TopdownPoseEstimator(nn.Module):
-    """topdown.py:12-194 / base.py:17-243 for inference. Extra keyword: ``precision`` in {"bf16", "f32"}
-    (operand precision of the MFMA kernels; "f32" is the mode compared with the fp32 reference)."""
+    """topdown.py:12-194 / base.py:17-243 for inference. Extra keyword: ``precision`` in {"bf16", "f16x3", "f32"}
+    (operand precision of the MFMA kernels: "bf16" = throughput mode; "f16x3" = split-fp16 operands, three fp16 MFMAs per
+    product, meets the reference's 1e-3 tolerance; "f32" = exact fp32 products, bit-for-bit an fmaf chain, slowest)."""
 
     _version = 2
 

@@ -23,6 +23,27 @@ TOWERS = ("probability", "visibility", "oks", "error")
 BN_EPS = 1e-5  # nn.BatchNorm2d default, probmap_head.py:276
 
 
+def to_split(x: torch.Tensor) -> torch.Tensor:
+    """fp32 (..., K) -> the split-fp16 operand format of PP_PREC_F16X3 (include/probpose_mi355x.h, csrc/pp_split.h):
+    hi = fp16(x), lo = fp16(x - hi), stored in blocks of 32 elements along the last axis as 32 hi halves then 32 lo
+    halves. Returned as a float32 CONTAINER of the same shape (4 bytes per element; the values are not numbers)."""
+    K = x.shape[-1]
+    assert K % 32 == 0, f"split-fp16 tensors need a last dimension that is a multiple of 32, got {K}"
+    x = x.float()
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    lead = x.shape[:-1]
+    blocks = torch.stack([hi.reshape(*lead, K // 32, 32), lo.reshape(*lead, K // 32, 32)], dim=-2)
+    return blocks.reshape(*lead, 2 * K).contiguous().view(torch.float32)
+
+
+def from_split(c: torch.Tensor) -> torch.Tensor:
+    """Inverse of ``to_split`` (hi + lo in fp32)."""
+    K = c.shape[-1]
+    v = c.contiguous().view(torch.float16).reshape(*c.shape[:-1], K // 32, 2, 32).float()
+    return (v[..., 0, :] + v[..., 1, :]).reshape(c.shape)
+
+
 def normalize_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     if "state_dict" in sd and isinstance(sd["state_dict"], dict):
         sd = sd["state_dict"]
@@ -59,10 +80,15 @@ def _bn_fold(sd, name):
     return scale, shift
 
 
-def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device) -> PackedWeights:
+def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = False) -> PackedWeights:
+    """``dtype``: operand dtype of the MFMA kernels (bf16 / fp32); ``split=True``: split-fp16 operands in a float32
+    container (``to_split``)."""
     sd = {k: v.detach().cpu() for k, v in normalize_state_dict(sd).items()}
     f32 = lambda x: x.float().contiguous().to(device)  # noqa: E731
-    op = lambda x: x.float().contiguous().to(dtype).to(device)  # noqa: E731
+    if split:
+        op = lambda x: to_split(x.float().contiguous()).to(device)  # noqa: E731
+    else:
+        op = lambda x: x.float().contiguous().to(dtype).to(device)  # noqa: E731
     pw = sd["backbone.patch_embed.projection.weight"]
     E = pw.shape[0]
     L = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("backbone.layers."))

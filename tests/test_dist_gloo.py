@@ -23,18 +23,27 @@ def _worker(rank, world, port, n, ret):
     K = 17
     idx = shard_indices(n, rank, world)
     per = (n + world - 1) // world
-    # fake per-rank engine output whose values encode the dataset index
-    ids = torch.tensor(idx + [-1] * (per - len(idx)), dtype=torch.float64)
+    # fake per-rank engine output whose values encode the dataset index; the short rank hands over FEWER rows
+    # (round_up=False shards are uneven) - the padding is ResultGather's business, not the caller's
+    ids = torch.tensor(idx, dtype=torch.float64)
+    m = len(idx)
     out = dict(
-        keypoints=ids[:, None, None].expand(per, K, 2).clone(),
-        scores=ids[:, None].expand(per, K).float().clone(),
-        scalars=ids[None, :, None].expand(4, per, K).float().clone(),
+        keypoints=ids[:, None, None].expand(m, K, 2).clone(),
+        scores=ids[:, None].expand(m, K).float().clone(),
+        scalars=ids[None, :, None].expand(4, m, K).float().clone(),
     )
     g = ResultGather(per, K, "cpu", world)
+    g(dict(keypoints=torch.full((per, K, 2), 99.0, dtype=torch.float64), scores=torch.full((per, K), 99.0),
+           scalars=torch.full((4, per, K), 99.0)))  # an earlier, full step: its rows must not survive below
     host = g(out)
+    g.wait()
+    ok = g.counts == [len(shard_indices(n, r, world)) for r in range(world)]
     ordered = interleave(host, n)
-    ok = torch.equal(ordered[:, 0, 0], torch.arange(n, dtype=torch.float64)) and ordered.shape == (n, K, 7)
+    ok = ok and torch.equal(ordered[:, 0, 0], torch.arange(n, dtype=torch.float64)) and ordered.shape == (n, K, 7)
     ok = ok and torch.equal(ordered[:, 3, 5], torch.arange(n, dtype=torch.float64))
+    ok = ok and torch.equal(g.ordered(), ordered)
+    if m < per:
+        ok = ok and bool((g.gathered[rank, m:] == 0).all())
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

@@ -2,8 +2,11 @@
 -> test_step -> PoseDataSample.pred_instances -- against the torch-CPU oracle on identical crops.
 
 Tolerances (BASELINE.json north_star: keypoints / probabilities within 1e-3 of the reference CPU path):
-  * precision "f32" (exact-fp32 MFMA products, fp32 accumulate): every field <= 1e-3, keypoints in image px;
-  * precision "bf16": measured and bounded loosely; argmax flips are counted, not hidden.
+  * precision "f16x3" (split-fp16 operands, three fp16 MFMAs per product) and "f32" (exact-fp32 MFMA products): every
+    field <= 1e-3, keypoints in image px, no argmax flips - also at the bench's batch size 64;
+  * precision "bf16": measured (0.3-0.45 px, 3-8 % flips on these very sparse synthetic maps) and bounded just above
+    that; argmax flips are counted, not hidden;
+  * the hipGraph replay (what bench.py times) must equal the eager launch sequence bit for bit.
 """
 import os
 
@@ -45,9 +48,10 @@ def _run(sd, crops, center, scale, precision, cfg_options=None):
         return model, model.test_step(batch)
 
 
-def test_f32_pred_instances_within_1e3(setup):
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_parity_modes_pred_instances_within_1e3(setup, precision):
     sd, crops, center, scale, ref = setup
-    model, results = _run(sd, crops, center, scale, "f32", {"model.test_cfg.output_heatmaps": True})
+    model, results = _run(sd, crops, center, scale, precision, {"model.test_cfg.output_heatmaps": True})
     assert len(results) == B
     flips = 0
     for b, ds in enumerate(results):
@@ -66,7 +70,7 @@ def test_f32_pred_instances_within_1e3(setup):
         hm = ds.pred_fields.heatmaps
         assert tuple(hm.shape) == (17, 64, 48)
         assert np.abs(hm.cpu().numpy() - ref["heatmaps"][b]).max() <= 1e-3
-    assert flips <= 1, f"{flips} argmax flips of {B * 17} keypoints in fp32 mode"
+    assert flips == 0, f"{flips} argmax flips of {B * 17} keypoints in {precision} mode"
     # keypoint_scores is the OKS branch since freeze_oks=False (probmap_head.py:797-798)
     assert np.array_equal(results[0].pred_instances.keypoint_scores, results[0].pred_instances.keypoints_oks)
 
@@ -84,10 +88,56 @@ def test_bf16_pred_instances_bounded(setup):
         for f in ("keypoints_probs", "keypoints_visible", "keypoints_oks"):
             assert np.abs(getattr(pi, f) - ref[f][b]).max() <= 3e-2, f
     print(f"bf16: keypoint L_inf (same argmax) {worst:.3e} image px, argmax flips {flips}/{B * 17}")
-    # bf16 is the throughput mode, not the parity mode (that is f32, 1e-3): the bound only guards against gross
-    # errors - a fifth of a heatmap cell (5 image px at these crop scales) - and moves with every change of
-    # summation order; measured 0.3-0.5 image px
-    assert worst <= 1.0 and flips <= 0.15 * B * 17
+    # bf16 is the throughput mode, not the parity mode (that is f16x3, 1e-3). Measured here: 0.3-0.5 image px on agreeing
+    # argmaxes, 3-8 % flips (the synthetic maps have 2-10 px support, so near-ties are common); the bound sits just
+    # above the measured band so that a regression in any bf16 kernel shows
+    assert worst <= 0.75 and flips <= 0.10 * B * 17
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_full_path_bs64_within_1e3(precision):
+    """The bench workload (bs 64, flip test) end to end in the parity modes against the oracle: keypoints <= 1e-3
+    input-space px with zero argmax flips, scalar heads <= 1e-3."""
+    from oracle import model_ref as M
+    from probpose_code_amd import ProbPoseEngine
+    from probpose_code_amd import synthetic as S
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
+    crops = S.synthetic_crops(64, seed=100)
+    ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD)
+    eng = ProbPoseEngine(sd, 12, precision=precision)
+    out = eng.forward_graph(crops.cuda(), True, S.COCO_FLIP_INDICES)  # the replayed path, as bench.py runs it
+    torch.cuda.synchronize()
+    d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
+    assert (d < 2.0).all(), f"{int((d >= 2.0).sum())} argmax flips of {d.size}"
+    assert d.max() <= 1e-3, f"keypoint L_inf {d.max():.2e} px"
+    for i, name in enumerate(("keypoints_probs", "keypoints_visible", "keypoints_oks")):
+        assert np.abs(out["scalars"][i].cpu().numpy()[:, None] - ref[name]).max() <= 1e-3, name
+    assert np.abs(out["scores"].cpu().numpy()[:, None] - ref["keypoints_conf"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16x3"])
+def test_graph_replay_equals_eager_bit_for_bit(precision):
+    """bench.py times forward_graph (hipGraph replay): it must produce exactly what the eager launch sequence does,
+    on two DIFFERENT batches in a row (a capture that baked in stale pointers or inputs would repeat batch 1)."""
+    from probpose_code_amd import ProbPoseEngine
+    from probpose_code_amd import synthetic as S
+
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
+    eng = ProbPoseEngine(sd, 12, precision=precision)
+    keys = ("keypoints", "scores", "locs", "scalars")
+    prev = None
+    for seed in (100, 101):
+        crops = S.synthetic_crops(64, seed=seed).cuda()
+        g = {k: v.clone() for k, v in eng.forward_graph(crops, True, S.COCO_FLIP_INDICES).items() if k in keys}
+        e = {k: v.clone() for k, v in eng.forward(crops, True, S.COCO_FLIP_INDICES).items() if k in keys}
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(g[k], e[k]), f"{k}: graph replay differs from eager launches (batch seed {seed})"
+        if prev is not None:
+            assert not torch.equal(prev["keypoints"], g["keypoints"]), "second batch replayed the first batch's results"
+        prev = g
 
 
 def test_module_level_interfaces(setup):
@@ -97,14 +147,14 @@ def test_module_level_interfaces(setup):
     from probpose_code_amd import synthetic as S
 
     sd, crops, center, scale, ref = setup
-    model, fused = _run(sd, crops, center, scale, "f32")
+    model, fused = _run(sd, crops, center, scale, "f16x3")
     x = M.preprocess(crops, S.IMG_MEAN, S.IMG_STD).cuda()
     with torch.no_grad():
         feats = model.extract_feat(x)
         assert isinstance(feats, tuple) and tuple(feats[0].shape) == (B, 384, 16, 12)
         assert np.abs(feats[0].cpu().numpy() - ref["features"]).max() < 1e-4
-        feats = (feats[0].clone(),)
-        feats_flip = (model.extract_feat(x.flip(-1))[0].clone(),)
+        feats_flip = model.extract_feat(x.flip(-1))  # the reference's call pattern as written (topdown.py:109-112)
+        assert np.abs(feats[0].cpu().numpy() - ref["features"]).max() < 1e-4, "second call overwrote the first result"
         hm, prob, vis, oks, err = model.head.forward(feats)
         assert tuple(hm.shape) == (B, 17, 64, 48) and tuple(prob.shape) == (B, 17, 1, 1)
         assert torch.allclose(hm.sum((-1, -2)), torch.ones(B, 17, device="cuda"), atol=1e-5)
@@ -151,8 +201,16 @@ def test_config4_vit_base_384x288_bf16():
     assert tuple(out["heatmaps"].shape) == (3, 17, 96, 72)
     d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
     same = d < 2.0
-    assert same.mean() >= 0.85 and d[same].max() < 0.5
+    print(f"config 4 bf16: {float(1 - same.mean()):.3f} argmax flips, {d[same].max():.3f} px on the rest")
+    assert same.mean() >= 0.90 and d[same].max() < 0.5  # measured 3-8 % flips, 0.3-0.45 px
     assert np.abs(out["scalars"][0].cpu().numpy()[:, None] - ref["keypoints_probs"]).max() < 3e-2
     with pytest.raises(Exception, match="not instantiated"):  # fp32 at 432 x 64 does not fit one CU's LDS
         ProbPoseEngine(sd, 12, img_size=img, precision="f32", input_size=(288, 384)).forward(
             x.cuda(), True, S.COCO_FLIP_INDICES)
+    # the parity mode covers this geometry (attention in key stages): <= 1e-3 px, no flips
+    eng = ProbPoseEngine(sd, 12, img_size=img, precision="f16x3", input_size=(288, 384))
+    out = eng.forward(x.cuda(), True, S.COCO_FLIP_INDICES)
+    d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
+    assert (d < 2.0).all() and d.max() <= 1e-3, f"config 4 f16x3: {int((d >= 2).sum())} flips, L_inf {d[d < 2].max():.2e} px"
+    for i, name in enumerate(("keypoints_probs", "keypoints_visible", "keypoints_oks")):
+        assert np.abs(out["scalars"][i].cpu().numpy()[:, None] - ref[name]).max() <= 1e-3, name

@@ -1,0 +1,249 @@
+"""PP_PREC_F16X3 (split-fp16 operands, three fp16 MFMAs per product): the host-side format helpers on CPU and every
+kernel of the mode through the C ABI on the GPU, against a torch fp64 reference of the UNROUNDED fp32 inputs - the
+mode's claim is fp32-class accuracy (operand error ~2^-23), so the tolerances are the fp32 mode's, not bf16's."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+F16X3, SPLIT = 2, 2   # PP_PREC_F16X3, PP_OUT_SPLIT
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def test_split_format_roundtrip_and_layout():
+    """to_split: hi = fp16(x), lo = fp16(x - hi), blocks of 32 elements [32 hi | 32 lo]; hi + lo ~ x to fp32's own step."""
+    from probpose_code_amd.weights import from_split, to_split
+
+    x = _rand(3, 5, 96, seed=1) * torch.logspace(-4, 2, 96)  # seven decades: subnormal low halves included
+    c = to_split(x)
+    assert c.dtype == torch.float32 and c.shape == x.shape
+    back = from_split(c)
+    assert (back - x).abs().max() <= 2.0 ** -22 * x.abs().max()
+    assert ((back - x).abs() <= 2.0 ** -22 * x.abs() + 2.0 ** -25).all()  # relative, down to the fp16 subnormal step
+    raw = c.view(torch.float16).reshape(3, 5, 3, 2, 32)
+    assert torch.equal(raw[..., 0, :].reshape(3, 5, 96), x.half())
+    assert torch.equal(raw[..., 1, :].reshape(3, 5, 96), (x - x.half().float()).half())
+    with pytest.raises(AssertionError):
+        to_split(torch.zeros(4, 48))
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+gpu = pytest.mark.gpu
+
+
+def _lib():
+    from probpose_code_amd import _lib
+
+    return _lib
+
+
+def _sp(x):
+    from probpose_code_amd.weights import to_split
+
+    return to_split(x).cuda()
+
+
+def _unsp(c):
+    from probpose_code_amd.weights import from_split
+
+    return from_split(c.cpu()).double()
+
+
+@gpu
+@pytest.mark.parametrize("M,N,K,act,res,bias,split_out", [(384, 384, 384, 0, True, True, 0), (256, 1152, 384, 1, False, True, 1),
+                                                          (200, 160, 1536, 2, False, False, 1), (128, 17, 256, 0, False, True, 0),
+                                                          (130, 96, 64, 0, True, True, 1)])
+def test_gemm_split(M, N, K, act, res, bias, split_out):
+    L = _lib()
+    a, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K))
+    b = _rand(N, seed=3) if bias else None
+    r = _rand(M, N, seed=4) if res else None
+    ref = a.double() @ w.double().t()
+    if bias:
+        ref = ref + b.double()
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.relu(ref)
+    if res:
+        ref = ref + r.double()
+    ad, wd = _sp(a), _sp(w)
+    bd = b.cuda() if bias else None
+    rd = r.cuda() if res else None
+    ldc = N if N % 4 == 0 else (N + 3) // 4 * 4
+    out = torch.full((M, ldc), float("nan"), device="cuda")
+    L.call("pp_gemm", F16X3, ad.data_ptr(), wd.data_ptr(), L.ptr(bd), L.ptr(rd), 0, out.data_ptr(), M, N, K, K, K, ldc, act,
+           SPLIT if split_out else 0, 0, None)
+    got = _unsp(out) if split_out else out.cpu().double()[:, :N]
+    torch.testing.assert_close(got, ref, **TOL)
+
+
+@gpu
+def test_gemm_split_planar_posembed_and_errors():
+    L = _lib()
+    nb, P, K, N = 3, 96, 256, 17
+    a, w, b = _rand(nb * P, K, seed=5), _rand(N, K, seed=6, scale=0.06), _rand(N, seed=7)
+    ref = (a.double() @ w.double().t() + b.double()).reshape(nb, P, N).permute(0, 2, 1)
+    out = torch.full((nb, N, P), float("nan"), device="cuda")
+    ad, wd, bd = _sp(a), _sp(w), b.cuda()
+    L.call("pp_gemm", F16X3, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, 0, out.data_ptr(), nb * P, N, K, K, K, N,
+           0, 0, P, None)
+    torch.testing.assert_close(out.cpu().double(), ref, **TOL)
+    M, E, Np = 4 * 48, 128, 48
+    a, w, pe = _rand(M, 64, seed=8), _rand(E, 64, seed=9, scale=0.1), _rand(Np, E, seed=10)
+    ref = a.double() @ w.double().t() + pe.double().repeat(4, 1)
+    out = torch.empty((M, E), device="cuda")
+    ad, wd, ped = _sp(a), _sp(w), pe.cuda()
+    L.call("pp_gemm", F16X3, ad.data_ptr(), wd.data_ptr(), None, ped.data_ptr(), Np, out.data_ptr(), M, E, 64, 64, 64, E,
+           0, 0, 0, None)
+    torch.testing.assert_close(out.cpu().double(), ref, **TOL)
+    # split output with N % 32 != 0, and a bf16 output in this mode, are refused - not silently mis-stored
+    with pytest.raises(L.ProbPoseLibraryError):
+        L.call("pp_gemm", F16X3, ad.data_ptr(), wd.data_ptr(), None, None, 0, out.data_ptr(), M, 72, 64, 64, 64, 72, 0, SPLIT, 0, None)
+    with pytest.raises(L.ProbPoseLibraryError):
+        L.call("pp_gemm", F16X3, ad.data_ptr(), wd.data_ptr(), None, None, 0, out.data_ptr(), M, E, 64, 64, 64, E, 0, 1, 0, None)
+
+
+@gpu
+@pytest.mark.parametrize("K,res_mod", [(768, 48), (384, 0), (1536, 0)])
+def test_gemm_residual_layernorm_split(K, res_mod):
+    L = _lib()
+    M, E = 96 * 3 - 40, 384
+    a, w, b = _rand(M, K, seed=11), _rand(E, K, seed=12, scale=1 / math.sqrt(K)), _rand(E, seed=13, scale=0.1)
+    r = _rand(res_mod if res_mod else M, E, seed=14)
+    g, be = 1 + 0.1 * _rand(E, seed=15), _rand(E, seed=16, scale=0.1)
+    x_ref = a.double() @ w.double().t() + b.double() + (r.double().repeat(M // res_mod + 1, 1)[:M] if res_mod else r.double())
+    h_ref = F.layer_norm(x_ref, (E,), g.double(), be.double(), 1e-6)
+    ad, wd, bd, rd, gd, bed = _sp(a), _sp(w), b.cuda(), r.cuda(), g.cuda(), be.cuda()
+    x_out = torch.empty((M, E), device="cuda")
+    h_out = torch.empty((M, E), device="cuda")
+    L.call("pp_gemm_residual_layernorm", F16X3, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(), res_mod,
+           x_out.data_ptr(), gd.data_ptr(), bed.data_ptr(), 1e-6, h_out.data_ptr(), SPLIT, M, E, K, K, K, None)
+    torch.testing.assert_close(x_out.cpu().double(), x_ref, **TOL)
+    torch.testing.assert_close(_unsp(h_out), h_ref, **TOL)
+
+
+@gpu
+@pytest.mark.parametrize("hd,S", [(32, 192), (64, 192), (32, 432), (64, 432)])
+def test_attention_split(hd, S):
+    L = _lib()
+    n_seq, heads = 3, 4
+    E = heads * hd
+    qkv = _rand(n_seq * S, 3 * E, seed=16, scale=1.3)
+    qd = _sp(qkv)
+    out = torch.empty((n_seq * S, E), device="cuda")
+    L.call("pp_attention", F16X3, qd.data_ptr(), out.data_ptr(), n_seq, S, heads, hd, hd ** -0.5, None)
+    x = qkv.double().reshape(n_seq, S, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    att = ((x[0] @ x[1].transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    ref = (att @ x[2]).transpose(1, 2).reshape(n_seq * S, E)
+    torch.testing.assert_close(_unsp(out), ref, **TOL)
+
+
+@gpu
+def test_conv3x3_grouped_and_splitk_split():
+    L = _lib()
+    G, B, H, W, C = 4, 3, 8, 6, 128
+    x = _rand(G, B, C, H, W, seed=11)
+    w = _rand(G, C, C, 3, 3, seed=12, scale=1 / math.sqrt(9 * C))
+    b = _rand(G, C, seed=13)
+    ref = torch.stack([F.conv2d(x[g].double(), w[g].double(), b[g].double(), padding=1) for g in range(G)])
+    xd = _sp(x.permute(0, 1, 3, 4, 2).contiguous())
+    wd = _sp(w.permute(0, 1, 3, 4, 2).reshape(G, C, 9 * C).contiguous())
+    bd = b.cuda()
+    for fmt in (0, SPLIT):
+        out = torch.empty((G, B, H, W, C), device="cuda")
+        L.call("pp_conv_gemm", F16X3, 1, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, C, C,
+               0, 0, G, B * H * W * C, C * 9 * C, B * H * W * C, C, C, 0, fmt, None)
+        got = (_unsp(out) if fmt else out.cpu().double()).permute(0, 1, 4, 2, 3)
+        torch.testing.assert_close(got, ref, **TOL)
+    # split-K partial sums + the pooling kernel that reduces them (shared input: stride 0)
+    part = torch.empty((3, G, B, H, W, C), device="cuda")
+    x0 = _sp(x[0].permute(0, 2, 3, 1).contiguous())
+    L.call("pp_conv3x3_splitk", F16X3, x0.data_ptr(), wd.data_ptr(), part.data_ptr(), B, H, W, C, C, G, 0, C * 9 * C, 3, None)
+    pooled = torch.empty((G * B, H // 2, W // 2, C), device="cuda")
+    L.call("pp_sum_maxpool_relu_nhwc", part.data_ptr(), 3, G * B * H * W * C, bd.data_ptr(), B, pooled.data_ptr(), SPLIT,
+           G * B, H, W, C, 2, 2, None)
+    ref2 = torch.stack([F.conv2d(x[0].double(), w[g].double(), b[g].double(), padding=1) for g in range(G)])
+    ref2 = F.relu(F.max_pool2d(ref2.reshape(G * B, C, H, W), 2, 2)).permute(0, 2, 3, 1)
+    torch.testing.assert_close(_unsp(pooled), ref2, **TOL)
+
+
+@gpu
+def test_deconv_all_phases_split():
+    L = _lib()
+    B, H, W, Cin, Cout = 2, 8, 6, 128, 64
+    x = _rand(B, Cin, H, W, seed=14)
+    w = _rand(Cin, Cout, 4, 4, seed=15, scale=1 / math.sqrt(4 * Cin))
+    b = _rand(Cout, seed=17)
+    ref = F.relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+    xd = _sp(x.permute(0, 2, 3, 1).contiguous())
+    ph = torch.empty((2, 2, Cout, 4 * Cin))
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    t = ty * 2 + tx
+                    ph[py, px, :, t * Cin:(t + 1) * Cin] = w[:, :, 3 - 2 * ty - py, 3 - 2 * tx - px].t()
+    pd, bd = _sp(ph), b.cuda()
+    out = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
+    L.call("pp_conv_gemm", F16X3, 2, xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout,
+           -1, 0, 1, 0, 0, 0, 0, Cout, 2, SPLIT, None)
+    torch.testing.assert_close(_unsp(out).permute(0, 3, 1, 2), ref, **TOL)
+
+
+@gpu
+def test_elementwise_kernels_split():
+    """im2col (+ preprocessing), LayerNorm, MaxPool + ReLU, tower_final with split-fp16 inputs / outputs."""
+    from oracle import model_ref as Mref
+
+    L = _lib()
+    # --- im2col: hi + lo reproduces the fp32 patch matrix to the format's resolution; hi alone is its fp16 rounding
+    B, H, W = 2, 64, 48
+    g = torch.Generator().manual_seed(20)
+    img = torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8)
+    mean = np.array([123.675, 116.28, 103.53], np.float32)
+    std = np.array([58.395, 57.12, 57.375], np.float32)
+    Hp, Wp = (H + 4 - 16) // 16 + 1, (W + 4 - 16) // 16 + 1
+    out = torch.empty((2 * B * Hp * Wp, 768), device="cuda")
+    imgd = img.cuda()
+    L.call("pp_preproc_im2col", F16X3, imgd.data_ptr(), 0, out.data_ptr(), B, 2, H, W, 16, 2, mean.ctypes.data,
+           std.ctypes.data, 1, None)
+    x = Mref.preprocess(img, mean, std)
+    both = torch.cat([x, x.flip(-1)])
+    ref = F.unfold(F.pad(both, (2, 2, 2, 2))[:, :, : Hp * 16, : Wp * 16], 16, stride=16).transpose(1, 2).reshape(-1, 768)
+    from probpose_code_amd.weights import to_split
+
+    assert torch.equal(out.cpu(), to_split(ref)), "the device split of the fp32 patch matrix is the host's to_split, bit for bit"
+    # --- LayerNorm
+    M, E = 203, 768
+    xx, gg, bb = _rand(M, E, seed=17, scale=3.0) + 0.7, 1 + 0.1 * _rand(E, seed=18), _rand(E, seed=19)
+    y = torch.empty((M, E), device="cuda")
+    xd, gd, bd = xx.cuda(), gg.cuda(), bb.cuda()
+    L.call("pp_layernorm", xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, E, 1e-6, SPLIT, None)
+    torch.testing.assert_close(_unsp(y), F.layer_norm(xx.double(), (E,), gg.double(), bb.double(), 1e-6), rtol=1e-5, atol=1e-5)
+    # --- MaxPool + ReLU: split -> split, fp32 -> split, split -> fp32
+    N, H2, W2, C = 5, 16, 12, 64
+    t = _rand(N, H2, W2, C, seed=21)
+    refp = F.relu(F.max_pool2d(t.permute(0, 3, 1, 2), (4, 3), (4, 3))).permute(0, 2, 3, 1).double()
+    for fi, fo in ((SPLIT, SPLIT), (0, SPLIT), (SPLIT, 0)):
+        src = _sp(t) if fi else t.cuda()
+        dst = torch.empty((N, 4, 4, C), device="cuda")
+        L.call("pp_maxpool_relu_nhwc", src.data_ptr(), fi, dst.data_ptr(), fo, N, H2, W2, C, 4, 3, None)
+        torch.testing.assert_close(_unsp(dst) if fo else dst.cpu().double(), refp, rtol=1e-6, atol=1e-7)
+    # --- tower_final on split features
+    Bt, K, Ct = 3, 17, 384
+    feat, w, b = _rand(4, 2 * Bt, Ct, seed=22), _rand(4, K, Ct, seed=23, scale=0.05), _rand(4, K, seed=24, scale=0.3)
+    fi = [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]
+    o = torch.empty((4, Bt, K), device="cuda")
+    fd, wd, bd2, fid = _sp(feat), w.cuda(), b.cuda(), torch.tensor(fi, dtype=torch.int32).cuda()
+    L.call("pp_tower_final", fd.data_ptr(), SPLIT, wd.data_ptr(), bd2.data_ptr(), fid.data_ptr(), o.data_ptr(), Bt, 2, Ct, K, 1.0, None)
+    z = torch.einsum("tbc,tkc->tbk", feat.double(), w.double()) + b.double()[:, None]
+    a = torch.cat([torch.sigmoid(z[:3]), F.relu(z[3:])])
+    torch.testing.assert_close(o.cpu().double(), (a[:, :Bt] + a[:, Bt:][:, :, fi]) * 0.5, rtol=1e-5, atol=1e-6)
