@@ -328,9 +328,9 @@ def reduce_times(dt, dist_mod, dev, world, local_dev_index):
     if dist_mod is None:
         return dt, [dt], [local_dev_index]
     t = torch.tensor([dt, float(local_dev_index)], dtype=torch.float64, device=dev)
-    allt = torch.empty((world, 2), dtype=torch.float64, device=dev)
+    allt = torch.empty(world * 2, dtype=torch.float64, device=dev)  # (flat: gloo wants the concatenated form)
     dist_mod.all_gather_into_tensor(allt, t)
-    allt = allt.cpu()
+    allt = allt.cpu().view(world, 2)
     return float(allt[:, 0].max()), [float(x) for x in allt[:, 0]], [int(x) for x in allt[:, 1]]
 
 
