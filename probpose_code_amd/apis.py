@@ -24,6 +24,23 @@ def coco_dataset_meta() -> dict:
     return dict(dataset_name="coco", num_keypoints=17, flip_indices=list(COCO_FLIP_INDICES))
 
 
+def load_state_dict_checked(model, state_dict: dict) -> None:
+    """``load_state_dict`` through the model's pre-hooks (base.py:212-243, probmap_head.py:1014-1061), then account for
+    every key. mmengine's ``load_checkpoint`` loads non-strictly and LOGS mismatches; here a checkpoint that leaves any
+    parameter of the model unset is an error (the model would silently run on its random init), and keys the model
+    does not know are reported with a warning, as mmengine does."""
+    import warnings
+
+    res = model.load_state_dict(dict(state_dict), strict=False)
+    missing = [k for k in res.missing_keys if not k.endswith("num_batches_tracked")]
+    if missing:
+        raise RuntimeError(f"checkpoint does not provide {len(missing)} parameter(s) of the model, e.g. {missing[:8]} "
+                           "(key names must be the reference's: backbone.* as mmpretrain's VisionTransformer, head.* as ProbMapHead)")
+    if res.unexpected_keys:
+        warnings.warn(f"unexpected key(s) in the checkpoint's state_dict, ignored: {list(res.unexpected_keys)[:8]}"
+                      f"{' ...' if len(res.unexpected_keys) > 8 else ''}", RuntimeWarning, stacklevel=2)
+
+
 def init_model(config: Union[str, Config, dict], checkpoint: Optional[Union[str, dict]] = None, device: str = "cuda:0",
                cfg_options: Optional[dict] = None):
     """apis/inference.py:66-130. ``checkpoint`` may be a path (torch.load) or a state dict."""
@@ -40,9 +57,10 @@ def init_model(config: Union[str, Config, dict], checkpoint: Optional[Union[str,
     model = build_pose_estimator(model_cfg)
     dataset_meta = None
     if checkpoint is not None:
-        ckpt = torch.load(checkpoint, map_location="cpu") if isinstance(checkpoint, str) else checkpoint
+        # mmengine's load_checkpoint (apis/inference.py:103) unpickles the whole file: meta holds numpy arrays
+        ckpt = torch.load(checkpoint, map_location="cpu", weights_only=False) if isinstance(checkpoint, str) else checkpoint
         sd = ckpt.get("state_dict", ckpt)
-        model.load_state_dict(sd, strict=False)
+        load_state_dict_checked(model, sd)
         dataset_meta = ckpt.get("meta", {}).get("dataset_meta") if isinstance(ckpt.get("meta", None), dict) else None
     model.dataset_meta = dataset_meta or coco_dataset_meta()
     model.cfg = config

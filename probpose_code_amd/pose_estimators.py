@@ -238,7 +238,11 @@ class ProbMapHead(nn.Module):
                 nn.init.ones_(m.weight)
 
     def _load_state_dict_pre_hook(self, state_dict, prefix, local_meta, *args, **kwargs):
-        """probmap_head.py:1014-1061: old checkpoints name the last conv ``final_layer.n.*``."""
+        """probmap_head.py:1014-1061: pre-v2 checkpoints name the convs behind the deconvolutions ``final_layer.n.*``
+        (intermediate conv layers first, the last one the final layer). This head has no intermediate conv layers
+        (ProbPose: ``conv_layers`` is ``nn.Identity``), and for that case the reference's hook asserts
+        (``assert isinstance(self.conv_layers, nn.Sequential)``, :1047; pinned in tests/golden/head_estimator.npz) - so
+        does this one; ``final_layer.weight / .bias`` pass through unchanged."""
         version = local_meta.get("version", None)
         if version and version >= self._version:
             return
@@ -247,9 +251,8 @@ class ProbMapHead(nn.Module):
                 continue
             k_parts = _k[len(prefix):].split(".")
             if k_parts[0] == "final_layer" and len(k_parts) == 3:
-                v = state_dict.pop(_k)
-                assert isinstance(self.final_layer, nn.Conv2d)
-                state_dict[prefix + "final_layer." + k_parts[2]] = v
+                assert False, ("old-style key '" + _k + "' (final_layer.n.*) belongs to a head with intermediate conv "
+                               "layers; the ProbPose head has none")
 
     # -- engine access
     @property

@@ -77,3 +77,80 @@ def test_vit_shapes_and_token_order():
     g, b = sd["backbone.ln1.weight"], sd["backbone.ln1.bias"]
     tok = ((f.permute(0, 2, 3, 1) - b) / g)
     assert torch.allclose(tok.mean(-1), torch.zeros(2, 4, 3), atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Pinned to the REFERENCE's own ProbMapHead / TopdownPoseEstimator code: tests/golden/head_estimator.npz comes from
+# tests/golden/make_golden_head.py, which imports probmap_head.py / base_head.py / topdown.py / base.py / tta.py and the
+# real codec behind stubs for mmcv / mmengine (only Sparsemax and the ViT - the two un-vendored third-party pieces -
+# are the restatements of this file's oracle).
+import os  # noqa: E402
+
+import pytest  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "head_estimator.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    from probpose_code_amd import synthetic as S
+
+    g = np.load(GOLD)
+    sd = S.synthetic_state_dict("small", seed=int(g["seed_weights"]), logit_scale=2.0)
+    crops = S.synthetic_crops(int(g["batch"]), seed=int(g["seed_crops"]))
+    return g, sd, crops
+
+
+def test_oracle_head_forward_matches_reference_head(gold):
+    """oracle head_forward == reference ProbMapHead.forward (probmap_head.py:600-713) on the same features."""
+    g, sd, _ = gold
+    feat = torch.from_numpy(g["feat"])
+    with torch.no_grad():
+        hm, prob, vis, oks, err = M.head_forward(sd, feat)
+    for got, name in ((hm, "fwd_heatmaps"), (prob, "fwd_prob"), (vis, "fwd_vis"), (oks, "fwd_oks"), (err, "fwd_err")):
+        assert got.shape == g[name].shape, name
+        assert np.abs(got.numpy() - g[name]).max() <= 1e-6, name  # same torch ops in the same order: fp32 noise only
+
+
+def test_oracle_predict_matches_reference_head_predict_and_estimator(gold):
+    """oracle predict == reference ProbMapHead.predict with flip test (:715-804: flip_heatmaps, averages, BaseHead.decode
+    through the real codec, error / diagonal, oks -> keypoint_scores) and == TopdownPoseEstimator.forward(mode='predict')
+    (topdown.py:86-194: input -> image space, bboxes copied)."""
+    from probpose_code_amd import synthetic as S
+
+    g, sd, crops = gold
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD, input_size=(192, 256), input_center=g["input_center"],
+                    input_scale=g["input_scale"])
+    assert np.abs(ref["features"] - g["feat"]).max() <= 1e-6
+    assert np.abs(ref["heatmaps"] - g["pred_heatmaps"]).max() <= 1e-6
+    assert np.abs(ref["keypoints_input_space"] - g["pred_keypoints"]).max() <= 1e-4
+    for f in ("keypoints_conf", "keypoints_probs", "keypoints_visible", "keypoints_oks", "keypoints_error", "keypoint_scores"):
+        assert ref[f].shape == g["pred_" + f].shape, f
+        assert np.abs(ref[f] - g["pred_" + f]).max() <= 1e-6, f
+    assert np.array_equal(g["pred_keypoint_scores"], g["pred_keypoints_oks"])  # freeze_oks=False (:797-798)
+    assert sorted(g["pred_instance_fields"]) == ["keypoint_scores", "keypoints", "keypoints_conf", "keypoints_error",
+                                                 "keypoints_oks", "keypoints_probs", "keypoints_visible"]
+    assert np.abs(ref["keypoints"] - g["est_keypoints"]).max() <= 1e-3  # image px (scales up to 2.5 x 1.25 x the input)
+    assert np.array_equal(g["est_keypoints_visible"], g["pred_keypoints_visible"])
+    assert np.abs(g["est_heatmaps"] - g["pred_heatmaps"]).max() == 0
+
+
+def test_product_state_dict_keys_are_the_reference_heads(gold):
+    """The product's parameter containers expose exactly the reference ProbMapHead.state_dict() keys and shapes
+    (checked against the reference class, not against synthetic.py), and the synthetic weights use them too."""
+    from probpose_code_amd import Config, build_pose_estimator
+
+    g, sd, _ = gold
+    cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs",
+                                       "td-pm_ProbPose-small_mi355x_coco-256x192.py"))
+    model = build_pose_estimator(dict(cfg.model))
+    ref_keys = [str(k) for k in g["state_dict_keys"]]
+    ref_shapes = dict(zip(ref_keys, [str(s) for s in g["state_dict_shapes"]]))
+    head_sd = model.head.state_dict()
+    assert sorted(head_sd.keys()) == sorted(ref_keys)
+    for k, v in head_sd.items():
+        assert str(tuple(v.shape)) == ref_shapes[k], k
+    assert sorted(k[len("head."):] for k in sd if k.startswith("head.")) == sorted(ref_keys)
+    assert [str(k) for k in g["est_state_dict_keys"]] == ["head." + k for k in ref_keys]  # (stub backbone: no parameters)
+    assert str(g["bad_mode_message"]) == 'Invalid mode "bogus". Only supports loss, predict and tensor mode.'
