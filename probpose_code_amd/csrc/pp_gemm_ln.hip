@@ -128,7 +128,9 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_res_ln_kernel(const Params p)
     // K-steps are walked in a per-workgroup rotation: every CU streams the same weight tiles, in lockstep they would
     // all hit the same L2 lines at once.
     const int nk = p.K / BK;
-    const int k_rot = blockIdx.x % nk;
+    // (rank inside the XCD, blockIdx.x >> 3: the CUs behind one L2 then cover every rotation; blockIdx.x % nk gives an XCD's
+    // 32 CUs only nk / gcd(nk, 8) distinct ones)
+    const int k_rot = (int)(blockIdx.x >> 3) % nk;
     auto kstep = [&](int i) { const int k = i + k_rot; return k >= nk ? k - nk : k; };
     stage(kstep(0), 0);
 

@@ -47,6 +47,15 @@ namespace mlp {
 // dev ablation switches (scripts/micro/mlp_ablate.sh), 0 in the product build: 2 no GELU, 4 no MFMA, 8 no DMA,
 // 16 no LDS fragment reads, 32 no barriers, 64 no b1 loads, 512 per-step time stamps, 1024 no qkv stores
 constexpr int DBG = MLP_DBG;
+#ifndef MLP_ROT_MORE
+#define MLP_ROT_MORE 1  // dev A/B switch: rotate the projection's k-steps and the qkv tail's column blocks per workgroup too
+#endif
+#ifndef MLP_ROT_XCD
+#define MLP_ROT_XCD 1
+#endif
+#ifndef MLP_XCD_PAIR
+#define MLP_XCD_PAIR 1  // dev A/B switch: 0 = tile = blockIdx.x (sequence halves on different XCDs)
+#endif
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_VMEM = 0x010, SG_DS_READ = 0x100;
 constexpr int BM = 96, E = 384, CHUNK = 128;
@@ -143,9 +152,16 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
 // weight rows each: slot q = 3 t + third holds rows 192 b + 64 third + (0..63), k in [64 kt, +64), plain 128-byte lines
 // like a W1 slot. Past the last slot the DMA is issued out of bounds (a plain function: a value-returning lambda for this
 // inside the kernel template made the host pass drop the kernel stubs without a diagnostic).
-__device__ __forceinline__ unsigned wq_slot_offset(int q, unsigned lane_off) {
+__device__ __forceinline__ int rot_mod(int v, int rot, int n) {  // (v + rot) mod n for v, rot in [0, n)
+    const int r = v + rot;
+    return r >= n ? r - n : r;
+}
+// The column blocks are visited in a per-workgroup rotation (block (t / 6 + rot) % 6 at step t), like the hidden chunks of
+// the FFN: every CU streams the same Wq, in lockstep they would all pull the same lines out of their L2 at once.
+__device__ __forceinline__ unsigned wq_slot_offset(int q, unsigned lane_off, int rot) {
     const int t = q / 3;
-    return q < 108 ? (unsigned)((t / 6) * 192 + (q % 3) * 64) * (unsigned)(E * 2) + (unsigned)((t % 6) * 128) + lane_off : OOB;
+    const int blk = rot_mod(t / 6, rot, 6);
+    return q < 108 ? (unsigned)(blk * 192 + (q % 3) * 64) * (unsigned)(E * 2) + (unsigned)((t % 6) * 128) + lane_off : OOB;
 }
 
 // PROJ = true puts the attention output projection in front:  x' = x + a Wp^T + bp ;  h = LayerNorm2(x')  and then the
@@ -170,7 +186,13 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wv >> 2, cg = wv & 3;
     const int f_row = lane & 15, f_kg = lane >> 4;
-    const int m0 = blockIdx.x * BM;
+    // Row tile of this workgroup. Hardware hands consecutive block ids to the 8 XCDs in turn; with ATT the two 96-row halves
+    // of a 192-token sequence read the same K and V, so they are placed on ONE XCD (shared L2): XCD x takes the contiguous
+    // run of tiles [x * G / 8, (x + 1) * G / 8). Without this both halves fetched K / V from HBM on their own
+    // (r01: 262 MB per launch of counter traffic against 186 MB algorithmic).
+    int tile = blockIdx.x;
+    if (MLP_XCD_PAIR && (gridDim.x & 15) == 0) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
+    const int m0 = tile * BM;
 
     const __amdgpu_buffer_rsrc_t h_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.h), 0, p.h_bytes, 0x00020000);
@@ -198,7 +220,14 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     const int nchunks = p.F / CHUNK;
     // Every workgroup walks the hidden chunks in a different rotation: all 256 CUs stream the SAME weights, and in
     // lockstep they would all hit the same L2 lines at the same moment.
-    const int c_rot = blockIdx.x % nchunks;
+    // (the rotation index is the workgroup's rank inside its XCD - blockIdx.x >> 3 - so that the CUs behind one L2 are
+    // spread over all rotations; blockIdx.x % nchunks gave the 32 CUs of an XCD only three distinct ones)
+    const int xcd_rank = MLP_ROT_XCD ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int c_rot = xcd_rank % nchunks;
+    const int p_rot = MLP_ROT_MORE ? xcd_rank % 12 : 0;  // k-steps of the projection (a sum: any order)
+    const int q_rot = MLP_ROT_MORE ? xcd_rank % 6 : 0;   // column blocks of the qkv tail
+    // (tried and dropped: a second level - the k-steps INSIDE a chunk's phase A / phase B rotated too, for the CUs of an
+    // XCD that share a chunk rotation - 169 us against 143: the run-time address arithmetic lands in the FFN loop)
     auto chunk_of = [&](int i) { const int c = i + c_rot; return c >= nchunks ? c - nchunks : c; };
 
     char* const ring = smem + OFF_RING;
@@ -223,13 +252,14 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     // ring position = stream index & 7.
     auto issue_wp = [&](int q, int pos) {
         if (DBG & 8) return;
-        const unsigned vo = (unsigned)((q % 3) * 64) * (E * 2) + (unsigned)(32 * (q / 3) * 2) + wp_lane;
+        const int j = rot_mod(q / 3, p_rot, 12);
+        const unsigned vo = (unsigned)((q % 3) * 64) * (E * 2) + (unsigned)(32 * j * 2) + wp_lane;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wp_rsrc, (lds_ptr_t)(ring + pos * SLOT + wv * 1024), 16, vo, 0, 0, 0);
     };
     // (in the qkv tail only waves 0-3 issue DMA, two of the eight 1 KiB pieces of a slot each: lines 16 w .. 16 w + 15)
     auto issue_wq = [&](int q, int pos, unsigned lane_off) {
         if (DBG & 8) return;
-        const unsigned vo = wq_slot_offset(q, lane_off);
+        const unsigned vo = wq_slot_offset(q, lane_off, q_rot);
         char* dst = ring + pos * SLOT + (wv & 3) * 2048;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wq_rsrc, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wq_rsrc, (lds_ptr_t)(dst + 1024), 16, vo == OOB ? OOB : vo + 8 * (E * 2), 0, 0, 0);
@@ -579,7 +609,8 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         // ================= attention output projection: acc (= x + bp) += a Wp^T, twelve steps of k = 32 in the style
         // of phase B with the input rows as the row operand; then h = LayerNorm2(acc) replaces the rows in LDS.
         read_Bw(-PRE, 0, wb[0]);  // the projection tiles start the stream: ring position = slot index
-        read_rows(OFF_HS, 0, gb[0]);
+        // (rot_mod(j, p_rot, 12): the k-step whose weights arrive at stream step j)
+        read_rows(OFF_HS, rot_mod(0, p_rot, 12), gb[0]);
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             const int cur = j & 1;
@@ -589,7 +620,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
             for (int i = 0; i < 3; ++i) issue_rel(0, -48 + 3 * j + NSLOT + i);
             if (j < 11) {
                 read_Bw(-PRE, j + 1, wb[cur ^ 1]);
-                read_rows(OFF_HS, j + 1, gb[cur ^ 1]);
+                read_rows(OFF_HS, rot_mod(j + 1, p_rot, 12), gb[cur ^ 1]);
             }
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf)
@@ -764,7 +795,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     f32x4 bq_f[3];
     auto load_bias = [&](int bb) {
 #pragma unroll
-        for (int nfr = 0; nfr < 3; ++nfr) bq_f[nfr] = *reinterpret_cast<const f32x4*>(p.bq + bb * 192 + cg * 48 + nfr * 16 + e_kg * 4);
+        for (int nfr = 0; nfr < 3; ++nfr) bq_f[nfr] = *reinterpret_cast<const f32x4*>(p.bq + rot_mod(bb, q_rot, 6) * 192 + cg * 48 + nfr * 16 + e_kg * 4);
     };
     auto stage_half = [&](int ps, int set) {
         if (rg != ps) return;
@@ -791,7 +822,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                 const int m = m0 + ps * 48 + row;
                 const u32x4 raw = *reinterpret_cast<const u32x4*>(gst + row * 512 + ((ch ^ (row & 7)) << 4));
                 if (m < p.M && !(DBG & 1024))
-                    *reinterpret_cast<u32x4*>(p.qkv + (size_t)m * (3 * E) + bb * 192 + ch * 8) = raw;
+                    *reinterpret_cast<u32x4*>(p.qkv + (size_t)m * (3 * E) + rot_mod(bb, q_rot, 6) * 192 + ch * 8) = raw;
             }
         }
     };

@@ -86,6 +86,7 @@ class ProbPoseEngine:
         self.fuse_head = os.environ.get("PP_FUSE_HEAD", "1") != "0"
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
+        self.stage_hook = None  # callable(name) invoked between stages of the launch plan ("embed", "layer<i>", "backbone"); dev / scheduling experiments
         # tower pooling schedule (probmap_head.py:264) and the spatial sizes it produces
         self.pools = ((4, 3), (2, 2), (2, 2))
         hs, ws_ = self.Hp, self.Wp
@@ -191,6 +192,8 @@ class ProbPoseEngine:
         for i in range(L):
             if not qkv_done:
                 self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], qcur, M, 3 * E, E)
+            if self.stage_hook is not None:
+                self.stage_hook("embed" if i == 0 else f"layer{i - 1}")
             if one_launch:
                 # a ViT layer in ONE launch: attention, projection, ln2, FFN, next LayerNorm and the next layer's qkv
                 last = i + 1 == L
