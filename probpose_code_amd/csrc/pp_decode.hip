@@ -36,15 +36,22 @@ __device__ __forceinline__ bool better(float v, int idx, float bv, int bidx) {
 }
 
 // ---- separable convolution passes, radius known at compile time
+// Both passes run over a BOX of outputs only (see the kernel: the support of the map dilated by the radius); everything
+// outside is exactly zero in the reference's result too.
+struct Box {
+    int y0, y1, x0, x1;  // inclusive; empty when y1 < y0
+};
+
 template <int R>
 __device__ __forceinline__ void row_pass(const float* __restrict__ mapf, double* __restrict__ rowd,
-                                         const double* __restrict__ tap_g, int H, int W, int Wp, int tid) {
+                                         const double* __restrict__ tap_g, int H, int W, int Wp, int tid, Box bx) {
     double tap[R + 1];  // the kernel is symmetric bit for bit (exp(-t^2/2s) / sum): R + 1 distinct factors, in SGPRs
 #pragma unroll
     for (int j = 0; j <= R; ++j) tap[j] = tap_g[j];
-    const int nxg = (W + GX - 1) / GX;
-    for (int it = tid; it < H * nxg; it += DEC_THREADS) {
-        const int y = it / nxg, x0 = (it - y * nxg) * GX;
+    const int xa = max(bx.x0 - R, 0), xb = min(bx.x1 + R, W - 1);  // columns the support reaches through the row kernel
+    const int nxg = (xb - xa + GX) / GX, ny = bx.y1 - bx.y0 + 1;
+    for (int it = tid; it < ny * nxg; it += DEC_THREADS) {
+        const int yr = it / nxg, y = bx.y0 + yr, x0 = xa + (it - yr * nxg) * GX;
         const float* p = mapf + y * Wp + x0 + (RM - R);  // window starts R samples left of output x0
         double win[GX + 2 * R];
 #pragma unroll
@@ -58,20 +65,22 @@ __device__ __forceinline__ void row_pass(const float* __restrict__ mapf, double*
             for (int g = 0; g < GX; ++g) acc[g] = fma(win[g + j], tap[j <= R ? j : 2 * R - j], acc[g]);
 #pragma unroll
         for (int g = 0; g < GX; ++g)
-            if (x0 + g < W) rowd[(y + RM) * W + x0 + g] = acc[g];
+            if (x0 + g <= xb) rowd[(y + RM) * W + x0 + g] = acc[g];
     }
 }
 
 template <int R>
 __device__ __forceinline__ ArgBest col_pass(const double* __restrict__ rowd, float* __restrict__ convf,
-                                            const double* __restrict__ tap_g, int H, int W, int tid) {
+                                            const double* __restrict__ tap_g, int H, int W, int tid, Box bx) {
     double tap[R + 1];
 #pragma unroll
     for (int j = 0; j <= R; ++j) tap[j] = tap_g[j];
     ArgBest best{-__builtin_inff(), 0x7fffffff};
-    const int nyg = (H + GY - 1) / GY;
-    for (int it = tid; it < W * nyg; it += DEC_THREADS) {
-        const int yg = it / W, x = it - yg * W, y0 = yg * GY;
+    const int xa = max(bx.x0 - R, 0), xb = min(bx.x1 + R, W - 1);
+    const int ya = max(bx.y0 - R, 0), yb = min(bx.y1 + R, H - 1);
+    const int nyg = (yb - ya + GY) / GY, nx = xb - xa + 1;
+    for (int it = tid; it < nx * nyg; it += DEC_THREADS) {
+        const int yg = it / nx, x = xa + it - yg * nx, y0 = ya + yg * GY;
         const double* p = rowd + (y0 + RM - R) * W + x;
         double win[GY + 2 * R];
 #pragma unroll
@@ -85,7 +94,7 @@ __device__ __forceinline__ ArgBest col_pass(const double* __restrict__ rowd, flo
             for (int g = 0; g < GY; ++g) acc[g] = fma(win[g + j], tap[j <= R ? j : 2 * R - j], acc[g]);
 #pragma unroll
         for (int g = 0; g < GY; ++g) {
-            if (y0 + g < H) {
+            if (y0 + g <= yb) {
                 const float v = (float)acc[g];  // the single rounding scipy does on output
                 const int idx = (y0 + g) * W + x;
                 convf[idx] = v;
@@ -295,6 +304,48 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         }
     }
     __syncthreads();
+    // ---- the averaged map is complete. Every thread parks its share (pixels tid + 256 i) in registers - the score is the
+    // RAW map value at the final argmax, and the convolved map will take this region's place - and the workgroup finds
+    // the bounding box of the non-zero pixels: a Sparsemax row has 2 - 10 px of support, and an output further than the
+    // kernel radius from that box is a sum of exact zeros (fp64 accumulation of +0 terms, reflect padding included: a
+    // mirrored sample lies within the radius of the border it mirrors). Only the dilated box is convolved; the rest
+    // is written as 0.0f - bit for bit what scipy.ndimage.convolve returns there.
+    float mine[4 * NV];
+    Box bx{1 << 20, -1, 1 << 20, -1};
+#pragma unroll
+    for (int i = 0; i < 4 * NV; ++i) {
+        const int px = tid + i * DEC_THREADS;
+        const int y = px / W, x = px - y * W;
+        mine[i] = px < HW ? mapf[y * Wp + RM + x] : 0.f;
+        if (px < HW && mine[i] != 0.f) {  // (NaN counts as non-zero)
+            bx.y0 = min(bx.y0, y); bx.y1 = max(bx.y1, y);
+            bx.x0 = min(bx.x0, x); bx.x1 = max(bx.x1, x);
+        }
+    }
+    {
+#pragma unroll
+        for (int off = WAVE / 2; off > 0; off >>= 1) {
+            bx.y0 = min(bx.y0, __shfl_xor(bx.y0, off)); bx.y1 = max(bx.y1, __shfl_xor(bx.y1, off));
+            bx.x0 = min(bx.x0, __shfl_xor(bx.x0, off)); bx.x1 = max(bx.x1, __shfl_xor(bx.x1, off));
+        }
+        int* bscr = reinterpret_cast<int*>(smem + 256);  // (the Sparsemax scratch below it is out of use past the barrier above)
+        if (lane_id() == 0) {
+            bscr[4 * wave_id() + 0] = bx.y0; bscr[4 * wave_id() + 1] = bx.y1;
+            bscr[4 * wave_id() + 2] = bx.x0; bscr[4 * wave_id() + 3] = bx.x1;
+        }
+        // the row-pass result starts from zeros: rows outside the box feed the column pass as exact zeros
+        double* rz = rowd;
+        for (int i = tid; i < (H + 2 * RM) * W; i += DEC_THREADS) rz[i] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < DEC_THREADS / WAVE; ++w) {
+            bx.y0 = min(bx.y0, bscr[4 * w + 0]); bx.y1 = max(bx.y1, bscr[4 * w + 1]);
+            bx.x0 = min(bx.x0, bscr[4 * w + 2]); bx.x1 = max(bx.x1, bscr[4 * w + 3]);
+        }
+        bx.y0 = __builtin_amdgcn_readfirstlane(bx.y0); bx.y1 = __builtin_amdgcn_readfirstlane(bx.y1);
+        bx.x0 = __builtin_amdgcn_readfirstlane(bx.x0); bx.x1 = __builtin_amdgcn_readfirstlane(bx.x1);
+    }
+    const bool empty = bx.y1 < bx.y0;
     // half-sample symmetric x-padding (scipy.ndimage 'reflect'): -1 -> 0, -2 -> 1, W -> W-1, ...
     for (int i = tid; i < H * 2 * RM; i += DEC_THREADS) {
         const int y = i / (2 * RM), p = i - y * (2 * RM);
@@ -308,17 +359,17 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     const int r = __builtin_amdgcn_readfirstlane(radius[k]);
     const double* tap_g = taps + k * PP_MAX_TAPS;
     // ---- row pass: rowd[y][x] = sum_t map[y][x+t] * tap[t], f64
-    switch (r) {
-        case 0: row_pass<0>(mapf, rowd, tap_g, H, W, Wp, tid); break;
-        case 1: row_pass<1>(mapf, rowd, tap_g, H, W, Wp, tid); break;
-        case 2: row_pass<2>(mapf, rowd, tap_g, H, W, Wp, tid); break;
-        case 3: row_pass<3>(mapf, rowd, tap_g, H, W, Wp, tid); break;
-        case 4: row_pass<4>(mapf, rowd, tap_g, H, W, Wp, tid); break;
-        case 5: row_pass<5>(mapf, rowd, tap_g, H, W, Wp, tid); break;
-        case 6: row_pass<6>(mapf, rowd, tap_g, H, W, Wp, tid); break;
-        case 7: row_pass<7>(mapf, rowd, tap_g, H, W, Wp, tid); break;
-        case 8: row_pass<8>(mapf, rowd, tap_g, H, W, Wp, tid); break;
-        default: row_pass<9>(mapf, rowd, tap_g, H, W, Wp, tid); break;
+    if (!empty) switch (r) {
+        case 0: row_pass<0>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
+        case 1: row_pass<1>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
+        case 2: row_pass<2>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
+        case 3: row_pass<3>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
+        case 4: row_pass<4>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
+        case 5: row_pass<5>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
+        case 6: row_pass<6>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
+        case 7: row_pass<7>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
+        case 8: row_pass<8>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
+        default: row_pass<9>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
     }
     __syncthreads();
     // symmetric y-padding of the row-pass result
@@ -329,28 +380,23 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         else
             rowd[(RM + H + (p - RM)) * W + x] = rowd[(RM + H - 1 - (p - RM)) * W + x];
     }
-    float mine[4 * NV];  // averaged map at pixels tid + 256 i
-#pragma unroll
-    for (int i = 0; i < 4 * NV; ++i) {
-        const int px = tid + i * DEC_THREADS;
-        const int y = px / W, x = px - y * W;
-        mine[i] = px < HW ? mapf[y * Wp + RM + x] : 0.f;
-    }
-    __syncthreads();  // (also: every thread has its copy before the column pass overwrites the map)
+    __syncthreads();  // the row pass has read the map for the last time: its region becomes the convolved map,
+    for (int i = tid; i < HW; i += DEC_THREADS) convf[i] = 0.0f;  // zero outside the box
+    __syncthreads();
 
     // ---- column pass + running argmax
-    ArgBest best;
-    switch (r) {
-        case 0: best = col_pass<0>(rowd, convf, tap_g, H, W, tid); break;
-        case 1: best = col_pass<1>(rowd, convf, tap_g, H, W, tid); break;
-        case 2: best = col_pass<2>(rowd, convf, tap_g, H, W, tid); break;
-        case 3: best = col_pass<3>(rowd, convf, tap_g, H, W, tid); break;
-        case 4: best = col_pass<4>(rowd, convf, tap_g, H, W, tid); break;
-        case 5: best = col_pass<5>(rowd, convf, tap_g, H, W, tid); break;
-        case 6: best = col_pass<6>(rowd, convf, tap_g, H, W, tid); break;
-        case 7: best = col_pass<7>(rowd, convf, tap_g, H, W, tid); break;
-        case 8: best = col_pass<8>(rowd, convf, tap_g, H, W, tid); break;
-        default: best = col_pass<9>(rowd, convf, tap_g, H, W, tid); break;
+    ArgBest best{-__builtin_inff(), 0x7fffffff};
+    if (!empty) switch (r) {
+        case 0: best = col_pass<0>(rowd, convf, tap_g, H, W, tid, bx); break;
+        case 1: best = col_pass<1>(rowd, convf, tap_g, H, W, tid, bx); break;
+        case 2: best = col_pass<2>(rowd, convf, tap_g, H, W, tid, bx); break;
+        case 3: best = col_pass<3>(rowd, convf, tap_g, H, W, tid, bx); break;
+        case 4: best = col_pass<4>(rowd, convf, tap_g, H, W, tid, bx); break;
+        case 5: best = col_pass<5>(rowd, convf, tap_g, H, W, tid, bx); break;
+        case 6: best = col_pass<6>(rowd, convf, tap_g, H, W, tid, bx); break;
+        case 7: best = col_pass<7>(rowd, convf, tap_g, H, W, tid, bx); break;
+        case 8: best = col_pass<8>(rowd, convf, tap_g, H, W, tid, bx); break;
+        default: best = col_pass<9>(rowd, convf, tap_g, H, W, tid, bx); break;
     }
     // wave-level then block-level argmax
 #pragma unroll
@@ -361,10 +407,20 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     }
     if (lane_id() == 0) red[wave_id()] = best;
     __syncthreads();
+    // The pixels outside the convolved box hold 0.0f: the first of them (row-major) competes as well - it wins when the
+    // map is all zero, or when nothing inside the box is positive.
+    int zidx = -1;
+    {
+        const int xa = max(bx.x0 - r, 0), xb = min(bx.x1 + r, W - 1), ya = max(bx.y0 - r, 0), yb = min(bx.y1 + r, H - 1);
+        if (empty || ya > 0 || xa > 0) zidx = 0;
+        else if (xb < W - 1) zidx = xb + 1;
+        else if (yb < H - 1) zidx = (yb + 1) * W;
+    }
+    ArgBest bb = red[0];
     {  // every thread finds the winner; the owner of that pixel hands its parked map value over
-        ArgBest bb = red[0];
         for (int w = 1; w < DEC_THREADS / WAVE; ++w)
             if (better(red[w].v, red[w].idx, bb.v, bb.idx)) bb = red[w];
+        if (zidx >= 0 && better(0.0f, zidx, bb.v, bb.idx)) bb = ArgBest{0.0f, zidx};
         if ((bb.idx & (DEC_THREADS - 1)) == tid) {
             float sv = mine[0];
 #pragma unroll
@@ -377,8 +433,7 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         for (int i = tid; i < HW; i += DEC_THREADS) conv_out[(size_t)bk * HW + i] = convf[i];
 
     if (tid == 0) {
-        for (int w = 1; w < DEC_THREADS / WAVE; ++w)
-            if (better(red[w].v, red[w].idx, best.v, best.idx)) best = red[w];
+        best = bb;
         const int yi = best.idx / W, xi = best.idx - yi * W;
         float lx = (float)xi, ly = (float)yi;
         // post_processing.py:384-430 -- interior peaks only, f32, zero curvature -> 1e-6, no clamp

@@ -41,6 +41,10 @@ namespace panel {
 // dev ablation switches (scripts/micro/panel_ablate.sh), 0 in the product build: 1 DMA out of bounds (no traffic),
 // 4 no MFMA, 8 no DMA, 16 no LDS fragment reads
 constexpr int DBG = PANEL_DBG;
+#ifndef PANEL_KROT
+#define PANEL_KROT 0  // dev A/B switch. Measured: rotation ON is 2 - 12 % SLOWER here (conv1 274 -> 283 us, deconv1 83 -> 92) - unlike the layer kernel, these
+                      // tiles gain from sweeping K in step (only the current weight slice is hot in the XCD's L2)
+#endif
 
 constexpr int THREADS = 512;
 constexpr int STAGE = 56 * 1024, NSTAGE = 2;
@@ -108,8 +112,11 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
     int a_yx[JA];     // pixel of the lane's activation row: y << 16 | x, y = -30000 for tail rows (fails every bounds test)
     unsigned w_voff;  // weight row of instruction j = JA; the later ones are 64 rows further each
     __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
-    int i_tile = blockIdx.x, i_step = 0, i_tap = 0, i_c0 = 0, i_py = 0, i_px = 0;
+    int i_tile = blockIdx.x, i_step = 0, i_tap = 0, i_c0 = 0, i_py = 0, i_px = 0, i_tap_lo = 0;
     bool i_live = true;
+    // The K sweep of a tile starts at a per-workgroup rotation (a sum: any order) and wraps: the 32 workgroups of an XCD
+    // read the same weight slices, in step they would all pull the same L2 lines at the same moment (pp_mlp.hip: 7 %).
+    const int k_rot = PANEL_KROT ? (int)(blockIdx.x >> 3) % nsteps : 0;
     auto setup_issue_tile = [&]() {
         int z = 0, m0 = 0, n0 = 0;
         i_live = i_tile < ntiles;
@@ -140,8 +147,10 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         }
         w_voff = (unsigned)(n0 + 8 * (wv + 8 * JA - NA) + d_l) * (unsigned)(p.ldw * 2) + d_kbytes;  // n < N: N % BN == 0
         i_step = 0;
-        i_tap = tap0;
-        i_c0 = 0;
+        i_tap_lo = tap0;
+        const int cps = p.Cin / 64;  // K-steps per tap
+        i_tap = tap0 + k_rot / cps;
+        i_c0 = (k_rot - (k_rot / cps) * cps) * 64;
     };
     // issue instruction j of the stage at the cursor into ring buffer `buf`
     auto issue_instr = [&](int buf, int j) {
@@ -171,6 +180,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         if (i_c0 == p.Cin) {
             i_c0 = 0;
             ++i_tap;
+            if (i_tap == i_tap_lo + nsteps / (p.Cin / 64)) i_tap = i_tap_lo;  // wrap (rotated sweep)
         }
         if (++i_step == nsteps) {
             i_tile += gridDim.x;
