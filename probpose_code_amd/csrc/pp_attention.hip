@@ -525,7 +525,7 @@ __global__ __launch_bounds__(ATT_THREADS, (HD == 32 ? 3 : 1)) void attention_spl
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float p = exp2f(__builtin_fmaf(s[kt][i], scale_log2e, -mb));  // full-precision exp2 (the parity mode)
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], scale_log2e, -mb));  // arg <= 0: raw v_exp_f32 (1 ulp)
                 s[kt][i] = p;
                 sum += p;
             }
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(THREADS, 1) void attention_split_stream_kernel(cons
                 mx = fmaxf(mx, __shfl_xor(mx, 16));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 if (st > 0) {  // rescale what the earlier stages accumulated (exp2(-inf) = 0 never occurs: st 0 set m_run)
-                    const float alpha = exp2f((m_run[t] - mx) * scale_log2e);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[t] - mx) * scale_log2e);
                     l_run[t] *= alpha;
 #pragma unroll
                     for (int dt = 0; dt < C::DT; ++dt) o[t][dt] *= alpha;
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(THREADS, 1) void attention_split_stream_kernel(cons
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float p = exp2f(__builtin_fmaf(sc[kt][i], scale_log2e, -mb));
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], scale_log2e, -mb));
                         sc[kt][i] = p;
                         sum += p;
                     }

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
             v += bvec[nf];
             if (p.act == ACT_GELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                for (int j = 0; j < 4; ++j) v[j] = __is_same(T, SplitH) ? gelu_erfc_as(v[j]) : gelu_erf(v[j]);
             } else if (p.act == ACT_RELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -513,6 +513,7 @@ extern "C" int pp_gemm(int prec, const void* act, const void* weight, const floa
     PP_REQUIRE(ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_gemm: operands must be smaller than 2 GiB");
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     PP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, PP_ERR_UNSUPPORTED, "pp_gemm: lda/ldw must be multiples of 8 elements");
+    if (panel_enabled() && panel_split_supported(p, prec, 1)) return panel_split_gemm(p, 1, reinterpret_cast<hipStream_t>(stream));
     return gemm(p, prec, 1, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -548,6 +549,7 @@ extern "C" int pp_conv_gemm(int prec, int kind, const void* act_nhwc, const void
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     p.strideA_z = stride_act_g; p.strideW_z = stride_w_g; p.strideC_z = stride_out_g; p.strideBias_z = stride_bias_g;
     if (panel_enabled() && panel_gemm_supported(p, prec, groups)) return panel_gemm(p, groups, reinterpret_cast<hipStream_t>(stream));
+    if (panel_enabled() && panel_split_supported(p, prec, groups)) return panel_split_gemm(p, groups, reinterpret_cast<hipStream_t>(stream));
     return gemm(p, prec, groups, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -1,0 +1,367 @@
+// Wide-tile GEMM for PP_PREC_F16X3 (split-fp16 operands, pp_split.h) on gfx950: the dense layers with long output rows
+// of the parity mode - qkv and fc1 Linear layers, the two deconvolutions, the first tower convolution.
+//
+// In this format an operand element costs 4 bytes in LDS and HBM but an algorithmic product costs THREE fp16 MFMAs, so
+// per byte staged the matrix pipe has 3x the work of the bf16 path: the 128 x 128 tiles of pp_gemm.hip (32 KiB per
+// K-step per workgroup) leave it waiting for the L2 -> LDS fill. Here a workgroup owns the CU and a 192 x 256 or
+// 256 x 192 tile - the layout of pp_panel_gemm.hip, which this file follows:
+//
+//   * 512 threads = 8 waves = two per SIMD, wave (rg, cg): row half rg, column quarter cg, RF x CF fragments of 16 x 16
+//     (6 x 4 or 8 x 3), fp32 accumulators;
+//   * a stage is ONE 128-byte block of K per row (32 elements: 32 hi halves | 32 lo halves), BM activation rows + BN
+//     weight rows = 56 KiB, XOR-swizzled, filled by LDS-DMA; two stages; persistent workgroups, the stream of stages
+//     runs on across output tiles;
+//   * per stage 72 MFMAs per wave in two halves around ONE barrier:
+//       first half   acc += Wh Ah          while the lo fragments (chunks 4..7) are read
+//       -- barrier: every wave holds the stage in registers, its buffer takes the DMA of stage s + 2; stage s + 1 has landed
+//       second half  acc += Wl Ah, then acc += Wh Al; the hi fragments of stage s + 1 are read into the registers of
+//                    Ah / Wh as those die (row fragments during the first product, column fragments during the second);
+//   * implicit im2col for the convolutions (a DMA lane computes its pixel / tap address, out-of-image taps are
+//     out-of-bounds offsets = zeros), plain rows for Linear layers;
+//   * epilogue: + bias, GELU (pp_split.h: erfc form, 1.5e-7) / ReLU, then a quarter of the tile's rows at a time as fp32 through a 48 KiB
+//     staging region and out as the split format (8 elements per lane: 16 bytes of hi halves + 16 bytes of lo halves),
+//     deconvolutions to the phase-interleaved output pixel.
+#include "pp_common.h"
+#include "pp_gemm.h"
+#include "pp_split.h"
+
+namespace pp {
+namespace psplit {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int THREADS = 512;
+constexpr int STAGE = 56 * 1024, NSTAGE = 2;
+constexpr int OFF_CST = NSTAGE * STAGE;
+constexpr int CST_BYTES = 48 * 1024;
+constexpr int LDS = OFF_CST + CST_BYTES;  // 160 KiB
+constexpr int KS = 32;                    // elements of K per stage
+constexpr unsigned OOB = 0x7ffffff0u;
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+}
+
+__device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int GATHER, int RF, int CF>
+__global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParams p) {
+    constexpr int BM = 32 * RF, BN = 64 * CF;
+    constexpr int NA = BM / 8, JA = NA / 8;  // DMA instructions of the activation tile (8 lines each); per wave j < JA
+    static_assert(BM * 128 + BN * 128 == STAGE, "a stage is 56 KiB");
+    static_assert((BM / 4) * BN * 4 == CST_BYTES, "a quarter of the fp32 tile fills the staging region");
+    static_assert(NA % 8 == 0 && JA <= 4 && RF % 2 == 0, "instruction split");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wv >> 2, cg = wv & 3;
+    const int f_row = lane & 15, f_kg = lane >> 4;
+
+    const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
+    const int ntiles = ntn * ntm * p.groups;
+    const int nsteps = p.K / KS;
+    const int cps = p.Cin / KS;  // stages per tap (Linear: Cin = K, one "tap")
+
+    // XCD-aware tile order as in pp_panel_gemm.hip: row panel -> group -> column tile, contiguous runs per XCD
+    auto decode_tile = [&](int t, int& z, int& m0, int& n0) {
+        if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);
+        n0 = (t % ntn) * BN;
+        const int r = t / ntn;
+        z = r % p.groups;
+        m0 = (r / p.groups) * BM;
+    };
+
+    // ---- DMA cursor (tile, stage), two stages ahead of the MFMAs
+    const int d_l = lane >> 3;
+    const unsigned d_kbytes = (unsigned)(((lane & 7) ^ d_l) << 4);
+    unsigned a_voff[JA];
+    int a_y[JA], a_x[JA];
+    unsigned w_voff;
+    __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
+    int i_tile = blockIdx.x, i_step = 0, i_tap = 0, i_c0 = 0, i_py = 0, i_px = 0;
+    bool i_live = true;
+    auto setup_issue_tile = [&]() {
+        int z = 0, m0 = 0, n0 = 0;
+        i_live = i_tile < ntiles;
+        if (i_live) decode_tile(i_tile, z, m0, n0);
+        if (GATHER == G_DECONV) {
+            i_py = p.py < 0 ? (z >> 1) : p.py;
+            i_px = p.py < 0 ? (z & 1) : p.px;
+        }
+        const char* Act = reinterpret_cast<const char*>(p.A) + (size_t)z * p.strideA_z * 4;
+        const char* Wt = reinterpret_cast<const char*>(p.W) + (size_t)z * p.strideW_z * 4;
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Act), 0, p.a_bytes, 0x00020000);
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wt), 0, p.w_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            const int m = m0 + 8 * (wv + 8 * j) + d_l;
+            const bool ok = i_live && m < p.M;
+            if (GATHER == G_LINEAR) {
+                a_y[j] = ok ? 0 : -100000;
+                a_x[j] = 0;
+                a_voff[j] = (unsigned)m * (unsigned)(p.lda * 4) + d_kbytes;
+            } else {
+                const int hw = p.H * p.Wd;
+                const int b = m / hw, rr = m - b * hw;
+                a_y[j] = ok ? rr / p.Wd : -100000;
+                a_x[j] = rr - (rr / p.Wd) * p.Wd;
+                a_voff[j] = (unsigned)m * (unsigned)(p.Cin * 4) + d_kbytes;  // NHWC pixel origin
+            }
+        }
+        w_voff = (unsigned)(n0 + 8 * (wv + 8 * JA - NA) + d_l) * (unsigned)(p.ldw * 4) + d_kbytes;  // n < N: N % BN == 0
+        i_step = 0;
+        i_tap = 0;
+        i_c0 = 0;
+    };
+    auto issue_instr = [&](int buf, int j) {
+        char* dst = smem + buf * STAGE + (wv + 8 * j) * 1024;
+        if (j < JA) {
+            int dy = 0, dx = 0;
+            if (GATHER == G_CONV3) {
+                dy = i_tap / 3 - 1;
+                dx = i_tap - (i_tap / 3) * 3 - 1;
+            } else if (GATHER == G_DECONV) {
+                dy = (i_tap >> 1) - 1 + i_py;
+                dx = (i_tap & 1) - 1 + i_px;
+            }
+            const int jj = j < JA ? j : 0;
+            const int yy = a_y[jj] + dy, xx = a_x[jj] + dx;
+            const bool ok = GATHER == G_LINEAR ? a_y[jj] >= 0 : (yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd);
+            const int tap_off = GATHER == G_LINEAR ? i_c0 * 4 : ((dy * p.Wd + dx) * p.Cin + i_c0) * 4;
+            const unsigned va = ok ? (unsigned)((int)a_voff[jj] + tap_off) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)dst, 16, va, 0, 0, 0);
+        } else {
+            const unsigned kb = (unsigned)((i_tap * p.Cin + i_c0) * 4) + (unsigned)((j - JA) * 64) * (unsigned)(p.ldw * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, i_live ? w_voff + kb : OOB, 0, 0, 0);
+        }
+    };
+    auto advance_cursor = [&]() {
+        i_c0 += KS;
+        if (i_c0 == p.Cin) {
+            i_c0 = 0;
+            ++i_tap;
+        }
+        if (++i_step == nsteps) {
+            i_tile += gridDim.x;
+            setup_issue_tile();
+        }
+    };
+    (void)cps;
+
+    // ---- fragment addresses: hi halves in chunk f_kg, lo halves in chunk 4 + f_kg of the row (swizzled by row & 7)
+    const int sw = f_row & 7;
+    const int a_frag_off = (rg * (BM / 2) + f_row) * 128;
+    const int w_frag_off = BM * 128 + (cg * (BN / 4) + f_row) * 128;
+    auto frag_a = [&](int buf, int lo, int rf) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(smem + buf * STAGE + (((lo * 4 + f_kg) ^ sw) << 4) + a_frag_off + rf * 2048);
+    };
+    auto frag_w = [&](int buf, int lo, int cf) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(smem + buf * STAGE + (((lo * 4 + f_kg) ^ sw) << 4) + w_frag_off + cf * 2048);
+    };
+
+    if ((int)blockIdx.x >= ntiles) return;
+
+    setup_issue_tile();
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) issue_instr(s, j);
+        advance_cursor();
+    }
+    wait_vm_lgkm<7>();
+    __builtin_amdgcn_s_barrier();
+    u32x4 ah[RF], wh[CF], al[RF], wl[CF];
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf) wh[cf] = frag_w(0, 0, cf);
+#pragma unroll
+    for (int rf = 0; rf < RF; ++rf) ah[rf] = frag_a(0, 0, rf);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x4 acc[CF][RF];
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf) acc[cf][rf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int k2 = 0; k2 < nsteps; k2 += 2) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {  // stage k2 + s lives in buffer s (nsteps is even)
+                // ---- first half: hi x hi, the lo fragments of this stage arrive underneath
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) wl[cf] = frag_w(s, 1, cf);
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) al[rf] = frag_a(s, 1, rf);
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                    for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma(wh[cf], ah[rf], acc[cf][rf]);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_vm_lgkm<0>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- second half: refill buffer s with stage + 2; lo x hi (row fragments die one by one and take the next
+                // stage's hi fragments), then hi x lo (column fragments likewise)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) issue_instr(s, j);
+                advance_cursor();
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) {
+#pragma unroll
+                    for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma(wl[cf], ah[rf], acc[cf][rf]);
+                    ah[rf] = frag_a(s ^ 1, 0, rf);
+                }
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) {
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf) acc[cf][rf] = mma(wh[cf], al[rf], acc[cf][rf]);
+                    wh[cf] = frag_w(s ^ 1, 0, cf);
+                }
+            }
+        }
+
+        // ---- epilogue (lane id laundered: the addresses below must not be hoisted above the K loop)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int e_row = lane_e & 15, e_kg = lane_e >> 4, tid_e = (tid & ~63) | lane_e;
+        int z, m0, n0;
+        decode_tile(tile, z, m0, n0);
+        const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias_z : nullptr;
+        char* cst = smem + OFF_CST;
+        constexpr int ROWB = BN * 4;            // bytes per staged fp32 row
+        constexpr int LPR = BN / 8;             // lanes per row, 8 elements each (32 or 24)
+        constexpr int RPP = THREADS / LPR;      // rows per pass (16 or 21)
+        constexpr int QR = BM / 4;              // rows per quarter (48 or 64)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (rg == (q >> 1)) {
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) {
+                    const int nl = cg * (BN / 4) + cf * 16 + e_kg * 4;
+                    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n0 + nl);
+#pragma unroll
+                    for (int r2 = 0; r2 < RF / 2; ++r2) {
+                        const int rf = (q & 1) * (RF / 2) + r2;
+                        f32x4 v = acc[cf][rf] + bv;
+                        if (p.act == ACT_RELU) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        } else if (p.act == ACT_GELU) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = gelu_erfc_as(v[j]);
+                        }
+                        const int ml = r2 * 16 + e_row;
+                        *reinterpret_cast<f32x4*>(cst + ml * ROWB + ((((nl >> 2)) ^ (ml & 7)) << 4)) = v;
+                    }
+                }
+            }
+            wait_vm_lgkm<63>();  // LDS writes only: the DMA of the next tile stays in flight
+            __builtin_amdgcn_s_barrier();
+            const int cl = tid_e % LPR, rl = tid_e / LPR;
+            if (rl < RPP) {
+                for (int r0 = 0; r0 < QR; r0 += RPP) {
+                    const int ml = r0 + rl;
+                    const int m = m0 + q * QR + ml;
+                    if (ml >= QR || m >= p.M) continue;
+                    size_t orow = m;
+                    if (GATHER == G_DECONV) {  // phase-interleaved output pixel (2y+py, 2x+px) of a (2H, 2W) map
+                        const int hw = p.H * p.Wd;
+                        const int b = m / hw, r = m - b * hw;
+                        const int y = r / p.Wd, x = r - y * p.Wd;
+                        const int py = p.py < 0 ? (z >> 1) : p.py, px = p.py < 0 ? (z & 1) : p.px;
+                        orow = ((size_t)b * (2 * p.H) + 2 * y + py) * (2 * p.Wd) + 2 * x + px;
+                    }
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(cst + ml * ROWB + (((2 * cl) ^ (ml & 7)) << 4));
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + ml * ROWB + (((2 * cl + 1) ^ (ml & 7)) << 4));
+                    const size_t eoff = (size_t)z * p.strideC_z + orow * p.ldc + n0 + cl * 8;
+                    if (p.out_bf16 == 2) {
+                        f16x8 hv, lv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            hv[j] = split_hi(v0[j]);
+                            lv[j] = split_lo(v0[j], hv[j]);
+                            hv[4 + j] = split_hi(v1[j]);
+                            lv[4 + j] = split_lo(v1[j], hv[4 + j]);
+                        }
+                        char* o = split_addr(p.C, eoff);
+                        *reinterpret_cast<f16x8*>(o) = hv;
+                        *reinterpret_cast<f16x8*>(o + 64) = lv;
+                    } else {
+                        float* o = reinterpret_cast<float*>(p.C) + eoff;
+                        *reinterpret_cast<f32x4*>(o) = v0;
+                        *reinterpret_cast<f32x4*>(o + 4) = v1;
+                    }
+                }
+            }
+            wait_vm_lgkm<63>();
+            __builtin_amdgcn_s_barrier();  // the staging region is reused by the next quarter / the next tile
+        }
+        // stores and loads share vmcnt but may retire out of order with respect to each other: drain before the counted
+        // waits of the next tile rely on the count again
+        wait_vm_lgkm<0>();
+    }
+}
+
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+}  // namespace psplit
+
+// which tile shape serves this problem, or 0: deconvolutions 192 x 256 (N % 256), everything else 256 x 192 (N % 192)
+static int panel_split_shape(const GemmParams& p) {
+    if (p.gather == G_DECONV) return p.N % 256 == 0 ? 1 : 0;
+    return p.N % 192 == 0 ? 2 : 0;
+}
+
+bool panel_split_supported(const GemmParams& p, int prec, int groups) {
+    if (prec != PP_PREC_F16X3 || p.residual || p.planar_P > 0 || p.ksplit > 1) return false;
+    if (p.out_bf16 != 0 && p.out_bf16 != 2) return false;
+    if (p.K % 64 != 0 || p.Cin % 32 != 0 || p.ldc % 32 != 0 || p.lda % 32 != 0 || p.ldw % 32 != 0) return false;
+    if (p.strideA_z % 32 != 0 || p.strideW_z % 32 != 0 || p.strideC_z % 32 != 0) return false;
+    const int shape = panel_split_shape(p);
+    if (!shape) return false;
+    const int BM = shape == 1 ? 192 : 256, BN = shape == 1 ? 256 : 192;
+    const long long ntiles = (long long)(p.N / BN) * ((p.M + BM - 1) / BM) * groups;
+    return ntiles >= 192;  // one workgroup per CU: with fewer tiles the 128 x 128 kernel spreads the work better
+}
+
+int panel_split_gemm(const GemmParams& p_in, int groups, hipStream_t s) {
+    using namespace psplit;
+    GemmParams p = p_in;
+    p.groups = groups;
+    if (p.gather == G_LINEAR) p.Cin = p.K;
+    PP_REQUIRE(p.a_bytes > 0 && p.w_bytes > 0 && p.a_bytes < OOB && p.w_bytes < OOB, PP_ERR_UNSUPPORTED,
+               "pp panel split gemm: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    void (*kern)(const GemmParams) = nullptr;
+    int BM = 256, BN = 192;
+    switch (p.gather) {
+        case G_DECONV: kern = panel_split_kernel<G_DECONV, 6, 4>; BM = 192; BN = 256; break;
+        case G_CONV3: kern = panel_split_kernel<G_CONV3, 8, 3>; break;
+        default: kern = panel_split_kernel<G_LINEAR, 8, 3>; break;
+    }
+    const long long ntiles = (long long)(p.N / BN) * ((p.M + BM - 1) / BM) * groups;
+    PP_REQUIRE(ntiles < (1ll << 30), PP_ERR_UNSUPPORTED, "pp panel split gemm: too many output tiles");
+    int slots = device_cus();
+    slots -= slots % 8;
+    const int grid = (int)(ntiles < slots ? ntiles : slots);
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS, s, p);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // namespace pp

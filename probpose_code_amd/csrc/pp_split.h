@@ -61,4 +61,23 @@ __device__ __forceinline__ split_f32x4 split_mma(const f16x8& ah, const f16x8& a
     return c;
 }
 
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) for the parity mode's epilogues. libdevice erff costs ~57 VALU instructions per
+// element - 55 us of a 166 us fc1 launch at bs 64 (scripts/bench_split_gemm.py). This form is Abramowitz & Stegun 7.1.26,
+//     erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p z),  z >= 0,  |error| <= 1.5e-7,
+// used WITHOUT the cancellation 1 - erfc for negative arguments: 1 + erf(-z) = erfc(z) directly; 1 + erf(z) = 2 - erfc(z)
+// for z >= 0. Evaluated in fp32 against the fp64 definition over [-12, 12] (2 M points): |error| <= 4.3e-7 absolute -
+// 3.5e-8 relative to the activation where it is largest (x ~ 12); in the far negative tail (GELU ~ 1e-6) the relative
+// error reaches 1.7e-3 of a value that is itself 1e-6. One v_rcp_f32, one v_exp_f32, a dozen plain fp32 instructions.
+__device__ __forceinline__ float gelu_erfc_as(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float q = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    q = __builtin_fmaf(t, q, 1.421413741f);
+    q = __builtin_fmaf(t, q, -0.284496736f);
+    q = __builtin_fmaf(t, q, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.44269504088896340736f);  // argument <= 0: raw v_exp_f32
+    const float erfc_z = t * q * e;
+    return 0.5f * x * (x < 0.f ? erfc_z : 2.0f - erfc_z);
+}
+
 }  // namespace pp

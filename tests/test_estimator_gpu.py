@@ -214,3 +214,32 @@ def test_config4_vit_base_384x288_bf16():
     assert (d < 2.0).all() and d.max() <= 1e-3, f"config 4 f16x3: {int((d >= 2).sum())} flips, L_inf {d[d < 2].max():.2e} px"
     for i, name in enumerate(("keypoints_probs", "keypoints_visible", "keypoints_oks")):
         assert np.abs(out["scalars"][i].cpu().numpy()[:, None] - ref[name]).max() <= 1e-3, name
+
+
+@pytest.mark.parametrize("switch", ["PP_FUSE_ATTN", "PP_FUSE_QKV", "PP_FUSE_PROJ", "PP_FUSE_MLP", "PP_SPLIT_K", "PP_FUSE_HEAD"])
+def test_bf16_fallback_launch_plans_end_to_end(switch, monkeypatch):
+    """Every PP_FUSE_* / PP_SPLIT_K switch selects a different launch plan for the bf16 mode (two launches per layer, the
+    plain qkv GEMM, separate projection, unfused FFN, unsplit tower convolutions, separate final 1x1 conv): each plan, end
+    to end, against the default plan - same network, different rounding points, so the comparison is at bf16 resolution -
+    and against the fp32 oracle's argmax."""
+    from oracle import model_ref as M
+    from probpose_code_amd import ProbPoseEngine
+    from probpose_code_amd import synthetic as S
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
+    crops = S.synthetic_crops(8, seed=21)
+    base = ProbPoseEngine(sd, 12, precision="bf16").forward(crops.cuda(), True, S.COCO_FLIP_INDICES, return_heatmaps=True)
+    base = {k: v.clone() for k, v in base.items()}
+    monkeypatch.setenv(switch, "0")
+    eng = ProbPoseEngine(sd, 12, precision="bf16")
+    assert getattr(eng, {"PP_SPLIT_K": "split_k"}.get(switch, switch[3:].lower())) is False
+    out = eng.forward(crops.cuda(), True, S.COCO_FLIP_INDICES, return_heatmaps=True)
+    torch.cuda.synchronize()
+    assert (out["heatmaps"] - base["heatmaps"]).abs().max().item() <= 0.12, "heatmaps drift beyond bf16 noise"
+    for i in range(3):
+        assert (out["scalars"][i] - base["scalars"][i]).abs().max().item() <= 2e-2
+    ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD)
+    d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
+    same = d < 2.0
+    assert same.mean() >= 0.88 and d[same].max() <= 0.75, f"{switch}=0: {float(1 - same.mean()):.3f} flips, {d[same].max():.3f} px"

@@ -247,3 +247,60 @@ def test_elementwise_kernels_split():
     z = torch.einsum("tbc,tkc->tbk", feat.double(), w.double()) + b.double()[:, None]
     a = torch.cat([torch.sigmoid(z[:3]), F.relu(z[3:])])
     torch.testing.assert_close(o.cpu().double(), (a[:, :Bt] + a[:, Bt:][:, :, fi]) * 0.5, rtol=1e-5, atol=1e-6)
+
+
+# ---- the wide-tile kernel (pp_panel_split.hip) takes these problems once there are enough 256 x 192 / 192 x 256 tiles to
+# fill the chip; shapes with tail rows and image borders
+@gpu
+@pytest.mark.parametrize("act,split_out,K", [(1, 1, 384), (0, 0, 128), (2, 1, 64)])
+def test_panel_split_linear(act, split_out, K):
+    L = _lib()
+    M, N = 96 * 256 + 40, 384   # 97 row tiles x 2 column tiles = 194 tiles, last row tile 40 rows
+    a, w, b = _rand(M, K, seed=41), _rand(N, K, seed=42, scale=1 / math.sqrt(K)), _rand(N, seed=43)
+    ref = a.double() @ w.double().t() + b.double()
+    ref = F.gelu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+    ad, wd, bd = _sp(a), _sp(w), b.cuda()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    L.call("pp_gemm", F16X3, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, 0, out.data_ptr(), M, N, K, K, K, N, act,
+           SPLIT if split_out else 0, 0, None)
+    torch.testing.assert_close(_unsp(out) if split_out else out.cpu().double(), ref, **TOL)
+
+
+@gpu
+def test_panel_split_conv3x3_groups():
+    L = _lib()
+    G, B, H, W, C = 4, 124, 8, 6, 384    # M = 5952 -> 24 tiles of 256 rows (tail: 64) x 2 column tiles x 4 groups = 192
+    x = _rand(B, C, H, W, seed=34)
+    w = _rand(G, C, C, 3, 3, seed=35, scale=1 / math.sqrt(9 * C))
+    b = _rand(G, C, seed=36)
+    ref = torch.stack([F.conv2d(x, w[g], b[g], padding=1) for g in range(G)]).double()  # fp32 reference (K = 3456: ~1e-6)
+    xd = _sp(x.permute(0, 2, 3, 1).contiguous())
+    wd = _sp(w.permute(0, 1, 3, 4, 2).reshape(G, C, 9 * C).contiguous())
+    out = torch.full((G, B, H, W, C), float("nan"), device="cuda")
+    bd = b.cuda()
+    L.call("pp_conv_gemm", F16X3, 1, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, C, C,
+           0, 0, G, 0, C * 9 * C, B * H * W * C, C, C, 0, SPLIT, None)
+    torch.testing.assert_close(_unsp(out).permute(0, 1, 4, 2, 3), ref, rtol=3e-5, atol=3e-5)
+
+
+@gpu
+def test_panel_split_deconv_all_phases():
+    L = _lib()
+    B, H, W, Cin, Cout = 51, 16, 12, 128, 256          # M = 9792 = 51 tiles of 192 rows, x 4 phases = 204 tiles
+    x = _rand(B, Cin, H, W, seed=31)
+    w = _rand(Cin, Cout, 4, 4, seed=32, scale=1 / math.sqrt(4 * Cin))
+    b = _rand(Cout, seed=33)
+    ref = F.relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+    xd = _sp(x.permute(0, 2, 3, 1).contiguous())
+    ph = torch.empty((2, 2, Cout, 4 * Cin))
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    t = ty * 2 + tx
+                    ph[py, px, :, t * Cin:(t + 1) * Cin] = w[:, :, 3 - 2 * ty - py, 3 - 2 * tx - px].t()
+    pd, bd = _sp(ph), b.cuda()
+    out = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
+    L.call("pp_conv_gemm", F16X3, 2, xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout,
+           -1, 0, 1, 0, 0, 0, 0, Cout, 2, SPLIT, None)
+    torch.testing.assert_close(_unsp(out).permute(0, 3, 1, 2), ref, **TOL)
