@@ -88,7 +88,9 @@ int pp_probmap_decode(const float* hm, const float* hm_flip, const int32_t* flip
  * * normalize -> clamp(0, 1)  (probmap_head.py:637-646; Sparsemax = PyPI `sparsemax` [3P],
  * probmap_head.py:11,251), to the row itself and -- under the flip test -- to the mirror
  * partner's row, then averages and decodes as above. Logits are read from HBM once; the
- * probability maps only leave the CU when avg_out is requested. H*W <= 7168. */
+ * probability maps only leave the CU when avg_out is requested. H*W <= 7168.
+ * normalize < 0 stands for the head's `normalize=None` (probmap_head.py:249: normalize_layer = Identity): no Sparsemax,
+ * the map is clamp(x / temperature, 0, 1). */
 int pp_probmap_head_decode(const float* logits, const float* logits_flip, const int32_t* flip_indices,
                            const double* taps, const int32_t* radius,
                            int B, int K, int H, int W, double in_w, double in_h,

@@ -97,7 +97,18 @@ def pack_crops(crops_u8: torch.Tensor, input_center: np.ndarray, input_scale: np
 
 def load_image_bgr(path: str) -> np.ndarray:
     """LoadImage for a file path (mmpose/datasets/transforms/loading.py:47-107 -> mmcv.imread, BGR uint8). mmcv decodes
-    with cv2; this build has Pillow only, whose JPEG decoder may differ from cv2's by one grey level in a few pixels."""
+    with cv2 (flag 'color': IMREAD_COLOR, EXIF orientation ignored by `imdecode`): when cv2 is importable the same call is
+    used, so the crops see the very bytes the reference sees. Without cv2 (this image) Pillow decodes; its JPEG decoder
+    may differ from cv2's bundled libjpeg-turbo by one grey level in a few pixels."""
+    try:
+        import cv2  # type: ignore
+
+        img = cv2.imdecode(np.fromfile(path, dtype=np.uint8), cv2.IMREAD_COLOR)
+        if img is None:
+            raise OSError(f"cv2 could not decode {path}")
+        return img
+    except ImportError:
+        pass
     from PIL import Image
 
     with Image.open(path) as im:

@@ -222,14 +222,21 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
             }
         }
         block_max2(m0, m1, fscr);
+        // normalize < 0 stands for the head's `normalize=None` (probmap_head.py:249,642-646): no Sparsemax, the map is
+        // clamp(x / T, 0, 1) - the same code with threshold 0, no shift and scale 1
+        const bool smx = normalize >= 0.f;
+        if (!smx) {
+            m0 = m1 = 0.f;
+            normalize = 1.f;
+        }
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             z0[e] -= m0;
             z1[e] -= m1;
         }
-        float tau0 = -1.0f, tau1 = -1.0f;
+        float tau0 = smx ? -1.0f : 0.f, tau1 = tau0;
         int prev0 = -1, prev1 = -1;
-        for (int iter = 0; iter < 64; ++iter) {
+        for (int iter = 0; iter < (smx ? 64 : 0); ++iter) {
             SmxStat st{0.f, 0.f, 0, 0};
 #pragma unroll
             for (int e = 0; e < NV; ++e)

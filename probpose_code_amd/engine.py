@@ -347,8 +347,6 @@ class ProbPoseEngine:
         assert feat_nhwc.dtype == self.dtype and feat_nhwc.is_contiguous() and feat_nhwc.is_cuda
         if flip_test and flip_indices is None:
             raise ValueError("flip_test needs flip_indices (dataset meta)")
-        if self.normalize is None:
-            raise NotImplementedError("normalize=None (no Sparsemax) is not a ProbPose configuration")
         B = nb // passes
         ws = self._workspace(B, passes)
         with torch.cuda.device(self.device):
@@ -358,7 +356,7 @@ class ProbPoseEngine:
             lf = logits[B:] if flip_test else None
             self._call("head_decode", "pp_probmap_head_decode_phased" if self._logits_phased else "pp_probmap_head_decode", logits.data_ptr(), _lib.ptr(lf), _lib.ptr(fi), self.taps.data_ptr(),
                       self.radius.data_ptr(), B, self.K, self.Hh, self.Wh, float(self.input_size[0]),
-                      float(self.input_size[1]), self.temperature, float(self.normalize),
+                      float(self.input_size[1]), self.temperature, -1.0 if self.normalize is None else float(self.normalize),  # (< 0: no Sparsemax)
                       ws["heatmaps"].data_ptr() if return_heatmaps else None, None, ws["locs"].data_ptr(),
                       ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), st)
             scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, st)

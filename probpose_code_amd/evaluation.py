@@ -369,6 +369,29 @@ def oks_nms(kpts_db, thr, sigmas=None, vis_thr=None, score_per_joint=False):
     return np.array(keep)
 
 
+def soft_oks_nms(kpts_db, thr, max_dets=20, sigmas=None, vis_thr=None, score_per_joint=False):
+    """Soft OKS suppression (nms.py:173-259): the highest score is kept, the scores of the rest decay by
+    exp(-oks^2 / thr) (gaussian rescoring), re-sort, repeat until ``max_dets`` are kept. Returns the indices kept, in
+    the order they were picked."""
+    if len(kpts_db) == 0:
+        return []
+    scores = np.array([k["score"].mean() if score_per_joint else k["score"] for k in kpts_db])
+    kpts = np.array([np.asarray(k["keypoints"]).flatten() for k in kpts_db])
+    areas = np.array([k["area"] for k in kpts_db])
+    order = scores.argsort()[::-1]
+    scores = scores[order]
+    keep = []
+    while len(order) > 0 and len(keep) < max_dets:
+        i = order[0]
+        ovr = oks_iou(kpts[i], kpts[order[1:]], areas[i], areas[order[1:]], sigmas, vis_thr)
+        order = order[1:]
+        scores = scores[1:] * np.exp(-(ovr ** 2) / thr)
+        tmp = scores.argsort()[::-1]
+        order, scores = order[tmp], scores[tmp]
+        keep.append(i)
+    return np.array(keep, dtype=np.intp)
+
+
 def instance_score(bbox_score, keypoint_scores, keypoint_probs, score_mode="bbox_keypoint", score_thresh_type="score",
                    keypoint_score_thr=0.2):
     """Detection score of one instance (coco_metric.py:549-572)."""
@@ -414,8 +437,8 @@ class CocoMetric:
             raise ValueError(f"`score_mode` should be one of 'bbox', 'bbox_keypoint', 'bbox_rle', but got {score_mode}")
         if score_thresh_type not in ("score", "prob"):
             raise ValueError("'score_thresh_type' should be one of 'score' or 'prob'")
-        if nms_mode not in ("oks_nms", "none"):
-            raise ValueError(f"`nms_mode` should be one of 'oks_nms', 'none' (soft_oks_nms is not provided), but got {nms_mode}")
+        if nms_mode not in ("oks_nms", "soft_oks_nms", "none"):
+            raise ValueError("`nms_mode` should be one of 'oks_nms', 'soft_oks_nms', " f"'none', but got {nms_mode}")
         extended, match_by_bbox, ignore_border_points = list(extended), list(match_by_bbox), list(ignore_border_points)
         n = max(len(extended), len(match_by_bbox))
         if len(extended) == 1 and n > 1:
@@ -488,7 +511,8 @@ class CocoMetric:
             if self.nms_mode == "none":
                 valid[img_id] = persons
             else:
-                valid[img_id] = [persons[k] for k in oks_nms(persons, self.nms_thr, sigmas=self.sigmas)]
+                nms = oks_nms if self.nms_mode == "oks_nms" else soft_oks_nms  # coco_metric.py:576
+                valid[img_id] = [persons[k] for k in nms(persons, self.nms_thr, sigmas=self.sigmas)]
         return valid
 
     def _gt_list(self):

@@ -1,5 +1,5 @@
 """Golden vectors for the OKS suppression of the metric driver, from the REFERENCE's own
-``mmpose/evaluation/functional/nms.py`` (``oks_iou`` :58-116, ``oks_nms`` :119-170). Build container only:
+``mmpose/evaluation/functional/nms.py`` (``oks_iou`` :58-116, ``oks_nms`` :119-170, ``soft_oks_nms`` :173-259). Build container only:
 
     python tests/golden/make_golden_nms.py
 
@@ -33,6 +33,8 @@ def main():
         keep = np.asarray(nms.oks_nms(db, thr, sigmas=None), np.int64)
         out[f"n{n}/kpts"], out[f"n{n}/score"], out[f"n{n}/area"], out[f"n{n}/thr"] = kp, score, area, np.array(thr)
         out[f"n{n}/keep"] = keep
+        out[f"n{n}/soft_keep"] = np.asarray(nms.soft_oks_nms([dict(d) for d in db], thr, sigmas=None), np.int64)
+        out[f"n{n}/soft_keep_max5"] = np.asarray(nms.soft_oks_nms([dict(d) for d in db], thr, max_dets=5, sigmas=None), np.int64)
         out[f"n{n}/iou0"] = nms.oks_iou(kp[0].flatten(), kp[1:].reshape(N - 1, -1), area[0], area[1:]) if N > 1 else np.zeros(0, np.float32)
         out[f"n{n}/iou0_vis"] = nms.oks_iou(kp[0].flatten(), kp[1:].reshape(N - 1, -1), area[0], area[1:], vis_thr=0.4) if N > 1 else np.zeros(0, np.float32)
     out["n_cases"] = np.array(len(cases))

@@ -243,3 +243,23 @@ def test_bf16_fallback_launch_plans_end_to_end(switch, monkeypatch):
     d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
     same = d < 2.0
     assert same.mean() >= 0.88 and d[same].max() <= 0.75, f"{switch}=0: {float(1 - same.mean()):.3f} flips, {d[same].max():.3f} px"
+
+
+def test_normalize_none_head_without_sparsemax():
+    """`normalize=None` (probmap_head.py:249,642-646: Identity instead of Sparsemax, then clamp(x / T, 0, 1)) through
+    the fused decode, against the oracle; not a ProbPose configuration but part of the head's constructor surface."""
+    from oracle import model_ref as M
+    from probpose_code_amd import ProbPoseEngine
+    from probpose_code_amd import synthetic as S
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=0.3)  # small logits: the clamp must not saturate everywhere
+    crops = S.synthetic_crops(3, seed=31)
+    ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD, normalize=None)
+    eng = ProbPoseEngine(sd, 12, precision="f16x3", normalize=None)
+    out = eng.forward(crops.cuda(), True, S.COCO_FLIP_INDICES, return_heatmaps=True)
+    hm = out["heatmaps"].cpu().numpy()
+    assert 0.05 < float((ref["heatmaps"] > 0).mean()) < 0.95, "the reference maps must exercise both sides of the clamp"
+    assert np.abs(hm - ref["heatmaps"]).max() <= 1e-4
+    d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
+    assert (d < 2.0).mean() >= 0.9 and d[d < 2.0].max() <= 1e-2  # dense maps: flat maxima, looser than the Sparsemax case
