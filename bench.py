@@ -239,6 +239,62 @@ def roofline_record(eng, B, prof, reps):
     return kernel_ms, rec
 
 
+def secondary_rooflines(eng, B, prof, reps):
+    """The two kernels BASELINE.json's `north_star` sets targets for - ViT attention (>= 70 % MFMA) and the ProbMap decode
+    (>= 60 % HBM) - with the datasheet fraction AND the ceiling their arithmetic allows at this shape, with the
+    instruction-count derivation. Measured live from the same instrumented pass."""
+    per_tag = {k: (float(np.sum(v)) / reps, len(v) // reps) for k, v in prof.items()}
+    out = {}
+    S, hd, heads, nseq = eng.Np, eng.hd, eng.heads, 2 * B
+    if "head_decode" in per_tag:
+        ms, n = per_tag["head_decode"]
+        by = 2 * B * eng.K * eng.Hh * eng.Wh * 4  # both logit maps of every (crop, keypoint), read once (SURVEY 8d: 417 792 B / crop)
+        wgs, slots = B * eng.K, 3 * 256
+        rounds = -(-wgs // slots)
+        chain_us = 15.0  # one workgroup's dependent chain, measured: scripts/bench_decode.py (17-workgroup launch 18.9 us - ~4 us launch)
+        ceil_gbs = by / (rounds * chain_us * 1e-6) / 1e9
+        out["head_decode"] = {
+            "bound": "hbm", "achieved": by / (ms / n * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": by / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms / n, "algorithmic_mbytes_per_launch": by / 1e6,
+            "derived_ceiling": {
+                "GBps": ceil_gbs, "frac_of_ceiling": by / (ms / n * 1e-3) / 1e9 / ceil_gbs,
+                "why": f"latency-bound, not bandwidth-bound: the {by / 1e6:.1f} MB are L2 / MALL resident and each (crop, keypoint) "
+                       f"workgroup runs a dependent chain - loads, block max, ~5 Michelot threshold iterations (a block reduction + "
+                       f"barrier each), flip merge, bounding box, fp64 row pass, fp64 column pass, block argmax: a dozen barriers, "
+                       f"~{chain_us:.0f} us measured for one workgroup alone; {wgs} workgroups on {slots} slots (3 per CU at 49 KiB "
+                       f"LDS) = {rounds} rounds -> >= {rounds * chain_us:.0f} us per launch",
+            },
+        }
+    att_fl = 4.0 * nseq * heads * S * S * hd  # QK^T + PV per layer
+    # VALU issue per (16-query tile, head) at head dim 32 / 192 keys, per wave: 48 v_max + 48 v_fma + 48 v_exp_f32 (quarter
+    # rate: 16 cycles) + 48 v_add + 24 v_cvt_pk + ~25 cross-lane / scale ops at 4 cycles = ~1540 cycles, against 24 MFMAs x
+    # 16 = 384 cycles: the phase is VALU-bound. Six tiles on four SIMDs put two tiles on two of them.
+    if S == 192 and hd == 32:
+        valu_cycles, tiles_on_busiest_simd, clk = 1540.0, 2, 2.0e9
+        t_min = heads * valu_cycles * tiles_on_busiest_simd / clk          # per workgroup (96 rows) = per launch at one tile per CU
+        rounds = max(1, -(-(nseq * S // 96) // 256))  # 96-row workgroups over 256 CUs (bs 64 + flip test: exactly one round)
+        ceil_tf = att_fl / (t_min * rounds) / 1e12
+        rec = {"bound": "valu", "algorithmic_gflop_per_layer": att_fl / 1e9, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+               "derived_ceiling": {"TFLOPs": ceil_tf, "frac_of_datasheet_peak": ceil_tf / PEAK_TFLOPS["bf16"],
+                                   "why": "softmax VALU issue bounds the phase: per (16-query tile, head) and wave ~1540 VALU cycles "
+                                          "(48 max, 48 fma, 48 v_exp_f32 at quarter rate, 48 add, 24 cvt_pk, cross-lane) against 384 "
+                                          "MFMA cycles (128 FLOP per v_exp_f32 at head dim 32); 6 tiles on 4 SIMDs = 2 on the busiest; "
+                                          f"12 heads x 2 x 1540 cycles at 2.0 GHz = {t_min * 1e6:.1f} us per 96-row workgroup. The 70 % "
+                                          "MFMA target of BASELINE.json is not reachable at 192 tokens x 32 dims."}}
+        if "attention" in per_tag:  # stand-alone kernel (PP_FUSE_ATTN=0 and the f16x3 / f32 modes)
+            ms, n = per_tag["attention"]
+            rec.update(achieved=att_fl / (ms / n * 1e-3) / 1e12, avg_launch_ms=ms / n, kernel="attention")
+            rec["frac"] = rec["achieved"] / PEAK_TFLOPS["bf16"]
+            if eng.precision == "bf16":
+                rec["derived_ceiling"]["frac_of_ceiling"] = rec["achieved"] / ceil_tf
+        else:  # inside the fused layer kernel: phase time from the kernel's own stamps (scripts/micro/layer_trace.py, DESIGN.md 5)
+            rec.update(kernel="vit_layer (attention phase)", phase_us_from_stamps=25.0, achieved=att_fl / 25.0e-6 / 1e12)
+            rec["frac"] = rec["achieved"] / PEAK_TFLOPS["bf16"]
+            rec["derived_ceiling"]["frac_of_ceiling"] = rec["achieved"] / ceil_tf
+        out["attention"] = rec
+    return out
+
+
 def cpu_baseline(sd, crops_cpu, n_crops, threads):
     from oracle import model_ref as M
     from probpose_code_amd import synthetic as S
@@ -453,6 +509,7 @@ def main(argv=None):
             print(json.dumps(line))
         else:
             line["kernel_ms_per_step"], line["roofline"] = roofline_record(eng, B, *prof)
+            line["roofline_targets"] = secondary_rooflines(eng, B, *prof)
             ref = None
             if world == 1 and not args.no_cpu_baseline:
                 threads = min(16, len(os.sched_getaffinity(0)))
