@@ -9,7 +9,7 @@ for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
-  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d /tmp/pmc_$out/p$i -- "$@" > $root/gpurun_out/$out/log$i.txt 2>&1
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d /tmp/pmc_$out/p$i -- "$@"  # (cwd is /tmp: pass absolute paths) > $root/gpurun_out/$out/log$i.txt 2>&1
 done
 python3 - "$out" "$pat" <<'PY'
 import csv, glob, re, sys, collections, os
