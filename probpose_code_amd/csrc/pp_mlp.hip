@@ -45,7 +45,7 @@ namespace mlp {
 #define MLP_DBG 0
 #endif
 // dev ablation switches (scripts/micro/mlp_ablate.sh), 0 in the product build: 2 no GELU, 4 no MFMA, 8 no DMA,
-// 16 no LDS fragment reads, 32 no barriers, 64 no b1 loads, 512 per-step time stamps, 1024 no qkv stores
+// 16 no LDS fragment reads, 32 no barriers, 64 no b1 loads, 512 per-step time stamps, 1024 no qkv stores, 2048 no qkv staging / stores at all
 constexpr int DBG = MLP_DBG;
 #ifndef MLP_ROT_MORE
 #define MLP_ROT_MORE 1  // dev A/B switch: rotate the projection's k-steps and the qkv tail's column blocks per workgroup too
@@ -718,6 +718,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     wait_dma_and_barrier<63>();
     float mean[3], rstd[3];
     row_stats(reinterpret_cast<float*>(smem + OFF_GS), mean, rstd);
+    stamp(21, 0);  // row statistics done
     // Everything lane-dependent below is recomputed from a laundered lane id: these addresses are loop-invariant, the
     // compiler would hoist them above the FFN loop, and that loop has no register to spare (the same trick as in the
     // epilogue of pp_gemm.hip).
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 #pragma unroll
     for (int b = 0; b < 7; ++b) {  // block 6 is the drain: no MFMAs, only block 5 leaving
         const int set = b & 1;
-        if (b < 6) {
+        if (b < 6 && !(DBG & 2048)) {  // (ablation 2048: keep accumulating so that no MFMA of the tail is dead code)
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
             // The previous block leaves in the shadow of this block's MFMAs (which were issued first): rows 0-47 are
             // staged at step 0 and stored over steps 1-2, rows 48-95 staged at step 3 and stored over steps 4-5 (the
             // drain block has five steps: its second half goes out in one piece).
-            if (b > 0) {
+            if (b > 0 && !(DBG & 2048)) {
                 if (kt == 0) stage_half(0, set ^ 1);
                 if (kt == 1) store_half(b - 1, 0, 0, 3);
                 if (kt == 2) store_half(b - 1, 0, 3, 5);
@@ -874,6 +875,14 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                 if (kt == 5) store_half(b - 1, 1, 3, 5);
             }
         }
+    }
+    if (DBG & 2048) {  // one live use of every accumulator
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 6; ++nf) t += acc[rf][nf];
+        if (t[0] + t[1] + t[2] + t[3] == 123.456f) p.qkv[tid] = (__bf16)t[0];
     }
     stamp(20, 5);  // qkv tail done
     wait_dma_and_barrier<0>();  // the out-of-bounds DMAs past the last tile must not outlive the workgroup

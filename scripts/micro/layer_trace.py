@@ -26,6 +26,7 @@ for w in (0, 1):
     print(f"wave {4*w}: total {ph[6]-ph[0]} ticks")
     for i, n in enumerate(names):
         print(f"   {n:30s} {ph[i+1]-ph[i]:7d}")
+    print(f"      (of 'LN + x_out stores': row statistics {t[w * 4096 + 210] - ph[3]}, LayerNorm + store issue {ph[4] - t[w * 4096 + 210]})")
 if os.environ.get("VIT"):  # the same through pp_vit_layer (attention phase in front): stamps of its twelve heads
     fv = lib.pp_vit_layer
     fv.restype = ctypes.c_int
