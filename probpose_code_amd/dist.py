@@ -58,8 +58,9 @@ class ResultGather:
     every rank's block are valid. ``__call__`` returns the pinned host tensor (world, batch, K, 7) right after ENQUEUING
     the device-to-host copy: ``wait()`` (or a device synchronize) must come before the host reads it."""
 
-    def __init__(self, batch: int, num_keypoints: int, device, world: int = 1, group=None):
+    def __init__(self, batch: int, num_keypoints: int, device, world: int = 1, group=None, force_collective: bool = False):
         self.world, self.group, self.batch = world, group, batch
+        self.collective = world > 1 or force_collective  # (force: run the all_gather even on a 1-rank group - tests)
         self.device = torch.device(device)
         K, F = num_keypoints, len(RECORD_FIELDS)
         # one extra row per rank carries the rank's valid-row count, so sizes and records are ONE collective
@@ -75,12 +76,12 @@ class ResultGather:
         n = int(out["keypoints"].shape[0])
         if n > self.batch:
             raise ValueError(f"ResultGather was built for at most {self.batch} rows per rank, got {n}")
-        dst = self._send if self.world > 1 else self._recv[0]
+        dst = self._send if self.collective else self._recv[0]
         pack_records(out, into=dst[:n])
         if n < self.batch:
             dst[n:self.batch].zero_()  # no stale rows from an earlier, fuller batch
         dst[self.batch].fill_(float(n))
-        if self.world > 1:
+        if self.collective:
             dist.all_gather_into_tensor(self._recv.flatten(0, 1), self._send, group=self.group)
         self._host.copy_(self._recv, non_blocking=True)
         if self._event is not None:

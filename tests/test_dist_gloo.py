@@ -79,3 +79,28 @@ def test_pack_records_kernel_matches_the_torch_form():
     host = g(out)
     torch.cuda.synchronize()
     assert torch.equal(host[0], ref)
+
+
+@pytest.mark.gpu
+def test_rccl_all_gather_path_on_one_rank():
+    """The box the GPU tests run on has ONE MI355X, so the N > 1 exchange cannot run there; what can is the RCCL call itself:
+    a 1-rank `nccl` (= RCCL on ROCm) process group and ResultGather's collective branch forced on - the library loads, the
+    communicator initialises, `all_gather_into_tensor` of the (B + 1, K, 7) float64 record runs on the device, and the
+    padding / count row arrives."""
+    from probpose_code_amd.dist import ResultGather, pack_records
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B, K = 6, 17
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        out = dict(keypoints=torch.rand(4, K, 2, dtype=torch.float64, device="cuda", generator=gen),
+                   scores=torch.rand(4, K, device="cuda", generator=gen), scalars=torch.rand(4, 4, K, device="cuda", generator=gen))
+        g = ResultGather(B, K, "cuda", 1, force_collective=True)
+        host = g(out)
+        g.wait()
+        assert g.counts == [4]
+        assert torch.equal(host[0, :4], pack_records({k: v.cpu() for k, v in out.items()}))
+        assert bool((host[0, 4:] == 0).all())
+    finally:
+        dist.destroy_process_group()

@@ -263,3 +263,44 @@ def test_normalize_none_head_without_sparsemax():
     assert np.abs(hm - ref["heatmaps"]).max() <= 1e-4
     d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
     assert (d < 2.0).mean() >= 0.9 and d[d < 2.0].max() <= 1e-2  # dense maps: flat maxima, looser than the Sparsemax case
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16x3"])
+@pytest.mark.parametrize("B,flip", [(1, True), (3, False), (5, True)])
+def test_ragged_batch_sizes_and_single_pass(precision, B, flip):
+    """Batch sizes that fill no tile (1, 3, 5 crops: 192 - 960 token rows against 96 / 128 / 256-row tiles, 17 - 85
+    decode workgroups) and the single-pass path (`flip_test=False`: no flip copy, no TTA merge) against the oracle."""
+    from oracle import model_ref as M
+    from probpose_code_amd import ProbPoseEngine
+    from probpose_code_amd import synthetic as S
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
+    crops = S.synthetic_crops(B, seed=40 + B)
+    ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD, flip_test=flip)
+    eng = ProbPoseEngine(sd, 12, precision=precision)
+    out = eng.forward(crops.cuda(), flip, S.COCO_FLIP_INDICES if flip else None)
+    d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
+    same = d < 2.0
+    if precision == "f16x3":
+        assert same.all() and d.max() <= 1e-3, f"{int((~same).sum())} flips, {d[same].max():.2e} px"
+        assert np.abs(out["scalars"][0].cpu().numpy()[:, None] - ref["keypoints_probs"]).max() <= 1e-3
+    else:
+        assert same.mean() >= 0.85 and d[same].max() <= 0.75
+    # the replayed graph of the same shape agrees with the eager launches
+    g = eng.forward_graph(crops.cuda(), flip, S.COCO_FLIP_INDICES if flip else None)
+    torch.cuda.synchronize()
+    assert torch.equal(g["keypoints"], out["keypoints"])
+
+
+def test_output_keypoint_indices_selects_fields(setup):
+    """test_cfg.output_keypoint_indices (topdown.py:172-190): every `keypoint*` field and the heatmaps are sliced."""
+    sd, crops, center, scale, ref = setup
+    idx = [0, 5, 6, 11, 12]
+    _, results = _run(sd, crops, center, scale, "f16x3", {"model.test_cfg.output_keypoint_indices": idx,
+                                                          "model.test_cfg.output_heatmaps": True})
+    for b, ds in enumerate(results):
+        pi = ds.pred_instances
+        assert pi.keypoints.shape == (1, 5, 2) and pi.keypoints_probs.shape == (1, 5) and pi.keypoint_scores.shape == (1, 5)
+        assert np.abs(pi.keypoints - ref["keypoints"][b][:, idx]).max() <= 1e-3
+        assert tuple(ds.pred_fields.heatmaps.shape) == (5, 64, 48)
