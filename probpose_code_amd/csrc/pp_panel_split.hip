@@ -21,9 +21,16 @@
 //   * epilogue: + bias, GELU (pp_split.h: erfc form, 1.5e-7) / ReLU, then a quarter of the tile's rows at a time as fp32 through a 48 KiB
 //     staging region and out as the split format (8 elements per lane: 16 bytes of hi halves + 16 bytes of lo halves),
 //     deconvolutions to the phase-interleaved output pixel.
+//
+// SPLIT = false instantiates the same kernel for bf16 operands (a stage is 64 elements of K, the two halves are its two
+// 32-element k-blocks, one MFMA per fragment pair) for the long-K Linear layers with an fp32 residual epilogue that
+// pp_panel_gemm.hip (convolutions, bf16 out) does not cover: fc2 of ViT-B (K = 3072) ran at ~550 TFLOP/s on the 128 x 128
+// tiles. Short-K layers stay there (12 K-steps do not amortise this kernel's un-overlapped epilogue).
 #include "pp_common.h"
 #include "pp_gemm.h"
 #include "pp_split.h"
+
+#include <cstdlib>
 
 namespace pp {
 namespace psplit {
@@ -37,7 +44,7 @@ constexpr int STAGE = 56 * 1024, NSTAGE = 2;
 constexpr int OFF_CST = NSTAGE * STAGE;
 constexpr int CST_BYTES = 48 * 1024;
 constexpr int LDS = OFF_CST + CST_BYTES;  // 160 KiB
-constexpr int KS = 32;                    // elements of K per stage
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr unsigned OOB = 0x7ffffff0u;
 
 template <int N>
@@ -45,12 +52,20 @@ __device__ __forceinline__ void wait_vm_lgkm() {
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
 }
 
+template <bool SPLIT>
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    if constexpr (SPLIT)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int GATHER, int RF, int CF>
+__device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int GATHER, int RF, int CF, bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParams p) {
+    constexpr int ESZ = SPLIT ? 4 : 2;   // bytes per operand element
+    constexpr int KS = 128 / ESZ;        // elements of K per stage: one 128-byte line per row
     constexpr int BM = 32 * RF, BN = 64 * CF;
     constexpr int NA = BM / 8, JA = NA / 8;  // DMA instructions of the activation tile (8 lines each); per wave j < JA
     static_assert(BM * 128 + BN * 128 == STAGE, "a stage is 56 KiB");
@@ -93,8 +108,8 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
             i_py = p.py < 0 ? (z >> 1) : p.py;
             i_px = p.py < 0 ? (z & 1) : p.px;
         }
-        const char* Act = reinterpret_cast<const char*>(p.A) + (size_t)z * p.strideA_z * 4;
-        const char* Wt = reinterpret_cast<const char*>(p.W) + (size_t)z * p.strideW_z * 4;
+        const char* Act = reinterpret_cast<const char*>(p.A) + (size_t)z * p.strideA_z * ESZ;
+        const char* Wt = reinterpret_cast<const char*>(p.W) + (size_t)z * p.strideW_z * ESZ;
         a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Act), 0, p.a_bytes, 0x00020000);
         w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wt), 0, p.w_bytes, 0x00020000);
 #pragma unroll
@@ -104,16 +119,16 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
             if (GATHER == G_LINEAR) {
                 a_y[j] = ok ? 0 : -100000;
                 a_x[j] = 0;
-                a_voff[j] = (unsigned)m * (unsigned)(p.lda * 4) + d_kbytes;
+                a_voff[j] = (unsigned)m * (unsigned)(p.lda * ESZ) + d_kbytes;
             } else {
                 const int hw = p.H * p.Wd;
                 const int b = m / hw, rr = m - b * hw;
                 a_y[j] = ok ? rr / p.Wd : -100000;
                 a_x[j] = rr - (rr / p.Wd) * p.Wd;
-                a_voff[j] = (unsigned)m * (unsigned)(p.Cin * 4) + d_kbytes;  // NHWC pixel origin
+                a_voff[j] = (unsigned)m * (unsigned)(p.Cin * ESZ) + d_kbytes;  // NHWC pixel origin
             }
         }
-        w_voff = (unsigned)(n0 + 8 * (wv + 8 * JA - NA) + d_l) * (unsigned)(p.ldw * 4) + d_kbytes;  // n < N: N % BN == 0
+        w_voff = (unsigned)(n0 + 8 * (wv + 8 * JA - NA) + d_l) * (unsigned)(p.ldw * ESZ) + d_kbytes;  // n < N: N % BN == 0
         i_step = 0;
         i_tap = 0;
         i_c0 = 0;
@@ -132,11 +147,11 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
             const int jj = j < JA ? j : 0;
             const int yy = a_y[jj] + dy, xx = a_x[jj] + dx;
             const bool ok = GATHER == G_LINEAR ? a_y[jj] >= 0 : (yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd);
-            const int tap_off = GATHER == G_LINEAR ? i_c0 * 4 : ((dy * p.Wd + dx) * p.Cin + i_c0) * 4;
+            const int tap_off = GATHER == G_LINEAR ? i_c0 * ESZ : ((dy * p.Wd + dx) * p.Cin + i_c0) * ESZ;
             const unsigned va = ok ? (unsigned)((int)a_voff[jj] + tap_off) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)dst, 16, va, 0, 0, 0);
         } else {
-            const unsigned kb = (unsigned)((i_tap * p.Cin + i_c0) * 4) + (unsigned)((j - JA) * 64) * (unsigned)(p.ldw * 4);
+            const unsigned kb = (unsigned)((i_tap * p.Cin + i_c0) * ESZ) + (unsigned)((j - JA) * 64) * (unsigned)(p.ldw * ESZ);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, i_live ? w_voff + kb : OOB, 0, 0, 0);
         }
     };
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
 #pragma unroll
                 for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
-                    for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma(wh[cf], ah[rf], acc[cf][rf]);
+                    for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma<SPLIT>(wh[cf], ah[rf], acc[cf][rf]);
                 __builtin_amdgcn_sched_barrier(0);
                 wait_vm_lgkm<0>();
                 __builtin_amdgcn_s_barrier();
@@ -210,17 +225,28 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
 #pragma unroll
                 for (int j = 0; j < 7; ++j) issue_instr(s, j);
                 advance_cursor();
+                if constexpr (SPLIT) {
 #pragma unroll
-                for (int rf = 0; rf < RF; ++rf) {
+                    for (int rf = 0; rf < RF; ++rf) {
 #pragma unroll
-                    for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma(wl[cf], ah[rf], acc[cf][rf]);
-                    ah[rf] = frag_a(s ^ 1, 0, rf);
-                }
+                        for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma<SPLIT>(wl[cf], ah[rf], acc[cf][rf]);
+                        ah[rf] = frag_a(s ^ 1, 0, rf);
+                    }
 #pragma unroll
-                for (int cf = 0; cf < CF; ++cf) {
+                    for (int cf = 0; cf < CF; ++cf) {
 #pragma unroll
-                    for (int rf = 0; rf < RF; ++rf) acc[cf][rf] = mma(wh[cf], al[rf], acc[cf][rf]);
-                    wh[cf] = frag_w(s ^ 1, 0, cf);
+                        for (int rf = 0; rf < RF; ++rf) acc[cf][rf] = mma<SPLIT>(wh[cf], al[rf], acc[cf][rf]);
+                        wh[cf] = frag_w(s ^ 1, 0, cf);
+                    }
+                } else {  // bf16: the second k-block of the stage; the next stage's first block replaces the dead fragments
+#pragma unroll
+                    for (int cf = 0; cf < CF; ++cf) wh[cf] = frag_w(s ^ 1, 0, cf);
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf) ah[rf] = frag_a(s ^ 1, 0, rf);
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                        for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma<SPLIT>(wl[cf], al[rf], acc[cf][rf]);
                 }
             }
         }
@@ -254,7 +280,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
                             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                         } else if (p.act == ACT_GELU) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = gelu_erfc_as(v[j]);
+                            for (int j = 0; j < 4; ++j) v[j] = SPLIT ? gelu_erfc_as(v[j]) : gelu_erf_exact(v[j]);
                         }
                         const int ml = r2 * 16 + e_row;
                         *reinterpret_cast<f32x4*>(cst + ml * ROWB + ((((nl >> 2)) ^ (ml & 7)) << 4)) = v;
@@ -277,10 +303,19 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
                         const int py = p.py < 0 ? (z >> 1) : p.py, px = p.py < 0 ? (z & 1) : p.px;
                         orow = ((size_t)b * (2 * p.H) + 2 * y + py) * (2 * p.Wd) + 2 * x + px;
                     }
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(cst + ml * ROWB + (((2 * cl) ^ (ml & 7)) << 4));
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + ml * ROWB + (((2 * cl + 1) ^ (ml & 7)) << 4));
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(cst + ml * ROWB + (((2 * cl) ^ (ml & 7)) << 4));
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + ml * ROWB + (((2 * cl + 1) ^ (ml & 7)) << 4));
                     const size_t eoff = (size_t)z * p.strideC_z + orow * p.ldc + n0 + cl * 8;
-                    if (p.out_bf16 == 2) {
+                    if (p.residual) {  // fp32, same indexing as the output, or a (res_mod, N) table broadcast over the rows
+                        const float* r = p.residual + (p.res_mod > 0 ? (size_t)(m % p.res_mod) * p.ldres : orow * p.ldres) + n0 + cl * 8;
+                        v0 += *reinterpret_cast<const f32x4*>(r);
+                        v1 += *reinterpret_cast<const f32x4*>(r + 4);
+                    }
+                    if (p.out_bf16 == 1) {
+                        const bf16x8 ov = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3],
+                                           (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.C) + eoff) = ov;
+                    } else if (p.out_bf16 == 2) {
                         f16x8 hv, lv;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -327,11 +362,25 @@ static int panel_split_shape(const GemmParams& p) {
     return p.N % 192 == 0 ? 2 : 0;
 }
 
+static int panel_linear_min_k() {  // bf16 Linear layers shorter than this stay on the 128 x 128 kernel (dev: PP_PANEL_LINEAR_MINK)
+    static const int v = getenv("PP_PANEL_LINEAR_MINK") ? atoi(getenv("PP_PANEL_LINEAR_MINK")) : 1536;
+    return v;
+}
+
 bool panel_split_supported(const GemmParams& p, int prec, int groups) {
-    if (prec != PP_PREC_F16X3 || p.residual || p.planar_P > 0 || p.ksplit > 1) return false;
-    if (p.out_bf16 != 0 && p.out_bf16 != 2) return false;
-    if (p.K % 64 != 0 || p.Cin % 32 != 0 || p.ldc % 32 != 0 || p.lda % 32 != 0 || p.ldw % 32 != 0) return false;
-    if (p.strideA_z % 32 != 0 || p.strideW_z % 32 != 0 || p.strideC_z % 32 != 0) return false;
+    if (p.planar_P > 0 || p.ksplit > 1) return false;
+    if (prec == PP_PREC_F16X3) {
+        if (p.out_bf16 != 0 && p.out_bf16 != 2) return false;
+        if (p.K % 64 != 0 || p.Cin % 32 != 0 || p.ldc % 32 != 0 || p.lda % 32 != 0 || p.ldw % 32 != 0) return false;
+        if (p.strideA_z % 32 != 0 || p.strideW_z % 32 != 0 || p.strideC_z % 32 != 0) return false;
+    } else if (prec == PP_PREC_BF16) {  // convolutions have their own kernel (pp_panel_gemm.hip: fused head, split-K partials)
+        if (p.gather != G_LINEAR || p.K < panel_linear_min_k() || p.K % 128 != 0) return false;
+        if (p.out_bf16 != 0 && p.out_bf16 != 1) return false;
+        if (p.ldc % 8 != 0 || p.lda % 8 != 0 || p.ldw % 8 != 0) return false;
+    } else {
+        return false;
+    }
+    if (p.residual && (p.out_bf16 == 2 || (p.ldres % 4) != 0)) return false;
     const int shape = panel_split_shape(p);
     if (!shape) return false;
     const int BM = shape == 1 ? 192 : 256, BN = shape == 1 ? 256 : 192;
@@ -339,7 +388,7 @@ bool panel_split_supported(const GemmParams& p, int prec, int groups) {
     return ntiles >= 192;  // one workgroup per CU: with fewer tiles the 128 x 128 kernel spreads the work better
 }
 
-int panel_split_gemm(const GemmParams& p_in, int groups, hipStream_t s) {
+int panel_split_gemm(const GemmParams& p_in, int prec, int groups, hipStream_t s) {
     using namespace psplit;
     GemmParams p = p_in;
     p.groups = groups;
@@ -348,10 +397,14 @@ int panel_split_gemm(const GemmParams& p_in, int groups, hipStream_t s) {
                "pp panel split gemm: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     void (*kern)(const GemmParams) = nullptr;
     int BM = 256, BN = 192;
-    switch (p.gather) {
-        case G_DECONV: kern = panel_split_kernel<G_DECONV, 6, 4>; BM = 192; BN = 256; break;
-        case G_CONV3: kern = panel_split_kernel<G_CONV3, 8, 3>; break;
-        default: kern = panel_split_kernel<G_LINEAR, 8, 3>; break;
+    if (prec == PP_PREC_BF16) {
+        kern = panel_split_kernel<G_LINEAR, 8, 3, false>;
+    } else {
+        switch (p.gather) {
+            case G_DECONV: kern = panel_split_kernel<G_DECONV, 6, 4, true>; BM = 192; BN = 256; break;
+            case G_CONV3: kern = panel_split_kernel<G_CONV3, 8, 3, true>; break;
+            default: kern = panel_split_kernel<G_LINEAR, 8, 3, true>; break;
+        }
     }
     const long long ntiles = (long long)(p.N / BN) * ((p.M + BM - 1) / BM) * groups;
     PP_REQUIRE(ntiles < (1ll << 30), PP_ERR_UNSUPPORTED, "pp panel split gemm: too many output tiles");

@@ -508,3 +508,22 @@ def test_vit_layer_one_launch(n_seq, with_qkv):
     torch.testing.assert_close(hout.cpu().double(), href, rtol=3e-2, atol=4e-2)
     if with_qkv:
         torch.testing.assert_close(qout.cpu().double(), qref, rtol=3e-2, atol=8e-2)
+
+
+@pytest.mark.parametrize("out_bf16,act,res", [(0, 0, True), (1, 1, False), (0, 2, False)])
+def test_wide_tile_bf16_linear_long_k(out_bf16, act, res):
+    """bf16 Linear layers with K >= 1536 and enough 256 x 192 tiles go to the wide-tile kernel (pp_panel_split.hip,
+    SPLIT = false): fp32 output with an fp32 residual (ViT-B fc2), bf16 output with GELU, tail rows."""
+    L = _lib()
+    M, N, K = 96 * 256 + 40, 384, 1536
+    a, w, b = _rand(M, K, seed=51), _rand(N, K, seed=52, scale=1 / math.sqrt(K)), _rand(N, seed=53)
+    r = _rand(M, N, seed=54) if res else None
+    ref = _q(a, BF16) @ _q(w, BF16).t() + b.double()
+    ref = F.gelu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+    if res:
+        ref = ref + r.double()
+    ad, wd, bd = a.bfloat16().cuda(), w.bfloat16().cuda(), b.cuda()
+    out = r.clone().cuda() if res else torch.full((M, N), float("nan"), dtype=torch.bfloat16 if out_bf16 else torch.float32, device="cuda")
+    L.call("pp_gemm", BF16, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr() if res else None, 0, out.data_ptr(), M, N, K, K, K, N,
+           act, out_bf16, 0, None)
+    torch.testing.assert_close(out.cpu().double(), ref, **(dict(rtol=2e-2, atol=2e-2) if out_bf16 else dict(rtol=2e-3, atol=2e-3)))
