@@ -84,12 +84,6 @@ class ProbPoseEngine:
         # (DESIGN.md 4); PP_FUSE_ATTN=0 switches back to two launches per layer
         self.fuse_attn = os.environ.get("PP_FUSE_ATTN", "1") != "0"
         self.fuse_head = os.environ.get("PP_FUSE_HEAD", "1") != "0"
-        # PP_PAR_HEAD=1: the four scalar towers on a second stream beside the heatmap branch (both only read the backbone
-        # features; the towers' later stages and the decode kernel are small launches that leave most CUs idle). Measured
-        # under hipGraph replay at bs 64: 2.57 / 2.59 ms with, 2.54 / 2.40 ms without - the big kernels of both branches
-        # own whole CUs (160 KiB LDS) and only take turns; off by default
-        self.par_head = os.environ.get("PP_PAR_HEAD", "0") == "1"
-        self._side = None
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
         self.stage_hook = None  # callable(name) invoked between stages of the launch plan ("embed", "layer<i>", "backbone"); dev / scheduling experiments
@@ -357,15 +351,6 @@ class ProbPoseEngine:
         ws = self._workspace(B, passes)
         with torch.cuda.device(self.device):
             st = _lib.stream_ptr(self.device)
-            if self.par_head and self.profile is None:
-                main = torch.cuda.current_stream(self.device)
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device)
-                self._side.wait_stream(main)  # (the features are ready on the main stream)
-                with torch.cuda.stream(self._side):
-                    scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, _lib.stream_ptr(self.device))
-            else:
-                scalars = None
             logits = self.heatmap_logits(feat_nhwc, nb, ws, st)
             fi = self._flip_indices(flip_indices) if flip_test else None
             lf = logits[B:] if flip_test else None
@@ -374,10 +359,7 @@ class ProbPoseEngine:
                       float(self.input_size[1]), self.temperature, -1.0 if self.normalize is None else float(self.normalize),  # (< 0: no Sparsemax)
                       ws["heatmaps"].data_ptr() if return_heatmaps else None, None, ws["locs"].data_ptr(),
                       ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), st)
-            if scalars is None:
-                scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, st)
-            else:
-                torch.cuda.current_stream(self.device).wait_stream(self._side)
+            scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, st)
         out = dict(keypoints=ws["keypoints"], scores=ws["scores"], locs=ws["locs"], scalars=scalars)
         if return_heatmaps:
             out["heatmaps"] = ws["heatmaps"]
