@@ -8,7 +8,9 @@
 //
 //   * grid = M / 96 workgroups of 768 threads (12 waves, 3 per SIMD); at bs 64 with flip test M = 24 576 -> 256
 //     workgroups = one per CU, a single balanced round;
-//   * wave (rw, cw) owns rows 16 rw .. +15 x columns 192 cw .. +191: 12 MFMA 16x16 fragments, fp32 accumulators;
+//   * wave (rw, cw) owns rows 32 rw .. +31 x columns 96 cw .. +95: 2 x 6 MFMA 16x16 fragments, fp32 accumulators
+//     (round 1 had 16 x 192 wave tiles: 13 LDS fragment reads per 12 MFMAs - with twelve waves the LDS read port, 128 B/clk,
+//     was busier than the matrix pipe; 32 x 96 reads 8 per 12);
 //   * the activation K-tile (96 x 128 B) and the WHOLE weight K-tile (384 x 128 B) are staged by LDS-DMA into a
 //     2-deep ring (120 KiB), chunk-swizzled on the source side exactly as in pp_gemm.hip; each activation byte is
 //     read from HBM once, the weights stream from L2;
@@ -36,7 +38,10 @@ constexpr int A_TILE = BM * ROW_BYTES;            // 12 KiB
 constexpr int STAGE = W_TILE + A_TILE;            // 60 KiB
 constexpr int DMA_PER_STAGE = (BN + BM) / 8;      // 60 instructions of 8 rows
 constexpr int DPW = DMA_PER_STAGE / WAVES;        // 5 per wave
-constexpr int STAT_BYTES = 2 * BM * 4;            // row statistics exchanged between the two column halves
+constexpr int RW = 3, CW = 4;                      // waves as 3 row groups x 4 column groups
+constexpr int RFW = BM / 16 / RW, NFW = BN / 16 / CW;  // wave tile: 2 x 6 fragments = 32 rows x 96 columns
+static_assert(RW * CW == WAVES && RFW * RW * 16 == BM && NFW * CW * 16 == BN, "wave tiling");
+constexpr int STAT_BYTES = CW * BM * 4;           // row statistics exchanged between the column groups
 constexpr int LDS = 2 * STAGE + 2 * STAT_BYTES;
 constexpr unsigned OOB_OFFSET = 0x7ffffff0u;
 
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_res_ln_kernel(const Params p)
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][W tile | A tile] [stats]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rw = wv % 6, cw = wv / 6;
+    const int rw = wv % RW, cw = wv / RW;
     const int f_row = lane & 15, f_kg = lane >> 4;
     const int m0 = blockIdx.x * BM;
 
@@ -135,19 +140,24 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_res_ln_kernel(const Params p)
     stage(kstep(0), 0);
 
     // The accumulators start from residual + bias: those HBM reads fly under the first DMA stage and the whole
-    // K-loop instead of stalling the epilogue (lane layout: columns 192 cw + 16 nf + 4 f_kg + (0..3) of row m).
-    const int m = m0 + rw * 16 + f_row;
-    const bool valid = m < p.M;
-    const size_t xrow = (size_t)m * BN;
-    const size_t rrow = p.res_mod > 0 ? (size_t)(m % p.res_mod) * BN : xrow;
-    f32x4 acc[12];
+    // K-loop instead of stalling the epilogue (lane layout: columns 96 cw + 16 nf + 4 f_kg + (0..3) of rows 32 rw + 16 rf + f_row).
+    bool valid[RFW];
+    size_t xrow[RFW];
+    f32x4 acc[RFW][NFW];
 #pragma unroll
-    for (int nf = 0; nf < 12; ++nf) {
-        const int n = cw * 192 + nf * 16 + f_kg * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.residual && valid) v += *reinterpret_cast<const f32x4*>(p.residual + rrow + n);
-        acc[nf] = v;
+    for (int rf = 0; rf < RFW; ++rf) {
+        const int m = m0 + rw * (16 * RFW) + rf * 16 + f_row;
+        valid[rf] = m < p.M;
+        xrow[rf] = (size_t)m * BN;
+        const size_t rrow = p.res_mod > 0 ? (size_t)(m % p.res_mod) * BN : xrow[rf];
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) {
+            const int n = cw * (16 * NFW) + nf * 16 + f_kg * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.residual && valid[rf]) v += *reinterpret_cast<const f32x4*>(p.residual + rrow + n);
+            acc[rf][nf] = v;
+        }
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -156,72 +166,100 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_res_ln_kernel(const Params p)
         const char* wbase = smem + buf * STAGE;
         const char* abase = wbase + W_TILE;
         if constexpr (__is_same(T, SplitH)) {
-            const f16x8 fah = *reinterpret_cast<const f16x8*>(abase + swz(rw * 16 + f_row, f_kg));
-            const f16x8 fal = *reinterpret_cast<const f16x8*>(abase + swz(rw * 16 + f_row, 4 + f_kg));
+            f16x8 fah[RFW], fal[RFW];
 #pragma unroll
-            for (int nf = 0; nf < 12; ++nf) {
-                const f16x8 fwh = *reinterpret_cast<const f16x8*>(wbase + swz(cw * 192 + nf * 16 + f_row, f_kg));
-                const f16x8 fwl = *reinterpret_cast<const f16x8*>(wbase + swz(cw * 192 + nf * 16 + f_row, 4 + f_kg));
-                acc[nf] = split_mma(fwh, fwl, fah, fal, acc[nf]);
+            for (int rf = 0; rf < RFW; ++rf) {
+                fah[rf] = *reinterpret_cast<const f16x8*>(abase + swz(rw * (16 * RFW) + rf * 16 + f_row, f_kg));
+                fal[rf] = *reinterpret_cast<const f16x8*>(abase + swz(rw * (16 * RFW) + rf * 16 + f_row, 4 + f_kg));
+            }
+#pragma unroll
+            for (int nf = 0; nf < NFW; ++nf) {
+                const f16x8 fwh = *reinterpret_cast<const f16x8*>(wbase + swz(cw * (16 * NFW) + nf * 16 + f_row, f_kg));
+                const f16x8 fwl = *reinterpret_cast<const f16x8*>(wbase + swz(cw * (16 * NFW) + nf * 16 + f_row, 4 + f_kg));
+#pragma unroll
+                for (int rf = 0; rf < RFW; ++rf) acc[rf][nf] = split_mma(fwh, fwl, fah[rf], fal[rf], acc[rf][nf]);
             }
         } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const u32x4 fa = *reinterpret_cast<const u32x4*>(abase + swz(rw * 16 + f_row, ks * 4 + f_kg));
+                u32x4 fa[RFW];
 #pragma unroll
-                for (int nf = 0; nf < 12; ++nf) {
-                    const u32x4 fw = *reinterpret_cast<const u32x4*>(wbase + swz(cw * 192 + nf * 16 + f_row, ks * 4 + f_kg));
-                    acc[nf] = mma(fw, fa, acc[nf], T{});
+                for (int rf = 0; rf < RFW; ++rf) fa[rf] = *reinterpret_cast<const u32x4*>(abase + swz(rw * (16 * RFW) + rf * 16 + f_row, ks * 4 + f_kg));
+#pragma unroll
+                for (int nf = 0; nf < NFW; ++nf) {
+                    const u32x4 fw = *reinterpret_cast<const u32x4*>(wbase + swz(cw * (16 * NFW) + nf * 16 + f_row, ks * 4 + f_kg));
+#pragma unroll
+                    for (int rf = 0; rf < RFW; ++rf) acc[rf][nf] = mma(fw, fa[rf], acc[rf][nf], T{});
                 }
             }
         }
         __syncthreads();
     }
 
-    // ---- epilogue: row statistics straight from the accumulators
-    float s = 0.f;
+    // ---- epilogue: row statistics straight from the accumulators; a row's 384 values sit in 4 lane groups x CW waves
+    float* stat = reinterpret_cast<float*>(smem + 2 * STAGE);  // [2 passes][CW column groups][96 rows]
+    float mean[RFW], rstd[RFW];
 #pragma unroll
-    for (int nf = 0; nf < 12; ++nf) {
-        const f32x4 v = acc[nf];
-        s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    float* stat = reinterpret_cast<float*>(smem + 2 * STAGE);  // [2 passes][2 halves][96 rows]
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (f_kg == 0) stat[cw * BM + rw * 16 + f_row] = s;
-    __syncthreads();
-    const float mean = (stat[rw * 16 + f_row] + stat[BM + rw * 16 + f_row]) * (1.0f / BN);
-    float q = 0.f;
+    for (int rf = 0; rf < RFW; ++rf) {
+        float s = 0.f;
 #pragma unroll
-    for (int nf = 0; nf < 12; ++nf)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float d = acc[nf][j] - mean;
-            q = __builtin_fmaf(d, d, q);
+        for (int nf = 0; nf < NFW; ++nf) {
+            const f32x4 v = acc[rf][nf];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
         }
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    if (f_kg == 0) stat[2 * BM + cw * BM + rw * 16 + f_row] = q;
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (f_kg == 0) stat[cw * BM + rw * (16 * RFW) + rf * 16 + f_row] = s;
+    }
     __syncthreads();
-    const float var = (stat[2 * BM + rw * 16 + f_row] + stat[3 * BM + rw * 16 + f_row]) * (1.0f / BN);
-    const float rstd = 1.0f / sqrtf(var + p.eps);
-    if (!valid) return;
 #pragma unroll
-    for (int nf = 0; nf < 12; ++nf) {
-        const int n = cw * 192 + nf * 16 + f_kg * 4;
-        const f32x4 v = acc[nf];
-        *reinterpret_cast<f32x4*>(p.x_out + xrow + n) = v;
+    for (int rf = 0; rf < RFW; ++rf) {
+        const int r = rw * (16 * RFW) + rf * 16 + f_row;
+        float sm = 0.f;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) sm += stat[c * BM + r];
+        mean[rf] = sm * (1.0f / BN);
+        float q = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = acc[rf][nf][j] - mean[rf];
+                q = __builtin_fmaf(d, d, q);
+            }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        if (f_kg == 0) stat[(CW + cw) * BM + r] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rf = 0; rf < RFW; ++rf) {
+        const int r = rw * (16 * RFW) + rf * 16 + f_row;
+        float var = 0.f;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) var += stat[(CW + c) * BM + r];
+        rstd[rf] = 1.0f / sqrtf(var * (1.0f / BN) + p.eps);
+    }
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) {
+        const int n = cw * (16 * NFW) + nf * 16 + f_kg * 4;
         const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + n), b = *reinterpret_cast<const f32x4*>(p.beta + n);
-        f32x4 h;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h[j] = (v[j] - mean) * rstd * g[j] + b[j];
-        if (p.h_bf16 == 2) {  // PP_OUT_SPLIT
-            split_store4(p.h_out, xrow + n, h);
-        } else if (p.h_bf16) {
-            const bf16x4 hv = {(__bf16)h[0], (__bf16)h[1], (__bf16)h[2], (__bf16)h[3]};
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.h_out) + xrow + n) = hv;
-        } else {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.h_out) + xrow + n) = h;
+        for (int rf = 0; rf < RFW; ++rf) {
+            if (!valid[rf]) continue;
+            const f32x4 v = acc[rf][nf];
+            *reinterpret_cast<f32x4*>(p.x_out + xrow[rf] + n) = v;
+            f32x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = (v[j] - mean[rf]) * rstd[rf] * g[j] + b[j];
+            if (p.h_bf16 == 2) {  // PP_OUT_SPLIT
+                split_store4(p.h_out, xrow[rf] + n, h);
+            } else if (p.h_bf16) {
+                const bf16x4 hv = {(__bf16)h[0], (__bf16)h[1], (__bf16)h[2], (__bf16)h[3]};
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.h_out) + xrow[rf] + n) = hv;
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.h_out) + xrow[rf] + n) = h;
+            }
         }
     }
 }

@@ -180,6 +180,8 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
     };
 
     if ((int)blockIdx.x >= ntiles) return;
+    // (tried: every other workgroup of an XCD starting 8 / 16 us late so that the epilogue store bursts of the two groups
+    // fall into each other's main loops - qkv 90 -> 96 / 103 us: the delay just adds, the lockstep stores are not the limit)
 
     setup_issue_tile();
 #pragma unroll

@@ -3,12 +3,15 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from probpose_code_amd import _lib as L
+import ctypes
+if os.environ.get("LIB"):
+    _alt = ctypes.CDLL(os.environ["LIB"]); _alt.pp_gemm.restype = ctypes.c_int; _alt.pp_gemm.argtypes = L.SIGNATURES["pp_gemm"][1]
 from probpose_code_amd.weights import to_split
 M = 24576
 for name, N, K, act in (("qkv", 1152, 384, 0), ("fc1", 1536, 384, 1), ("fc1 no gelu", 1536, 384, 0)):
     a = to_split(torch.randn(M, K)).cuda(); w = to_split(torch.randn(N, K) / K ** 0.5).cuda(); b = torch.randn(N).cuda()
     out = torch.empty(M, N, device="cuda")
-    run = lambda: L.call("pp_gemm", 2, a.data_ptr(), w.data_ptr(), b.data_ptr(), None, 0, out.data_ptr(), M, N, K, K, K, N, act, 2, 0, None)
+    run = (lambda: _alt.pp_gemm(2, a.data_ptr(), w.data_ptr(), b.data_ptr(), None, 0, out.data_ptr(), M, N, K, K, K, N, act, 2, 0, None)) if os.environ.get("LIB") else lambda: L.call("pp_gemm", 2, a.data_ptr(), w.data_ptr(), b.data_ptr(), None, 0, out.data_ptr(), M, N, K, K, K, N, act, 2, 0, None)
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
