@@ -148,3 +148,24 @@ def inference_topdown(model, img: Union[np.ndarray, torch.Tensor], bboxes=None, 
         ds.set_metainfo(dict(ori_shape=(h, w), img_shape=(h, w)))
     with torch.no_grad():
         return model.test_step(batch)
+
+
+def process_one_image(img, detector, pose_estimator, det_cat_id: int = 0, bbox_thr: float = 0.3, nms_thr: float = 0.3):
+    """The multi-person flow of ``demo/topdown_demo_with_mmdet.py:30-66`` without the drawing: detector -> boxes of category
+    ``det_cat_id`` above ``bbox_thr`` -> box NMS -> ``inference_topdown`` (all persons of the frame in one batch: one warp
+    launch, one pass of the hot path) -> ``merge_data_samples``. ``detector`` is any callable ``img -> (bboxes (N, 4) xyxy,
+    scores (N,), labels (N,))`` - with mmdet installed: ``lambda im: (lambda r: (r.bboxes, r.scores, r.labels))(
+    inference_detector(det_model, im).pred_instances.cpu().numpy())``. Returns the merged PoseDataSample (its
+    ``pred_instances`` hold every person; ``None`` when nothing was detected, as the reference returns)."""
+    from .evaluation import nms
+    from .structures import merge_data_samples
+
+    if isinstance(img, str):
+        img = load_image_bgr(img)
+    boxes, scores, labels = (np.asarray(a) for a in detector(img))
+    dets = np.concatenate((boxes.reshape(-1, 4), scores.reshape(-1, 1)), axis=1)
+    dets = dets[np.logical_and(labels.reshape(-1) == det_cat_id, scores.reshape(-1) > bbox_thr)]
+    dets = dets[nms(dets, nms_thr), :4]
+    if len(dets) == 0:
+        return None
+    return merge_data_samples(inference_topdown(pose_estimator, img, dets))

@@ -369,6 +369,27 @@ def oks_nms(kpts_db, thr, sigmas=None, vis_thr=None, score_per_joint=False):
     return np.array(keep)
 
 
+def nms(dets, thr):
+    """Greedy box suppression of the multi-person demo (mmpose/evaluation/functional/nms.py:16-55): ``dets`` (N, 5)
+    [x1, y1, x2, y2, score]; keep the highest score, drop boxes that overlap it by more than ``thr`` (IoU with the
+    reference's +1 pixel convention). Returns the indices kept."""
+    dets = np.asarray(dets)
+    if len(dets) == 0:
+        return []
+    x1, y1, x2, y2, scores = (dets[:, i] for i in range(5))
+    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
+    order = scores.argsort()[::-1]
+    keep = []
+    while len(order) > 0:
+        i, rest = order[0], order[1:]
+        keep.append(i)
+        w = np.maximum(0.0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + 1)
+        h = np.maximum(0.0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + 1)
+        inter = w * h
+        order = rest[inter / (areas[i] + areas[rest] - inter) <= thr]
+    return keep
+
+
 def soft_oks_nms(kpts_db, thr, max_dets=20, sigmas=None, vis_thr=None, score_per_joint=False):
     """Soft OKS suppression (nms.py:173-259): the highest score is kept, the scores of the rest decay by
     exp(-oks^2 / thr) (gaussian rescoring), re-sort, repeat until ``max_dets`` are kept. Returns the indices kept, in

@@ -37,6 +37,17 @@ def main():
         out[f"n{n}/soft_keep_max5"] = np.asarray(nms.soft_oks_nms([dict(d) for d in db], thr, max_dets=5, sigmas=None), np.int64)
         out[f"n{n}/iou0"] = nms.oks_iou(kp[0].flatten(), kp[1:].reshape(N - 1, -1), area[0], area[1:]) if N > 1 else np.zeros(0, np.float32)
         out[f"n{n}/iou0_vis"] = nms.oks_iou(kp[0].flatten(), kp[1:].reshape(N - 1, -1), area[0], area[1:], vis_thr=0.4) if N > 1 else np.zeros(0, np.float32)
+    # box NMS of the multi-person demo (nms.py:16-55)
+    for n, (N, thr) in enumerate([(0, 0.3), (1, 0.3), (9, 0.3), (30, 0.5), (30, 0.1)]):
+        xy = rng.uniform(0, 400, (N, 2))
+        wh = rng.uniform(20, 200, (N, 2))
+        dets = np.concatenate([xy, xy + wh, np.round(rng.uniform(0.05, 1.0, (N, 1)), 2)], 1)
+        if N >= 9:
+            dets[1, :4] = dets[0, :4] + 3.0   # near-duplicates and a tied score
+            dets[2, 4] = dets[3, 4]
+        out[f"box{n}/dets"], out[f"box{n}/thr"] = dets, np.array(thr)
+        out[f"box{n}/keep"] = np.asarray(nms.nms(dets, thr), np.int64)
+    out["n_box_cases"] = np.array(5)
     out["n_cases"] = np.array(len(cases))
     np.savez_compressed(os.path.join(HERE, "nms_cases.npz"), **out)
     print("nms_cases.npz", os.path.getsize(os.path.join(HERE, "nms_cases.npz")), [out[f"n{n}/keep"].tolist() for n in range(len(cases))])

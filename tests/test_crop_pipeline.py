@@ -104,6 +104,15 @@ def test_inference_topdown_end_to_end():
     xywh = apis.inference_topdown(model, img, np.array([[100, 50, 120, 350]], np.float32), bbox_format="xywh")
     # (not bit-identical: the residual GEMM rotates its K order per workgroup, so the last bit depends on the batch position)
     assert np.allclose(xywh[0].pred_instances.keypoints, res[0].pred_instances.keypoints, atol=1e-3)
+    # the multi-person flow (demo/topdown_demo_with_mmdet.py:30-66) with a stand-in detector: category filter, score
+    # threshold, box NMS (a near-duplicate of box 0 goes), one batched pass, merged sample
+    det = lambda im: (np.concatenate([boxes, boxes[:1] + 2.0, boxes[1:2]]),                     # noqa: E731
+                      np.array([0.9, 0.8, 0.7, 0.6, 0.95], np.float32), np.array([0, 0, 0, 0, 1]))
+    merged = apis.process_one_image(img, det, model, det_cat_id=0, bbox_thr=0.65, nms_thr=0.3)
+    pi = merged.pred_instances
+    assert pi.keypoints.shape == (3, 17, 2) and pi.bboxes.shape == (3, 4)
+    assert np.allclose(pi.bboxes, boxes) and np.allclose(pi.keypoints, np.concatenate([r.pred_instances.keypoints for r in res]), atol=1e-3)
+    assert apis.process_one_image(img, det, model, det_cat_id=2) is None
 
 
 def test_merge_data_samples_and_image_loading(tmp_path):

@@ -27,6 +27,13 @@ def test_oks_suppression_matches_reference_outputs():
     assert oks_nms([], 0.9) == [] and soft_oks_nms([], 0.9) == []
 
 
+def test_box_nms_matches_reference_outputs():
+    from probpose_code_amd.evaluation import nms
+
+    for n in range(int(NMS["n_box_cases"])):
+        assert [int(i) for i in nms(NMS[f"box{n}/dets"], float(NMS[f"box{n}/thr"]))] == NMS[f"box{n}/keep"].tolist(), n
+
+
 def test_instance_score_modes():
     from probpose_code_amd.evaluation import instance_score
 
