@@ -168,6 +168,9 @@ def kernel_work_per_step(eng, B, passes, tag):
     if eng.precision == "f32":  # every output is fp32: one instantiation
         return act_fl + res_fl, act_by + res_by, act_n + res_n, "_ZN2pp11gemm_kernelIfLi0ELi0EEEvNS_10GemmParamsE"
     if tag == "gemm_bf16out":  # "operand-dtype output": bf16 or split-fp16
+        if eng.precision == "f16x3" and (3 * E) % 192 == 0 and Fd % 192 == 0 and (M + 255) // 256 * ((3 * E) // 192) >= 192:
+            # the Linear layers with long output rows run on the wide-tile kernel (pp_panel_split.hip)
+            return act_fl, act_by, act_n, "_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1EEEvNS_10GemmParamsE"
         return act_fl, act_by, act_n, f"_ZN2pp11gemm_kernelI{t}Li0ELi{op_fmt}EEEvNS_10GemmParamsE"
     return res_fl, res_by, res_n, f"_ZN2pp11gemm_kernelI{t}Li0ELi0EEEvNS_10GemmParamsE"
 
