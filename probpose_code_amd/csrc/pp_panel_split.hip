@@ -1,5 +1,5 @@
-// Wide-tile GEMM for PP_PREC_F16X3 (split-fp16 operands, pp_split.h) on gfx950: the dense layers with long output rows
-// of the parity mode - qkv and fc1 Linear layers, the two deconvolutions, the first tower convolution.
+// Wide-tile GEMM for PP_PREC_F16X3 (split-fp16 operands, pp_split.h; the precision mode that meets the 1e-3 tolerance) on
+// gfx950: its dense layers with long output rows - qkv and fc1 Linear layers, the two deconvolutions, the first tower convolution.
 //
 // In this format an operand element costs 4 bytes in LDS and HBM but an algorithmic product costs THREE fp16 MFMAs, so
 // per byte staged the matrix pipe has 3x the work of the bf16 path: the 128 x 128 tiles of pp_gemm.hip (32 KiB per
