@@ -40,10 +40,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int THREADS = 512;
-constexpr int STAGE = 56 * 1024, NSTAGE = 2;
-constexpr int OFF_CST = NSTAGE * STAGE;
-constexpr int CST_BYTES = 48 * 1024;
-constexpr int LDS = OFF_CST + CST_BYTES;  // 160 KiB
+constexpr int CST_BYTES = 48 * 1024;  // epilogue staging of the two-stage form
+// LDS of one instantiation: NST stages of (BM + BN) rows x 128 B; the two-stage form adds a separate staging region, the
+// three-stage form stages the epilogue through the buffer of the stage it has just consumed
+constexpr int lds_bytes(int BM, int BN, int NST) { return NST * (BM + BN) * 128 + (NST == 2 ? CST_BYTES : 0); }
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr unsigned OOB = 0x7ffffff0u;
 
@@ -62,15 +62,25 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
 
 __device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int GATHER, int RF, int CF, bool SPLIT>
+// NST = 3 (round 2): with two stages exactly ONE stage is in flight - the DMA of stage s + 1 is issued at the barrier of
+// stage s - 1 and must have landed at the barrier of stage s, so a stage can never be shorter than the L2 -> LDS latency
+// plus the transfer of its own bytes (measured 1.46 us per 56 KiB stage in the bf16 convolutions against 0.73 us of MFMA
+// issue). Three stages keep two in flight (wait vmcnt(NI) instead of vmcnt(0)); they only fit with smaller stages
+// (192 x 192 / 128 x 256 tiles: 48 KiB), and the epilogue staging then borrows the buffer of the last stage consumed -
+// its refill is deferred until the epilogue is through.
+template <int GATHER, int RF, int CF, bool SPLIT, int NST>
 __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParams p) {
     constexpr int ESZ = SPLIT ? 4 : 2;   // bytes per operand element
     constexpr int KS = 128 / ESZ;        // elements of K per stage: one 128-byte line per row
     constexpr int BM = 32 * RF, BN = 64 * CF;
     constexpr int NA = BM / 8, JA = NA / 8;  // DMA instructions of the activation tile (8 lines each); per wave j < JA
-    static_assert(BM * 128 + BN * 128 == STAGE, "a stage is 56 KiB");
-    static_assert((BM / 4) * BN * 4 == CST_BYTES, "a quarter of the fp32 tile fills the staging region");
-    static_assert(NA % 8 == 0 && JA <= 4 && RF % 2 == 0, "instruction split");
+    constexpr int STAGE = (BM + BN) * 128;   // bytes per stage
+    constexpr int NI = (BM + BN) / 64;       // DMA instructions per wave and stage
+    constexpr int OFF_CST = NST * STAGE;
+    static_assert(NST == 2 || NST == 3, "two or three stages");
+    static_assert((BM / 4) * BN * 4 <= (NST == 2 ? CST_BYTES : STAGE), "a quarter of the fp32 tile fits the staging region");
+    static_assert(lds_bytes(BM, BN, NST) <= 160 * 1024, "LDS");
+    static_assert(NA % 8 == 0 && JA <= 4 && RF % 2 == 0 && (BM + BN) % 64 == 0, "instruction split");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -185,13 +195,14 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
 
     setup_issue_tile();
 #pragma unroll
-    for (int s = 0; s < NSTAGE; ++s) {
+    for (int s = 0; s < NST; ++s) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j) issue_instr(s, j);
+        for (int j = 0; j < NI; ++j) issue_instr(s, j);
         advance_cursor();
     }
-    wait_vm_lgkm<7>();
+    wait_vm_lgkm<(NST - 1) * NI>();  // the first stage has landed
     __builtin_amdgcn_s_barrier();
+    int cb = 0;  // ring buffer of the stage being consumed (runs on across tiles)
     u32x4 ah[RF], wh[CF], al[RF], wl[CF];
 #pragma unroll
     for (int cf = 0; cf < CF; ++cf) wh[cf] = frag_w(0, 0, cf);
@@ -205,53 +216,58 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
 #pragma unroll
             for (int rf = 0; rf < RF; ++rf) acc[cf][rf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int k2 = 0; k2 < nsteps; k2 += 2) {
+        for (int k = 0; k < nsteps; ++k) {
+            const int nb = cb + 1 == NST ? 0 : cb + 1;  // buffer of the next stage
+            // ---- first half: hi x hi (bf16: the first k-block), the other half's fragments of this stage arrive underneath
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {  // stage k2 + s lives in buffer s (nsteps is even)
-                // ---- first half: hi x hi, the lo fragments of this stage arrive underneath
-                __builtin_amdgcn_sched_barrier(0);
+            for (int cf = 0; cf < CF; ++cf) wl[cf] = frag_w(cb, 1, cf);
 #pragma unroll
-                for (int cf = 0; cf < CF; ++cf) wl[cf] = frag_w(s, 1, cf);
+            for (int rf = 0; rf < RF; ++rf) al[rf] = frag_a(cb, 1, rf);
 #pragma unroll
-                for (int rf = 0; rf < RF; ++rf) al[rf] = frag_a(s, 1, rf);
+            for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma<SPLIT>(wh[cf], ah[rf], acc[cf][rf]);
+            __builtin_amdgcn_sched_barrier(0);
+            // every wave holds the rest of this stage in registers -> its buffer is free; the next stage must have landed:
+            // two stages: it is the only one outstanding; three: the newest one (NI instructions per wave) may still fly
+            wait_vm_lgkm<NST == 2 ? 0 : NI>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- second half: refill the freed buffer (three stages: not after a tile's last stage - the epilogue stages
+            // through that buffer first); lo x hi, then hi x lo (bf16: the second k-block), the next stage's first fragments
+            // replace the dying ones
+            if (NST == 2 || k + 1 < nsteps) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) issue_instr(cb, j);
+                advance_cursor();
+            }
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) {
+#pragma unroll
+                    for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma<SPLIT>(wl[cf], ah[rf], acc[cf][rf]);
+                    ah[rf] = frag_a(nb, 0, rf);
+                }
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) {
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf) acc[cf][rf] = mma<SPLIT>(wh[cf], al[rf], acc[cf][rf]);
+                    wh[cf] = frag_w(nb, 0, cf);
+                }
+            } else {
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) wh[cf] = frag_w(nb, 0, cf);
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) ah[rf] = frag_a(nb, 0, rf);
 #pragma unroll
                 for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
-                    for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma<SPLIT>(wh[cf], ah[rf], acc[cf][rf]);
-                __builtin_amdgcn_sched_barrier(0);
-                wait_vm_lgkm<0>();
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- second half: refill buffer s with stage + 2; lo x hi (row fragments die one by one and take the next
-                // stage's hi fragments), then hi x lo (column fragments likewise)
-#pragma unroll
-                for (int j = 0; j < 7; ++j) issue_instr(s, j);
-                advance_cursor();
-                if constexpr (SPLIT) {
-#pragma unroll
-                    for (int rf = 0; rf < RF; ++rf) {
-#pragma unroll
-                        for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma<SPLIT>(wl[cf], ah[rf], acc[cf][rf]);
-                        ah[rf] = frag_a(s ^ 1, 0, rf);
-                    }
-#pragma unroll
-                    for (int cf = 0; cf < CF; ++cf) {
-#pragma unroll
-                        for (int rf = 0; rf < RF; ++rf) acc[cf][rf] = mma<SPLIT>(wh[cf], al[rf], acc[cf][rf]);
-                        wh[cf] = frag_w(s ^ 1, 0, cf);
-                    }
-                } else {  // bf16: the second k-block of the stage; the next stage's first block replaces the dead fragments
-#pragma unroll
-                    for (int cf = 0; cf < CF; ++cf) wh[cf] = frag_w(s ^ 1, 0, cf);
-#pragma unroll
-                    for (int rf = 0; rf < RF; ++rf) ah[rf] = frag_a(s ^ 1, 0, rf);
-#pragma unroll
-                    for (int rf = 0; rf < RF; ++rf)
-#pragma unroll
-                        for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma<SPLIT>(wl[cf], al[rf], acc[cf][rf]);
-                }
+                    for (int cf = 0; cf < CF; ++cf) acc[cf][rf] = mma<SPLIT>(wl[cf], al[rf], acc[cf][rf]);
             }
+            cb = nb;
         }
+        const int last_buf = cb == 0 ? NST - 1 : cb - 1;  // buffer of the stage consumed last: free
 
         // ---- epilogue (lane id laundered: the addresses below must not be hoisted above the K loop)
         int lane_e = lane;
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
         int z, m0, n0;
         decode_tile(tile, z, m0, n0);
         const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias_z : nullptr;
-        char* cst = smem + OFF_CST;
+        char* cst = NST == 2 ? smem + OFF_CST : smem + last_buf * STAGE;
         constexpr int ROWB = BN * 4;            // bytes per staged fp32 row
         constexpr int LPR = BN / 8;             // lanes per row, 8 elements each (32 or 24)
         constexpr int RPP = THREADS / LPR;      // rows per pass (16 or 21)
@@ -342,6 +358,11 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
         // stores and loads share vmcnt but may retire out of order with respect to each other: drain before the counted
         // waits of the next tile rely on the count again
         wait_vm_lgkm<0>();
+        if (NST == 3) {  // the refill deferred above (every wave is past the last barrier of the staging region)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) issue_instr(last_buf, j);
+            advance_cursor();
+        }
     }
 }
 
@@ -358,15 +379,41 @@ static int device_cus() {
 
 }  // namespace psplit
 
-// which tile shape serves this problem, or 0: deconvolutions 192 x 256 (N % 256), everything else 256 x 192 (N % 192)
-static int panel_split_shape(const GemmParams& p) {
-    if (p.gather == G_DECONV) return p.N % 256 == 0 ? 1 : 0;
-    return p.N % 192 == 0 ? 2 : 0;
+// which tile shape serves this problem, or 0: 1 = 192 x 256 (deconvolutions, N % 256), 2 = 256 x 192 (N % 192);
+// three-stage forms (PP_PSPLIT_NST=3, dev): 3 = 128 x 256, 4 = 192 x 192
+static int psplit_nst() {  // 0 (default): by shape, see panel_split_shape; 2 / 3 force the two- / three-stage forms (dev)
+    static const int v = getenv("PP_PSPLIT_NST") ? atoi(getenv("PP_PSPLIT_NST")) : 0;
+    return v;
+}
+static int panel_split_shape(const GemmParams& p, int groups) {
+    const bool three = psplit_nst() == 3;
+    if (p.gather == G_DECONV) return p.N % 256 == 0 ? (three ? 3 : 1) : 0;
+    if (p.N % 192 != 0) return 0;
+    if (three) return 4;
+    // Linear layers: the persistent grid walks whole rounds of tiles (one per CU); the 192 x 192 three-stage form wins where
+    // it turns a ragged last round into full ones (qkv at bs 64: 576 tiles of 256 x 192 = 2.25 rounds -> 768 tiles of
+    // 192 x 192 = 3.0: 91 -> 79 us) and loses otherwise (fc1: 3 rounds either way but 12 % more fill per FLOP: 117 -> 125 us)
+    if (p.gather == G_LINEAR && psplit_nst() != 2) {
+        const long long cus = 256;
+        const long long t2 = (long long)(p.N / 192) * ((p.M + 255) / 256) * groups, t4 = (long long)(p.N / 192) * ((p.M + 191) / 192) * groups;
+        const long long c2 = ((t2 + cus - 1) / cus) * 256 * 192, c4 = ((t4 + cus - 1) / cus) * 192 * 192;
+        if (c4 * 10 < c2 * 9) return 4;
+    }
+    return 2;
 }
 
 static int panel_linear_min_k() {  // bf16 Linear layers shorter than this stay on the 128 x 128 kernel (dev: PP_PANEL_LINEAR_MINK)
     static const int v = getenv("PP_PANEL_LINEAR_MINK") ? atoi(getenv("PP_PANEL_LINEAR_MINK")) : 1536;
     return v;
+}
+static bool panel_bf16_conv() {  // dev: bf16 convolutions through this kernel instead of pp_panel_gemm.hip
+    static const bool v = getenv("PP_PSPLIT_BF16_CONV") && atoi(getenv("PP_PSPLIT_BF16_CONV")) != 0;
+    return v;
+}
+
+static void shape_dims(int shape, int& BM, int& BN) {
+    BM = shape == 1 ? 192 : shape == 2 ? 256 : shape == 3 ? 128 : 192;
+    BN = shape == 1 ? 256 : shape == 2 ? 192 : shape == 3 ? 256 : 192;
 }
 
 bool panel_split_supported(const GemmParams& p, int prec, int groups) {
@@ -376,16 +423,18 @@ bool panel_split_supported(const GemmParams& p, int prec, int groups) {
         if (p.K % 64 != 0 || p.Cin % 32 != 0 || p.ldc % 32 != 0 || p.lda % 32 != 0 || p.ldw % 32 != 0) return false;
         if (p.strideA_z % 32 != 0 || p.strideW_z % 32 != 0 || p.strideC_z % 32 != 0) return false;
     } else if (prec == PP_PREC_BF16) {  // convolutions have their own kernel (pp_panel_gemm.hip: fused head, split-K partials)
-        if (p.gather != G_LINEAR || p.K < panel_linear_min_k() || p.K % 128 != 0) return false;
+        if (p.gather == G_LINEAR ? (p.K < panel_linear_min_k()) : !panel_bf16_conv()) return false;
+        if (p.K % 128 != 0 || p.Cin % 64 != 0 || p.head_w) return false;
         if (p.out_bf16 != 0 && p.out_bf16 != 1) return false;
         if (p.ldc % 8 != 0 || p.lda % 8 != 0 || p.ldw % 8 != 0) return false;
     } else {
         return false;
     }
     if (p.residual && (p.out_bf16 == 2 || (p.ldres % 4) != 0)) return false;
-    const int shape = panel_split_shape(p);
+    const int shape = panel_split_shape(p, groups);
     if (!shape) return false;
-    const int BM = shape == 1 ? 192 : 256, BN = shape == 1 ? 256 : 192;
+    int BM, BN;
+    shape_dims(shape, BM, BN);
     const long long ntiles = (long long)(p.N / BN) * ((p.M + BM - 1) / BM) * groups;
     return ntiles >= 192;  // one workgroup per CU: with fewer tiles the 128 x 128 kernel spreads the work better
 }
@@ -398,23 +447,25 @@ int panel_split_gemm(const GemmParams& p_in, int prec, int groups, hipStream_t s
     PP_REQUIRE(p.a_bytes > 0 && p.w_bytes > 0 && p.a_bytes < OOB && p.w_bytes < OOB, PP_ERR_UNSUPPORTED,
                "pp panel split gemm: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     void (*kern)(const GemmParams) = nullptr;
-    int BM = 256, BN = 192;
-    if (prec == PP_PREC_BF16) {
-        kern = panel_split_kernel<G_LINEAR, 8, 3, false>;
-    } else {
-        switch (p.gather) {
-            case G_DECONV: kern = panel_split_kernel<G_DECONV, 6, 4, true>; BM = 192; BN = 256; break;
-            case G_CONV3: kern = panel_split_kernel<G_CONV3, 8, 3, true>; break;
-            default: kern = panel_split_kernel<G_LINEAR, 8, 3, true>; break;
-        }
+    const int shape = panel_split_shape(p, groups);
+    int BM, BN;
+    shape_dims(shape, BM, BN);
+    const bool sp = prec != PP_PREC_BF16;
+#define PP_PS(G, RF, CF, NST) (sp ? panel_split_kernel<G, RF, CF, true, NST> : panel_split_kernel<G, RF, CF, false, NST>)
+    switch (p.gather) {
+        case G_DECONV: kern = shape == 3 ? PP_PS(G_DECONV, 4, 4, 3) : PP_PS(G_DECONV, 6, 4, 2); break;
+        case G_CONV3: kern = shape == 4 ? PP_PS(G_CONV3, 6, 3, 3) : PP_PS(G_CONV3, 8, 3, 2); break;
+        default: kern = shape == 4 ? PP_PS(G_LINEAR, 6, 3, 3) : PP_PS(G_LINEAR, 8, 3, 2); break;
     }
+#undef PP_PS
+    const int lds = lds_bytes(BM, BN, shape >= 3 ? 3 : 2);
     const long long ntiles = (long long)(p.N / BN) * ((p.M + BM - 1) / BM) * groups;
     PP_REQUIRE(ntiles < (1ll << 30), PP_ERR_UNSUPPORTED, "pp panel split gemm: too many output tiles");
     int slots = device_cus();
     slots -= slots % 8;
     const int grid = (int)(ntiles < slots ? ntiles : slots);
-    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS, s, p);
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, s, p);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
