@@ -53,6 +53,32 @@ def test_oracle_warp_identity_and_shift():
     assert np.array_equal(half[:, 1:], exp.astype(np.uint8))
 
 
+def test_oracle_warp_tracks_scipy_bilinear():
+    """cv2 is absent, so the fixed-point restatement cannot be pinned to it. Independent cross-check: scipy's float
+    bilinear resampling (`ndimage.map_coordinates(order=1)`) at the same source coordinates of a rotated + scaled UDP-like
+    warp. cv2 quantises the interpolation weights to 1/32 px (INTER_BITS = 5), so the two may differ by the image gradient
+    x 1/64 px plus rounding - bounded here by 2 grey levels + |gradient| / 32 on a smooth image, inside the valid region."""
+    from scipy import ndimage
+
+    from oracle import warp_ref
+
+    yy, xx = np.mgrid[0:120, 0:160].astype(np.float64)
+    img = (127 + 80 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 30 * np.sin((xx + yy) / 23.0)).round().astype(np.uint8)[..., None]
+    th, sc = 0.3, 1.37
+    m = np.array([[sc * np.cos(th), -sc * np.sin(th), 10.2], [sc * np.sin(th), sc * np.cos(th), -3.7]], np.float32)  # src -> dst
+    out = warp_ref.warp_affine_u8(img, m, (96, 128))[..., 0].astype(np.float64)
+    inv = warp_ref.invert_affine(m)
+    oy, ox = np.mgrid[0:128, 0:96].astype(np.float64)
+    sx, sy = inv[0, 0] * ox + inv[0, 1] * oy + inv[0, 2], inv[1, 0] * ox + inv[1, 1] * oy + inv[1, 2]
+    ref = ndimage.map_coordinates(img[..., 0].astype(np.float64), [sy, sx], order=1, mode="constant", cval=0.0)
+    valid = (sx > 1) & (sx < 158) & (sy > 1) & (sy < 118)
+    gy, gx = np.gradient(img[..., 0].astype(np.float64))
+    g = ndimage.map_coordinates(np.hypot(gx, gy), [sy, sx], order=1, mode="nearest")
+    assert valid.mean() > 0.5
+    assert (np.abs(out - ref)[valid] <= 2.0 + g[valid] / 32.0 * 2.0).all(), float(np.abs(out - ref)[valid].max())
+    assert np.abs(out - ref)[valid].mean() < 0.5
+
+
 @pytest.mark.gpu
 def test_hip_warp_bit_exact_vs_oracle():
     import torch
