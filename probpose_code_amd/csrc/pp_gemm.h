@@ -40,6 +40,10 @@ int gemm(const GemmParams& p, int prec, int groups, hipStream_t s);
 bool panel_gemm_supported(const GemmParams& p, int prec, int groups);
 int panel_gemm(const GemmParams& p, int groups, hipStream_t s);
 
+// pp_conv_halo.hip: 3x3 convolution on 192-pixel images with the activations staged once per channel chunk (bf16)
+bool conv_halo_supported(const GemmParams& p, int prec, int groups);
+int conv_halo(const GemmParams& p, int groups, hipStream_t s);
+
 // pp_panel_split.hip: the same wide tiles for PP_PREC_F16X3 (split-fp16 operands): Linear layers (N % 192 == 0), conv 3x3,
 // deconvolutions; output split fp16 or fp32 rows (+ fp32 residual); and for the long-K bf16 Linear layers (K >= 1536)
 bool panel_split_supported(const GemmParams& p, int prec, int groups);

@@ -549,6 +549,7 @@ extern "C" int pp_conv_gemm(int prec, int kind, const void* act_nhwc, const void
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     p.strideA_z = stride_act_g; p.strideW_z = stride_w_g; p.strideC_z = stride_out_g; p.strideBias_z = stride_bias_g;
     if (panel_enabled() && panel_split_supported(p, prec, groups)) return panel_split_gemm(p, prec, groups, reinterpret_cast<hipStream_t>(stream));
+    if (panel_enabled() && conv_halo_supported(p, prec, groups)) return conv_halo(p, groups, reinterpret_cast<hipStream_t>(stream));
     if (panel_enabled() && panel_gemm_supported(p, prec, groups)) return panel_gemm(p, groups, reinterpret_cast<hipStream_t>(stream));
     return gemm(p, prec, groups, reinterpret_cast<hipStream_t>(stream));
 }

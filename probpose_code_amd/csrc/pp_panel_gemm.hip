@@ -39,7 +39,8 @@ namespace panel {
 #define PANEL_DBG 0
 #endif
 // dev ablation switches (scripts/micro/panel_ablate.sh), 0 in the product build: 1 DMA out of bounds (no traffic),
-// 4 no MFMA, 8 no DMA, 16 no LDS fragment reads
+// 4 no MFMA, 8 no DMA, 16 no LDS fragment reads, 32 activation DMA out of bounds only, 64 weight DMA out of bounds only,
+// 256 clock probe
 constexpr int DBG = PANEL_DBG;
 #ifndef PANEL_KROT
 #define PANEL_KROT 0  // dev A/B switch. Measured: rotation ON is 2 - 12 % SLOWER here (conv1 274 -> 283 us, deconv1 83 -> 92) - unlike the layer kernel, these
@@ -168,11 +169,11 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
             const int yy = (a_yx[j < JA ? j : 0] >> 16) + dy, xx = (a_yx[j < JA ? j : 0] & 0xffff) + dx;
             const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
             const int tap_off = ((dy * p.Wd + dx) * p.Cin + i_c0) * 2;
-            const unsigned va = (ok && !(DBG & 1)) ? (unsigned)((int)a_voff[j < JA ? j : 0] + tap_off) : OOB;
+            const unsigned va = (ok && !(DBG & (1 | 32))) ? (unsigned)((int)a_voff[j < JA ? j : 0] + tap_off) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)dst, 16, va, 0, 0, 0);
         } else {
             const unsigned kb = (unsigned)((i_tap * p.Cin + i_c0) * 2) + (unsigned)((j - JA) * 64) * (unsigned)(p.ldw * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, (i_live && !(DBG & 1)) ? w_voff + kb : OOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, (i_live && !(DBG & (1 | 64))) ? w_voff + kb : OOB, 0, 0, 0);
         }
     };
     auto advance_cursor = [&]() {
@@ -206,6 +207,11 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
     };
 
     if ((int)blockIdx.x >= ntiles) return;
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
+    if (DBG & 256) {  // dev: shader-clock cycles against the 100 MHz reference over the launch -> the clock the kernel ran at
+        dbg_t0 = __builtin_readcyclecounter();
+        dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    }
 
     // ---- prologue: both stages in flight, the first half of the first one into registers
     setup_issue_tile();
@@ -387,6 +393,11 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         // Stores and loads both count in vmcnt but may retire out of order with respect to each other: drain them
         // before the counted waits of the next tile rely on the count again.
         wait_vm_lgkm<0>();
+    }
+    if ((DBG & 256) && blockIdx.x == 0 && tid == 0) {  // (first 16 bytes of the output)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.C);
+        o[0] = __builtin_readcyclecounter() - dbg_t0;
+        o[1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
     }
 }
 

@@ -37,4 +37,8 @@ for name, kind, H, W, Cin, Cout, G in cases:
     for _ in range(20): call(*args)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
-    print(f"{name:18s} {ms*1e3:8.1f} us  {flops/ms/1e9:7.0f} TF")
+    extra = ""
+    if os.environ.get("CLOCK_PROBE") and (kind == 1 or os.environ["CLOCK_PROBE"] == "all"):  # library built with HALO_DBG & 256
+        t = out.view(torch.int64).flatten()[:2].tolist()
+        extra = f"  shader clock {t[0] / max(t[1], 1) * 100:.0f} MHz over {t[1] / 100:.1f} us"
+    print(f"{name:18s} {ms*1e3:8.1f} us  {flops/ms/1e9:7.0f} TF{extra}")

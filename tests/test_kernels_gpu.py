@@ -168,6 +168,34 @@ def test_panel_conv3x3_groups_vs_torch():
     torch.testing.assert_close(out.cpu().double().permute(0, 1, 4, 2, 3), ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("B,act", [(33, 2), (64, 0)])
+def test_halo_conv3x3_groups_vs_torch(B, act):
+    """Halo-staged 3x3 convolution (pp_conv_halo.hip: 16 x 12 images, two images x 128 channels per tile, activations
+    staged once per 64-channel chunk): four towers on a shared input, bias, ReLU or none; B = 33 leaves the second image
+    of the last tile past the batch. Border pixels (every tap that leaves the image) are the point of the check."""
+    L = _lib()
+    G, H, W, C = 4, 16, 12, 384          # 3 column tiles x 17 / 32 image pairs x 4 groups >= 192 tiles
+    x = _rand(B, C, H, W, seed=134)
+    w = _rand(G, C, C, 3, 3, seed=135, scale=1 / math.sqrt(9 * C))
+    b = _rand(G, C, seed=136)
+    xq, wq = x.bfloat16().float(), w.bfloat16().float()
+    ref = torch.stack([F.conv2d(xq, wq[g], b[g], padding=1) for g in range(G)]).double()
+    if act == 2:
+        ref = ref.clamp_min(0)
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    wd = w.permute(0, 1, 3, 4, 2).reshape(G, C, 9 * C).contiguous().bfloat16().cuda()
+    out = torch.full((G, B + 1, H, W, C), float("nan"), dtype=torch.bfloat16, device="cuda")  # one guard image per group
+    bd = b.cuda()
+    L.call("pp_conv_gemm", BF16, 1, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, C, C,
+           0, 0, G, 0, C * 9 * C, (B + 1) * H * W * C, C, C, act, 1, None)
+    got = out.cpu()
+    assert torch.isnan(got[:, B].float()).all(), "rows past the batch were written"
+    torch.testing.assert_close(got[:, :B].double().permute(0, 1, 4, 2, 3), ref, rtol=2e-2, atol=2e-2)
+    # tighter, against the implicit-GEMM arithmetic: same bf16 products, fp32 accumulation in another order
+    err = (got[:, :B].double().permute(0, 1, 4, 2, 3) - ref).abs().max().item()
+    assert err < 1.6e-2, err
+
+
 @pytest.mark.parametrize("prec,hd,S", [(F32, 32, 192), (BF16, 32, 192), (BF16, 64, 192), (F32, 64, 192), (BF16, 64, 432), (BF16, 32, 432),
                                        (F32, 32, 432)])
 def test_attention_vs_torch(prec, hd, S):
