@@ -198,6 +198,24 @@ def pmc_traffic(kernel_mangled, precision, B):
     return None, None
 
 
+def sustained_mfma_rate():
+    """What the MFMA pipes sustain on realistic operands, measured (scripts/micro/mfma_power.hip, committed output): the
+    chip is power-limited there - N(0,1) bf16 fragments re-read from LDS, no other traffic, run the 16x16x32 MFMA stream at
+    ~1.78 PFLOP/s with the shader clock at ~1.9 GHz (all-zero operands: 2.33 PFLOP/s at 2.39 GHz). Instruction rate, so an
+    f16x3 product counts three times."""
+    path = os.path.join(ROOT, "profiles", "r02_mfma_power.txt")
+    try:
+        for line in open(path):
+            if line.startswith("LDS-fed") and "N(0,1)" in line:
+                tok = line.split()
+                return {"TFLOPs": float(tok[tok.index("TFLOP/s") - 1]), "shader_clock_MHz": float(tok[tok.index("MHz") - 1]),
+                        "source": "profiles/r02_mfma_power.txt (register double-buffered MFMA stream, 10 ds_read_b128 per 24 MFMAs, "
+                                  "N(0,1) bf16 operands, 256 CUs x 8 waves; power-limited clock)"}
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def roofline_record(eng, B, prof, reps):
     """`roofline` of the kernel tag with the largest time per step in the instrumented pass."""
     per_tag = {k: (float(np.sum(v)) / reps, len(v) // reps) for k, v in prof.items()}  # ms per step, launches per step
@@ -235,6 +253,9 @@ def roofline_record(eng, B, prof, reps):
         "mfma_view": mfma_view, "hbm_view": hbm_view,
     }
     if bound == "mfma":
+        power = sustained_mfma_rate()
+        if power:
+            rec["sustained_mfma_rate"] = dict(power, frac_of_sustained=mfma_view["achieved_TFLOPs"] * MFMA_PER_PRODUCT[prec] / power["TFLOPs"])
         # the ceiling this kernel's arithmetic format can reach: the MFMA pipe issues MFMA_PER_PRODUCT instructions per
         # algorithmic product, and sustains ~1.93 PF of the 2.5 PF datasheet peak under load (the clock drops to ~1.85 GHz)
         rec["derived_ceiling"] = {"TFLOPs": ceil, "why": f"{MFMA_PER_PRODUCT[prec]} MFMA per algorithmic product on the {peak:.0f} TF pipe",

@@ -1,7 +1,9 @@
 // Microbenchmark (dev only): what the MFMA pipes sustain on REGISTER-RESIDENT operands - no LDS, no memory traffic in
 // the loop - as a function of the operand data, and the shader clock the chip holds meanwhile (s_memtime cycles
 // against the 100 MHz s_memrealtime). 256 workgroups x 8 waves (two per SIMD), each wave 24 independent accumulators,
-// 4 + 6 operand fragments loaded once. Data: zeros, constant, N(0,1) bf16 (what the convolutions see).
+// 4 + 6 operand fragments loaded once. Data: zeros, constant, N(0,1) bf16 (what the convolutions see). The clock is taken
+// over wave 0's loop only: the SIMD arbiter favours the older of its two waves (wave 0 gets ~3/4 of the MFMA slots and is
+// done after 60 % of the launch), so the TFLOP/s figure comes from the launch time, the MHz figure from that window.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -41,16 +43,53 @@ __global__ __launch_bounds__(512, 2) void k(const u32x4* src, int iters, float* 
     sink[blockIdx.x * 512 + tid] = s;
     if (blockIdx.x == 0 && tid == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
     if (blockIdx.x == 0 && tid == 0) { span[0] = r0; span[1] = r1; }
-    if (tid == 0) {  // per-block window and placement
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        clk[2 + blockIdx.x * 4 + 0] = r0;
-        clk[2 + blockIdx.x * 4 + 1] = r1;
-        clk[2 + blockIdx.x * 4 + 2] = hw;
-        clk[2 + blockIdx.x * 4 + 3] = xcc;
+}
+
+// the same MFMA stream with its operands re-read from LDS at the convolution kernels' ratio (10 ds_read_b128 per 24 MFMAs,
+// register double-buffered), still no global traffic in the loop: what the fragment reads cost in clock
+__global__ __launch_bounds__(512, 2) void k_lds(const u32x4* src, int iters, float* sink, unsigned long long* clk, unsigned long long* span) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 8192; i += 512) reinterpret_cast<u32x4*>(smem)[i] = src[i % 4096];  // 128 KiB
+    __syncthreads();
+    const int f_row = lane & 15, f_kg = lane >> 4;
+    const char* base = smem + (wv >> 2) * 12288 + f_row * 128 + ((f_kg ^ (f_row & 7)) << 4);
+    const char* wbase = smem + 65536 + (wv & 3) * 8192 + f_row * 128 + ((f_kg ^ (f_row & 7)) << 4);
+    f32x4 acc[4][6];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 a[2][6], b[2][4];
+    for (int j = 0; j < 6; ++j) a[0][j] = *reinterpret_cast<const u32x4*>(base + j * 2048);
+    for (int i = 0; i < 4; ++i) b[0][i] = *reinterpret_cast<const u32x4*>(wbase + i * 2048);
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = ((it + s + 1) & 3) * 64;  // the other K half / stage: addresses change every step
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[s ^ 1][i] = *reinterpret_cast<const u32x4*>(wbase + ((i * 2048 + off) ^ ((it & 4) << 10)));
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a[s ^ 1][j] = *reinterpret_cast<const u32x4*>(base + ((j * 2048 + off) ^ ((it & 4) << 12)));
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[s][i]), __builtin_bit_cast(bf16x8, a[s][j]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (q < 9) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
     }
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sm = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 6; ++j) sm += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    sink[blockIdx.x * 512 + tid] = sm;
+    if (blockIdx.x == 0 && tid == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; span[0] = r0; span[1] = r1; }
 }
 
 static uint16_t bf16_of(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
@@ -81,26 +120,25 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
         unsigned long long c[2]; hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost);
         const double flop = (double)grid * 8 * 24 * iters * 16384.0;
-        printf("%-48s %8.1f us  %7.0f TFLOP/s  shader clock %4.0f MHz  (MFMA issue %.1f %% of the cycles)\n", names[mode], ms * 1e3, flop / ms / 1e9,
-               (double)c[0] / c[1] * 100.0, 100.0 * 2 * 24 * iters * 16.0 / c[0]);
-        if (mode == 2) {
-            std::vector<unsigned long long> b(2 + 1024);
-            hipMemcpy(b.data(), clk, 16 + 256 * 32, hipMemcpyDeviceToHost);
-            unsigned long long lo = ~0ull, hi = 0;
-            for (int i = 0; i < grid; ++i) { lo = b[2 + 4 * i] < lo ? b[2 + 4 * i] : lo; hi = b[3 + 4 * i] > hi ? b[3 + 4 * i] : hi; }
-            printf("      launch window %llu ticks; blocks: ", hi - lo);
-            for (int i = 0; i < grid; i += 17) printf("[%d: +%llu..+%llu xcc %llu cu %llu se %llu] ", i, b[2 + 4 * i] - lo, b[3 + 4 * i] - lo, b[5 + 4 * i] & 15, (b[4 + 4 * i] >> 8) & 15, (b[4 + 4 * i] >> 13) & 7);
-            printf("\n");
+        printf("%-48s %8.1f us  %7.0f TFLOP/s  shader clock %4.0f MHz\n", names[mode], ms * 1e3, flop / ms / 1e9, (double)c[0] / c[1] * 100.0);
+    }
+    hipFuncSetAttribute((const void*)k_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    for (int mode = 0; mode < 3; mode += 2) {
+        srand(1);
+        for (int i = 0; i < n16; ++i) {
+            float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = (rand() + 1.0f) / (RAND_MAX + 2.0f);
+            h[i] = mode == 0 ? 0 : bf16_of(sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2));
         }
-        {
-            unsigned long long sp[20];
-            hipMemcpy(sp, span, 160, hipMemcpyDeviceToHost);
-            printf("      block 0 of the ten launches (100 MHz ticks): ");
-            for (int w = 0; w < 10; ++w) printf("run %llu%s", sp[2 * w + 1] - sp[2 * w], w < 9 ? ", gap " : "\n");
-            for (int w = 0; w + 1 < 10; ++w) printf("%llu ", sp[2 * w + 2] - sp[2 * w + 1]);
-            printf("(gaps)\n");
-        }
-        printf("      raw: %llu cycles, %llu realtime ticks (block 0)\n", c[0], c[1]);
+        hipMemcpy(d, h.data(), n16 * 2, hipMemcpyHostToDevice);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k_lds, dim3(grid), dim3(512), 131072, 0, d, iters, sink, clk, span);
+        hipEventRecord(e0);
+        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(k_lds, dim3(grid), dim3(512), 131072, 0, d, iters, sink, clk, span);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+        unsigned long long c[2]; hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost);
+        printf("LDS-fed (10 ds_read_b128 per 24 MFMAs), %-12s %8.1f us  %7.0f TFLOP/s  shader clock %4.0f MHz\n", mode == 0 ? "zeros" : "N(0,1) bf16", ms * 1e3,
+               (double)grid * 8 * 24 * iters * 16384.0 / ms / 1e9, (double)c[0] / c[1] * 100.0);
     }
     return 0;
 }
