@@ -402,9 +402,12 @@ static int panel_split_shape(const GemmParams& p, int groups) {
     return 2;
 }
 
-static int panel_linear_min_k() {  // bf16 Linear layers shorter than this stay on the 128 x 128 kernel (dev: PP_PANEL_LINEAR_MINK)
-    static const int v = getenv("PP_PANEL_LINEAR_MINK") ? atoi(getenv("PP_PANEL_LINEAR_MINK")) : 1536;
-    return v;
+// bf16 Linear layers shorter than this stay on the 128 x 128 kernel, whose co-resident workgroups overlap one tile's epilogue
+// with another's main loop (dev: PP_PANEL_LINEAR_MINK). Measured on ViT-B at bs 64 (scripts/bench_base.py): K = 768 with bf16
+// output (qkv, fc1) 8.66 ms on the 128 x 128 kernel vs 9.83 ms here; K = 768 with fp32 output + residual (proj) 6.65 vs 6.28 ms
+static int panel_linear_min_k(bool out_bf16) {
+    static const int v = getenv("PP_PANEL_LINEAR_MINK") ? atoi(getenv("PP_PANEL_LINEAR_MINK")) : 0;
+    return v > 0 ? v : (out_bf16 ? 1536 : 768);
 }
 static bool panel_bf16_conv() {  // dev: bf16 convolutions through this kernel instead of pp_panel_gemm.hip
     static const bool v = getenv("PP_PSPLIT_BF16_CONV") && atoi(getenv("PP_PSPLIT_BF16_CONV")) != 0;
@@ -423,7 +426,7 @@ bool panel_split_supported(const GemmParams& p, int prec, int groups) {
         if (p.K % 64 != 0 || p.Cin % 32 != 0 || p.ldc % 32 != 0 || p.lda % 32 != 0 || p.ldw % 32 != 0) return false;
         if (p.strideA_z % 32 != 0 || p.strideW_z % 32 != 0 || p.strideC_z % 32 != 0) return false;
     } else if (prec == PP_PREC_BF16) {  // convolutions have their own kernel (pp_panel_gemm.hip: fused head, split-K partials)
-        if (p.gather == G_LINEAR ? (p.K < panel_linear_min_k()) : !panel_bf16_conv()) return false;
+        if (p.gather == G_LINEAR ? (p.K < panel_linear_min_k(p.out_bf16 != 0)) : !panel_bf16_conv()) return false;
         if (p.K % 128 != 0 || p.Cin % 64 != 0 || p.head_w) return false;
         if (p.out_bf16 != 0 && p.out_bf16 != 1) return false;
         if (p.ldc % 8 != 0 || p.lda % 8 != 0 || p.ldw % 8 != 0) return false;
