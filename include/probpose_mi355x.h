@@ -220,6 +220,15 @@ int pp_layernorm(const float* x, const float* gamma, const float* beta, void* y,
 int pp_maxpool_relu_nhwc(const void* in, int in_bf16, void* out, int out_bf16, int N, int H, int W, int C,
                          int ph, int pw, void* stream);
 
+/* First stage of the four scalar towers in one launch: Conv2d(Cin->Cout, k3, p1) + folded BN -> MaxPool2d(ph, pw) -> ReLU
+ * (probmap_head.py:261-278), i.e. PP_CONV3X3 of pp_conv_gemm followed by pp_maxpool_relu_nhwc with the full-resolution
+ * tensor never stored: out_pooled (groups, B, H/ph, W/pw, Cout). One launch for bf16 operands on 16x12 feature maps with
+ * (4, 3) windows (the halo-staged kernel holds whole images per tile); every other shape / precision runs the two entry points
+ * through scratch_full (groups, B, H, W, Cout), which may be NULL only when the fused form applies. fmt: PP_OUT_*. */
+int pp_conv3x3_maxpool_relu(int prec, const void* act_nhwc, const void* weight, const float* bias, void* out_pooled,
+                            void* scratch_full, int B, int H, int W, int Cin, int Cout, int ph, int pw, int groups,
+                            long long stride_act_g, long long stride_w_g, long long stride_bias_g, int fmt, void* stream);
+
 /* A whole ViT-S encoder layer in one launch (bf16 operands), from the qkv of this layer to the qkv of the next:
  *   a     = softmax(q k^T * scale) v per head                  (mmpretrain MultiheadAttention [3P], as pp_attention)
  *   x1    = residual + a Wp^T + bp ;          h  = LayerNorm(x1; gamma2, beta2, eps)

@@ -102,6 +102,7 @@ SIGNATURES = {
     "pp_preproc_im2col": (c_int, [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "pp_layernorm": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_int, _P]),
     "pp_maxpool_relu_nhwc": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pp_conv3x3_maxpool_relu": (c_int, [c_int, _P, _P, _P, _P, _P] + [c_int] * 8 + [c_longlong] * 3 + [c_int, _P]),
     "pp_tower_final": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
 }
 

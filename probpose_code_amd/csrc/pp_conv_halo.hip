@@ -68,6 +68,9 @@ __device__ __forceinline__ void wait_vm_lgkm() {
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
 }
 
+// POOL: the towers' MaxPool2d(kernel = stride = (pool_h, pool_w)) + ReLU (probmap_head.py:264,277-278) applied to the staged image in the
+// epilogue - a tile holds whole images, so the pooling windows never leave it; C is then the pooled tensor (N, H / ph, W / pw, Cout)
+template <bool POOL>
 __global__ __launch_bounds__(THREADS, 2) void conv3_halo_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -314,12 +317,40 @@ __global__ __launch_bounds__(THREADS, 2) void conv3_halo_kernel(const GemmParams
             wait_vm_lgkm<63>();  // LDS writes only: the DMA of the next tile stays in flight
             __builtin_amdgcn_s_barrier();
             const int cl = tid_e % LPR, rl = tid_e / LPR;
+            if (POOL) {
+                // one thread per (pooled pixel, 4 channels): max over the window's staged rows (bf16 -> fp32 is exact and the
+                // rounding to bf16 was monotonic, so this equals pooling the stored tensor), then ReLU
+                // (16 x 12 image, 4 x 3 windows - compile-time here: run-time divisors cost the K loop its registers)
+                constexpr int PH = 4, PWD = 3, IW = 12, Ho = 4, Wo = 4;
+                const int img = (m0 + h * (BM / 2)) / IMG_PIX;
+                const int c8 = tid_e & 31, pr = tid_e >> 5;  // 8-byte piece of the 256-byte row, pooled pixel
+                if (img * IMG_PIX < p.M) {
+                    const int yo = pr >> 2, xo = pr & 3;
+                    float mx[4] = {0.f, 0.f, 0.f, 0.f};  // ReLU folded into the start value
+#pragma unroll
+                    for (int i = 0; i < PH; ++i)
+#pragma unroll
+                        for (int j = 0; j < PWD; ++j) {
+                            const int ml = (yo * PH + i) * IW + xo * PWD + j;
+                            const uint2 raw = *reinterpret_cast<const uint2*>(cst + ml * ROWB + (((c8 >> 1) ^ (ml & 7)) << 4) + (c8 & 1) * 8);
+                            mx[0] = fmaxf(mx[0], __builtin_bit_cast(float, raw.x << 16));
+                            mx[1] = fmaxf(mx[1], __builtin_bit_cast(float, raw.x & 0xffff0000u));
+                            mx[2] = fmaxf(mx[2], __builtin_bit_cast(float, raw.y << 16));
+                            mx[3] = fmaxf(mx[3], __builtin_bit_cast(float, raw.y & 0xffff0000u));
+                        }
+                    uint2 o;
+                    o.x = (__builtin_bit_cast(unsigned, mx[0]) >> 16) | (__builtin_bit_cast(unsigned, mx[1]) & 0xffff0000u);
+                    o.y = (__builtin_bit_cast(unsigned, mx[2]) >> 16) | (__builtin_bit_cast(unsigned, mx[3]) & 0xffff0000u);
+                    *reinterpret_cast<uint2*>(Cb + ((size_t)img * (Ho * Wo) + pr) * p.ldc + n0 + c8 * 4) = o;
+                }
+            } else {
             for (int r0 = 0; r0 < BM / 2; r0 += RPP) {
                 const int ml = r0 + rl;
                 const int m = m0 + h * (BM / 2) + ml;
                 if (m >= p.M) continue;
                 const u32x4 raw = *reinterpret_cast<const u32x4*>(cst + ml * ROWB + ((cl ^ (ml & 7)) << 4));
                 *reinterpret_cast<u32x4*>(Cb + (size_t)m * p.ldc + n0 + cl * 8) = raw;
+            }
             }
             wait_vm_lgkm<63>();
             __builtin_amdgcn_s_barrier();  // the staging buffer is reused by the other image / the next chunk's DMA
@@ -363,6 +394,7 @@ bool conv_halo_supported(const GemmParams& p, int prec, int groups) {
     if (p.ksplit > 1 || (p.act != ACT_NONE && p.act != ACT_RELU)) return false;
     if (p.H * p.Wd != IMG_PIX || (p.H + 2) * (p.Wd + 2) != HALO_ROWS || p.M % IMG_PIX != 0) return false;
     if (p.Cin % 128 != 0 || p.K != 9 * p.Cin || p.N % BN != 0 || p.ldc % 8 != 0) return false;
+    if (p.pool_h > 0 && (p.pool_h != 4 || p.pool_w != 3 || p.H != 16 || p.Wd != 12 || p.act != ACT_NONE)) return false;  // the pooled epilogue is built for this geometry
     const long long ntiles = (long long)(p.N / BN) * ((p.M + BM - 1) / BM) * groups;
     return ntiles >= 192;  // one workgroup per CU: below that the 128 x 128 kernel spreads the work better
 }
@@ -378,10 +410,46 @@ int conv_halo(const GemmParams& p_in, int groups, hipStream_t s) {
     int slots = device_cus();
     slots -= slots % 8;
     const int grid = (int)(ntiles < slots ? ntiles : slots);
-    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    hipLaunchKernelGGL(conv3_halo_kernel, dim3(grid), dim3(THREADS), LDS, s, p);
+    void (*kern)(const GemmParams) = p.pool_h > 0 ? conv3_halo_kernel<true> : conv3_halo_kernel<false>;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS, s, p);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
 
 }  // namespace pp
+
+// Conv2d 3x3 (+ folded BN bias) -> MaxPool2d(ph, pw) -> ReLU of the first tower stage in one launch where the halo kernel
+// covers the shape; otherwise the two separate entry points through `scratch_full`.
+extern "C" int pp_conv3x3_maxpool_relu(int prec, const void* act_nhwc, const void* weight, const float* bias, void* out_pooled,
+                                       void* scratch_full, int B, int H, int W, int Cin, int Cout, int ph, int pw, int groups,
+                                       long long stride_act_g, long long stride_w_g, long long stride_bias_g, int fmt, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(act_nhwc && weight && out_pooled, PP_ERR_INVALID_ARG, "pp_conv3x3_maxpool_relu: act, weight and out must be non-NULL");
+    PP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && groups >= 1 && ph > 0 && pw > 0, PP_ERR_INVALID_ARG,
+               "pp_conv3x3_maxpool_relu: bad shape");
+    PP_REQUIRE(H % ph == 0 && W % pw == 0, PP_ERR_UNSUPPORTED, "pp_conv3x3_maxpool_relu: the pooling windows must tile the image");
+    const int Ho = H / ph, Wo = W / pw;
+    if (prec == PP_PREC_BF16 && fmt == PP_OUT_BF16) {
+        GemmParams p{};
+        p.A = act_nhwc; p.W = weight; p.C = out_pooled; p.bias = bias;
+        p.M = B * H * W; p.N = Cout; p.K = 9 * Cin;
+        p.lda = Cin; p.ldw = p.K; p.ldc = Cout; p.ldres = Cout;
+        p.H = H; p.Wd = W; p.Cin = Cin;
+        p.act = ACT_NONE; p.out_bf16 = 1; p.gather = G_CONV3;
+        p.pool_h = ph; p.pool_w = pw;
+        const size_t ab = (size_t)B * H * W * Cin * 2, wb = (size_t)Cout * p.K * 2;
+        if (ab < 0x70000000u && wb < 0x70000000u) {
+            p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+            p.strideA_z = stride_act_g; p.strideW_z = stride_w_g; p.strideBias_z = stride_bias_g;
+            p.strideC_z = (long long)B * Ho * Wo * Cout;
+            if (conv_halo_supported(p, prec, groups)) return conv_halo(p, groups, reinterpret_cast<hipStream_t>(stream));
+        }
+    }
+    PP_REQUIRE(scratch_full, PP_ERR_UNSUPPORTED,
+               "pp_conv3x3_maxpool_relu: this shape / precision takes the two-launch path and needs scratch_full (groups, B, H, W, Cout)");
+    const int st = pp_conv_gemm(prec, PP_CONV3X3, act_nhwc, weight, bias, scratch_full, B, H, W, Cin, Cout, 0, 0, groups, stride_act_g,
+                                stride_w_g, (long long)B * H * W * Cout, stride_bias_g, Cout, PP_ACT_NONE, fmt, stream);
+    if (st != PP_OK) return st;
+    return pp_maxpool_relu_nhwc(scratch_full, fmt, out_pooled, fmt, groups * B, H, W, Cout, ph, pw, stream);
+}

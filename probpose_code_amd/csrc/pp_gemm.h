@@ -29,6 +29,7 @@ struct GemmParams {
     int ksplit;             // >1: split-K launch - `groups` counts (K slice, problem) pairs, z = slice * (groups / ksplit) + problem;
                             // K is the length of one slice, ldw the full row; conv gathers start at tap slice * K / Cin
     int groups;             // independent problems in one launch (the four towers); tiles of all groups share the persistent grid
+    int pool_h, pool_w;     // pp_conv_halo.hip only, > 0: C is the MaxPool2d(pool_h, pool_w) + ReLU of the convolution, (N, H / pool_h, W / pool_w, Cout)
     int planar_P;           // >0: store planar, out[((m / P) * N + n) * P + m % P]  (NHWC rows -> (B, N, P) planes)
     unsigned a_bytes, w_bytes;  // extent of the activation / weight tensor of ONE group (buffer-descriptor bound)
     long long strideA_z, strideW_z, strideC_z, strideBias_z;  // grouped launch (blockIdx.z), in elements

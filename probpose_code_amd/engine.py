@@ -84,6 +84,7 @@ class ProbPoseEngine:
         # (DESIGN.md 4); PP_FUSE_ATTN=0 switches back to two launches per layer
         self.fuse_attn = os.environ.get("PP_FUSE_ATTN", "1") != "0"
         self.fuse_head = os.environ.get("PP_FUSE_HEAD", "1") != "0"
+        self.fuse_pool = os.environ.get("PP_FUSE_POOL", "1") != "0"  # first tower stage: conv + pool + ReLU in one launch
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
         self.stage_hook = None  # callable(name) invoked between stages of the launch plan ("embed", "layer<i>", "backbone"); dev / scheduling experiments
@@ -291,11 +292,18 @@ class ProbPoseEngine:
                 src = ws[f"p{j}"]
                 stride_src = nb * (th // ph) * (tw // pw_) * E
                 continue
-            self._call("conv3x3", "pp_conv_gemm", self.prec, CONV3X3, src.data_ptr(), w[f"tower{j}.w"].data_ptr(),
-                      w[f"tower{j}.b"].data_ptr(), out.data_ptr(), nb, th, tw, E, E, 0, 0, 4, stride_src,
-                      E * 9 * E, nb * th * tw * E, E, E, ACT_NONE, ob, st)
-            self._call("maxpool", "pp_maxpool_relu_nhwc", out.data_ptr(), ob, ws[f"p{j}"].data_ptr(), ob, 4 * nb, th, tw, E, ph,
-                      pw_, st)
+            if self.fuse_pool:
+                # conv + BN -> MaxPool -> ReLU in one launch where the halo-staged kernel holds whole images per tile (bf16,
+                # 16 x 12 maps); the C side takes the two-launch route through `out` for every other shape
+                self._call("conv3x3", "pp_conv3x3_maxpool_relu", self.prec, src.data_ptr(), w[f"tower{j}.w"].data_ptr(),
+                           w[f"tower{j}.b"].data_ptr(), ws[f"p{j}"].data_ptr(), out.data_ptr(), nb, th, tw, E, E, ph, pw_, 4,
+                           stride_src, E * 9 * E, E, ob, st)
+            else:
+                self._call("conv3x3", "pp_conv_gemm", self.prec, CONV3X3, src.data_ptr(), w[f"tower{j}.w"].data_ptr(),
+                           w[f"tower{j}.b"].data_ptr(), out.data_ptr(), nb, th, tw, E, E, 0, 0, 4, stride_src,
+                           E * 9 * E, nb * th * tw * E, E, E, ACT_NONE, ob, st)
+                self._call("maxpool", "pp_maxpool_relu_nhwc", out.data_ptr(), ob, ws[f"p{j}"].data_ptr(), ob, 4 * nb, th, tw, E, ph,
+                           pw_, st)
             src = ws[f"p{j}"]
             stride_src = nb * (th // ph) * (tw // pw_) * E
         fi = self._flip_indices(flip_indices) if passes == 2 else None

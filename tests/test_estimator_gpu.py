@@ -216,7 +216,7 @@ def test_config4_vit_base_384x288_bf16():
         assert np.abs(out["scalars"][i].cpu().numpy()[:, None] - ref[name]).max() <= 1e-3, name
 
 
-@pytest.mark.parametrize("switch", ["PP_FUSE_ATTN", "PP_FUSE_QKV", "PP_FUSE_PROJ", "PP_FUSE_MLP", "PP_SPLIT_K", "PP_FUSE_HEAD"])
+@pytest.mark.parametrize("switch", ["PP_FUSE_ATTN", "PP_FUSE_QKV", "PP_FUSE_PROJ", "PP_FUSE_MLP", "PP_SPLIT_K", "PP_FUSE_HEAD", "PP_FUSE_POOL"])
 def test_bf16_fallback_launch_plans_end_to_end(switch, monkeypatch):
     """Every PP_FUSE_* / PP_SPLIT_K switch selects a different launch plan for the bf16 mode (two launches per layer, the
     plain qkv GEMM, separate projection, unfused FFN, unsplit tower convolutions, separate final 1x1 conv): each plan, end

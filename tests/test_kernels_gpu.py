@@ -196,6 +196,37 @@ def test_halo_conv3x3_groups_vs_torch(B, act):
     assert err < 1.6e-2, err
 
 
+@pytest.mark.parametrize("B,H,W,ph,pw", [(33, 16, 12, 4, 3), (64, 16, 12, 4, 3), (40, 8, 6, 2, 2)])
+def test_conv3x3_maxpool_relu_vs_two_launches(B, H, W, ph, pw):
+    """pp_conv3x3_maxpool_relu (first tower stage: conv + folded BN -> MaxPool -> ReLU): the one-launch form on 16 x 12 maps
+    (pooling in the epilogue of the halo-staged kernel, odd batch = tail image) and the two-launch route through the
+    scratch tensor for another shape, both against torch and BIT-EXACT against pp_conv_gemm + pp_maxpool_relu_nhwc."""
+    L = _lib()
+    G, C = 4, 384
+    x = _rand(B, C, H, W, seed=234)
+    w = _rand(G, C, C, 3, 3, seed=235, scale=1 / math.sqrt(9 * C))
+    b = _rand(G, C, seed=236)
+    xq, wq = x.bfloat16().float(), w.bfloat16().float()
+    ref = torch.stack([F.max_pool2d(F.conv2d(xq, wq[g], b[g], padding=1), (ph, pw)).clamp_min(0) for g in range(G)]).double()
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    wd = w.permute(0, 1, 3, 4, 2).reshape(G, C, 9 * C).contiguous().bfloat16().cuda()
+    bd = b.cuda()
+    Ho, Wo = H // ph, W // pw
+    pooled = torch.full((G, B, Ho, Wo, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    scratch = torch.zeros((G, B, H, W, C), dtype=torch.bfloat16, device="cuda")
+    L.call("pp_conv3x3_maxpool_relu", BF16, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), pooled.data_ptr(), scratch.data_ptr(),
+           B, H, W, C, C, ph, pw, G, 0, C * 9 * C, C, 1, None)
+    full = torch.empty((G, B, H, W, C), dtype=torch.bfloat16, device="cuda")
+    two = torch.empty_like(pooled)
+    L.call("pp_conv_gemm", BF16, 1, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), full.data_ptr(), B, H, W, C, C,
+           0, 0, G, 0, C * 9 * C, B * H * W * C, C, C, 0, 1, None)
+    L.call("pp_maxpool_relu_nhwc", full.data_ptr(), 1, two.data_ptr(), 1, G * B, H, W, C, ph, pw, None)
+    assert torch.equal(pooled.view(torch.int16), two.view(torch.int16))
+    if (H, W) == (16, 12):
+        assert not scratch.any(), "the one-launch form must not touch the scratch tensor"
+    torch.testing.assert_close(pooled.cpu().double().permute(0, 1, 4, 2, 3), ref, rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("prec,hd,S", [(F32, 32, 192), (BF16, 32, 192), (BF16, 64, 192), (F32, 64, 192), (BF16, 64, 432), (BF16, 32, 432),
                                        (F32, 32, 432)])
 def test_attention_vs_torch(prec, hd, S):
