@@ -40,7 +40,7 @@ namespace panel {
 #endif
 // dev ablation switches (scripts/micro/panel_ablate.sh), 0 in the product build: 1 DMA out of bounds (no traffic),
 // 4 no MFMA, 8 no DMA, 16 no LDS fragment reads, 32 activation DMA out of bounds only, 64 weight DMA out of bounds only,
-// 256 clock probe
+// 128 no epilogue, 256 clock probe, 512 fused head without its weight loads
 constexpr int DBG = PANEL_DBG;
 #ifndef PANEL_KROT
 #define PANEL_KROT 0  // dev A/B switch. Measured: rotation ON is 2 - 12 % SLOWER here (conv1 274 -> 283 us, deconv1 83 -> 92) - unlike the layer kernel, these
@@ -279,6 +279,15 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
             }
         }
 
+        if (DBG & 128) {  // dev: no epilogue at all (keeps the accumulators alive through one store that never happens)
+            f32x4 sum = acc[0][0];
+#pragma unroll
+            for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) sum += acc[cf][rf];
+            if (p.M < 0) reinterpret_cast<f32x4*>(p.C)[tid] = sum;
+            continue;
+        }
         // ---- epilogue. Accumulator layout: lane holds n = 4 f_kg + (0..3) of fragment column cf for row f_row of
         // fragment row rf. One row half (one rg) at a time through the staging region, 16-byte chunks XOR-swizzled by
         // (row & 7); then every thread stores 16-byte pieces of whole output rows.
@@ -349,7 +358,8 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
                         const u32x4 a = *reinterpret_cast<const u32x4*>(cst + ml * ROWB + (((4 * ks + e_kg) ^ (ml & 7)) << 4));
 #pragma unroll
                         for (int nf = 0; nf < 2; ++nf) {
-                            const u32x4 b = *reinterpret_cast<const u32x4*>(hw_ + (size_t)(nf * 16 + e_row) * BN + ks * 32 + e_kg * 8);
+                            const u32x4 b = (DBG & 512) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, (unsigned)e_row}  // dev: no head-weight loads
+                                                        : *reinterpret_cast<const u32x4*>(hw_ + (size_t)(nf * 16 + e_row) * BN + ks * 32 + e_kg * 8);
                             hacc[nf] = mma(a, b, hacc[nf]);
                         }
                     }
