@@ -247,7 +247,8 @@ int pp_vit_layer(const void* qkv_in, int seq_len, int heads, float scale, const 
  *   ConvTranspose2d(Cin -> 256, k4, s2, p1) + BN + ReLU  ->  Conv2d(256 -> K, k1)
  * (probmap_head.py:435-472 and :244-249; reshaped to (B, K, H'W') at :627-648). weight / bias as PP_DECONV4X4S2 of
  * pp_conv_gemm with py < 0 (four phase matrices, folded BatchNorm); head_w (32, 256) bf16 = the 1x1 kernel, rows >= K
- * zero; head_b (K) fp32. The 256-channel feature map is never stored. logits_phased (B, K, 4, H*W) fp32: output pixel
+ * zero; head_b (K) fp32, K <= 28 (the kernel keeps both biases in the unused weight rows of its LDS image). The 256-channel
+ * feature map is never stored. logits_phased (B, K, 4, H*W) fp32: output pixel
  * (2y + py, 2x + px) of map (b, k) sits at [b, k, 2 py + px, y W + x] - the layout pp_probmap_head_decode_phased reads. */
 int pp_deconv_head(const void* act_nhwc, const void* weight, const float* bias, const void* head_w, const float* head_b,
                    float* logits_phased, int B, int H, int W, int Cin, int Cout, int K, void* stream);

@@ -585,8 +585,8 @@ extern "C" int pp_deconv_head(const void* act_nhwc, const void* weight, const fl
     using namespace pp;
     PP_REQUIRE(act_nhwc && weight && head_w && head_b && logits_phased, PP_ERR_INVALID_ARG, "pp_deconv_head: NULL argument");
     PP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0, PP_ERR_INVALID_ARG, "pp_deconv_head: bad shape");
-    PP_REQUIRE(Cout == 256 && K >= 1 && K <= 32 && Cin % 32 == 0 && (4 * Cin) % 128 == 0 && (H * W) % 4 == 0, PP_ERR_UNSUPPORTED,
-               "pp_deconv_head: built for 256 deconvolution channels, at most 32 output maps, Cin % 32 == 0, H*W % 4 == 0");
+    PP_REQUIRE(Cout == 256 && K >= 1 && K <= 28 && Cin % 32 == 0 && (4 * Cin) % 128 == 0 && (H * W) % 4 == 0, PP_ERR_UNSUPPORTED,
+               "pp_deconv_head: built for 256 deconvolution channels, at most 28 output maps, Cin % 32 == 0, H*W % 4 == 0");
     GemmParams p{};
     p.A = act_nhwc; p.W = weight; p.C = logits_phased; p.bias = bias; p.residual = nullptr;
     p.M = B * H * W; p.N = Cout; p.K = 4 * Cin;

@@ -40,7 +40,7 @@ namespace panel {
 #endif
 // dev ablation switches (scripts/micro/panel_ablate.sh), 0 in the product build: 1 DMA out of bounds (no traffic),
 // 4 no MFMA, 8 no DMA, 16 no LDS fragment reads, 32 activation DMA out of bounds only, 64 weight DMA out of bounds only,
-// 128 no epilogue, 256 clock probe, 512 fused head without its weight loads
+// 128 no epilogue, 256 clock probe, 512 fused head without its weight reads
 constexpr int DBG = PANEL_DBG;
 #ifndef PANEL_KROT
 #define PANEL_KROT 0  // dev A/B switch. Measured: rotation ON is 2 - 12 % SLOWER here (conv1 274 -> 283 us, deconv1 83 -> 92) - unlike the layer kernel, these
@@ -213,6 +213,26 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         dbg_r0 = __builtin_amdgcn_s_memrealtime();
     }
 
+    // fused 1x1 convolution (pp_deconv_head): its weights (32 rows x BN bf16 = 16 KiB) stay in the last third of the staging
+    // region for the whole launch, in the swizzled row image the MFMA fragments are read from
+    constexpr int HEAD_ROWS = 64, OFF_HEADW = HEAD_ROWS * BN * 2;  // the head epilogue stages 64 rows at a time
+    // Rows 29 - 31 of that image (pp_deconv_head takes at most 28 output maps: zero weights whose products are never stored)
+    // carry the 1x1 bias and the deconvolution's folded-BN bias: read from global memory in the epilogue - or through a
+    // pointer the compiler turns into a FLAT load, which counts in vmcnt too - either of them queues behind the next
+    // tile's stages and the previous pass's logit stores (PANEL_DBG 1024 on the global-bias form: 32 us per launch).
+    constexpr int HEAD_BIAS_ROW = 30, HEAD_B_ROW = 29;
+    if (GATHER == G_DECONV && p.head_w) {
+        for (int i = tid; i < HEAD_B_ROW * (BN / 8); i += THREADS) {
+            const int n = i / (BN / 8), c = i - n * (BN / 8);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.head_w) + (size_t)n * (BN * 2) + c * 16);
+            *reinterpret_cast<u32x4*>(smem + OFF_CST + OFF_HEADW + n * (BN * 2) + ((c ^ (n & 7)) << 4)) = v;
+        }
+        float* brow = reinterpret_cast<float*>(smem + OFF_CST + OFF_HEADW + HEAD_BIAS_ROW * (BN * 2));
+        float* hrow = reinterpret_cast<float*>(smem + OFF_CST + OFF_HEADW + HEAD_B_ROW * (BN * 2));
+        for (int i = tid; i < BN; i += THREADS) brow[i] = p.bias ? p.bias[i] : 0.f;  // (one bias for all four phases, N == BN)
+        for (int i = tid; i < BN / 2; i += THREADS) hrow[i] = i < p.head_n ? p.head_b[i] : 0.f;
+    }
+
     // ---- prologue: both stages in flight, the first half of the first one into registers
     setup_issue_tile();
 #pragma unroll
@@ -310,7 +330,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
                 for (int cf = 0; cf < CF; ++cf)
                     *reinterpret_cast<f32x4*>(Cp + (size_t)m * p.ldc + n0 + cg * (BN / 4) + cf * 16 + e_kg * 4) = acc[cf][rf];
             }
-            wait_vm_lgkm<0>();  // (stores share vmcnt with the DMA of the next tile: drain, as below)
+            if (!(DBG & 2048)) wait_vm_lgkm<0>();  // (stores share vmcnt with the DMA of the next tile: drain, as below)
             continue;
         }
         const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias_z : nullptr;
@@ -319,6 +339,71 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         constexpr int ROWB = BN * 2;         // bytes per staged row
         constexpr int LPR = ROWB / 16;       // 16-byte lanes per row (32 or 24)
         constexpr int RPP = THREADS / LPR;   // rows per pass (16 or 21)
+        if (GATHER == G_DECONV && p.head_w) {
+            // Fused 1x1 convolution (the heatmap head's final layer, probmap_head.py:244-249): a staged row holds ALL BN = N
+            // channels of a pixel, so logits[pixel, n] = sum_c tile[pixel, c] Wf[n, c] + bf[n] is 2 x 8 more MFMAs per row
+            // fragment and the 201 MB feature map never reaches HBM. Three passes of 64 rows (four row fragments, waves 0-3
+            // one each): 32 KiB of staging + the 16 KiB of Wf resident beside it - read from L2 per tile instead they cost
+            // 33 us per launch, every read queueing behind the next tile's stages (in-order vmcnt). Activations are the
+            // MFMA "A" operand here: a lane ends up with 4 consecutive pixels of one channel, which is contiguous in the
+            // phase-separated logits layout (B, n, phase, y * W + x).
+            static_assert(GATHER != G_DECONV || (RF == 6 && BM == 192 && OFF_HEADW + 32 * BN * 2 <= CST_BYTES), "head epilogue geometry");
+            const char* wfl = cst + OFF_HEADW;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) {
+                    const int g = rg * RF + rf;  // row fragment of the tile (wave-uniform)
+                    if ((g >> 2) != q) continue;
+#pragma unroll
+                    for (int cf = 0; cf < CF; ++cf) {
+                        const int nl = cg * (BN / 4) + cf * 16 + e_kg * 4;
+                        f32x4 v = acc[cf][rf];
+                        v += *reinterpret_cast<const f32x4*>(wfl + HEAD_BIAS_ROW * ROWB + nl * 4);
+                        if (p.act == ACT_RELU) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        }
+                        const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        const int ml = (g & 3) * 16 + e_row;
+                        const int byte = nl * 2;
+                        *reinterpret_cast<bf16x4*>(cst + ml * ROWB + ((((byte >> 4) ^ (ml & 7)) << 4) | (byte & 15))) = ov;
+                    }
+                }
+                wait_vm_lgkm<63>();  // LDS writes only: the DMA of the next tile stays in flight
+                __builtin_amdgcn_s_barrier();
+                if (wv < 4) {
+                    const int ml = wv * 16 + e_row;
+                    f32x4 hacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int ks = 0; ks < BN / 32; ++ks) {
+                        const u32x4 a = *reinterpret_cast<const u32x4*>(cst + ml * ROWB + (((4 * ks + e_kg) ^ (ml & 7)) << 4));
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) {
+                            const u32x4 b = (DBG & 512) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, (unsigned)e_row}
+                                                        : *reinterpret_cast<const u32x4*>(wfl + (nf * 16 + e_row) * ROWB + (((4 * ks + e_kg) ^ (e_row & 7)) << 4));
+                            hacc[nf] = mma(a, b, hacc[nf]);
+                        }
+                    }
+                    const int hw = p.H * p.Wd;
+                    const int m = m0 + q * HEAD_ROWS + wv * 16 + e_kg * 4;  // first of the lane's four pixels
+                    if (m < p.M) {
+                        const int b_img = m / hw, r = m - b_img * hw;
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) {
+                            const int n = nf * 16 + e_row;
+                            if (n < p.head_n) {
+                                const f32x4 v = hacc[nf] + *reinterpret_cast<const float*>(wfl + HEAD_B_ROW * ROWB + n * 4);
+                                *reinterpret_cast<f32x4*>(p.head_out + (((size_t)b_img * p.head_n + n) * 4 + z) * hw + r) = v;
+                            }
+                        }
+                    }
+                }
+                wait_vm_lgkm<63>();
+                __builtin_amdgcn_s_barrier();  // the staging rows are reused by the next pass / the next tile
+            }
+            continue;  // (no drain: the K loop's waits are vmcnt(0), the logit stores retire under the next tile's first half-step)
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (rg == h) {
@@ -343,41 +428,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
             }
             wait_vm_lgkm<63>();  // LDS writes only: the DMA of the next tile stays in flight
             __builtin_amdgcn_s_barrier();
-            if (GATHER == G_DECONV && p.head_w) {
-                // Fused 1x1 convolution (the heatmap head's final layer, probmap_head.py:244-249): the staged half tile
-                // holds ALL BN = N channels of 96 pixels, so logits[pixel, n] = sum_c tile[pixel, c] Wf[n, c] + bf[n] is
-                // 6 x 2 x 8 more MFMAs (waves 0-5, one row fragment each) and the 201 MB feature map never reaches HBM.
-                // Activations are the MFMA "A" operand here: a lane ends up with 4 consecutive pixels of one channel,
-                // which is contiguous in the phase-separated logits layout (B, n, phase, y * W + x).
-                if (wv < 6) {
-                    const int rf = wv, ml = rf * 16 + e_row;
-                    f32x4 hacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                    const __bf16* hw_ = reinterpret_cast<const __bf16*>(p.head_w);
-#pragma unroll
-                    for (int ks = 0; ks < BN / 32; ++ks) {
-                        const u32x4 a = *reinterpret_cast<const u32x4*>(cst + ml * ROWB + (((4 * ks + e_kg) ^ (ml & 7)) << 4));
-#pragma unroll
-                        for (int nf = 0; nf < 2; ++nf) {
-                            const u32x4 b = (DBG & 512) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, (unsigned)e_row}  // dev: no head-weight loads
-                                                        : *reinterpret_cast<const u32x4*>(hw_ + (size_t)(nf * 16 + e_row) * BN + ks * 32 + e_kg * 8);
-                            hacc[nf] = mma(a, b, hacc[nf]);
-                        }
-                    }
-                    const int hw = p.H * p.Wd;
-                    const int m = m0 + h * (BM / 2) + rf * 16 + e_kg * 4;  // first of the lane's four pixels
-                    if (m < p.M) {
-                        const int b_img = m / hw, r = m - b_img * hw;
-#pragma unroll
-                        for (int nf = 0; nf < 2; ++nf) {
-                            const int n = nf * 16 + e_row;
-                            if (n < p.head_n) {
-                                const f32x4 v = hacc[nf] + p.head_b[n];
-                                *reinterpret_cast<f32x4*>(p.head_out + (((size_t)b_img * p.head_n + n) * 4 + z) * hw + r) = v;
-                            }
-                        }
-                    }
-                }
-            } else {
+            {
             const int cl = tid_e % LPR, rl = tid_e / LPR;
             if (rl < RPP) {
                 for (int r0 = 0; r0 < BM / 2; r0 += RPP) {
@@ -402,7 +453,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         }
         // Stores and loads both count in vmcnt but may retire out of order with respect to each other: drain them
         // before the counted waits of the next tile rely on the count again.
-        wait_vm_lgkm<0>();
+        if (!(DBG & 2048)) wait_vm_lgkm<0>();
     }
     if ((DBG & 256) && blockIdx.x == 0 && tid == 0) {  // (first 16 bytes of the output)
         unsigned long long* o = reinterpret_cast<unsigned long long*>(p.C);

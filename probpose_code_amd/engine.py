@@ -254,7 +254,7 @@ class ProbPoseEngine:
             dst = ws[f"d{j}"]
             wj = w[f"deconv{j}.w"]
             if (j == nd - 1 and self.fuse_head and ob == 1 and cout == 256 and w.has("final.w_pad") and cin % 32 == 0
-                    and ww % 4 == 0):
+                    and ww % 4 == 0 and self.K <= 28):
                 # last deconvolution + the 1x1 conv behind it in one kernel; the 256-channel map is never stored and the
                 # logits come out phase-separated (the decode kernel reads that layout directly)
                 self._call("deconv_head", "pp_deconv_head", src.data_ptr(), wj.data_ptr(), w[f"deconv{j}.b"].data_ptr(),
