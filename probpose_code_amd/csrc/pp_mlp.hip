@@ -503,7 +503,12 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     f32x4 pold[3][2];                // P of the previous chunk, on its way through GELU
     f32x4 b1v[2];                    // b1 of the chunk in pold
     auto load_b1 = [&](int ci) {
-        if (DBG & 64) return;
+        if (DBG & 64) {  // dev: a register-only stand-in (an undefined b1v would let the compiler drop the GELU with it)
+            const float t = (float)(ci + lane) * 1e-3f;
+            b1v[0] = f32x4{t, t, t, t};
+            b1v[1] = b1v[0];
+            return;
+        }
         const int c = chunk_of(ci < nchunks ? ci : 0);
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) b1v[nf] = *reinterpret_cast<const f32x4*>(p.b1 + c * CHUNK + cg * 32 + nf * 16 + f_kg * 4);
