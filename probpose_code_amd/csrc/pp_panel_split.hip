@@ -35,6 +35,13 @@
 namespace pp {
 namespace psplit {
 
+#ifndef PSPLIT_DBG
+#define PSPLIT_DBG 0
+#endif
+// dev ablation switches (scripts/micro/psplit_ablate.sh), 0 in the product build: 1 no bias loads, 2 no residual loads,
+// 128 no epilogue at all
+constexpr int DBG = PSPLIT_DBG;
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -215,6 +222,18 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
         for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
             for (int rf = 0; rf < RF; ++rf) acc[cf][rf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The bias of this wave's columns is fetched HERE, not in the epilogue: a vector load there queues behind the next
+        // tile's stages already in flight and behind the stores of the quarter before (vmcnt retires in order) - 5 - 9 % of
+        // the f16x3 Linear launches (PSPLIT_DBG 1). The K loop's first wait covers it.
+        f32x4 bias_r[CF];
+        {
+            int zb, mb, nb0;
+            decode_tile(tile, zb, mb, nb0);
+#pragma unroll
+            for (int cf = 0; cf < CF; ++cf)
+                bias_r[cf] = (p.bias && !(DBG & 1)) ? *reinterpret_cast<const f32x4*>(p.bias + (size_t)zb * p.strideBias_z + nb0 + cg * (BN / 4) + cf * 16 + f_kg * 4)
+                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
         for (int k = 0; k < nsteps; ++k) {
             const int nb = cb + 1 == NST ? 0 : cb + 1;  // buffer of the next stage
@@ -269,26 +288,57 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
         }
         const int last_buf = cb == 0 ? NST - 1 : cb - 1;  // buffer of the stage consumed last: free
 
+        if (DBG & 128) {  // dev: no epilogue (one store that never happens keeps the accumulators alive)
+            f32x4 sum = acc[0][0];
+#pragma unroll
+            for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) sum += acc[cf][rf];
+            if (p.M < 0) reinterpret_cast<f32x4*>(p.C)[tid] = sum;
+            if (NST == 3) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) issue_instr(last_buf, j);
+                advance_cursor();
+            }
+            continue;
+        }
         // ---- epilogue (lane id laundered: the addresses below must not be hoisted above the K loop)
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int e_row = lane_e & 15, e_kg = lane_e >> 4, tid_e = (tid & ~63) | lane_e;
         int z, m0, n0;
         decode_tile(tile, z, m0, n0);
-        const float* __restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias_z : nullptr;
         char* cst = NST == 2 ? smem + OFF_CST : smem + last_buf * STAGE;
         constexpr int ROWB = BN * 4;            // bytes per staged fp32 row
         constexpr int LPR = BN / 8;             // lanes per row, 8 elements each (32 or 24)
         constexpr int RPP = THREADS / LPR;      // rows per pass (16 or 21)
         constexpr int QR = BM / 4;              // rows per quarter (48 or 64)
+        // bf16 Linear layers with an fp32 residual (ViT-B projection / fc2): the residual rows of a quarter are requested
+        // before that quarter is staged; fetched inside the store loop, every row pass is its own load -> wait -> store
+        // round trip (proj at bs 64: 167 us with, 117 us without the loads - PSPLIT_DBG 2)
+        constexpr bool RES_PREFETCH = !SPLIT && GATHER == G_LINEAR;
+        constexpr int NIT = (QR + RPP - 1) / RPP;
+        f32x4 resv[RES_PREFETCH ? NIT : 1][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (RES_PREFETCH && p.residual && !(DBG & 2)) {
+                const int cl = tid_e % LPR, rl = tid_e / LPR;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int ml = it * RPP + rl;
+                    const int m = m0 + q * QR + ml;
+                    if (rl < RPP && ml < QR && m < p.M) {
+                        const float* r = p.residual + (p.res_mod > 0 ? (size_t)(m % p.res_mod) * p.ldres : (size_t)m * p.ldres) + n0 + cl * 8;
+                        resv[it][0] = *reinterpret_cast<const f32x4*>(r);
+                        resv[it][1] = *reinterpret_cast<const f32x4*>(r + 4);
+                    }
+                }
+            }
             if (rg == (q >> 1)) {
 #pragma unroll
                 for (int cf = 0; cf < CF; ++cf) {
                     const int nl = cg * (BN / 4) + cf * 16 + e_kg * 4;
-                    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n0 + nl);
+                    const f32x4 bv = bias_r[cf];
 #pragma unroll
                     for (int r2 = 0; r2 < RF / 2; ++r2) {
                         const int rf = (q & 1) * (RF / 2) + r2;
@@ -309,8 +359,9 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
             __builtin_amdgcn_s_barrier();
             const int cl = tid_e % LPR, rl = tid_e / LPR;
             if (rl < RPP) {
-                for (int r0 = 0; r0 < QR; r0 += RPP) {
-                    const int ml = r0 + rl;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int ml = it * RPP + rl;
                     const int m = m0 + q * QR + ml;
                     if (ml >= QR || m >= p.M) continue;
                     size_t orow = m;
@@ -324,7 +375,12 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
                     f32x4 v0 = *reinterpret_cast<const f32x4*>(cst + ml * ROWB + (((2 * cl) ^ (ml & 7)) << 4));
                     f32x4 v1 = *reinterpret_cast<const f32x4*>(cst + ml * ROWB + (((2 * cl + 1) ^ (ml & 7)) << 4));
                     const size_t eoff = (size_t)z * p.strideC_z + orow * p.ldc + n0 + cl * 8;
-                    if (p.residual) {  // fp32, same indexing as the output, or a (res_mod, N) table broadcast over the rows
+                    if (RES_PREFETCH) {
+                        if (p.residual && !(DBG & 2)) {
+                            v0 += resv[it][0];
+                            v1 += resv[it][1];
+                        }
+                    } else if (p.residual && !(DBG & 2)) {  // fp32, same indexing as the output, or a (res_mod, N) table broadcast over the rows
                         const float* r = p.residual + (p.res_mod > 0 ? (size_t)(m % p.res_mod) * p.ldres : orow * p.ldres) + n0 + cl * 8;
                         v0 += *reinterpret_cast<const f32x4*>(r);
                         v1 += *reinterpret_cast<const f32x4*>(r + 4);
@@ -356,8 +412,9 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
             __builtin_amdgcn_s_barrier();  // the staging region is reused by the next quarter / the next tile
         }
         // stores and loads share vmcnt but may retire out of order with respect to each other: drain before the counted
-        // waits of the next tile rely on the count again
-        wait_vm_lgkm<0>();
+        // waits of the next tile rely on the count again (three-stage form; the two-stage K loop waits vmcnt(0) itself, there
+        // the stores retire under the next tile's first step)
+        if (NST == 3) wait_vm_lgkm<0>();
         if (NST == 3) {  // the refill deferred above (every wave is past the last barrier of the staging region)
 #pragma unroll
             for (int j = 0; j < NI; ++j) issue_instr(last_buf, j);

@@ -20,3 +20,18 @@ for name, N, K, act in (("qkv", 1152, 384, 0), ("fc1", 1536, 384, 1), ("fc1 no g
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     print(f"PP_PANEL={os.environ.get('PP_PANEL', '1')} {name:12s} {us:7.1f} us  {2 * M * N * K / us / 1e6:6.0f} TF algorithmic")
+# ViT-B (bs 64, flip: 55296 rows) bf16 Linear layers with fp32 output + residual: proj (K 768) and fc2 (K 3072)
+Mb = 55296
+for name, N, K in (("vit-b proj", 768, 768), ("vit-b fc2", 768, 3072)):
+    a = torch.randn(Mb, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16(); b = torch.randn(N).cuda()
+    res = torch.randn(Mb, N, device="cuda"); out = torch.empty(Mb, N, device="cuda")
+    args = (0, a.data_ptr(), w.data_ptr(), b.data_ptr(), res.data_ptr(), 0, out.data_ptr(), Mb, N, K, K, K, N, 0, 0, 0, None)
+    run = (lambda: _alt.pp_gemm(*args)) if os.environ.get("LIB") else (lambda: L.call("pp_gemm", *args))
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    print(f"{name:12s} {us:7.1f} us  {2 * Mb * N * K / us / 1e6:6.0f} TF")
