@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- person-crops/sec of the ProbPose top-down inference hot path on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--precision bf16|f16x3|f32] [--no-graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--precision bf16|f16x3|f32] [--no-graph] [--in-flight 2]
 
 One process per GPU. The driver launches N>1 as
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`;
@@ -15,6 +15,10 @@ One "step" = the whole hot path over one batch of synthetic uint8 crops ALREADY 
 preprocess + flip copy -> ViT-S backbone (both flip-test passes) -> ProbMapHead (deconv heatmap branch +
 Sparsemax, 4 scalar towers, flip average) -> ProbMap decode -> result tensors copied to pinned host memory
 (+ RCCL all_gather of the results when N>1). Random-init (seeded) weights, synthetic crops.
+Steps are submitted through probpose_code_amd.pipeline.StepPipeline: by default TWO steps are in flight (each slot its own
+HIP stream, workspace, captured graph and pinned record buffer), so the low-occupancy tail of one batch shares the chip with
+the head of the next; each step is the complete launch sequence and delivers its own record; all K have completed at the
+closing synchronize. `one_step_in_flight` in the JSON line is the same engine strictly one batch at a time.
 
 Rank 0 prints ONE JSON line:
   * `value` etc. for --precision (default bf16, the throughput mode BASELINE.md names);
@@ -73,6 +77,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the second bench in the 1e-3-qualified precision")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="steps in flight (StepPipeline slots: own HIP stream, workspace and graph each); 1 = strictly one batch "
+                         "at a time on one stream")
     ap.add_argument("--stub", action="store_true", help="tests only: fake engine on CPU + gloo (no GPU needed)")
     return ap.parse_args(argv)
 
@@ -355,12 +362,12 @@ def parity_record(precision, B, snap, ref, source):
 class StubEngine:
     """Stands in for ProbPoseEngine where there is no GPU: outputs encode (rank, crop index) so that the test can check
     the gather; a fixed sleep stands in for the kernels."""
-    precision, K = "stub", 17
+    precision, K, device = "stub", 17, torch.device("cpu")
 
     def __init__(self, rank):
         self.rank = rank
 
-    def forward(self, crops, flip_test=True, flip_indices=None):
+    def forward(self, crops, flip_test=True, flip_indices=None, slot=0):
         B = crops.shape[0]
         time.sleep(0.002)
         ids = (self.rank * 1000 + torch.arange(B, dtype=torch.float64))
@@ -371,20 +378,33 @@ class StubEngine:
 
 
 # ------------------------------------------------------------------------------------------ one timed run
-def timed_run(eng, crops, gather, flip, steps, warmup, use_graph, dist_mod, dev):
+def timed_run(eng, crops, gather, flip, steps, warmup, use_graph, dist_mod, dev, depth=1, world=1):
     """W untimed + exactly K timed steps bracketed by barrier + synchronize; returns this rank's seconds and host
-    copies of the LAST TIMED step's outputs (what the graph replay left in the engine's output buffers)."""
+    copies of the LAST TIMED step's outputs (what the graph replay left in the engine's output buffers).
+    ``depth`` > 1: consecutive steps go to consecutive slots of a StepPipeline (own stream, workspace, graph and pinned
+    record buffer per slot), so up to ``depth`` steps are in flight; every step still runs the whole captured launch
+    sequence and delivers its own record, and all K of them have completed at the closing synchronize."""
     is_cuda = dev.type == "cuda"
-    if use_graph and is_cuda:
+    pipe = None
+    if depth > 1:  # (also with the CPU stub engine of the gloo tests: slots without streams)
+        from probpose_code_amd.pipeline import StepPipeline
+
+        pipe = StepPipeline(eng, crops.shape[0], flip, True, depth, world, use_graph=use_graph)
+    elif use_graph and is_cuda:
         eng.capture(crops.shape[0], True, flip).copy_(crops)
-    out = None
+    out, ticket = None, -1
 
     def step():
-        nonlocal out
+        nonlocal out, ticket
+        if pipe is not None:
+            ticket = pipe.submit(crops)
+            return
         out = eng.forward_graph(crops, True, flip) if use_graph else eng.forward(crops, True, flip)
-        return gather(out)
+        gather(out)
 
     def barrier():
+        if is_cuda:
+            torch.cuda.synchronize()  # every stream of the device
         if dist_mod is not None:
             dist_mod.barrier()
         if is_cuda:
@@ -398,8 +418,13 @@ def timed_run(eng, crops, gather, flip, steps, warmup, use_graph, dist_mod, dev)
         step()
     barrier()
     dt = time.perf_counter() - t0
+    if pipe is not None:
+        out = pipe.device_outputs(ticket)
+        records = pipe.result(ticket)
+    else:
+        records = gather.wait()
     snap = {k: out[k].detach().cpu().numpy().copy() for k in ("keypoints", "scores", "scalars")}
-    snap["records"] = gather.wait().numpy().copy()  # what the step delivered to the host (world, B, K, 7)
+    snap["records"] = records.numpy().copy()  # what the step delivered to the host (world, B, K, 7)
     return dt, snap
 
 
@@ -483,8 +508,15 @@ def main(argv=None):
 
     eng = make_engine(args.precision)
     gather = ResultGather(B, eng.K, dev, world)  # fixed-layout result record, pinned host copy, RCCL all_gather
-    dt_rank, snap = timed_run(eng, crops, gather, flip, args.steps, args.warmup, use_graph, dist, dev)
+    depth = max(1, args.in_flight)
+    dt_rank, snap = timed_run(eng, crops, gather, flip, args.steps, args.warmup, use_graph, dist, dev, depth, world)
     dt, rank_secs, rank_devs = reduce_times(dt_rank, dist, dev, world, local_rank)
+    # the same engine strictly one batch at a time (one stream, one graph replay after the other): the latency figure
+    dt1 = None
+    if depth > 1:
+        k1, w1 = min(args.steps, 20), min(args.warmup, 5)
+        dt1_rank, _ = timed_run(eng, crops, gather, flip, k1, w1, use_graph, dist, dev, 1, world)
+        dt1 = reduce_times(dt1_rank, dist, dev, world, local_rank)[0] / k1
     prof = instrumented_pass(eng, crops, flip) if not args.stub else None
 
     # ---- the same bench in the precision that meets the 1e-3 tolerance (every rank takes part: barriers inside)
@@ -492,9 +524,13 @@ def main(argv=None):
     if not args.stub and not args.no_parity_mode and args.precision != PARITY_PRECISION:
         eng_p = make_engine(PARITY_PRECISION)
         k_p, w_p = min(args.steps, 20), min(args.warmup, 5)
-        dt_p_rank, snap_p = timed_run(eng_p, crops, gather, flip, k_p, w_p, use_graph, dist, dev)
+        dt_p_rank, snap_p = timed_run(eng_p, crops, gather, flip, k_p, w_p, use_graph, dist, dev, depth, world)
         dt_p, _, _ = reduce_times(dt_p_rank, dist, dev, world, local_rank)
-        pm = (eng_p, k_p, w_p, dt_p, snap_p, instrumented_pass(eng_p, crops, flip))
+        dt1_p = None
+        if depth > 1:
+            dt1_p_rank, _ = timed_run(eng_p, crops, gather, flip, k_p, w_p, use_graph, dist, dev, 1, world)
+            dt1_p = reduce_times(dt1_p_rank, dist, dev, world, local_rank)[0] / k_p
+        pm = (eng_p, k_p, w_p, dt_p, snap_p, instrumented_pass(eng_p, crops, flip), dt1_p)
 
     if rank == 0:
         line = {
@@ -516,7 +552,9 @@ def main(argv=None):
                             "flip_test=True, seeded random-init weights: preprocess -> backbone x2 passes -> ProbMapHead "
                             "(heatmap branch + Sparsemax + 4 towers) -> ProbMap decode -> results in pinned host memory",
                 "crops_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                "launch": "hipGraph replay" if use_graph else "eager launches",
+                "launch": ("hipGraph replay" if use_graph else "eager launches")
+                          + (f", {depth} steps in flight (one HIP stream, workspace and captured graph per slot)" if depth > 1 else ""),
+                "steps_in_flight": depth,
                 "gflop_per_crop": GFLOP_PER_CROP_FLIP,
             },
             "path_tflops": B * world * args.steps * GFLOP_PER_CROP_FLIP / dt / 1e3,
@@ -527,6 +565,9 @@ def main(argv=None):
             "rank_crops_per_s": [B * args.steps / s for s in rank_secs],
             "max_rank_ms_per_step": dt / args.steps * 1e3,
         }
+        if dt1 is not None:
+            line["one_step_in_flight"] = {"ms_per_step": dt1 * 1e3, "value": B * world / dt1, "unit": "crops/s",
+                                          "what": "the same engine, one hipGraph replay after the other on one stream (--in-flight 1)"}
         if args.stub:
             rec = snap["records"]  # (world, B, K, 7): x of crop i on rank r is r * 1000 + i
             line["stub_gather_ok"] = bool(all(rec[r, i, 0, 0] == r * 1000 + i for r in range(world) for i in (0, B - 1)))
@@ -551,11 +592,12 @@ def main(argv=None):
                               f"{threads} threads + per-sample scipy decode loop on 1 thread, {secs:.1f} s; host has "
                               f"{os.cpu_count()} logical CPUs, cgroup quota {threads}",
                 }
-            src = "last timed step (hipGraph replay)" if use_graph else "last timed step (eager launches)"
+            src = ("last timed step (hipGraph replay)" if use_graph else "last timed step (eager launches)") + \
+                  (f" of the {depth}-deep pipeline" if depth > 1 else "")
             if ref is not None and not args.no_parity:
                 line["parity_vs_oracle"] = parity_record(args.precision, B, snap, ref, src)
             if pm is not None:
-                eng_p, k_p, w_p, dt_p, snap_p, prof_p = pm
+                eng_p, k_p, w_p, dt_p, snap_p, prof_p, dt1_p = pm
                 kms, roof = roofline_record(eng_p, B, *prof_p)
                 line["parity_mode"] = {
                     "precision": PARITY_PRECISION, "dtype_detail": DTYPE_DETAIL[PARITY_PRECISION],
@@ -564,6 +606,8 @@ def main(argv=None):
                     "path_tflops": B * world * k_p * GFLOP_PER_CROP_FLIP / dt_p / 1e3,
                     "kernel_ms_per_step": kms, "roofline": roof,
                 }
+                if dt1_p is not None:
+                    line["parity_mode"]["one_step_in_flight"] = {"ms_per_step": dt1_p * 1e3, "value": B * world / dt1_p, "unit": "crops/s"}
                 if ref is not None and not args.no_parity:
                     line["parity_mode"]["parity_vs_oracle"] = parity_record(PARITY_PRECISION, B, snap_p, ref, src)
             print(json.dumps(line))

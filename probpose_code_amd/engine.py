@@ -102,8 +102,10 @@ class ProbPoseEngine:
             )
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, B: int, passes: int) -> Dict[str, torch.Tensor]:
-        key = (B, passes)
+    def _workspace(self, B: int, passes: int, slot: int = 0) -> Dict[str, torch.Tensor]:
+        """Buffers of one step at batch size B. ``slot`` > 0: a second (third ...) independent set, so that consecutive
+        steps can be in flight at once on different streams (pipeline.py)."""
+        key = (B, passes, slot)
         if key in self._ws:
             return self._ws[key]
         dev, T, f32 = self.device, self.dtype, torch.float32
@@ -318,13 +320,13 @@ class ProbPoseEngine:
         assert tuple(imgs.shape[1:]) == (3, self.H, self.W), f"crop shape {tuple(imgs.shape)} != (B,3,{self.H},{self.W})"
 
     @torch.no_grad()
-    def run_backbone(self, imgs: torch.Tensor, flip_test: bool) -> torch.Tensor:
+    def run_backbone(self, imgs: torch.Tensor, flip_test: bool, slot: int = 0) -> torch.Tensor:
         """(B,3,H,W) uint8 raw crops (or fp32 preprocessed) -> NHWC features (passes*B, Hp, Wp, E); with
         flip_test rows [B:] are the features of the horizontally flipped crops (topdown.py:109-112)."""
         self._check_imgs(imgs)
         imgs = imgs.contiguous()
         B, passes = imgs.shape[0], 2 if flip_test else 1
-        ws = self._workspace(B, passes)
+        ws = self._workspace(B, passes, slot)
         with torch.cuda.device(self.device):
             feat = self.backbone(imgs, passes, ws, _lib.stream_ptr(self.device))
         return feat.view(B * passes, self.Hp, self.Wp, self.E)
@@ -346,7 +348,7 @@ class ProbPoseEngine:
 
     @torch.no_grad()
     def run_head(self, feat_nhwc: torch.Tensor, flip_test: bool, flip_indices=None,
-                 return_heatmaps: bool = False) -> Dict[str, torch.Tensor]:
+                 return_heatmaps: bool = False, slot: int = 0) -> Dict[str, torch.Tensor]:
         """NHWC features (passes*B, Hp, Wp, E) in the engine's operand dtype -> decoded results
         (ProbMapHead.forward + the flip-test merge + BaseHead.decode, probmap_head.py:746-779)."""
         passes = 2 if flip_test else 1
@@ -356,7 +358,7 @@ class ProbPoseEngine:
         if flip_test and flip_indices is None:
             raise ValueError("flip_test needs flip_indices (dataset meta)")
         B = nb // passes
-        ws = self._workspace(B, passes)
+        ws = self._workspace(B, passes, slot)
         with torch.cuda.device(self.device):
             st = _lib.stream_ptr(self.device)
             logits = self.heatmap_logits(feat_nhwc, nb, ws, st)
@@ -375,22 +377,23 @@ class ProbPoseEngine:
 
     @torch.no_grad()
     def forward(self, imgs: torch.Tensor, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False,
-                return_features: bool = False) -> Dict[str, torch.Tensor]:
+                return_features: bool = False, slot: int = 0) -> Dict[str, torch.Tensor]:
         """imgs: (B, 3, H, W) uint8 on the device (BGR CHW as PackPoseInputs emits). Returns device
         tensors (views into the cached workspace, valid until the next call with the same batch size):
         ``keypoints`` (B,K,2) f64 input-pixel space, ``scores`` (B,K) f32 (keypoints_conf), ``locs``,
         ``scalars`` (4,B,K) f32 [probability, visibility, oks, raw error], optionally ``heatmaps``."""
-        feat = self.run_backbone(imgs, flip_test)
-        out = self.run_head(feat, flip_test, flip_indices, return_heatmaps)
+        feat = self.run_backbone(imgs, flip_test, slot)
+        out = self.run_head(feat, flip_test, flip_indices, return_heatmaps, slot)
         if return_features:
             out["features"] = feat
         return out
 
     # ------------------------------------------------------------------ hipGraph replay
-    def capture(self, B: int, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False):
+    def capture(self, B: int, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False, slot: int = 0):
         """Capture the whole launch sequence for batch size B into a HIP graph (the ~110 launches of one
-        forward are launch-latency-bound from Python). Returns the static input buffer to fill."""
-        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps)
+        forward are launch-latency-bound from Python). Returns the static input buffer to fill. Every ``slot`` has its
+        own workspace, input buffer and graph."""
+        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps, slot)
         if key in self._graphs:
             return self._graphs[key][1]
         static_in = torch.zeros((B, 3, self.H, self.W), dtype=torch.uint8, device=self.device)
@@ -398,21 +401,21 @@ class ProbPoseEngine:
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):  # warm-up: allocates the workspace, sets kernel attributes
             for _ in range(2):
-                self.forward(static_in, flip_test, flip_indices, return_heatmaps)
+                self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            out = self.forward(static_in, flip_test, flip_indices, return_heatmaps)
+            out = self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot)
         self._graphs[key] = (graph, static_in, out)
         return static_in
 
     def forward_graph(self, imgs: torch.Tensor, flip_test: bool = True, flip_indices=None,
-                      return_heatmaps: bool = False) -> Dict[str, torch.Tensor]:
-        """Same contract as ``forward`` for uint8 crops, replaying the captured graph."""
+                      return_heatmaps: bool = False, slot: int = 0) -> Dict[str, torch.Tensor]:
+        """Same contract as ``forward`` for uint8 crops, replaying the captured graph (on torch's current stream)."""
         B = imgs.shape[0]
-        static_in = self.capture(B, flip_test, flip_indices, return_heatmaps)
-        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps)
+        static_in = self.capture(B, flip_test, flip_indices, return_heatmaps, slot)
+        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps, slot)
         graph, _, out = self._graphs[key]
         if imgs.data_ptr() != static_in.data_ptr():
             static_in.copy_(imgs, non_blocking=True)
