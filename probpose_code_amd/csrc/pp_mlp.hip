@@ -53,6 +53,9 @@ constexpr int DBG = MLP_DBG;
 #ifndef MLP_ROT_XCD
 #define MLP_ROT_XCD 1
 #endif
+#ifndef MLP_ATT_RR
+#define MLP_ATT_RR 1  // dev A/B switch: 0 = round-2 attention phase (wave w = query tile w for every head, waves 6-7 idle)
+#endif
 #ifndef MLP_XCD_PAIR
 #define MLP_XCD_PAIR 1  // dev A/B switch: 0 = tile = blockIdx.x (sequence halves on different XCDs)
 #endif
@@ -327,6 +330,197 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     bool valid[3];
 #pragma unroll
     for (int rf = 0; rf < 3; ++rf) valid[rf] = m0 + rg * 48 + f_row + rf * 16 < p.M;
+#if MLP_ATT_RR
+    if (ATT) {
+        // ================= attention of this workgroup's 96 query rows. Sequence = 192 tokens = this workgroup's rows and its
+        // neighbour's. The work is 12 heads x 6 query tiles of 16 = 72 (head, tile) tasks, dealt round-robin to the EIGHT waves
+        // in nine rounds: task t = 8 round + wave -> head t / 6, tile t % 6, so every SIMD carries two waves in every round
+        // (round 2 kept wave w on tile w for every head: six busy waves, two SIMDs with two tiles each and the phase as long
+        // as those - 12 x 2.0 us; the softmax is VALU-bound, 1540 VALU cycles per task against 384 of MFMA). A round touches
+        // two consecutive heads. K and V of a head (192 x 32 each, 12 KiB + 12 KiB) arrive by LDS-DMA, all eight waves issuing,
+        // into FOUR buffers in rotation (head h -> buffer h & 3): two in the ring's region and one in the G region, which the
+        // weight stream / the FFN only need afterwards, and one made of the last quarter of the ring (K) and the LAST k-block of
+        // the row image (V): that block only receives the outputs of heads 10 and 11 (rounds 7, 8), the buffer's last tenant
+        // is head 8 (round 6). Head h + 4 is requested when the last round that reads head h has ended, one or two rounds
+        // before its own first round.
+        // Both operands stay row-major by key:
+        //   * K chunk (key, c) sits at 16-byte position 4 key + (c ^ ((key >> 2) & 3)) - the 16 keys x one chunk a
+        //     ds_read_b128 of the S^T = K Q^T operand touches then hit 16 different bank groups;
+        //   * V chunk (key, c) at 4 key + (c ^ 2 ((key >> 2) & 1)); the O^T = V^T P^T operand - eight keys of one head
+        //     dimension per lane - comes out of two ds_read_b64_tr_b16, the gfx950 transposing read: within 16 lanes, lane
+        //     4 r + q supplies the address of four consecutive 16-bit elements M[r][4 q ..], lane i receives M[0..3][i]
+        //     (scripts/micro/tr_probe.hip). No register staging, no 16-bit scatter.
+        constexpr int SEQ = 192, NKT = SEQ / 16, HEADS = E / 32, RS = 3 * E, NR = 9, TILES = BM / 16;
+        constexpr int KBYTES = SEQ * 64;  // K [192][64 B] or V [192][64 B] of one head
+        static_assert(HEADS * TILES == NR * WAVES, "72 tasks in nine rounds of eight");
+        static_assert(4 * KBYTES + KBYTES <= NSLOT * SLOT && 2 * KBYTES <= 2 * HS_KB && KBYTES == HS_KB, "buffer map");
+        const int srow0 = (m0 / SEQ) * SEQ;
+        const __amdgpu_buffer_rsrc_t qkv_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.qkv_in), 0, (unsigned)p.M * (unsigned)(RS * 2), 0x00020000);
+        // byte offsets inside the LDS allocation of the K and the V half of head hd's buffer
+        auto k_off = [](int hd) -> int { const int b = hd & 3; return b == 0 ? OFF_RING + 4 * KBYTES : b == 1 ? OFF_RING : b == 2 ? OFF_RING + 2 * KBYTES : OFF_GS; };
+        auto v_off = [](int hd) -> int { const int b = hd & 3; return b == 0 ? OFF_HS + 5 * HS_KB : b == 1 ? OFF_RING + KBYTES : b == 2 ? OFF_RING + 3 * KBYTES : OFF_GS + KBYTES; };
+        // instruction i of a head (24 of 1 KiB): i < 12 K keys 16 i .., else V keys 16 (i - 12) ..; lane = (key, position)
+        const int a_key = lane >> 2, a_pos = lane & 3;
+        auto issue_head = [&](int hd) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = wv + 8 * u;
+                const bool isv = i >= 12;
+                const int key = 16 * (isv ? i - 12 : i) + a_key;
+                const int c = isv ? (a_pos ^ (2 * ((key >> 2) & 1))) : (a_pos ^ ((key >> 2) & 3));
+                const unsigned vo = (unsigned)(srow0 + key) * (unsigned)(RS * 2) + (unsigned)((isv ? 2 * E : E) * 2 + hd * 64 + c * 16);
+                char* dst = smem + (isv ? v_off(hd) + (i - 12) * 1024 : k_off(hd) + i * 1024);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qkv_rsrc, (lds_ptr_t)dst, 16, vo, 0, 0, 0);  // rows past M: out of bounds = zeros
+            }
+        };
+        // order of the first requests: K / V of heads 0 and 1 (round 0), the Q fragments of this wave's nine tasks, heads 2, 3
+        issue_head(0);
+        issue_head(1);
+        u32x4 qf[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int t = 8 * r + wv, hd = t / TILES, tl = t - hd * TILES;
+            const int qm = m0 + tl * 16 + f_row;
+            qf[r] = *reinterpret_cast<const u32x4*>(p.qkv_in + (size_t)(qm < p.M ? qm : p.M - 1) * RS + hd * 32 + f_kg * 8);
+        }
+        issue_head(2);
+        issue_head(3);
+        const int k_frag_off = f_row * 64 + ((f_kg ^ ((f_row >> 2) & 3)) << 4);  // + kt * 1024
+        // transposing V read: lane supplies key 4 f_kg + (f_row >> 2) of the 16-key tile, elements 4 (f_row & 3) .. + 3 of the
+        // 16-dimension tile dt: chunk 2 dt + ((f_row & 3) >> 1), swizzled by 2 (f_kg & 1), upper or lower half
+        // (chunk (2 dt + q) ^ 2 (f_kg & 1) = 2 (dt ^ (f_kg & 1)) + q)
+        const int v_frag_off = (4 * f_kg + (f_row >> 2)) * 64 + (((f_row & 3) >> 1) << 4) + (f_row & 1) * 8;
+        const int v_dt_off[2] = {(f_kg & 1) * 32, ((f_kg & 1) ^ 1) * 32};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            stamp(30, r);
+            // The heads of round r have landed. Program order of this wave's vector-memory requests:
+            //   h0 h1 | Q x9 | h2 h3 || r0: res | r1: h4 res | r2: h5 res | r3: h6 h7 res | r4: h8 res | r5: h9 res | r6: h10 h11 res |
+            //   r7: res | r8: res + 3 weight slots      (a head = 3 requests per wave, res = 2 residual loads)
+            // first rounds of the heads: 0 0 1 2 3 3 4 5 6 6 7 8; the wait of round r lets exactly the requests YOUNGER than the
+            // last head it needs fly on ("at most as many outstanding as there are younger requests" is always safe)
+            if (r == 0) wait_dma_and_barrier<NR + 6>();
+            else if (r % 3 == 1) wait_dma_and_barrier<5>();                   // r1: h3 res0 - r4: h7 res3 - r7: h11 res6
+            else if (r == 2 || r == 5) wait_dma_and_barrier<7>();             // r2: res0 h4 res1 - r5: res3 h8 res4
+            else if (r == 8) wait_dma_and_barrier<4>();                       // res6 res7
+            else wait_dma_and_barrier<2>();                                   // r3: res2 - r6: res5
+            stamp(32, r);
+            // past the barrier the heads whose last round was r - 1 are done with: their buffers take the heads four further on
+            if (r == 1) issue_head(4);
+            if (r == 2) issue_head(5);
+            if (r == 3) { issue_head(6); issue_head(7); }
+            if (r == 4) issue_head(8);
+            if (r == 5) issue_head(9);
+            if (r == 6) { issue_head(10); issue_head(11); }
+            {
+                // The residual rows (147 KB per workgroup, fp32) trickle in under the attention math, two loads per round:
+                // plain loads into the accumulators - the bias is added after the phase, an add (or a select: rows past M
+                // read row M - 1, nothing of them is ever stored) here would wait for them.
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = r * 2 + u, rf = i / 6, nf = i % 6;
+                    const int m = m0 + rg * 48 + f_row + rf * 16;
+                    acc[rf][nf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(m < p.M ? m : p.M - 1) * E + cg * 96 + nf * 16 + f_kg * 4);
+                }
+            }
+            if (r + 1 == NR) {
+                // last round: heads 10 and 11 sit in the second ring buffer and in the G region; the first ring buffer (head 9,
+                // rounds 6-7) is free, the first three slots of the weight stream - the projection's first tile - fly under it
+#pragma unroll
+                for (int q = 0; q < 3; ++q) issue_rel(0, q - 12 - PRE);
+            }
+            {
+                const int t = 8 * r + wv, hd = t / TILES, tl = t - hd * TILES;  // wave-uniform
+                const char* Ks = smem + k_off(hd);
+                const char* Vs = smem + v_off(hd);
+                const u32x4 qh = qf[r];
+                f32x4 sc[NKT];
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)  // S^T: lane holds keys 16 kt + 4 f_kg + (0..3) of query f_row
+                    sc[kt] = mma(*reinterpret_cast<const u32x4*>(Ks + kt * 1024 + k_frag_off), qh, f32x4{0.f, 0.f, 0.f, 0.f});
+                float mx = -__builtin_inff();
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sc[kt][i]);
+                {
+                    // max over the four lane groups of a query: the gfx950 row swaps (v_permlane16_swap / v_permlane32_swap,
+                    // plain VALU) instead of two ds_bpermute round trips through the LDS queue
+                    const unsigned mu = __builtin_bit_cast(unsigned, mx);
+                    const auto s16 = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
+                    mx = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+                    const unsigned mv = __builtin_bit_cast(unsigned, mx);
+                    const auto s32 = __builtin_amdgcn_permlane32_swap(mv, mv, false, false);
+                    mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
+                }
+                const float mb = mx * p.scale_log2e;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sc[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], p.scale_log2e, -mb));  // arg <= 0
+                // The row sums come out of the matrix pipe: a third "V^T" fragment of all ones gives sum_k P[q][k] in every
+                // row of its 16 x 16 block - 48 additions and two cross-lane hops per lane less on the VALU, which bounds this
+                // phase; the pipe has the room (6 more MFMAs per task). It is the sum of the bf16-rounded weights, i.e. of
+                // exactly the numbers the output is a combination of.
+                f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                f32x4 osum = {0.f, 0.f, 0.f, 0.f};
+                const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
+                // O^T = V^T P^T; the key order inside a 32-key block is a permutation shared by both operands. The transposing
+                // reads are issued as inline asm with their own counted lgkmcnt waits (LDS returns in order; whatever else the
+                // compiler puts into that queue only makes a "<= N outstanding" wait stricter): as a builtin the read carries
+                // no memory operand, and the compiler then holds it back with a vmcnt wait until every LDS-DMA in flight has
+                // landed - including the K / V of FUTURE rounds requested a few hundred cycles earlier, whose whole point is to
+                // fly under this math (round 2 stamps: 4 000 cycles per head against 2 x 1 500 of VALU work).
+                const unsigned vaddr = (unsigned)(__SIZE_TYPE__)(lds_ptr_t)(Vs + v_frag_off);
+                u32x2 vr[2][2][2];  // [buffer][dt][lo / hi]
+                auto read_v = [&](int blk, u32x2 (&dst)[2][2]) {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const unsigned ad = vaddr + (unsigned)(blk * 2048) + (unsigned)v_dt_off[dt];  // keys 32 blk + .., chunks 2 dt, 2 dt + 1 (swizzled)
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[dt][0]) : "v"(ad));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(dst[dt][1]) : "v"(ad));
+                    }
+                };
+                read_v(0, vr[0]);
+#pragma unroll
+                for (int blk = 0; blk < NKT / 2; ++blk) {
+                    const int cur = blk & 1;
+                    if (blk + 1 < NKT / 2) {
+                        read_v(blk + 1, vr[cur ^ 1]);
+                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vr[cur][0][0]), "+v"(vr[cur][0][1]), "+v"(vr[cur][1][0]), "+v"(vr[cur][1][1]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[cur][0][0]), "+v"(vr[cur][0][1]), "+v"(vr[cur][1][0]), "+v"(vr[cur][1][1]));
+                    }
+                    const f32x4 p0 = sc[2 * blk], p1 = sc[2 * blk + 1];
+                    const bf16x8 pf = {(__bf16)p0[0], (__bf16)p0[1], (__bf16)p0[2], (__bf16)p0[3],
+                                       (__bf16)p1[0], (__bf16)p1[1], (__bf16)p1[2], (__bf16)p1[3]};
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const u32x4 vf = {vr[cur][dt][0][0], vr[cur][dt][0][1], vr[cur][dt][1][0], vr[cur][dt][1][1]};
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
+                    }
+                    osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, osum, 0, 0, 0);
+                }
+                // lane holds d = 16 dt + 4 f_kg + (0..3) of query f_row: 8 bytes into the row-operand image of the projection
+                // (column n = 32 hd + 16 dt + 4 f_kg: k-block hd >> 1, 16-byte chunk 4 (hd & 1) + 2 dt + (f_kg >> 1))
+                const float inv = 1.0f / osum[0];
+                const int row = tl * 16 + f_row;
+                char* orow = smem + OFF_HS + (hd >> 1) * HS_KB + row * ROW_BYTES + (f_kg & 1) * 8;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f32x4 v = o[dt] * inv;
+                    const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(orow + ((((hd & 1) * 4 + dt * 2 + (f_kg >> 1)) ^ (f_row & 7)) << 4)) = ov;
+                }
+            }
+        }
+        stamp(30, NR);
+        __syncthreads();  // the last round's math is done: the ring and the G region are free, the rows are in place
+#pragma unroll
+        for (int q = 3; q < NSLOT; ++q) issue_rel(0, q - 12 - PRE);  // the rest of the first eight weight slots
+    }
+#else
     if (ATT) {
         // ================= attention of this workgroup's 96 query rows (waves 0-5: one 16-query tile each). Sequence = 192
         // tokens = this workgroup's rows and its neighbour's. K and V of one head (192 x 32 each, 24 KiB together) arrive by
@@ -466,6 +660,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
         stamp(30, HEADS);
         __syncthreads();  // the last head's math is done: the ring and the G region are free, the rows are in place
     }
+#endif
 
     // ---- prologue: ring filled with the first eight slots, input rows into LDS, accumulators = residual + b2
     if (!ATT) {

@@ -4,7 +4,7 @@ import torch
 here = os.path.dirname(os.path.abspath(__file__))
 M, E, Fd = 24576, 384, 1536
 P = ctypes.c_void_p
-lib = ctypes.CDLL(os.path.join(here, "build", "libmlp_dbg512.so"))
+lib = ctypes.CDLL(os.path.join(here, "build", os.environ.get("LIB", "libmlp_dbg512.so")))
 trace = torch.zeros(8192, dtype=torch.int64, device="cuda")
 lib.pp_mlp_set_trace.argtypes = [P]; lib.pp_mlp_set_trace(trace.data_ptr())
 fn = lib.pp_proj_mlp_residual_layernorm
@@ -32,6 +32,7 @@ if os.environ.get("VIT"):  # the same through pp_vit_layer (attention phase in f
     fv.restype = ctypes.c_int
     fv.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_float] + [P] * 12 + [ctypes.c_float] + [P] * 4 + [ctypes.c_int] * 3 + [P]
     qi = torch.randn(M, 3 * E, device="cuda").bfloat16()
+    trace.zero_()
     for _ in range(3):
         assert fv(qi.data_ptr(), 192, 12, 32 ** -0.5, wp.data_ptr(), bp.data_ptr(), x.data_ptr(), g2.data_ptr(), be2.data_ptr(), w1.data_ptr(),
                   b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(), g.data_ptr(), be.data_ptr(), 1e-6, ho.data_ptr(), wq.data_ptr(),
@@ -42,8 +43,9 @@ if os.environ.get("VIT"):  # the same through pp_vit_layer (attention phase in f
         ph = t[w * 4096 + 200: w * 4096 + 207]
         hd = t[w * 4096 + 300: w * 4096 + 313]
         aw = t[w * 4096 + 320: w * 4096 + 332]
-        print(f"   wait + barrier per head {[int(aw[i]-hd[i]) for i in range(12)]}")
-        print(f"vit_layer wave {4*w}: total {ph[6]-ph[0]} ticks; prologue incl. attention {ph[1]-ph[0]}; start -> head 0 {hd[0]-ph[0]}; heads {[int(hd[i+1]-hd[i]) for i in range(12)]}")
+        nr = 9 if hd[10] == 0 else 12  # rounds of the round-robin attention phase / heads of the round-2 form (stale stamps cleared below)
+        print(f"   wait + barrier per round {[int(aw[i]-hd[i]) for i in range(nr)]}")
+        print(f"vit_layer wave {4*w}: total {ph[6]-ph[0]} ticks; prologue incl. attention {ph[1]-ph[0]}; start -> round 0 {hd[0]-ph[0]}; rounds {[int(hd[i+1]-hd[i]) for i in range(nr)]}")
     sys.exit(0)
 for w in (0, 1):
     for pair in range(4):
