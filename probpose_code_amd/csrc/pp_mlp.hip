@@ -56,6 +56,9 @@ constexpr int DBG = MLP_DBG;
 #ifndef MLP_ATT_RR
 #define MLP_ATT_RR 1  // dev A/B switch: 0 = round-2 attention phase (wave w = query tile w for every head, waves 6-7 idle)
 #endif
+#ifndef ATT_DBG
+#define ATT_DBG 0  // dev ablations of the attention rounds: 1 no v_exp, 2 no V reads, 4 no K reads, 8 no P V MFMAs (wrong results)
+#endif
 #ifndef MLP_XCD_PAIR
 #define MLP_XCD_PAIR 1  // dev A/B switch: 0 = tile = blockIdx.x (sequence halves on different XCDs)
 #endif
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                 f32x4 sc[NKT];
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)  // S^T: lane holds keys 16 kt + 4 f_kg + (0..3) of query f_row
-                    sc[kt] = mma(*reinterpret_cast<const u32x4*>(Ks + kt * 1024 + k_frag_off), qh, f32x4{0.f, 0.f, 0.f, 0.f});
+                    { u32x4 kf; if (ATT_DBG & 4) asm volatile("" : "=v"(kf)); else kf = *reinterpret_cast<const u32x4*>(Ks + kt * 1024 + k_frag_off); sc[kt] = mma(kf, qh, f32x4{0.f, 0.f, 0.f, 0.f}); }
                 float mx = -__builtin_inff();
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
@@ -455,10 +458,6 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                     mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
                 }
                 const float mb = mx * p.scale_log2e;
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sc[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], p.scale_log2e, -mb));  // arg <= 0
                 // The row sums come out of the matrix pipe: a third "V^T" fragment of all ones gives sum_k P[q][k] in every
                 // row of its 16 x 16 block - 48 additions and two cross-lane hops per lane less on the VALU, which bounds this
                 // phase; the pipe has the room (6 more MFMAs per task). It is the sum of the bf16-rounded weights, i.e. of
@@ -475,6 +474,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                 const unsigned vaddr = (unsigned)(__SIZE_TYPE__)(lds_ptr_t)(Vs + v_frag_off);
                 u32x2 vr[2][2][2];  // [buffer][dt][lo / hi]
                 auto read_v = [&](int blk, u32x2 (&dst)[2][2]) {
+                    if (ATT_DBG & 2) { for (int dt = 0; dt < 2; ++dt) for (int h = 0; h < 2; ++h) asm volatile("" : "=v"(dst[dt][h])); return; }
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
                         const unsigned ad = vaddr + (unsigned)(blk * 2048) + (unsigned)v_dt_off[dt];  // keys 32 blk + .., chunks 2 dt, 2 dt + 1 (swizzled)
@@ -482,12 +482,26 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(dst[dt][1]) : "v"(ad));
                     }
                 };
+                // exp of the scores of one 32-key block (arguments <= 0)
+                auto exp_blk = [&](int blk) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            sc[2 * blk + kk][i] = (ATT_DBG & 1) ? __builtin_fmaf(sc[2 * blk + kk][i], p.scale_log2e, -mb) : __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * blk + kk][i], p.scale_log2e, -mb));
+                };
+                // Software pipeline over the six key blocks: the V reads of block b + 1 are requested, then the exponentials of
+                // block b + 1 run while they are in flight, then block b's MFMAs. All eight waves are in the same phase of a round
+                // at the same time: as [all K reads | all exponentials | all V reads] the LDS pipe (192 KB per round = 1 536
+                // cycles) and the VALU took turns idling.
                 read_v(0, vr[0]);
+                exp_blk(0);
 #pragma unroll
                 for (int blk = 0; blk < NKT / 2; ++blk) {
                     const int cur = blk & 1;
                     if (blk + 1 < NKT / 2) {
                         read_v(blk + 1, vr[cur ^ 1]);
+                        exp_blk(blk + 1);
                         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vr[cur][0][0]), "+v"(vr[cur][0][1]), "+v"(vr[cur][1][0]), "+v"(vr[cur][1][1]));
                     } else {
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[cur][0][0]), "+v"(vr[cur][0][1]), "+v"(vr[cur][1][0]), "+v"(vr[cur][1][1]));
@@ -498,8 +512,10 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
                         const u32x4 vf = {vr[cur][dt][0][0], vr[cur][dt][0][1], vr[cur][dt][1][0], vr[cur][dt][1][1]};
+                        if (ATT_DBG & 8) { o[dt][0] += __builtin_bit_cast(float, vf[0] ^ vf[1] ^ vf[2] ^ vf[3]) + (float)pf[0] + (float)pf[2] + (float)pf[4] + (float)pf[6]; continue; }
                         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
                     }
+                    if (ATT_DBG & 8) osum[0] += 1.0f; else
                     osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, osum, 0, 0, 0);
                 }
                 // lane holds d = 16 dt + 4 f_kg + (0..3) of query f_row: 8 bytes into the row-operand image of the projection
