@@ -258,6 +258,10 @@ def roofline_record(eng, B, prof, reps):
         "algorithmic_gflop_per_launch": fl / n / 1e9, "algorithmic_mbytes_per_launch": alg_bytes / n / 1e6,
         "arithmetic_intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
         "mfma_view": mfma_view, "hbm_view": hbm_view,
+        "durations_from": "HIP events around every launch of an instrumented pass of the same step, one step at a time on the launch "
+                          "stream (the kernel with the chip to itself). The rocprofv3 trace of that mode is profiles/*_kernel_stats_one_in_flight.csv "
+                          "(`bench.py --in-flight 1`); in the trace of the default run (profiles/*_kernel_stats.csv, two steps in flight) a "
+                          "kernel's duration includes the time it shares CUs with the other step's kernels",
     }
     if bound == "mfma":
         power = sustained_mfma_rate()
@@ -511,6 +515,13 @@ def main(argv=None):
     depth = max(1, args.in_flight)
     dt_rank, snap = timed_run(eng, crops, gather, flip, args.steps, args.warmup, use_graph, dist, dev, depth, world)
     dt, rank_secs, rank_devs = reduce_times(dt_rank, dist, dev, world, local_rank)
+    # the PCIe-inclusive rate: every step's crops start in pinned HOST memory (never `value`: the boundary hands over device
+    # buffers); the host-to-device copy rides on the slot's stream under the other slot's kernels
+    dth = None
+    if depth > 1 and not args.stub:
+        kh, wh = min(args.steps, 20), min(args.warmup, 5)
+        dth_rank, _ = timed_run(eng, crops_cpu.pin_memory(), gather, flip, kh, wh, use_graph, dist, dev, depth, world)
+        dth = reduce_times(dth_rank, dist, dev, world, local_rank)[0] / kh
     # the same engine strictly one batch at a time (one stream, one graph replay after the other): the latency figure
     dt1 = None
     if depth > 1:
@@ -568,6 +579,10 @@ def main(argv=None):
         if dt1 is not None:
             line["one_step_in_flight"] = {"ms_per_step": dt1 * 1e3, "value": B * world / dt1, "unit": "crops/s",
                                           "what": "the same engine, one hipGraph replay after the other on one stream (--in-flight 1)"}
+        if dth is not None:
+            line["host_input"] = {"ms_per_step": dth * 1e3, "value": B * world / dth, "unit": "crops/s",
+                                  "what": "PCIe-inclusive: every step's crops start in pinned host memory (9.4 MB per bs64 batch), copied "
+                                          "on the slot's stream under the other slot's kernels; not the headline (inputs resident in HBM)"}
         if args.stub:
             rec = snap["records"]  # (world, B, K, 7): x of crop i on rank r is r * 1000 + i
             line["stub_gather_ok"] = bool(all(rec[r, i, 0, 0] == r * 1000 + i for r in range(world) for i in (0, B - 1)))

@@ -27,7 +27,7 @@ from .dist import ResultGather
 
 class StepPipeline:
     def __init__(self, engine, batch: int, flip_indices, flip_test: bool = True, depth: int = 2, world: int = 1, group=None,
-                 use_graph: bool = True):
+                 use_graph: bool = True, force_collective: bool = False):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.engine, self.batch, self.depth = engine, batch, depth
@@ -39,19 +39,25 @@ class StepPipeline:
         # depth 1 runs on the caller's current stream (exactly forward_graph + ResultGather); deeper pipelines own their streams
         self.streams: List[Optional[torch.cuda.Stream]] = \
             [None] * depth if (depth == 1 or not self.cuda) else [torch.cuda.Stream(device=dev) for _ in range(depth)]
-        self.gathers = [ResultGather(batch, engine.K, dev, world, group) for _ in range(depth)]
+        self.gathers = [ResultGather(batch, engine.K, dev, world, group, force_collective) for _ in range(depth)]
         self.outs: List[Optional[Dict[str, torch.Tensor]]] = [None] * depth
         self._ticket_of_slot = [-1] * depth
         self._next = 0
+        # device-side input buffer of a slot: the captured graph's static input, or (eager launches) a buffer of its own;
+        # batches that arrive in HOST memory are copied there on the slot's stream (see submit)
+        self._dev_in: List[Optional[torch.Tensor]] = [None] * depth
         if use_graph and self.cuda:
             for j in range(depth):
-                engine.capture(batch, flip_test, flip_indices, slot=j)
+                self._dev_in[j] = engine.capture(batch, flip_test, flip_indices, slot=j)
         if self.cuda:
             torch.cuda.synchronize(dev)
 
     def submit(self, crops_u8: torch.Tensor) -> int:
-        """Enqueue one batch (uint8 crops on the device, at most ``batch`` rows ... exactly ``batch`` under graph replay);
-        returns its ticket. The caller's current stream is the producer of ``crops_u8``: the slot's stream waits for it."""
+        """Enqueue one batch (uint8 crops, at most ``batch`` rows ... exactly ``batch`` under graph replay); returns its ticket.
+        Crops on the device: the caller's current stream is their producer, the slot's stream waits for it. Crops in HOST
+        memory (pinned, as a ``pin_memory`` data loader delivers them - pageable memory works but the copy then blocks):
+        the host-to-device copy is enqueued on the slot's stream in front of the step, so that it runs on the copy engine
+        under the OTHER slot's kernels; the tensor must stay untouched until ``result()`` of this ticket has returned."""
         t = self._next
         j = t % self.depth
         if self._ticket_of_slot[j] >= 0:
@@ -61,12 +67,18 @@ class StepPipeline:
             s.wait_stream(torch.cuda.current_stream(self.device))
         with (torch.cuda.stream(s) if s is not None else contextlib.nullcontext()):
             eng = self.engine
+            if self.cuda and not crops_u8.is_cuda:
+                if self._dev_in[j] is None:
+                    self._dev_in[j] = torch.empty((self.batch,) + tuple(crops_u8.shape[1:]), dtype=crops_u8.dtype, device=self.device)
+                n = crops_u8.shape[0]
+                self._dev_in[j][:n].copy_(crops_u8, non_blocking=True)
+                crops_u8 = self._dev_in[j][:n]
             if self.use_graph:
                 out = eng.forward_graph(crops_u8, self.flip_test, self.flip_indices, slot=j)
             else:
                 out = eng.forward(crops_u8, self.flip_test, self.flip_indices, slot=j)
             self.gathers[j](out)
-        if s is not None:
+        if s is not None and crops_u8.is_cuda:
             crops_u8.record_stream(s)
         self.outs[j] = out
         self._ticket_of_slot[j] = t

@@ -28,3 +28,14 @@ eng.forward(x, True, S.COCO_FLIP_INDICES)
 torch.cuda.synchronize()
 per = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in eng.profile.items()}
 print({k: round(v, 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1])})
+# the same through the captured graph, one and two steps in flight (pipeline.StepPipeline, what bench.py times for config 2)
+from probpose_code_amd.pipeline import StepPipeline
+for depth in (1, 2):
+    pipe = StepPipeline(eng, B, S.COCO_FLIP_INDICES, depth=depth)
+    for _ in range(4): pipe.submit(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20): pipe.submit(x)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    print(f"hipGraph replay, {depth} step(s) in flight: {ms:.2f} ms/step, {B / ms * 1e3:.0f} crops/s")

@@ -15,6 +15,12 @@ python $root/bench.py --steps 50 --warmup 10 --precision $prec > $out/${tag}_ben
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --precision $prec \
     > $out/${tag}_bench_under_rocprof.json 2> /tmp/prof_stats.log
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
+# the same with strictly one step at a time on one stream (bench.py's default keeps two steps in flight: kernels of two steps
+# then share the chip and the per-kernel durations of the trace include that)
+rm -rf /tmp/prof_stats1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- python $root/bench.py --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --precision $prec \
+    > $out/${tag}_bench_under_rocprof_one_in_flight.json 2> /tmp/prof_stats1.log
+cp $(find /tmp/prof_stats1 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_one_in_flight.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --precision $prec > /dev/null 2> /tmp/prof_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --precision $prec > /dev/null 2> /tmp/prof_write.log
 python3 - "$out/${tag}_hbm_traffic.json" <<'PY'

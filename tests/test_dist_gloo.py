@@ -104,3 +104,34 @@ def test_rccl_all_gather_path_on_one_rank():
         assert bool((host[0, 4:] == 0).all())
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_pipelined_steps_gather_over_rccl_on_one_rank():
+    """bench.py --gpus N keeps two steps in flight on every rank: the all_gather of a record is then issued from alternating
+    HIP streams. With one GPU on the box the communicator has one rank, but the calls are the real ones: 1-rank `nccl`
+    (= RCCL) group, StepPipeline depth 2 with the collective forced on, six different batches back to back - every record
+    must be the one the serial path produces (torch's process group orders the collectives on its own stream)."""
+    from probpose_code_amd import synthetic as S
+    from probpose_code_amd.dist import pack_records
+    from probpose_code_amd.engine import ProbPoseEngine
+    from probpose_code_amd.pipeline import StepPipeline
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B, flip = 16, S.COCO_FLIP_INDICES
+        eng = ProbPoseEngine(S.synthetic_state_dict("small", seed=0, logit_scale=2.0), 12, precision="bf16", device="cuda:0")
+        batches = [S.synthetic_crops(B, seed=300 + i).cuda() for i in range(6)]
+        want = [pack_records(eng.forward(x, True, flip)).cpu().clone() for x in batches]
+        pipe = StepPipeline(eng, B, flip, depth=2, world=1, force_collective=True)
+        assert all(g.collective for g in pipe.gathers)
+        tickets = []
+        for i, x in enumerate(batches):
+            tickets.append(pipe.submit(x))
+            if i >= 1:
+                assert torch.equal(pipe.result(tickets[i - 1])[0], want[i - 1])
+        assert torch.equal(pipe.result(tickets[-1])[0], want[-1])
+        assert pipe.gather_of(tickets[-1]).counts == [B]
+    finally:
+        dist.destroy_process_group()
