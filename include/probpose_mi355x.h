@@ -137,9 +137,9 @@ int pp_gemm(int prec, const void* act, const void* weight, const float* bias, co
  * (mmpretrain TransformerEncoderLayer [3P]: x = x + attn(ln1(x)); x = ffn(ln2(x)) + x; final ln1):
  *   x_out[m, :] = sum_k act[m, k] * weight[:, k] + bias + residual[r(m), :]        (fp32 residual stream)
  *   h_out[m, :] = LayerNorm(x_out[m, :]; gamma, beta, eps)                          (bf16 or fp32 operand of the next GEMM)
- * One workgroup owns 96 complete rows, so the row statistics never leave the CU and the separate
- * LayerNorm pass over the stream disappears. N must be 384 (ViT-S); callers fall back to
- * pp_gemm + pp_layernorm otherwise. residual may alias x_out; act may alias h_out (a workgroup
+ * One workgroup owns 96 (N = 384, ViT-S) or 112 (N = 768, ViT-B) complete rows, so the row statistics never
+ * leave the CU and the separate LayerNorm pass over the stream disappears. N must be 384 or 768; callers fall
+ * back to pp_gemm + pp_layernorm otherwise. residual may alias x_out; act may alias h_out (a workgroup
  * has consumed its own rows of act before it writes them). r(m) as in pp_gemm (res_mod). */
 int pp_gemm_residual_layernorm(int prec, const void* act, const void* weight, const float* bias,
                                const float* residual, int res_mod, float* x_out, const float* gamma,

@@ -84,6 +84,13 @@ class ProbPoseEngine:
         # (DESIGN.md 4); PP_FUSE_ATTN=0 switches back to two launches per layer
         self.fuse_attn = os.environ.get("PP_FUSE_ATTN", "1") != "0"
         self.fuse_head = os.environ.get("PP_FUSE_HEAD", "1") != "0"
+        # residual GEMM + LayerNorm in one launch (pp_gemm_ln.hip; 0: GEMM, then LayerNorm). Default on for E = 384. At E = 768
+        # (ViT-B) the row-owner kernel exists and is tested, but is OFF unless PP_FUSE_RESLN=1: measured at 384x288 bs 32 it saves
+        # the LayerNorm launches one step at a time (10.72 -> 10.47 ms) and loses with two steps in flight (9.64 -> 10.01 ms: one
+        # 124 KiB workgroup per CU cannot share a CU with the other step's kernels, the 128 x 128 GEMM tiles can)
+        env = os.environ.get("PP_FUSE_RESLN")
+        self.fuse_resln = env != "0"
+        self._resln_768 = env == "1"
         self.fuse_pool = os.environ.get("PP_FUSE_POOL", "1") != "0"  # first tower stage: conv + pool + ReLU in one launch
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
@@ -171,7 +178,8 @@ class ProbPoseEngine:
                   self.std.ctypes.data, int(self.bgr_to_rgb), st)
         Kp = 3 * self.P * self.P
         scale = self.hd ** -0.5
-        fused = E == 384  # residual GEMM + LayerNorm in one kernel (pp_gemm_ln.hip); other widths: GEMM then LN
+        # residual GEMM + LayerNorm in one kernel (pp_gemm_ln.hip: E = 384, and 768 = ViT-B); other widths: GEMM then LN
+        fused = self.fuse_resln and (E == 384 or (E == 768 and self._resln_768))
         L = w.num_layers
 
         def res_ln(a, wk, bk, K, gamma, beta, h_out, residual=None, res_mod=0):
@@ -189,7 +197,7 @@ class ProbPoseEngine:
         res_ln(ws["patches"], w["patch_w"], w["patch_b"], Kp, w["l0.ln1.w"], w["l0.ln1.b"], ws["h"],
                residual=w["pos_embed"], res_mod=self.Np)
         qkv_done = False  # the fused layer kernel has already produced this layer's qkv
-        one_launch = (fused and self.precision == "bf16" and Fd % 128 == 0 and self.fuse_mlp and self.fuse_proj and self.fuse_attn
+        one_launch = (fused and E == 384 and self.precision == "bf16" and Fd % 128 == 0 and self.fuse_mlp and self.fuse_proj and self.fuse_attn
                       and self.Np == 192 and self.hd == 32)
         qcur, qnext = ws["qkv"], ws["qkv2"]
         for i in range(L):
@@ -218,7 +226,7 @@ class ProbPoseEngine:
             last = i + 1 == L
             gn, bn = (w["ln_f.w"], w["ln_f.b"]) if last else (w[f"l{i + 1}.ln1.w"], w[f"l{i + 1}.ln1.b"])
             h_next = ws["feat"] if last else ws["h"]
-            fuse_ffn = fused and self.precision == "bf16" and Fd % 128 == 0 and self.fuse_mlp
+            fuse_ffn = fused and E == 384 and self.precision == "bf16" and Fd % 128 == 0 and self.fuse_mlp
             if fuse_ffn and self.fuse_proj:
                 # second half of the layer in one kernel: projection + residual, ln2, FFN + residual, next LayerNorm;
                 # the intermediate residual stream and ln2 output stay on the CU

@@ -216,7 +216,36 @@ def test_config4_vit_base_384x288_bf16():
         assert np.abs(out["scalars"][i].cpu().numpy()[:, None] - ref[name]).max() <= 1e-3, name
 
 
-@pytest.mark.parametrize("switch", ["PP_FUSE_ATTN", "PP_FUSE_QKV", "PP_FUSE_PROJ", "PP_FUSE_MLP", "PP_SPLIT_K", "PP_FUSE_HEAD", "PP_FUSE_POOL"])
+def test_config4_row_owner_residual_layernorm_plan(monkeypatch):
+    """PP_FUSE_RESLN=1 selects the E = 768 form of the fused residual GEMM + LayerNorm kernel (112-row tiles, two column
+    halves) for patch embed / projection / fc2 of ViT-B - off by default there (slower with two steps in flight, see
+    engine.py). The plan must hold the same parity as the default one: f16x3 <= 1e-3 px, no flips."""
+    from oracle import model_ref as M
+    from probpose_code_amd import ProbPoseEngine
+    from probpose_code_amd import synthetic as S
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    img = (384, 288)
+    sd = S.synthetic_state_dict("base", img_size=img, seed=0, logit_scale=2.0)
+    x = S.synthetic_crops(3, img_size=img, seed=1)
+    ref = M.predict(sd, x, 12, S.IMG_MEAN, S.IMG_STD, input_size=(288, 384))
+    monkeypatch.setenv("PP_FUSE_RESLN", "1")
+    for precision in ("f16x3", "bf16"):
+        eng = ProbPoseEngine(sd, 12, img_size=img, precision=precision, input_size=(288, 384))
+        assert eng._resln_768
+        eng.profile = {}
+        out = eng.forward(x.cuda(), True, S.COCO_FLIP_INDICES)
+        torch.cuda.synchronize()
+        assert len(eng.profile["gemm_res_ln"]) == 25 and "layernorm" not in eng.profile
+        d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
+        if precision == "f16x3":
+            assert (d < 2.0).all() and d.max() <= 1e-3, f"{int((d >= 2).sum())} flips, L_inf {d[d < 2].max():.2e} px"
+        else:
+            same = d < 2.0
+            assert same.mean() >= 0.90 and d[same].max() < 0.5
+
+
+@pytest.mark.parametrize("switch", ["PP_FUSE_ATTN", "PP_FUSE_QKV", "PP_FUSE_PROJ", "PP_FUSE_MLP", "PP_SPLIT_K", "PP_FUSE_HEAD", "PP_FUSE_POOL", "PP_FUSE_RESLN"])
 def test_bf16_fallback_launch_plans_end_to_end(switch, monkeypatch):
     """Every PP_FUSE_* / PP_SPLIT_K switch selects a different launch plan for the bf16 mode (two launches per layer, the
     plain qkv GEMM, separate projection, unfused FFN, unsplit tower convolutions, separate final 1x1 conv): each plan, end

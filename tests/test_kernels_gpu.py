@@ -356,12 +356,13 @@ def test_fused_sparsemax_decode_vs_oracle(hw, B, flip):
 
 
 @pytest.mark.parametrize("prec", [F32, BF16])
-@pytest.mark.parametrize("M,K,res_mod", [(192, 384, 0), (480, 1536, 0), (384, 768, 192)])
-def test_gemm_residual_layernorm_fused(prec, M, K, res_mod):
+@pytest.mark.parametrize("M,K,res_mod,E", [(192, 384, 0, 384), (480, 1536, 0, 384), (384, 768, 192, 384),
+                                           (250, 768, 0, 768), (448, 3072, 0, 768), (864, 768, 432, 768)])
+def test_gemm_residual_layernorm_fused(prec, M, K, res_mod, E):
     """x <- x + a W^T + b ; h <- LN(x): fused kernel vs torch, incl. the pos_embed-style broadcast residual,
-    a row count that is not a multiple of the 96-row tile, and act aliasing h_out."""
+    a row count that is not a multiple of the row tile, and act aliasing h_out. E = 384 (96-row tiles) and E = 768 (ViT-B:
+    112-row tiles, the columns as two halves of 384 through the K-loop)."""
     L = _lib()
-    E = 384
     a, w, b = _rand(M, K, seed=41), _rand(E, K, seed=42, scale=1 / math.sqrt(K)), _rand(E, seed=43)
     res = _rand(res_mod if res_mod else M, E, seed=44, scale=2.0)
     g, be = 1 + 0.1 * _rand(E, seed=45), _rand(E, seed=46)

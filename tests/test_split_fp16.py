@@ -112,10 +112,10 @@ def test_gemm_split_planar_posembed_and_errors():
 
 
 @gpu
-@pytest.mark.parametrize("K,res_mod", [(768, 48), (384, 0), (1536, 0)])
-def test_gemm_residual_layernorm_split(K, res_mod):
+@pytest.mark.parametrize("K,res_mod,E", [(768, 48, 384), (384, 0, 384), (1536, 0, 384), (768, 0, 768), (3072, 0, 768), (768, 48, 768)])
+def test_gemm_residual_layernorm_split(K, res_mod, E):
     L = _lib()
-    M, E = 96 * 3 - 40, 384
+    M = 96 * 3 - 40
     a, w, b = _rand(M, K, seed=11), _rand(E, K, seed=12, scale=1 / math.sqrt(K)), _rand(E, seed=13, scale=0.1)
     r = _rand(res_mod if res_mod else M, E, seed=14)
     g, be = 1 + 0.1 * _rand(E, seed=15), _rand(E, seed=16, scale=0.1)
