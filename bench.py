@@ -516,7 +516,7 @@ def main(argv=None):
     dt_rank, snap = timed_run(eng, crops, gather, flip, args.steps, args.warmup, use_graph, dist, dev, depth, world)
     dt, rank_secs, rank_devs = reduce_times(dt_rank, dist, dev, world, local_rank)
     # the PCIe-inclusive rate: every step's crops start in pinned HOST memory (never `value`: the boundary hands over device
-    # buffers); the host-to-device copy rides on the slot's stream under the other slot's kernels
+    # buffers); the host-to-device copy rides on a copy stream under the kernels in flight (pipeline.StepPipeline.submit)
     dth = None
     if depth > 1 and not args.stub:
         kh, wh = min(args.steps, 20), min(args.warmup, 5)
@@ -581,8 +581,9 @@ def main(argv=None):
                                           "what": "the same engine, one hipGraph replay after the other on one stream (--in-flight 1)"}
         if dth is not None:
             line["host_input"] = {"ms_per_step": dth * 1e3, "value": B * world / dth, "unit": "crops/s",
-                                  "what": "PCIe-inclusive: every step's crops start in pinned host memory (9.4 MB per bs64 batch), copied "
-                                          "on the slot's stream under the other slot's kernels; not the headline (inputs resident in HBM)"}
+                                  "what": "PCIe-inclusive: every step's crops start in pinned host memory (9.4 MB per bs64 batch); the H2D copy goes "
+                                          "on a copy stream ahead of the wait for the slot, i.e. under the kernels in flight, then 9.4 MB inside HBM "
+                                          "into the graph's input; not the headline (inputs resident in HBM)"}
         if args.stub:
             rec = snap["records"]  # (world, B, K, 7): x of crop i on rank r is r * 1000 + i
             line["stub_gather_ok"] = bool(all(rec[r, i, 0, 0] == r * 1000 + i for r in range(world) for i in (0, B - 1)))

@@ -46,6 +46,10 @@ class StepPipeline:
         # device-side input buffer of a slot: the captured graph's static input, or (eager launches) a buffer of its own;
         # batches that arrive in HOST memory are copied there on the slot's stream (see submit)
         self._dev_in: List[Optional[torch.Tensor]] = [None] * depth
+        self._staging: List[Optional[torch.Tensor]] = [None] * depth      # host batches land here first (copy stream)
+        self._staged_ev: List[Optional[torch.cuda.Event]] = [None] * depth
+        self._consumed_ev: List[Optional[torch.cuda.Event]] = [None] * depth
+        self._copy_stream = torch.cuda.Stream(device=dev) if (self.cuda and depth > 1) else None
         if use_graph and self.cuda:
             for j in range(depth):
                 self._dev_in[j] = engine.capture(batch, flip_test, flip_indices, slot=j)
@@ -56,22 +60,45 @@ class StepPipeline:
         """Enqueue one batch (uint8 crops, at most ``batch`` rows ... exactly ``batch`` under graph replay); returns its ticket.
         Crops on the device: the caller's current stream is their producer, the slot's stream waits for it. Crops in HOST
         memory (pinned, as a ``pin_memory`` data loader delivers them - pageable memory works but the copy then blocks):
-        the host-to-device copy is enqueued on the slot's stream in front of the step, so that it runs on the copy engine
-        under the OTHER slot's kernels; the tensor must stay untouched until ``result()`` of this ticket has returned."""
+        the host-to-device copy is enqueued at once on a copy stream, ahead of the wait for the slot, so that it runs on the
+        copy engine under the kernels still in flight; the tensor must stay untouched until ``result()`` of this ticket has
+        returned."""
         t = self._next
         j = t % self.depth
+        s = self.streams[j]
+        host_src = self.cuda and not crops_u8.is_cuda
+        if host_src and s is not None:
+            # Host batch: the host-to-device copy goes FIRST, on the copy stream, into the slot's staging buffer - before
+            # this call blocks on the slot's previous batch - so it runs on the copy engine under the kernels of the batches
+            # still in flight (enqueued behind the slot's own step it would start only when that slot has drained, and the
+            # other slot's step would run alone meanwhile: measured 2.43 against 2.07 ms per batch). The staging buffer is
+            # free again as soon as the device-to-device copy of the batch before has run (event below).
+            n = crops_u8.shape[0]
+            if self._staging[j] is None:
+                self._staging[j] = torch.empty((self.batch,) + tuple(crops_u8.shape[1:]), dtype=crops_u8.dtype, device=self.device)
+                self._staged_ev[j] = torch.cuda.Event()
+                self._consumed_ev[j] = torch.cuda.Event()
+            else:
+                self._copy_stream.wait_event(self._consumed_ev[j])
+            with torch.cuda.stream(self._copy_stream):
+                self._staging[j][:n].copy_(crops_u8, non_blocking=True)
+                self._staged_ev[j].record(self._copy_stream)
         if self._ticket_of_slot[j] >= 0:
             self.gathers[j].wait()  # batch t - depth has been delivered; its buffers may be reused
-        s = self.streams[j]
         if s is not None:
             s.wait_stream(torch.cuda.current_stream(self.device))
         with (torch.cuda.stream(s) if s is not None else contextlib.nullcontext()):
             eng = self.engine
-            if self.cuda and not crops_u8.is_cuda:
+            if host_src:
+                n = crops_u8.shape[0]
                 if self._dev_in[j] is None:
                     self._dev_in[j] = torch.empty((self.batch,) + tuple(crops_u8.shape[1:]), dtype=crops_u8.dtype, device=self.device)
-                n = crops_u8.shape[0]
-                self._dev_in[j][:n].copy_(crops_u8, non_blocking=True)
+                if s is not None:
+                    s.wait_event(self._staged_ev[j])
+                    self._dev_in[j][:n].copy_(self._staging[j][:n], non_blocking=True)  # 9.4 MB inside HBM
+                    self._consumed_ev[j].record(s)
+                else:  # depth 1: nothing to hide the copy under
+                    self._dev_in[j][:n].copy_(crops_u8, non_blocking=True)
                 crops_u8 = self._dev_in[j][:n]
             if self.use_graph:
                 out = eng.forward_graph(crops_u8, self.flip_test, self.flip_indices, slot=j)

@@ -97,3 +97,30 @@ def test_depth_one_is_the_plain_replay():
     pipe = StepPipeline(eng, B, flip, depth=1)
     assert pipe.streams == [None]
     assert np.array_equal(pipe.result(pipe.submit(x))[0].numpy(), want)
+
+
+@pytest.mark.gpu
+def test_host_batches_take_the_copy_stream_and_give_the_same_records():
+    """Batches handed over in pinned HOST memory: the H2D copy is enqueued on the copy stream before the call blocks on the
+    slot (so it hides under the kernels in flight); records must equal those of device-resident batches, also when the
+    slots and their staging buffers are reused."""
+    from probpose_code_amd.engine import ProbPoseEngine
+
+    B, flip = 32, S.COCO_FLIP_INDICES
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
+    eng = ProbPoseEngine(sd, 12, precision="bf16", device="cuda:0")
+    host = [S.synthetic_crops(B, seed=400 + i).pin_memory() for i in range(6)]
+    want = [pack_records(eng.forward(x.cuda(), True, flip)).cpu().numpy().copy() for x in host]
+    pipe = StepPipeline(eng, B, flip, depth=2)
+    tickets = []
+    for i, x in enumerate(host):
+        tickets.append(pipe.submit(x))
+        if i >= 1:
+            assert np.array_equal(pipe.result(tickets[i - 1])[0].numpy(), want[i - 1]), f"host batch {i - 1}"
+    assert np.array_equal(pipe.result(tickets[-1])[0].numpy(), want[-1])
+    # device and host batches interleaved through the same slots
+    t_dev = pipe.submit(host[2].cuda())
+    t_host = pipe.submit(host[4])
+    assert np.array_equal(pipe.result(t_dev)[0].numpy(), want[2]) and np.array_equal(pipe.result(t_host)[0].numpy(), want[4])
+    pipe1 = StepPipeline(eng, B, flip, depth=1)
+    assert np.array_equal(pipe1.result(pipe1.submit(host[5]))[0].numpy(), want[5])
