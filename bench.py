@@ -301,29 +301,40 @@ def secondary_rooflines(eng, B, prof, reps):
             },
         }
     att_fl = 4.0 * nseq * heads * S * S * hd  # QK^T + PV per layer
-    # VALU issue per (16-query tile, head) at head dim 32 / 192 keys, per wave: 48 v_max + 48 v_fma + 48 v_exp_f32 (quarter
-    # rate: 16 cycles) + 48 v_add + 24 v_cvt_pk + ~25 cross-lane / scale ops at 4 cycles = ~1540 cycles, against 24 MFMAs x
-    # 16 = 384 cycles: the phase is VALU-bound. Six tiles on four SIMDs put two tiles on two of them.
+    # Two ceilings for softmax(q k^T) v at 192 tokens x head dim 32, both far under the MFMA peak (128 FLOP per v_exp_f32):
+    #  * VALU: per (16-query tile, head) task 48 v_exp_f32 + ~50 v_fma + 24 v_max3 + 28 v_cvt_pk + ~30 others; SIMD retire rates
+    #    measured on gfx950 (scripts/micro/valu_rate.hip, 4 waves per SIMD): v_exp_f32 8.35, v_fma 2.75, v_max3 / v_cvt_pk 4.6
+    #    cycles per wave64 instruction -> ~870 cycles per task; 72 tasks per 96-row workgroup over 4 SIMDs (round-robin);
+    #  * HBM: the bytes the phase has to pull (q, k, v; in the fused layer kernel also the fp32 residual rows that load under
+    #    it) at the ~5 TB/s the chip sustains on reads when all 256 CUs ask at once (ATT_DBG ablations).
     if S == 192 and hd == 32:
-        valu_cycles, tiles_on_busiest_simd, clk = 1540.0, 2, 2.0e9
-        t_min = heads * valu_cycles * tiles_on_busiest_simd / clk          # per workgroup (96 rows) = per launch at one tile per CU
+        valu_cycles, clk, hbm_read_bps = 870.0, 2.1e9, 5.0e12
         rounds = max(1, -(-(nseq * S // 96) // 256))  # 96-row workgroups over 256 CUs (bs 64 + flip test: exactly one round)
-        ceil_tf = att_fl / (t_min * rounds) / 1e12
-        rec = {"bound": "valu", "algorithmic_gflop_per_layer": att_fl / 1e9, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+        t_valu = heads * 6 * valu_cycles / 4 / clk * rounds
+        fused = "attention" not in per_tag
+        qkv_bytes = nseq * S * 3 * heads * hd * 2
+        phase_bytes = qkv_bytes + (nseq * S * heads * hd * 4 if fused else nseq * S * heads * hd * 2)  # + residual rows in / + output rows out
+        t_hbm = phase_bytes / hbm_read_bps
+        t_min = max(t_valu, t_hbm)
+        ceil_tf = att_fl / t_min / 1e12
+        rec = {"bound": "hbm" if t_hbm >= t_valu else "valu", "algorithmic_gflop_per_layer": att_fl / 1e9, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
                "derived_ceiling": {"TFLOPs": ceil_tf, "frac_of_datasheet_peak": ceil_tf / PEAK_TFLOPS["bf16"],
-                                   "why": "softmax VALU issue bounds the phase: per (16-query tile, head) and wave ~1540 VALU cycles "
-                                          "(48 max, 48 fma, 48 v_exp_f32 at quarter rate, 48 add, 24 cvt_pk, cross-lane) against 384 "
-                                          "MFMA cycles (128 FLOP per v_exp_f32 at head dim 32); 6 tiles on 4 SIMDs = 2 on the busiest; "
-                                          f"12 heads x 2 x 1540 cycles at 2.0 GHz = {t_min * 1e6:.1f} us per 96-row workgroup. The 70 % "
-                                          "MFMA target of BASELINE.json is not reachable at 192 tokens x 32 dims."}}
-        if "attention" in per_tag:  # stand-alone kernel (PP_FUSE_ATTN=0 and the f16x3 / f32 modes)
+                                   "valu_floor_us": t_valu * 1e6, "hbm_floor_us": t_hbm * 1e6, "phase_mbytes": phase_bytes / 1e6,
+                                   "why": f"at 192 tokens x 32 dims the phase moves {phase_bytes / 1e6:.0f} MB for {att_fl / 1e9:.2f} GFLOP: at the ~5 TB/s "
+                                          f"the chip sustains on reads that is {t_hbm * 1e6:.1f} us; the softmax VALU work (48 v_exp_f32 at 8.35 cycles, "
+                                          f"fma / max3 / cvt_pk at 2.75 - 4.6, measured retire rates) is {t_valu * 1e6:.1f} us with the 72 tasks of a "
+                                          "workgroup dealt evenly to its four SIMDs; all arithmetic and LDS reads compiled out, a round of the "
+                                          "fused phase still takes 2 800 of its 4 000 cycles (ATT_DBG). The 70 % MFMA target of BASELINE.json "
+                                          "is not reachable at this shape."}}
+        if not fused:  # stand-alone kernel (PP_FUSE_ATTN=0 and the f16x3 / f32 modes)
             ms, n = per_tag["attention"]
             rec.update(achieved=att_fl / (ms / n * 1e-3) / 1e12, avg_launch_ms=ms / n, kernel="attention")
             rec["frac"] = rec["achieved"] / PEAK_TFLOPS["bf16"]
             if eng.precision == "bf16":
                 rec["derived_ceiling"]["frac_of_ceiling"] = rec["achieved"] / ceil_tf
-        else:  # inside the fused layer kernel: phase time from the kernel's own stamps (scripts/micro/layer_trace.py)
-            rec.update(kernel="vit_layer (attention phase)", phase_us_from_stamps=25.0, achieved=att_fl / 25.0e-6 / 1e12)
+        else:  # inside the fused layer kernel: phase time from the kernel's own stamps (scripts/micro/layer_trace.py):
+            # start -> round 0 ~3 us (cold q, k, v of two heads), then nine rounds of ~1.9 us
+            rec.update(kernel="vit_layer (attention phase)", phase_us_from_stamps=20.5, achieved=att_fl / 20.5e-6 / 1e12)
             rec["frac"] = rec["achieved"] / PEAK_TFLOPS["bf16"]
             rec["derived_ceiling"]["frac_of_ceiling"] = rec["achieved"] / ceil_tf
         out["attention"] = rec
