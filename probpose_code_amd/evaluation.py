@@ -225,6 +225,7 @@ class COCOeval:
         counts = np.stack([(h["gt_kpts"][:, :, 2] > 0).sum(1)] + [(h["gt_kpts"][:, :, 2] == v).sum(1) for v in self.gt_visibilities], 1) \
             if N_gt else np.zeros((0, L), np.int64)
         assert not bool((h["gt_ignore"].astype(bool) & (counts > 0)).any()), "k1 is negative but gt is not ignored"  # :654
+        self._gts_flat, self._dts_flat, self._matched_pairs = gts, dts, None  # (flat evaluation order; matched_pairs reads them)
         self._meta = dict(n_cells=len(cells), N_gt=N_gt, N_dt=N_dt, L=L, K=K, iou_total=int(cell_iou_off[-1]),
                           max_g=int(Gc.max()) if len(Gc) else 0, gt_ids=[g.get("id") for g in gts], dt_ids=[d.get("id") for d in dts],
                           gt_img=[img_ids[i] for i in g_img], dt_img=[img_ids[i] for i in d_img])
@@ -323,6 +324,45 @@ class COCOeval:
         names.append("OKS")
         stats.append(self.loc_similarity_mean)
         self.stats, self.stats_names = np.array(stats, np.float64), names
+
+    @property
+    def matched_pairs(self):
+        """``COCOeval.matched_pairs`` (_cocoeval.py:486-499 with the ``return_matching and match_by_bbox`` branch of
+        ``evaluateImg``, :762-777): for every image, detections in score order (at most maxDets) against the instances
+        in not-ignored-first order (level 0, all areas); the first instance whose box centre lies within an L1 distance of
+        2 px of the detection's is its partner. List of ``(detection dict, instance dict, similarity)``, similarity =
+        level-0 entry of the similarity matrix the GPU computed, ``nan`` for an instance ignored at level 0. Host
+        bookkeeping over the device-computed matrix, derived on first use."""
+        if self._d is None:
+            raise Exception("Please run evaluate() first")
+        if self._matched_pairs is not None:
+            return self._matched_pairs
+        m, h = self._meta, self._d
+        ious = self.ious.cpu().numpy()
+        g_off, d_off = h["cell_gt_off"].cpu().numpy(), h["cell_dt_off"].cpu().numpy()
+        i_off = h["cell_iou_off"].cpu().numpy()
+        g_ign0 = h["gt_ignore"].cpu().numpy().reshape(m["N_gt"], m["L"])[:, 0].astype(bool) if m["N_gt"] else np.zeros(0, bool)
+        g_area = h["gt_area_rng"].cpu().numpy()
+        gbb, dbb = h["gt_bbox"].cpu().numpy().reshape(-1, 4), h["dt_bbox"].cpu().numpy().reshape(-1, 4)
+        pairs = []
+        for c in range(m["n_cells"]):
+            g0, g1, d0, d1 = int(g_off[c]), int(g_off[c + 1]), int(d_off[c]), int(d_off[c + 1])
+            G, D = g1 - g0, d1 - d0
+            if G == 0 or D == 0:
+                continue
+            ign = g_ign0[g0:g1] | (g_area[g0:g1] < 0) | (g_area[g0:g1] > 1e5 ** 2)  # (:729-735 with aRng = [0, 1e5 ** 2])
+            gtind = np.argsort(ign.astype(np.int64), kind="mergesort")
+            sim0 = ious[int(i_off[c]):int(i_off[c]) + D * G].reshape(D, G)  # level 0 block: (detection, instance)
+            gc = gbb[g0:g1, :2] + gbb[g0:g1, 2:] / 2
+            for di in range(D):
+                dc = dbb[d0 + di, :2] + dbb[d0 + di, 2:] / 2
+                for gi in gtind:
+                    if np.abs(dc - gc[gi]).sum() < 2:
+                        iou = float("nan") if g_ign0[g0 + gi] else float(sim0[di, gi])
+                        pairs.append((self._dts_flat[d0 + di], self._gts_flat[g0 + gi], iou))
+                        break
+        self._matched_pairs = pairs
+        return pairs
 
     def image_results(self):
         """Per-image outcome of evaluate() as host arrays keyed like the reference's evalImgs entries: dt_match / gt_match

@@ -46,6 +46,7 @@ if os.environ.get("VIT"):  # the same through pp_vit_layer (attention phase in f
         nr = 9 if hd[10] == 0 else 12  # rounds of the round-robin attention phase / heads of the round-2 form (stale stamps cleared below)
         print(f"   wait + barrier per round {[int(aw[i]-hd[i]) for i in range(nr)]}")
         print(f"vit_layer wave {4*w}: total {ph[6]-ph[0]} ticks; prologue incl. attention {ph[1]-ph[0]}; start -> round 0 {hd[0]-ph[0]}; rounds {[int(hd[i+1]-hd[i]) for i in range(nr)]}")
+        print("   phases: " + "  ".join(f"{n} {int(ph[i+1]-ph[i])}" for i, n in enumerate(names)) + f"  (row statistics {int(t[w * 4096 + 210] - ph[3])})")
     sys.exit(0)
 for w in (0, 1):
     for pair in range(4):

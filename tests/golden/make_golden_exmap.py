@@ -159,6 +159,9 @@ def main():
         out[f"{tag}/img_dt_rows"] = np.array(rows_dt, np.int64).reshape(-1, 22)
         out[f"{tag}/img_gt_rows"] = np.array(rows_gt, np.int64).reshape(-1, 13)
         out[f"{tag}/img_none"] = np.array([r is None for r in e.evalImgs])
+        # COCOeval.matched_pairs (_cocoeval.py:486-499): detection / instance pairs whose box centres coincide, with their
+        # similarity at level 0 (nan for instances ignored there)
+        out[f"{tag}/matched_pairs"] = np.array([[d["id"], g["id"], iou] for d, g, iou in e.matched_pairs], np.float64).reshape(-1, 3)
         print(tag, "gts", len(gts), "dts", len(dts), "levels", e.gt_visibilities, "AP", e.stats[0], "OKS", e.stats[-1])
     out["n_cases"] = np.array(len(settings))
     np.savez_compressed(os.path.join(HERE, "exmap_cases.npz"), **out)

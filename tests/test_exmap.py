@@ -131,6 +131,22 @@ def test_hip_matching_matches_reference_per_image(lib_built, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", range(N))
+def test_matched_pairs_equal_the_reference(lib_built, n):
+    """COCOeval.matched_pairs (_cocoeval.py:486-499): same (detection id, instance id) pairs in the same order as the
+    reference's evaluator produced for this dataset, similarities to 1e-9, nan where the instance is ignored at level 0."""
+    e, _ = _run(n)
+    want = CASES[f"s{n}/matched_pairs"]
+    got = np.array([[d["id"], g["id"], iou] for d, g, iou in e.matched_pairs], np.float64).reshape(-1, 3)
+    assert got.shape == want.shape and len(want) > 0
+    assert np.array_equal(got[:, :2], want[:, :2])
+    assert np.array_equal(np.isnan(got[:, 2]), np.isnan(want[:, 2]))
+    ok = ~np.isnan(want[:, 2])
+    assert np.abs(got[ok, 2] - want[ok, 2]).max() <= 1e-9
+    assert e.matched_pairs is e.matched_pairs  # derived once
+
+
+@pytest.mark.gpu
 def test_hip_evaluator_matches_oracle_on_a_larger_dataset(lib_built):
     """~2000 detections (8 accumulate chunks), crowded images, ties; the oracle is the checker."""
     from oracle import exmap_ref
