@@ -56,6 +56,9 @@ constexpr int DBG = MLP_DBG;
 #ifndef MLP_ATT_RR
 #define MLP_ATT_RR 1  // dev A/B switch: 0 = round-2 attention phase (wave w = query tile w for every head, waves 6-7 idle)
 #endif
+#ifndef MLP_DEFER_X
+#define MLP_DEFER_X 1  // dev A/B switch: 0 = every wave stores its residual rows before the tail
+#endif
 #ifndef ATT_DBG
 #define ATT_DBG 0  // dev ablations of the attention rounds: 1 no v_exp, 2 no V reads, 4 no K reads, 8 no P V MFMAs (wrong results)
 #endif
@@ -967,7 +970,9 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                                (__bf16)((v[2] - mu) * rs * g[2] + b[2]), (__bf16)((v[3] - mu) * rs * g[3] + b[3])};
             if (QKV) *reinterpret_cast<bf16x4*>(hs + rf * 16 * ROW_BYTES) = hv;  // the row operand of the qkv steps
             if (m >= p.M) continue;
-            *reinterpret_cast<f32x4*>(p.x_out + off) = v;
+            // (MLP_DEFER_X, QKV: rows 48-95 - waves 4-7, which never count vmcnt in the tail - keep their x in registers across
+            // the barrier below and store it at the head of the tail, see there)
+            if (!(MLP_DEFER_X && QKV) || rg == 0) *reinterpret_cast<f32x4*>(p.x_out + off) = v;
             if (p.h_out) *reinterpret_cast<bf16x4*>(p.h_out + off) = hv;
         }
     }
@@ -985,6 +990,22 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     // vmcnt with the DMA stream and a counted wait would sit behind them: waves 0-3 issue all the DMA (and count it),
     // waves 4-7 do all the stores (and never wait for them before the end).
     wait_dma_and_barrier<0>();
+    if (MLP_DEFER_X && rg == 1) {
+        // The 37.7 MB of fp32 residual rows leave at the ~4.2 TB/s the chip sustains on writes, and the barrier above waits for
+        // them (the DMA-issuing waves 0-3 must drain their stores before their counted waits begin): 9 us per launch with
+        // no MFMA running. Waves 4-7 never wait on vmcnt in the tail, so THEIR half goes out here, after the barrier, under the
+        // first column block of the tail (whose own qkv stores only begin with the second block): the wait above then
+        // covers half the bytes. The accumulators are still intact (the tail zeroes its first set after this).
+#pragma unroll
+        for (int nf = 0; nf < 6; ++nf) {
+            const int n = cg * 96 + nf * 16 + e_kg * 4;
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) {
+                const int m = m0 + e_rows0 + rf * 16;
+                if (m < p.M) *reinterpret_cast<f32x4*>(p.x_out + (size_t)m * E + n) = acc[rf][nf];
+            }
+        }
+    }
     u32x4 wq_f[2][3][2], hq_f[2][3][2];  // fragments of the qkv steps, double-buffered: [buffer][fragment][k-half]
     auto read_Q = [&](int t, u32x4 (&wf)[3][2], u32x4 (&hf)[3][2]) {
         if (DBG & 16) {
