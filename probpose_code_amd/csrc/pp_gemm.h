@@ -50,4 +50,10 @@ int conv_halo(const GemmParams& p, int groups, hipStream_t s);
 bool panel_split_supported(const GemmParams& p, int prec, int groups);
 int panel_split_gemm(const GemmParams& p, int prec, int groups, hipStream_t s);
 
+
+// pp_linear_ovl.hip: split-fp16 Linear layers (qkv / fc1 of the f16x3 mode) on 192 x 192 tiles with two accumulator sets - the
+// epilogue of tile t (activation, split, stores) runs under the K-loop of tile t + 1
+bool linear_ovl_supported(const GemmParams& p, int prec, int groups);
+int linear_ovl_gemm(const GemmParams& p, hipStream_t s);
+
 }  // namespace pp

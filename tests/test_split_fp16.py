@@ -266,6 +266,26 @@ def test_panel_split_linear(act, split_out, K):
     torch.testing.assert_close(_unsp(out) if split_out else out.cpu().double(), ref, **TOL)
 
 
+# ---- the overlapped-epilogue kernel (pp_linear_ovl.hip) takes split Linear layers without residual once there are at least two
+# 192 x 192 tiles per CU (qkv / fc1 of the ViT at bs 64): tail rows, the three activations, both output formats, and a bias
+# that must come out of LDS for every column tile
+@gpu
+@pytest.mark.parametrize("act,split_out,N,K", [(1, 1, 1536, 384), (0, 1, 1152, 384), (2, 0, 1152, 192), (0, 0, 1536, 768)])
+def test_linear_overlapped_epilogue(act, split_out, N, K):
+    L = _lib()
+    M = 192 * 86 + 77   # 87 row tiles (the last one 77 rows) x 6 or 8 column tiles = 522 / 696 tiles: 2 - 3 per workgroup, uneven
+    a, w, b = _rand(M, K, seed=61), _rand(N, K, seed=62, scale=1 / math.sqrt(K)), _rand(N, seed=63)
+    ref = a.double() @ w.double().t() + b.double()
+    ref = F.gelu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+    ad, wd, bd = _sp(a), _sp(w), b.cuda()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    L.call("pp_gemm", F16X3, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, 0, out.data_ptr(), M, N, K, K, K, N, act,
+           SPLIT if split_out else 0, 0, None)
+    got = _unsp(out) if split_out else out.cpu().double()
+    assert not torch.isnan(got).any(), "rows or columns left unwritten"
+    torch.testing.assert_close(got, ref, **TOL)
+
+
 @gpu
 def test_panel_split_conv3x3_groups():
     L = _lib()
