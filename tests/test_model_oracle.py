@@ -188,3 +188,46 @@ def test_vit_layers_match_torch_transformer_encoder():
         ref = t.reshape(B, Hp, Wp, E).permute(0, 3, 1, 2)
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 2e-5, "oracle ViT disagrees with torch.nn.TransformerEncoderLayer"
+
+
+def test_vit_layers_match_huggingface_vit_layer():
+    """A second independent implementation of the block: Hugging Face `transformers` (installed in this image) ships the
+    reference ViT of Dosovitskiy et al. - `ViTLayer` = x + attn(layernorm_before(x)); x + mlp(layernorm_after(x)) with separate
+    q / k / v Linear layers, exact GELU, its own attention code path. mmpretrain packs qkv as one Linear whose output is reshaped
+    (B, N, 3, heads, head_dim): rows [0, E) = q, [E, 2E) = k, [2E, 3E) = v, head h = columns [h hd, (h + 1) hd) of each - the
+    same per-head split `ViTLayer` makes of its three projections. The oracle's ViT must reproduce three such layers."""
+    transformers = pytest.importorskip("transformers")
+    from transformers.models.vit.modeling_vit import ViTConfig, ViTLayer
+
+    from probpose_code_amd import synthetic as S
+
+    E, heads, Fd = 64, 4, 160
+    sd = S.synthetic_state_dict(dict(embed_dims=E, num_layers=3, num_heads=heads, feedforward_channels=Fd), img_size=(64, 48), seed=7)
+    x = torch.randn(2, 3, 64, 48, generator=torch.Generator().manual_seed(8))
+    got = M.vit_forward(sd, x, num_heads=heads)
+    cfg = ViTConfig(hidden_size=E, num_hidden_layers=3, num_attention_heads=heads, intermediate_size=Fd, hidden_act="gelu",
+                    layer_norm_eps=1e-6, qkv_bias=True, attention_probs_dropout_prob=0.0, hidden_dropout_prob=0.0)
+    with torch.no_grad():
+        t = F.conv2d(x, sd["backbone.patch_embed.projection.weight"], sd["backbone.patch_embed.projection.bias"], stride=16, padding=2)
+        B, _, Hp, Wp = t.shape
+        t = t.flatten(2).transpose(1, 2) + sd["backbone.pos_embed"]
+        for i in range(3):
+            q = lambda k: sd[f"backbone.layers.{i}.{k}"]  # noqa: E731
+            wq, bq = q("attn.qkv.weight"), q("attn.qkv.bias")
+            layer = ViTLayer(cfg).eval()
+            layer.load_state_dict({
+                "attention.q_proj.weight": wq[:E], "attention.q_proj.bias": bq[:E],
+                "attention.k_proj.weight": wq[E:2 * E], "attention.k_proj.bias": bq[E:2 * E],
+                "attention.v_proj.weight": wq[2 * E:], "attention.v_proj.bias": bq[2 * E:],
+                "attention.o_proj.weight": q("attn.proj.weight"), "attention.o_proj.bias": q("attn.proj.bias"),
+                "layernorm_before.weight": q("ln1.weight"), "layernorm_before.bias": q("ln1.bias"),
+                "layernorm_after.weight": q("ln2.weight"), "layernorm_after.bias": q("ln2.bias"),
+                "mlp.fc1.weight": q("ffn.layers.0.0.weight"), "mlp.fc1.bias": q("ffn.layers.0.0.bias"),
+                "mlp.fc2.weight": q("ffn.layers.1.weight"), "mlp.fc2.bias": q("ffn.layers.1.bias"),
+            })
+            out = layer(t)
+            t = out[0] if isinstance(out, tuple) else out
+        t = F.layer_norm(t, (E,), sd["backbone.ln1.weight"], sd["backbone.ln1.bias"], 1e-6)
+        ref = t.reshape(B, Hp, Wp, E).permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-5, f"oracle ViT disagrees with transformers.ViTLayer ({transformers.__version__})"
