@@ -286,6 +286,8 @@ __global__ __launch_bounds__(THREADS, 2) void linear_ovl_kernel(const GemmParams
         on0 = n0;
     }
     // ---- the workgroup's last tile leaves on its own (the staging buffer of slice ks was last read two barriers ago)
+    wait_vm_lgkm0<63>();
+    __builtin_amdgcn_s_barrier();  // waves 4-7 may still be reading the last half-slice of the tile before out of staging buffer 1
 #pragma unroll
     for (int ks = 0; ks < RF; ++ks) {
         stage_half(2 * ks, 0);
