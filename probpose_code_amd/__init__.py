@@ -11,6 +11,7 @@ from . import _lib  # noqa: F401  (fails loudly when the HIP library is missing)
 from .codecs import BaseKeypointCodec, ProbMap, oks_kernel_taps  # noqa: F401
 from .config import Config  # noqa: F401
 from .engine import ProbPoseEngine  # noqa: F401
+from .pipeline import StepPipeline  # noqa: F401
 from .pose_estimators import (  # noqa: F401
     PoseDataPreprocessor,
     ProbMapHead,

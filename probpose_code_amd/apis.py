@@ -121,6 +121,13 @@ def inference_topdown(model, img: Union[np.ndarray, torch.Tensor], bboxes=None, 
     cv2.imread produce), host array or device tensor; ``bboxes`` (N, 4) in ``bbox_format``, None or empty = the whole
     image as one box; ``img`` may also be a file path. Returns list[PoseDataSample], one per box, keypoints in image
     coordinates."""
+    batch = _frame_batch(model, img, bboxes, bbox_format)
+    with torch.no_grad():
+        return model.test_step(batch)
+
+
+def _frame_batch(model, img, bboxes, bbox_format):
+    """(image, boxes) -> the ``test_step`` batch dict of ``inference_topdown`` (box arithmetic on the host, one warp launch)."""
     if isinstance(img, str):
         img = load_image_bgr(img)
     h, w = img.shape[:2]
@@ -146,8 +153,17 @@ def inference_topdown(model, img: Union[np.ndarray, torch.Tensor], bboxes=None, 
     batch = pack_crops(crops, centers, scales, model.dataset_meta, bboxes=bboxes)
     for ds in batch["data_samples"]:
         ds.set_metainfo(dict(ori_shape=(h, w), img_shape=(h, w)))
+    return batch
+
+
+def inference_topdown_stream(model, frames, bbox_format: str = "xyxy", depth: int = 2, max_persons: int = 64):
+    """``inference_topdown`` over a sequence of frames - the video loop of demo/topdown_demo_with_mmdet.py:280-310
+    (``while cap.isOpened(): ... process_one_image(...)``) - with up to ``depth`` frames in flight on the device: ``frames``
+    yields ``(img, bboxes)`` pairs (``bboxes`` None / empty = the whole image), the generator yields one
+    ``list[PoseDataSample]`` per frame, in order, identical to what ``inference_topdown`` returns for that frame."""
     with torch.no_grad():
-        return model.test_step(batch)
+        yield from model.test_step_stream((_frame_batch(model, img, bb, bbox_format) for img, bb in frames), depth=depth,
+                                          max_batch=max_persons)
 
 
 def process_one_image(img, detector, pose_estimator, det_cat_id: int = 0, bbox_thr: float = 0.3, nms_thr: float = 0.3):

@@ -458,6 +458,51 @@ class TopdownPoseEstimator(nn.Module):
             batch_pred_instances, batch_pred_fields = preds, None
         return self.add_pred_to_datasample(batch_pred_instances, batch_pred_fields, data_samples)
 
+    def test_step_stream(self, batches, depth: int = 2, max_batch: int = 64):
+        """Generator over an iterable of ``test_step`` batch dicts (``inputs``, ``data_samples``): yields what ``test_step``
+        returns for each, in order, while up to ``depth`` batches are in flight on the device (pipeline.StepPipeline: own
+        stream and workspace per slot; the loop of tools/test.py / the video loop of demo/topdown_demo_with_mmdet.py finishes
+        one batch before the next starts). Batches may differ in size (persons per frame) up to ``max_batch``: kernel by
+        kernel launches, no graph. Results are bit-identical to ``test_step``: the records that come back are float64
+        images of the same float32 / float64 device results (``output_heatmaps`` is not carried by the record: use
+        ``test_step`` for that)."""
+        from .pipeline import StepPipeline
+
+        assert self.with_head, "The model must have head to perform prediction."
+        if bool(self.test_cfg.get("output_heatmaps", False)):
+            raise NotImplementedError("test_step_stream returns the per-keypoint records only; output_heatmaps needs test_step")
+        flip = bool(self.test_cfg.get("flip_test", False))
+        if flip and (self.test_cfg.get("flip_mode", "heatmap") != "heatmap" or self.test_cfg.get("shift_heatmap", False)):
+            raise NotImplementedError("MI355X path implements flip_mode='heatmap', shift_heatmap=False (ProbPose config)")
+        pipe, pending = None, []  # pending: (ticket, n, data_samples)
+
+        def collect(entry):
+            ticket, n, samples = entry
+            rec = pipe.result(ticket)[0, :n]  # (n, K, 7) float64: x, y, conf, prob, vis, oks, err (raw)
+            out = dict(keypoints=rec[..., :2].clone(), scores=rec[..., 2].to(torch.float32),
+                       scalars=rec[..., 3:7].permute(2, 0, 1).to(torch.float32).contiguous())
+            preds = self.head.pack_predictions(out, self.test_cfg)
+            return self.add_pred_to_datasample(preds, None, samples)
+
+        for data in batches:
+            data = self.data_preprocessor(data, False)
+            inputs, samples = data["inputs"], data["data_samples"]
+            if isinstance(inputs, list):
+                inputs = torch.stack(inputs)
+            if self.metainfo is not None:
+                for ds in samples:
+                    ds.set_metainfo(self.metainfo)
+            if pipe is None:
+                fi = samples[0].metainfo["flip_indices"] if flip else None
+                pipe = StepPipeline(self.engine, max_batch, fi, flip_test=flip, depth=depth, use_graph=False)
+            if inputs.shape[0] > max_batch:
+                raise ValueError(f"batch of {inputs.shape[0]} crops exceeds max_batch={max_batch}")
+            while len(pending) >= depth:  # the slot about to be reused must have been read
+                yield collect(pending.pop(0))
+            pending.append((pipe.submit(inputs), inputs.shape[0], samples))
+        while pending:
+            yield collect(pending.pop(0))
+
     def add_pred_to_datasample(self, batch_pred_instances, batch_pred_fields, batch_data_samples):
         """topdown.py:128-194."""
         assert len(batch_pred_instances) == len(batch_data_samples)
