@@ -124,3 +124,37 @@ def test_host_batches_take_the_copy_stream_and_give_the_same_records():
     assert np.array_equal(pipe.result(t_dev)[0].numpy(), want[2]) and np.array_equal(pipe.result(t_host)[0].numpy(), want[4])
     pipe1 = StepPipeline(eng, B, flip, depth=1)
     assert np.array_equal(pipe1.result(pipe1.submit(host[5]))[0].numpy(), want[5])
+
+
+@pytest.mark.gpu
+def test_random_mix_of_sizes_sources_and_collection_lags():
+    """Thirty batches through a 2-deep and a 3-deep pipeline without graphs: random sizes (1 .. 24 crops), device or pinned host
+    source, results collected with a random lag inside the depth window - every record equals the one-batch-at-a-time result,
+    rows beyond the batch's size are zero, the valid-row count travels with the record."""
+    from probpose_code_amd.engine import ProbPoseEngine
+
+    flip = S.COCO_FLIP_INDICES
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
+    eng = ProbPoseEngine(sd, 12, precision="bf16", device="cuda:0")
+    rng = np.random.default_rng(3)
+    pool = S.synthetic_crops(24, seed=500)
+    want = {}
+    for depth in (2, 3):
+        pipe = StepPipeline(eng, 24, flip, depth=depth, use_graph=False)
+        pending = []
+        for step in range(30):
+            n = int(rng.integers(1, 25))
+            x = pool[:n].clone()
+            x[0, 0, 0, 0] = step  # batches of equal size still differ
+            if n not in want or True:
+                ref = pack_records(eng.forward(x.cuda(), True, flip)).cpu().numpy().copy()
+            src = x.pin_memory() if rng.random() < 0.5 else x.cuda()
+            pending.append((pipe.submit(src), n, ref))
+            while len(pending) > int(rng.integers(0, depth)):
+                t, m, r = pending.pop(0)
+                got = pipe.result(t)[0].numpy()
+                assert np.array_equal(got[:m], r), (depth, step)
+                assert not got[m:].any()
+                assert pipe.gather_of(t).counts == [m]
+        for t, m, r in pending:
+            assert np.array_equal(pipe.result(t)[0].numpy()[:m], r)
