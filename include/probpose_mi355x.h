@@ -243,6 +243,22 @@ int pp_vit_layer(const void* qkv_in, int seq_len, int heads, float scale, const 
                  const void* w2, const float* b2, float* x_out, const float* gamma, const float* beta, float eps,
                  void* h_out, const void* wqkv, const float* bqkv, void* qkv_out, int M, int E, int F, void* stream);
 
+/* Whole feed-forward block of a ViT layer fused with the LayerNorm that follows it, in the parity precision
+ * (PP_PREC_F16X3: split-fp16 operands, three fp16 MFMAs per product):
+ *   x_out = residual + GELU(h_in W1^T + b1) W2^T + b2 ;  h_out = LayerNorm(x_out; gamma, beta, eps)
+ * (mmpretrain TransformerEncoderLayer.ffn [3P] = mmcv FFN: Linear(E, F) - GELU - Linear(F, E) + identity; call site
+ * mmpose/models/pose_estimators/base.py:206, ctor args td-pm_ProbPose-small_8xb64-210e_coco-256x192.py:56-67).
+ * The F-wide hidden activation stays on the CU. h_in, h_out (M, E) are PP_OUT_SPLIT tensors; b1, b2, residual, x_out,
+ * gamma, beta fp32. The weights come as ONE buffer in the kernel's consumption order, produced once per layer by
+ * pp_ffn_split_pack_weights from w1 (F, E) and w2 (E, F) in the split format (pp_ffn_split_packed_bytes(E, F) bytes;
+ * -1 for an unsupported shape). E must be 384, F a multiple of 128. residual may alias x_out, h_in may alias h_out
+ * (a workgroup has consumed its own rows before it writes them). */
+long long pp_ffn_split_packed_bytes(int E, int F);
+int pp_ffn_split_pack_weights(const void* w1_split, const void* w2_split, void* packed, int E, int F, void* stream);
+int pp_ffn_split_residual_layernorm(const void* h_in, const void* w_packed, const float* b1, const float* b2,
+                                    const float* residual, float* x_out, const float* gamma, const float* beta,
+                                    float eps, void* h_out, int M, int E, int F, void* stream);
+
 /* Last deconvolution of the heatmap branch fused with the 1x1 convolution that follows it (bf16 operands):
  *   ConvTranspose2d(Cin -> 256, k4, s2, p1) + BN + ReLU  ->  Conv2d(256 -> K, k1)
  * (probmap_head.py:435-472 and :244-249; reshaped to (B, K, H'W') at :627-648). weight / bias as PP_DECONV4X4S2 of

@@ -332,3 +332,71 @@ def test_panel_split_deconv_all_phases():
     L.call("pp_conv_gemm", F16X3, 2, xd.data_ptr(), pd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout,
            -1, 0, 1, 0, 0, 0, 0, Cout, 2, SPLIT, None)
     torch.testing.assert_close(_unsp(out).permute(0, 3, 1, 2), ref, **TOL)
+
+
+def _ffn_inputs(M, F_, E=384, seed=40):
+    h, r = _rand(M, E, seed=seed), _rand(M, E, seed=seed + 1)
+    w1, b1 = _rand(F_, E, seed=seed + 2, scale=1 / math.sqrt(E)), _rand(F_, seed=seed + 3, scale=0.2)
+    w2, b2 = _rand(E, F_, seed=seed + 4, scale=1 / math.sqrt(F_)), _rand(E, seed=seed + 5, scale=0.2)
+    g, be = 1 + 0.1 * _rand(E, seed=seed + 6), _rand(E, seed=seed + 7, scale=0.1)
+    return h, r, w1, b1, w2, b2, g, be
+
+
+def _ffn_pack(L, w1, w2, E, F_):
+    nbytes = L.lib.pp_ffn_split_packed_bytes(E, F_)
+    assert nbytes == (F_ // 128) * 384 * 1024
+    w1d, w2d = _sp(w1), _sp(w2)
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda")
+    L.call("pp_ffn_split_pack_weights", w1d.data_ptr(), w2d.data_ptr(), packed.data_ptr(), E, F_, None)
+    return packed
+
+
+@gpu
+@pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (24576, 1536)])
+def test_ffn_split_fused_vs_fp64(M, F_):
+    """pp_ffn_split_residual_layernorm (fc1 - GELU - fc2 + residual + LayerNorm in one launch, hidden activation on the CU)
+    against torch fp64 on the unrounded fp32 inputs; the bs 64 shape of the bench included; repeated launches bit-identical
+    (a ring / barrier race shows up as run-to-run differences long before it shows up as a tolerance failure)."""
+    L = _lib()
+    E = 384
+    h, r, w1, b1, w2, b2, g, be = _ffn_inputs(M, F_)
+    x_ref = r.double() + F.gelu(h.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    h_ref = F.layer_norm(x_ref, (E,), g.double(), be.double(), 1e-6)
+    packed = _ffn_pack(L, w1, w2, E, F_)
+    hd, rd = _sp(h), r.cuda()
+    dev = [t.cuda() for t in (b1, b2, g, be)]
+    outs = []
+    for _ in range(3):
+        x_out = torch.full((M, E), float("nan"), device="cuda")
+        h_out = torch.full((M, E), float("nan"), device="cuda")
+        L.call("pp_ffn_split_residual_layernorm", hd.data_ptr(), packed.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(),
+               rd.data_ptr(), x_out.data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), 1e-6, h_out.data_ptr(), M, E, F_, None)
+        outs.append((x_out.cpu(), h_out.cpu()))
+    torch.testing.assert_close(outs[0][0].double(), x_ref, **TOL)
+    torch.testing.assert_close(_unsp(outs[0][1]), h_ref, **TOL)
+    for x_o, h_o in outs[1:]:
+        assert torch.equal(x_o, outs[0][0]) and torch.equal(h_o.view(torch.int32), outs[0][1].view(torch.int32))
+
+
+@gpu
+def test_ffn_split_fused_in_place_and_errors():
+    """residual aliasing x_out and h_in aliasing h_out (how the engine calls it), and the argument checks."""
+    L = _lib()
+    M, E, F_ = 96 * 5 + 17, 384, 512
+    h, r, w1, b1, w2, b2, g, be = _ffn_inputs(M, F_, seed=60)
+    x_ref = r.double() + F.gelu(h.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    h_ref = F.layer_norm(x_ref, (E,), g.double(), be.double(), 1e-6)
+    packed = _ffn_pack(L, w1, w2, E, F_)
+    hd, xd = _sp(h), r.cuda()
+    dev = [t.cuda() for t in (b1, b2, g, be)]
+    L.call("pp_ffn_split_residual_layernorm", hd.data_ptr(), packed.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(),
+           xd.data_ptr(), xd.data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), 1e-6, hd.data_ptr(), M, E, F_, None)
+    torch.testing.assert_close(xd.cpu().double(), x_ref, **TOL)
+    torch.testing.assert_close(_unsp(hd), h_ref, **TOL)
+    assert L.lib.pp_ffn_split_packed_bytes(768, 3072) == -1 and L.lib.pp_ffn_split_packed_bytes(384, 100) == -1
+    with pytest.raises(L.ProbPoseLibraryError):
+        L.call("pp_ffn_split_residual_layernorm", hd.data_ptr(), packed.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(),
+               xd.data_ptr(), xd.data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), 1e-6, hd.data_ptr(), M, 768, F_, None)
+    with pytest.raises(L.ProbPoseLibraryError):
+        L.call("pp_ffn_split_residual_layernorm", None, packed.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(),
+               xd.data_ptr(), xd.data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), 1e-6, hd.data_ptr(), M, E, F_, None)
