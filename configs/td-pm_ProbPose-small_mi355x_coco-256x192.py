@@ -14,7 +14,10 @@ codec = dict(type="ProbMap", input_size=(192, 256), heatmap_size=(48, 64), sigma
 
 model = dict(
     type="TopdownPoseEstimator",
-    precision="bf16",  # MI355X-only key: operand precision of the MFMA kernels ("bf16" | "f32")
+    # MI355X-only key: operand precision of the MFMA kernels. "f16x3" (split-fp16 operands, three fp16 MFMAs per product) is
+    # the mode that matches the fp32 reference within 1e-3; "bf16" is ~3x faster and does not (0.3 - 0.45 px); "f32" = exact
+    # fp32 products, slowest
+    precision="f16x3",
     data_preprocessor=dict(
         type="PoseDataPreprocessor", mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], bgr_to_rgb=True
     ),

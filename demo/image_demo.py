@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--out-file", default=None)
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--bboxes", default=None, help="x0,y0,x1,y1;x0,y0,x1,y1;... (default: the whole image)")
-    ap.add_argument("--precision", default=None, choices=[None, "bf16", "f32"])
+    ap.add_argument("--precision", default=None, choices=[None, "f16x3", "bf16", "f32"],
+                    help="overrides model.precision of the config (default there: f16x3, the mode within 1e-3 of the fp32 reference)")
     args = ap.parse_args()
 
     from probpose_code_amd import apis, synthetic

@@ -14,23 +14,35 @@
 // the x k-blocks are re-streamed for each of the 12 hidden chunks next to the W1 blocks (+1.7 MB, L2-resident): 38.8 B/clk.
 //
 //   * one workgroup owns 96 complete token rows (one per CU at bs 64 with flip test), 512 threads = 8 waves,
-//     wave (rg, cg): rows 48 rg .. +47, column quarter cg;
+//     wave (rg, cg): rows 48 rg .. +47, column quarter cg; waves w and w + 4 share a SIMD;
 //   * the hidden layer runs in chunks of 128 units; per chunk twenty steps on a ring of FOUR 28 KiB slots:
 //       A-step kb (12 per chunk)   P += x[:, kb] W1[chunk, kb]^T   slot = W1 block (128 lines x 128 B) + x block (96 lines);
 //                                  wave tile 48 rows x 32 units, 18 MFMAs
 //       B-step (j, half) (8)       acc[:, half] += G[:, j] W2[half, chunk j]^T   slot = W2 half block (192 lines);
 //                                  wave tile 48 rows x 48 outputs, 27 MFMAs; the G fragments stay for both halves
-//     software-pipelined across chunks like pp_mlp.hip: the loop body is [A-steps of chunk c + 1 | B-steps of chunk c] and
-//     the GELU of chunk c (fp32 -> erfc form -> (hi, lo) -> LDS tile G, 48 KiB) is spread over the A-steps of chunk c + 1;
-//   * every step is [hi x hi products while the lo fragments are read | ONE barrier | the two cross products while the next
-//     step's hi fragments are read]: at the barrier the step's slot is free again (all of it has been read) and the next
-//     step's slot must have landed, so the DMA of step s + 4 goes into the slot of step s: three steps (up to 84 KiB) in flight;
+//     software-pipelined across chunks like pp_mlp.hip: the loop body is [A-steps of chunk c + 1 | B-steps of chunk c];
+//   * a step of a wave is two segments, L (its DMA share of step s + 3, every fragment read of step s, the side work)
+//     and C (the MFMAs, nothing else), and the two waves of a SIMD are never in the same kind: waves 4-7 run one segment
+//     behind waves 0-3, one barrier per segment (see the main loop);
+//   * GELU(P + b1) of a finished chunk (fp32 -> erfc form -> (hi, lo)) rides in the L segments of the NEXT twenty steps: one
+//     value pair per B-step (held in registers: the G tile is still being read), the last four pairs and the stores into
+//     the G tile (48 KiB, operand of the B-steps) in the following A-steps;
 //   * W1 / W2 come PRE-PACKED in consumption order (pp_ffn_split_pack_weights: per chunk 12 W1 blocks of 16 KiB, then
 //     8 W2 half blocks of 24 KiB, 128-byte lines with the LDS XOR swizzle already applied), so a weight DMA instruction
 //     is a linear 1 KiB copy; the x lines are 128-byte segments of the row-major split tensor, swizzled at the source;
 //   * the 96 x 384 accumulators start from residual + b2 (loaded under the first chunk's A-steps) and end in the LayerNorm
 //     epilogue (row statistics in registers, one LDS exchange between the column quarters).
 // LDS: 48 KiB G + 4 x 28 KiB ring = 160 KiB.
+//
+// Measured at bs 64 (M = 24 576, F = 1536; scripts/micro/ffs_variants.sh + ffs_variants_bench.py, round-robin minima):
+// 176 - 180 us against 232 us for pp_linear_ovl (fc1 + GELU) + pp_gemm_ln (fc2 + residual + LayerNorm), and 302 MB of HBM
+// traffic less per layer. Matrix pipe 48 % busy. What the ablations said (FFS_DBG / FFS_XSRC, same instruction stream):
+// MFMAs alone 110 us (the pipe's own time: 5400 per wave x 16 cycles + 25 us of prologue / epilogue), everything but the
+// MFMAs 116 us, no DMA traffic (empty descriptors) 155 us. Chunk order: every workgroup of an XCD walks the chunks in the SAME
+// order (rotated per XCD only) - W1 / W2 are 4.5 MiB, more than the 4 MiB L2, and with a rotation per workgroup (what
+// pp_mlp.hip does with its 3.2 MB) every chunk was in flight somewhere all the time: fill-only skeleton 143 -> 107 us.
+// All eight waves in the same phase (the form of pp_mlp.hip: next step's hi fragments read under the cross products,
+// DMA pieces and GELU placed between the MFMAs with sched_group_barrier) measured the same 180 us.
 #include "pp_common.h"
 #include "pp_split.h"
 
@@ -42,11 +54,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #ifndef FFS_DBG
-#define FFS_DBG 0  // dev ablations (timing only, wrong results): 2 no GELU, 4 no MFMA, 8 no DMA, 16 no fragment reads
+#define FFS_DBG 0  // dev ablations (timing only, wrong results): 2 no GELU, 4 no MFMA, 8 no DMA, 16 no fragment reads; 512 time stamps (pp_ffs_set_trace)
 #endif
 constexpr int DBG = FFS_DBG;
-#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_VMEM = 0x010, SG_DS_READ = 0x100, SG_DS_WRITE = 0x200;
 
 constexpr int BM = 96, E = 384, CHUNK = 128, THREADS = 512;
 constexpr int KB = E / 32;                       // 12 k-blocks of the input width
@@ -78,6 +88,7 @@ struct Params {
     int M, F;
     unsigned h_bytes, w_bytes;
     float eps;
+    unsigned long long* trace;  // dev only (FFS_DBG & 512): s_memtime at every barrier of block 0, waves 0 and 4
 };
 
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
@@ -109,83 +120,105 @@ __global__ __launch_bounds__(THREADS, 2) void ffn_split_kernel(const Params p) {
     const int f_row = lane & 15, f_kg = lane >> 4;
     const int m0 = blockIdx.x * BM;
     const int nchunks = p.F / CHUNK;
-    // every workgroup walks the hidden chunks in a different rotation (rank inside the XCD): all CUs stream the SAME weights
-    const int c_rot = (int)(blockIdx.x >> 3) % nchunks;
+    // the workgroups of an XCD walk the hidden chunks in the same order, the XCDs in different rotations
+#ifndef FFS_ROT
+#define FFS_ROT 2  // dev A/B switch: 0 no rotation, 1 by rank inside the XCD, 2 by XCD (see the file header)
+#endif
+    const int c_rot = FFS_ROT == 1 ? (int)(blockIdx.x >> 3) % nchunks : FFS_ROT == 2 ? (int)(blockIdx.x & 7) % nchunks : 0;
     auto chunk_of = [&](int i) { const int c = i + c_rot; return c >= nchunks ? c - nchunks : c; };
 
-    const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.h), 0, p.h_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wpack), 0, p.w_bytes, 0x00020000);
     char* const ring = smem + OFF_RING;
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (!(DBG & 512)) return;
+        if (blockIdx.x != 0 || (wv & 3) != 0) return;
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && stamp_i < 2048) p.trace[(wv >> 2) * 2048 + stamp_i] = t;
+        ++stamp_i;
+    };
 
     // ---- DMA addressing. A weight piece is a linear 1 KiB copy (lane i -> byte 16 i). An x piece is 8 rows x 128 B: lane
     // (row l = lane >> 3, physical chunk pc = lane & 7) fetches logical chunk pc ^ l (rows 8 p + l: (row & 7) == l).
-    const unsigned w_lane = (unsigned)lane * 16u;
+    // Every wave issues THREE pieces per step with the same instructions - what differs by wave half is data (descriptor,
+    // offsets, LDS destination), selected once - so that the pieces can sit between the MFMAs of a half-step as one basic
+    // block: a buffer_load ... lds holds its wave for 60 - 180 cycles when the texture path is busy (16 cycles per KiB,
+    // 28 KiB per A-step), and issued as a burst behind the barrier all eight waves - and the matrix pipe - waited for it.
+    //   A-step: waves 0-3 W1 pieces 3 w .. 3 w + 2 (+ one extra piece 12 + w, the only wave-half-dependent instruction),
+    //           waves 4-7 x pieces 3 (w - 4) .. + 2;      B-step: W2 pieces 3 w .. 3 w + 2.
     const int x_l = lane >> 3;
-    const unsigned x_lane = (unsigned)(((lane & 7) ^ x_l) << 4);
-    // step t of the iteration that handles chunk index `ci` as its A-chunk and `ci - 1` as its B-chunk
-    auto issue_a = [&](int ci, int kb, int slot) {
+    const unsigned v_w = (unsigned)lane * 16u;
+    const unsigned v_x = (unsigned)(m0 + 24 * (wv & 3) + x_l) * (unsigned)(E * 4) + (unsigned)(((lane & 7) ^ x_l) << 4);
+    const unsigned v_a = rg == 0 ? v_w : v_x;                       // voffset of an A-step piece
+    const int a_stride = rg == 0 ? 1024 : 8 * E * 4;                // soffset step from piece to piece
+    const int a_dst = rg == 0 ? 3 * wv * 1024 : X_OFF + 3 * (wv & 3) * 1024;
+#ifndef FFS_XSRC
+#define FFS_XSRC 0  // dev (timing only): 2 no x traffic, 3 no DMA traffic at all (every descriptor empty: same instructions, zeros)
+#endif
+    auto rsrc_a = [&](bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(rg == 0 ? p.wpack : p.h), 0,
+                                                 (live && FFS_XSRC != 3) ? (rg == 0 ? p.w_bytes : (FFS_XSRC == 2 ? 0u : p.h_bytes)) : 0u, 0x00020000);
+    };
+    auto rsrc_w = [&](bool live) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wpack), 0, (live && FFS_XSRC != 3) ? p.w_bytes : 0u, 0x00020000); };
+    // piece u (0..2; 3 = the extra W1 piece of waves 0-3) of A-step kb of the chunk visited ci-th into ring slot `slot`; past the
+    // last chunk the descriptor has no extent: the DMA writes zeros, every wave's vmcnt arithmetic stays the same
+    auto issue_a = [&](int ci, int kb, int slot, int u) {
         if (DBG & 8) return;
         const bool live = ci < nchunks;
-        char* dst = ring + slot * SLOTB;
-        if (rg == 0) {
-            const int so = live ? chunk_of(ci) * CHUNK_BYTES + kb * A_BLOCK : 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int pi = 4 * wv + u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(dst + pi * 1024), 16, live ? w_lane + (unsigned)(pi * 1024) : OOB, so, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int pi = 3 * (wv - 4) + u;
-                const int m = m0 + 8 * pi + x_l;
-                const unsigned vo = (unsigned)m * (unsigned)(E * 4) + x_lane;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(h_rsrc, (lds_ptr_t)(dst + X_OFF + pi * 1024), 16, (live && m < p.M) ? vo : OOB, kb * 128, 0, 0);
-            }
+        const int blk = chunk_of(live ? ci : 0) * CHUNK_BYTES + kb * A_BLOCK;
+        if (u < 3) {
+            const int so = (rg == 0 ? blk + 3 * wv * 1024 : kb * 128) + u * a_stride;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a(live), (lds_ptr_t)(ring + slot * SLOTB + a_dst + u * 1024), 16, v_a, so, 0, 0);
+        } else if (rg == 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w(live), (lds_ptr_t)(ring + slot * SLOTB + (12 + wv) * 1024), 16, v_w, blk + (12 + wv) * 1024, 0, 0);
         }
     };
-    auto issue_b = [&](int ci, int s, int slot) {
+    auto issue_b = [&](int ci, int sb, int slot, int u) {
         if (DBG & 8) return;
         const bool live = ci >= 0 && ci < nchunks;
-        char* dst = ring + slot * SLOTB;
-        const int so = live ? chunk_of(ci) * CHUNK_BYTES + B_PART + s * B_BLOCK : 0;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int pi = 3 * wv + u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(dst + pi * 1024), 16, live ? w_lane + (unsigned)(pi * 1024) : OOB, so, 0, 0);
-        }
+        const int so = chunk_of(live ? ci : 0) * CHUNK_BYTES + B_PART + sb * B_BLOCK + 3 * wv * 1024;
+        if (u < 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w(live), (lds_ptr_t)(ring + slot * SLOTB + (3 * wv + u) * 1024), 16, v_w, so + u * 1024, 0, 0);
     };
     // step index t relative to the start of iteration `it` (which runs A-steps of chunk it + 1 and B-steps of chunk it);
     // t < 0: the peeled A-steps of chunk 0 (t = -12 .. -1), t >= 20: the next iteration
-    auto issue_step = [&](int it, int t) {
+    auto issue_piece = [&](int it, int t, int u) {
         const int slot = (t + 4 * STEPS) & (NSLOT - 1);
-        if (t < 0) issue_a(0, t + NA, slot);
-        else if (t < NA) issue_a(it + 1, t, slot);
-        else if (t < STEPS) issue_b(it, t - NA, slot);
-        else issue_a(it + 2, t - STEPS, slot);
+        if (t < 0) issue_a(0, t + NA, slot, u);
+        else if (t < NA) issue_a(it + 1, t, slot, u);
+        else if (t < STEPS) issue_b(it, t - NA, slot, u);
+        else issue_a(it + 2, t - STEPS, slot, u);
+    };
+    auto issue_step = [&](int it, int t) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) issue_piece(it, t, u);
     };
 
-    // ---- fragment reads: hi halves in 16-byte chunk f_kg, lo halves in chunk 4 + f_kg of a line, swizzled by line & 7
+    // ---- fragment reads: hi halves in 16-byte chunk f_kg, lo halves in chunk 4 + f_kg of a line, swizzled by line & 7.
+    // Six per-lane byte offsets (three line sets x hi / lo) and a slot offset the compiler cannot fold (so that it does not keep
+    // a hoisted address register per (slot, line set): the loop has none to spare); fragment strides are instruction offsets.
     const int sw = f_row & 7;
     const int ch_hi = (f_kg ^ sw) << 4, ch_lo = ((4 + f_kg) ^ sw) << 4;
     const int rows0 = rg * 48 + f_row;
+    const int la[2] = {OFF_RING + (cg * 32 + f_row) * 128 + ch_hi, OFF_RING + (cg * 32 + f_row) * 128 + ch_lo};  // A-step W1 lines
+    const int lb[2] = {OFF_RING + (cg * 48 + f_row) * 128 + ch_hi, OFF_RING + (cg * 48 + f_row) * 128 + ch_lo};  // B-step W2 lines
+    const int lx[2] = {rows0 * 128 + ch_hi, rows0 * 128 + ch_lo};                                                  // row lines (x, G)
+    const int lxa[2] = {lx[0] + OFF_RING + X_OFF, lx[1] + OFF_RING + X_OFF};  // x lines of an A slot (instruction offsets stay < 64 KiB)
+    auto slot_off = [](int slot) { int so = slot * SLOTB; asm volatile("" : "+s"(so)); return so; };
     auto opaque = [](u32x4& v) { asm volatile("" : "=v"(v)); };
-    auto rd = [&](const char* ptr) -> u32x4 {
+    auto rd = [&](int off) -> u32x4 {
         u32x4 v;
-        if (DBG & 16) opaque(v); else v = *reinterpret_cast<const u32x4*>(ptr);
+        if (DBG & 16) opaque(v); else v = *reinterpret_cast<const u32x4*>(smem + off);
         return v;
     };
-    // A-step: W1 fragment nf (units 32 cg + 16 nf ..), x fragment rf (rows 48 rg + 16 rf ..)
-    auto a_w = [&](int slot, int nf, int lo) { return rd(ring + slot * SLOTB + (cg * 32 + nf * 16 + f_row) * 128 + (lo ? ch_lo : ch_hi)); };
-    auto a_x = [&](int slot, int rf, int lo) { return rd(ring + slot * SLOTB + X_OFF + (rows0 + rf * 16) * 128 + (lo ? ch_lo : ch_hi)); };
+    // A-step: W1 fragment nf (units 32 cg + 16 nf ..), x fragment rf (rows 48 rg + 16 rf ..); so = slot_off(slot)
+    auto a_w = [&](int so, int nf, int lo) { return rd(la[lo] + so + nf * 2048); };
+    auto a_x = [&](int so, int rf, int lo) { return rd(lxa[lo] + so + rf * 2048); };
     // B-step: W2 fragment nf (outputs 192 half + 48 cg + 16 nf ..), G fragment rf of k-block j
-    auto b_w = [&](int slot, int nf, int lo) { return rd(ring + slot * SLOTB + (cg * 48 + nf * 16 + f_row) * 128 + (lo ? ch_lo : ch_hi)); };
-    auto b_g = [&](int j, int rf, int lo) { return rd(smem + OFF_G + j * G_KB + (rows0 + rf * 16) * 128 + (lo ? ch_lo : ch_hi)); };
+    auto b_w = [&](int so, int nf, int lo) { return rd(lb[lo] + so + nf * 2048); };
+    auto b_g = [&](int j, int rf, int lo) { return rd(lx[lo] + OFF_G + j * G_KB + rf * 2048); };
 
     f32x4 acc[3][6];   // the 96 x 384 block: [row fragment][half * 3 + nf]: columns 192 half + 48 cg + 16 nf + 4 f_kg + (0..3)
     f32x4 pacc[3][2];  // P of the chunk in its A-steps
-    f32x4 pold[3][2];  // P of the previous chunk, on its way through GELU
-    f32x4 b1v[2];      // b1 of the chunk in pold
+    f32x4 b1v[2];      // b1 of the chunk whose A-steps come next (its accumulators start from it)
     u32x4 awh[2], awl[2], axh[3], axl[3];  // A-step fragments
     u32x4 bwh[3], bwl[3], bgh[3], bgl[3];  // B-step fragments
 
@@ -194,236 +227,265 @@ __global__ __launch_bounds__(THREADS, 2) void ffn_split_kernel(const Params p) {
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) b1v[nf] = *reinterpret_cast<const f32x4*>(p.b1 + c * CHUNK + cg * 32 + nf * 16 + f_kg * 4);
     };
-    // GELU of one accumulator fragment of pold -> (hi, lo) -> operand tile of the B-steps. Lane holds units
-    // 32 cg + 16 nf + 4 f_kg + (0..3) of its rows: k-block cg of the chunk, 16-byte chunk 2 nf + (f_kg >> 1) (+ 4 for lo),
-    // upper or lower 8 bytes.
-    auto gelu_frag = [&](int rf, int nf) {
-        char* gs = smem + OFF_G + cg * G_KB + (rows0 + rf * 16) * 128 + (f_kg & 1) * 8;
-        const f32x4 v = pold[rf][nf] + b1v[nf];
-        f16x4 hv, lv;
+    // GELU of the chunk whose A-steps have just ended runs under the B-steps of the chunk BEFORE it (one value pair per step; the last four pairs under
+    // the first A-steps of the next iteration, from a copy):
+    // the A-steps carry the fragment reads of two streamed operands and the x DMA, the B-steps have the issue slots to spare.
+    // The G tile is still being read then, so the (hi, lo) pairs wait in registers (24) and are stored at the head of the next
+    // iteration. Lane holds units 32 cg + 16 nf + 4 f_kg + (0..3) of its rows: k-block cg of the chunk, 16-byte chunk
+    // 2 nf + (f_kg >> 1) (+ 4 for lo), upper or lower 8 bytes.
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    f16x2 gq_hi[12], gq_lo[12];  // value pairs (2 q, 2 q + 1) of the 24 values of a lane: fragment q >> 1, elements 2 (q & 1) ..
+    // (written stage by stage over all values of the call: 2 * count independent dependency chains in program order, so that
+    // consecutive VALU instructions between two MFMAs do not wait for each other - a single chain issues one instruction per
+    // ~8 cycles and the matrix pipe idles behind it)
+    f32x4 pold[2];  // fragments 4, 5 of the finished chunk: their GELU runs under the first A-steps of the next iteration
+    auto gelu_pairs = [&](int first, int count, bool from_pold) {
+        constexpr int MAXV = 4;
+        float x[MAXV], z[MAXV], t[MAXV], q[MAXV], e[MAXV], g[MAXV];
+        const int n = 2 * count;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float g = (DBG & 2) ? v[i] : gelu_erfc_as(v[i]);
-            hv[i] = split_hi(g);
-            lv[i] = split_lo(g, hv[i]);
+        for (int u = 0; u < n; ++u) {
+            const int qq = first + (u >> 1), f = qq >> 1, i = 2 * (qq & 1) + (u & 1);
+            x[u] = from_pold ? pold[f - 4][i] : pacc[f >> 1][f & 1][i];  // (b1 is already in: the chunk's accumulators start from it)
         }
-        const int c = 2 * nf + (f_kg >> 1);
-        *reinterpret_cast<f16x4*>(gs + ((c ^ sw) << 4)) = hv;
-        *reinterpret_cast<f16x4*>(gs + (((4 + c) ^ sw) << 4)) = lv;
+        if (DBG & 2) {
+#pragma unroll
+            for (int u = 0; u < n; ++u) g[u] = x[u];
+        } else {
+            // gelu_erfc_as of pp_split.h (Abramowitz & Stegun 7.1.26), same operations in the same order per value
+#pragma unroll
+            for (int u = 0; u < n; ++u) z[u] = fabsf(x[u]) * 0.70710678118654752440f;
+#pragma unroll
+            for (int u = 0; u < n; ++u) t[u] = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z[u], 1.0f));
+#pragma unroll
+            for (int u = 0; u < n; ++u) e[u] = __builtin_amdgcn_exp2f(-(z[u] * z[u]) * 1.44269504088896340736f);
+#pragma unroll
+            for (int u = 0; u < n; ++u) q[u] = __builtin_fmaf(t[u], 1.061405429f, -1.453152027f);
+#pragma unroll
+            for (int u = 0; u < n; ++u) q[u] = __builtin_fmaf(t[u], q[u], 1.421413741f);
+#pragma unroll
+            for (int u = 0; u < n; ++u) q[u] = __builtin_fmaf(t[u], q[u], -0.284496736f);
+#pragma unroll
+            for (int u = 0; u < n; ++u) q[u] = __builtin_fmaf(t[u], q[u], 0.254829592f);
+#pragma unroll
+            for (int u = 0; u < n; ++u) {
+                const float erfc_z = t[u] * q[u] * e[u];
+                g[u] = 0.5f * x[u] * (x[u] < 0.f ? erfc_z : 2.0f - erfc_z);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < count; ++c) {
+            const f16x2 h = {split_hi(g[2 * c]), split_hi(g[2 * c + 1])};
+            const f16x2 l = {split_lo(g[2 * c], h[0]), split_lo(g[2 * c + 1], h[1])};
+            gq_hi[first + c] = h;
+            gq_lo[first + c] = l;
+            // pinned here: nothing reads the pairs before the next iteration, and the compiler would sink the arithmetic there
+            asm volatile("" : "+v"(gq_hi[first + c]), "+v"(gq_lo[first + c]));
+        }
     };
-
-    // ================= one A-step. On entry awh / axh hold the hi fragments of this step. NEXT_B: the step after this one is
-    // the first B-step (read its hi fragments instead of an A-step's).
-    // GE: 0 none, 1 first half of fragment gf (nothing stored yet), 2 whole fragment gf
-    auto a_step = [&](auto wait_fn, auto issue_fn, auto extra_fn, int slot, int nslot, bool next_b, int gelu_frag_idx) {
-        // ---- first half: hi x hi, lo fragments in
+    auto write_g = [&](int f0, int f1) {
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf) awl[nf] = a_w(slot, nf, 1);
+        for (int f = f0; f < f1; ++f) {
+            const int rf = f >> 1, nf = f & 1;
+            char* gs = smem + OFF_G + cg * G_KB + (rows0 + rf * 16) * 128 + (f_kg & 1) * 8;
+            const int c = 2 * nf + (f_kg >> 1);
+            const f16x4 hv = {gq_hi[2 * f][0], gq_hi[2 * f][1], gq_hi[2 * f + 1][0], gq_hi[2 * f + 1][1]};
+            const f16x4 lv = {gq_lo[2 * f][0], gq_lo[2 * f][1], gq_lo[2 * f + 1][0], gq_lo[2 * f + 1][1]};
+            *reinterpret_cast<f16x4*>(gs + ((c ^ sw) << 4)) = hv;
+            *reinterpret_cast<f16x4*>(gs + (((4 + c) ^ sw) << 4)) = lv;
+        }
+    };
+    // ================= main loop, role-alternating form. The two waves of a SIMD (wave w of rows 0-47 and wave w + 4 of rows
+    // 48-95) are never in the same kind of segment: a step of a wave is  L(s): its DMA share of step s + 3, all fragment reads
+    // of step s, the GELU / bias / residual side work  |  C(s): the 18 / 27 MFMAs of the step, nothing else.  Waves 4-7 run one
+    // segment behind waves 0-3 (one extra barrier at the start), so while one half's MFMAs own the matrix pipe the other half's
+    // LDS reads, DMA issue (60 - 180 cycles per instruction when the texture path is busy) and VALU work proceed beside them -
+    // with all eight waves in the same phase those costs add to the MFMA time.
+    // Ring: step s is read in time slots 2 s - 1 (waves 0-3) and 2 s (waves 4-7); L(s) refills the slot of step s - 1 with step
+    // s + 3; the wave half that ends an even time slot (0-3 after C(s), 4-7 after L(s)) waits for its pieces of step s + 1.
+    auto sync_l = [&](auto wait_rg1) {  // after L(s)
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        if (rg == 0) __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));  // lgkmcnt(0): the fragments are in
+        else wait_rg1();
+        __builtin_amdgcn_s_barrier();
+        stamp();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync_c = [&](auto wait_rg0) {  // after C(s)
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        if (rg == 0) wait_rg0();
+        __builtin_amdgcn_s_barrier();
+        stamp();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define FFS_WAIT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (0 << 8) | (((N) >> 4) << 14))
+    // allowed outstanding at the wait for step S + 1: pieces of steps S + 2, S + 3 (own share) + the extra loads of L(S - 1), L(S)
+    // L segments: this wave's DMA pieces alternate with its fragment reads - four waves issue at the same time, the texture
+    // path takes one piece per 16 cycles, and whoever finds its queue full stands still: the reads go out in those gaps
+    auto pin = [&]() { __builtin_amdgcn_sched_barrier(0); };
+    auto a_load = [&](int slot_i, auto issue_fn) {
+        const int so = slot_off(slot_i);
+        issue_fn(0);
+        pin();
 #pragma unroll
-        for (int rf = 0; rf < 3; ++rf) axl[rf] = a_x(slot, rf, 1);
+        for (int nf = 0; nf < 2; ++nf) { awh[nf] = a_w(so, nf, 0); awl[nf] = a_w(so, nf, 1); }
+        pin();
+        issue_fn(1);
+        pin();
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) axh[rf] = a_x(so, rf, 0);
+        pin();
+        issue_fn(2);
+        pin();
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) axl[rf] = a_x(so, rf, 1);
+        pin();
+        issue_fn(3);
+    };
+    auto a_compute = [&]() {
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(awh[nf], axh[rf], pacc[rf][nf]);
-        wait_fn();
-        extra_fn();
-        issue_fn();
-        // ---- second half: the cross products; the next step's hi fragments replace the dying ones
-        u32x4 nwh[3], nxh[3];
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(awl[nf], axh[rf], pacc[rf][nf]);
-        if (next_b) {
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf) nxh[rf] = b_g(0, rf, 0);
-#pragma unroll
-            for (int nf = 0; nf < 3; ++nf) nwh[nf] = b_w(nslot, nf, 0);
-        } else {
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf) nxh[rf] = a_x(nslot, rf, 0);
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) nwh[nf] = a_w(nslot, nf, 0);
-        }
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) pacc[rf][nf] = mma(awh[nf], axl[rf], pacc[rf][nf]);
-        if (gelu_frag_idx >= 0) gelu_frag(gelu_frag_idx >> 1, gelu_frag_idx & 1);
-        if (next_b) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { bgh[i] = nxh[i]; bwh[i] = nwh[i]; }
-        } else {
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf) axh[rf] = nxh[rf];
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) awh[nf] = nwh[nf];
-        }
     };
-
-    // ================= one B-step s = 2 j + half. On entry bwh (this half's W2 hi fragments) and bgh (k-block j) are loaded;
-    // bgl is loaded in the first half-step of a k-block and kept for the second.
-    // next: 0 = B-step of the same k-block (new W fragments only), 1 = B-step of the next k-block, 2 = an A-step
-    auto b_step = [&](auto wait_fn, auto issue_fn, auto extra_fn, int s, int slot, int nslot, int next) {
-        const int half = s & 1, j = s >> 1;
+    auto b_load = [&](int sb, int slot_i, auto issue_fn) {
+        const int so = slot_off(slot_i);
+        issue_fn(0);
+        pin();
 #pragma unroll
-        for (int nf = 0; nf < 3; ++nf) bwl[nf] = b_w(slot, nf, 1);
-        if (half == 0) {
+        for (int nf = 0; nf < 3; ++nf) bwh[nf] = b_w(so, nf, 0);
+        pin();
+        issue_fn(1);
+        pin();
 #pragma unroll
-            for (int rf = 0; rf < 3; ++rf) bgl[rf] = b_g(j, rf, 1);
+        for (int nf = 0; nf < 3; ++nf) bwl[nf] = b_w(so, nf, 1);
+        pin();
+        issue_fn(2);
+        pin();
+        if ((sb & 1) == 0) {
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) { bgh[rf] = b_g(sb >> 1, rf, 0); bgl[rf] = b_g(sb >> 1, rf, 1); }
         }
+        issue_fn(3);
+    };
+    auto b_compute = [&](int sb) {
+        const int half = sb & 1;
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(bwh[nf], bgh[rf], acc[rf][half * 3 + nf]);
-        wait_fn();
-        extra_fn();
-        issue_fn();
-        u32x4 nwh[3], nxh[3];
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(bwl[nf], bgh[rf], acc[rf][half * 3 + nf]);
-        if (next == 1) {
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf) nxh[rf] = b_g(j + 1, rf, 0);
-        } else if (next == 2) {
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf) nxh[rf] = a_x(nslot, rf, 0);
-        }
-        if (next == 2) {
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) nwh[nf] = a_w(nslot, nf, 0);
-        } else {
-#pragma unroll
-            for (int nf = 0; nf < 3; ++nf) nwh[nf] = b_w(nslot, nf, 0);
-        }
 #pragma unroll
         for (int nf = 0; nf < 3; ++nf)
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) acc[rf][half * 3 + nf] = mma(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
-        if (next == 2) {
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf) axh[rf] = nxh[rf];
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) awh[nf] = nwh[nf];
-        } else {
-            if (next == 1) {
-#pragma unroll
-                for (int rf = 0; rf < 3; ++rf) bgh[rf] = nxh[rf];
-            }
-#pragma unroll
-            for (int nf = 0; nf < 3; ++nf) bwh[nf] = nwh[nf];
-        }
     };
 
-    // ---- prologue: the first four steps' DMA, then the first step's hi fragments
+    // ---- prologue: b1 of the first chunk, the DMA of steps 0 - 2; the residual rows trickle in under the peeled A-steps
+    load_b1(0);  // (older than every DMA piece: landed at the first counted wait)
 #pragma unroll
-    for (int t = 0; t < NSLOT; ++t) issue_step(0, t - NA);
-    bool valid[3];
+    for (int t = 0; t < 3; ++t) issue_step(0, t - NA);
     int mrow[3];
 #pragma unroll
     for (int rf = 0; rf < 3; ++rf) {
         const int m = m0 + rows0 + rf * 16;
-        valid[rf] = m < p.M;
-        mrow[rf] = valid[rf] ? m : p.M - 1;  // rows past M read row M - 1; nothing of them is ever stored
+        mrow[rf] = m < p.M ? m : p.M - 1;  // rows past M read row M - 1; nothing of them is ever stored
     }
 #pragma unroll
     for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // step -12 has landed when at most the pieces of steps -11, -10, -9 are outstanding
-    wait_and_barrier<3 * n_ops(0, 0), 3 * n_ops(0, 1)>(rg);
-#pragma unroll
-    for (int nf = 0; nf < 2; ++nf) awh[nf] = a_w(0, nf, 0);
-#pragma unroll
-    for (int rf = 0; rf < 3; ++rf) axh[rf] = a_x(0, rf, 0);
+        for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf];
+    // step 0 has landed when at most the pieces of steps 1, 2 are outstanding
+    wait_and_barrier<2 * n_ops(0, 0), 2 * n_ops(0, 1)>(rg);
+    if (rg == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one segment behind
 
-    // ---- peeled A-steps of the first chunk; the residual rows (147 KB per workgroup, fp32) trickle in under them, two loads
-    // per step in steps 0-8: plain loads into the accumulators, issued between the counted wait and the step's DMA so that they
-    // are covered by the same counts (EX extra loads issued at the barrier of step t sit between the pieces of steps t + 3 and
-    // t + 4 in program order: two more outstanding operations are allowed at the barriers of steps t + 1 and t + 2)
+    // ---- peeled A-steps of the first chunk
 #pragma unroll
     for (int kt = 0; kt < NA; ++kt) {
-        const int t = kt - NA;
         constexpr int NX = 2;
-        auto wait_fn = [&]() {
-            // allowed outstanding: pieces of steps t + 2, t + 3 and the extra loads issued at the barriers of steps t - 2, t - 1
-            const int e = ((kt >= 1 && kt <= 9) ? NX : 0) + ((kt >= 2 && kt <= 10) ? NX : 0);
-            // (all four are A-steps in this phase except past the end: steps 0, 1 of the loop are A-steps too)
-            switch (e) {
-                case 0: wait_and_barrier<2 * 4, 2 * 3>(rg); break;
-                case NX: wait_and_barrier<2 * 4 + NX, 2 * 3 + NX>(rg); break;
-                default: wait_and_barrier<2 * 4 + 2 * NX, 2 * 3 + 2 * NX>(rg); break;
-            }
-        };
-        auto extra_fn = [&]() {
-            if (kt <= 8) {
+        // L: two residual loads (steps 0-8; plain loads into the accumulators, in front of the pieces), the pieces of step kt + 3
+        if (kt <= 8) {
 #pragma unroll
-                for (int u = 0; u < NX; ++u) {
-                    const int i = kt * NX + u, rf = i / 6, cf = i % 6;
-                    const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
-                    acc[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow[rf] * E + n);
-                }
+            for (int u = 0; u < NX; ++u) {
+                const int i = kt * NX + u, rf = i / 6, cf = i % 6;
+                const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
+                acc[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow[rf] * E + n);
             }
-        };
-        auto issue_fn = [&]() { issue_step(0, t + NSLOT); };
-        a_step(wait_fn, issue_fn, extra_fn, kt & 3, (kt + 1) & 3, false, -1);
+        }
+        a_load(kt & 3, [&](int u) { issue_piece(0, kt - NA + 3, u); });
+        // extra loads of L(kt - 1), L(kt) are allowed to be outstanding at the wait for step kt + 1
+        const int e = ((kt >= 1 && kt <= 9) ? NX : 0) + (kt <= 8 ? NX : 0);
+        sync_l([&]() { if (e == 0) FFS_WAIT(2 * 3); else if (e == NX) FFS_WAIT(2 * 3 + NX); else FFS_WAIT(2 * 3 + 2 * NX); });
+        a_compute();
+        sync_c([&]() { if (e == 0) FFS_WAIT(2 * 4); else if (e == NX) FFS_WAIT(2 * 4 + NX); else FFS_WAIT(2 * 4 + 2 * NX); });
     }
-    // + b2 (the residual loads were covered by the wait of the last peeled step)
+    // + b2; the first chunk's GELU has no other wave half's MFMAs... it runs beside the OTHER half's segments all the same,
+    // but this half's next L segment waits for it (once per launch)
 #pragma unroll
     for (int cf = 0; cf < 6; ++cf) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b2 + (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4);
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
     }
-    load_b1(0);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) gelu_pairs(2 * c, 2, false);
+    write_g(0, 6);
+    load_b1(1);
     __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8) | (0));  // vmcnt(0): b2, b1 in; (DMA pieces too - once per launch)
 
     for (int it = 0; it < nchunks; ++it) {
+        if (it > 0) {
+            pold[0] = pacc[2][0];
+            pold[1] = pacc[2][1];
+        }
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
-            for (int nf = 0; nf < 2; ++nf) {
-                pold[rf][nf] = pacc[rf][nf];
-                pacc[rf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        // ================= A-steps of chunk it + 1 over the GELU of chunk it: fragment f in steps 2 f, 2 f + 1 ... the writes
-        // of G must be complete at the barrier of step 11 (the first B-step's hi fragments are read behind it)
+            for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf];
+        // ================= A-steps of chunk it + 1. Their L segments carry the GELU leftovers of chunk it (B-steps below):
+        // fragments 0-3 are stored at step 0, pairs 8..11 (fragments 4, 5, kept in pold) run at steps 1, 3, 5, 7, stored at step 8
 #pragma unroll
         for (int kt = 0; kt < NA; ++kt) {
-            auto wait_fn = [&]() {
-                // pieces of steps t + 2, t + 3 (A A | A B | B B by position); the first iteration's vmcnt(0) above makes every
-                // count an upper bound there
-                if (kt <= 8) wait_and_barrier<n_ops(0, 0) * 2, n_ops(0, 1) * 2>(rg);
-                else if (kt == 9) wait_and_barrier<n_ops(0, 0) + 3, n_ops(0, 1) + 3>(rg);
-                else wait_and_barrier<6, 6>(rg);
-            };
-            auto issue_fn = [&]() { issue_step(it, kt + NSLOT); };
-            auto extra_fn = [&]() {};
-            // GELU schedule: six fragments over steps 0..10 (two steps per fragment would need half-fragment state; one
-            // fragment every other step keeps the code simple: steps 0, 2, 4, 6, 8, 10)
-            const int gf = (kt % 2 == 0 && kt <= 10) ? kt / 2 : -1;
-            a_step(wait_fn, issue_fn, extra_fn, kt & 3, (kt + 1) & 3, kt == NA - 1, gf);
+            a_load(kt & 3, [&](int u) { issue_piece(it, kt + 3, u); });
+            if (it > 0) {
+                if (kt == 0) write_g(0, 4);
+                if (kt >= 1 && kt <= 7 && (kt & 1)) gelu_pairs(8 + (kt >> 1), 1, true);
+                if (kt == 8) write_g(4, 6);
+            }
+            // pieces of steps kt + 2, kt + 3: A A up to 8, A B at 9, B B at 10, 11 (the first iteration's vmcnt(0) above makes
+            // every count an upper bound there)
+            sync_l([&]() { if (kt <= 8) FFS_WAIT(2 * 3); else if (kt == 9) FFS_WAIT(3 + 3); else FFS_WAIT(6); });
+            a_compute();
+            sync_c([&]() { if (kt <= 8) FFS_WAIT(2 * 4); else if (kt == 9) FFS_WAIT(4 + 3); else FFS_WAIT(6); });
         }
-        // ================= B-steps of chunk it
+        // ================= B-steps of chunk it; their L segments carry one GELU pair of chunk it + 1 each (pairs 0..7)
 #pragma unroll
-        for (int s = 0; s < NB; ++s) {
-            const int t = NA + s;
-            auto wait_fn = [&]() {
-                // pieces of steps t + 2, t + 3: B B up to t = 16, B A' at 17, A' A' at 18, 19; + the two b1 loads issued at
-                // the barrier of step 12 (allowed outstanding at the barriers of steps 13, 14)
-                if (t == 13 || t == 14) wait_and_barrier<6 + 2, 6 + 2>(rg);
-                else if (t <= 16) wait_and_barrier<6, 6>(rg);
-                else if (t == 17) wait_and_barrier<3 + n_ops(0, 0), 3 + n_ops(0, 1)>(rg);
-                else wait_and_barrier<2 * n_ops(0, 0), 2 * n_ops(0, 1)>(rg);
-            };
-            auto issue_fn = [&]() { issue_step(it, t + NSLOT); };
-            auto extra_fn = [&]() { if (s == 0) load_b1(it + 1); };
-            b_step(wait_fn, issue_fn, extra_fn, s, t & 3, (t + 1) & 3, s == NB - 1 ? 2 : (s & 1));
+        for (int sb = 0; sb < NB; ++sb) {
+            const int t = NA + sb;
+            if (sb == 0) load_b1(it + 2);  // (in front of this segment's pieces: two more operations outstanding at steps 12, 13)
+            b_load(sb, t & 3, [&](int u) { issue_piece(it, t + 3, u); });
+            gelu_pairs(sb, 1, false);
+            // pieces of steps t + 2, t + 3: B B up to t = 16, B A' at 17, A' A' at 18, 19
+            const int ex = (t == 12 || t == 13) ? 2 : 0;
+            sync_l([&]() { if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 3); else FFS_WAIT(2 * 3); });
+            b_compute(sb);
+            sync_c([&]() { if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 4); else FFS_WAIT(2 * 4); });
         }
     }
-
+    if (rg == 0) __builtin_amdgcn_s_barrier();  // waves 0-3 are one segment ahead
     // ---- LayerNorm epilogue: G is out of use, its region carries the statistics exchange; the ring may still receive the
     // out-of-bounds fillers issued past the last chunk
     __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));  // vmcnt(0) lgkmcnt(0)
@@ -472,7 +534,7 @@ __global__ __launch_bounds__(THREADS, 2) void ffn_split_kernel(const Params p) {
         const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + n), b = *reinterpret_cast<const f32x4*>(p.beta + n);
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
-            if (!valid[rf]) continue;
+            if (m0 + rows0 + rf * 16 >= p.M) continue;
             const size_t off = (size_t)(m0 + rows0 + rf * 16) * E + n;
             const f32x4 v = acc[rf][cf];
             const float mu = mean[rf], rs = rstd[rf];
@@ -507,8 +569,13 @@ __global__ void pack_kernel(const char* __restrict__ w1, const char* __restrict_
     *reinterpret_cast<u32x4*>(out + idx * 16) = *reinterpret_cast<const u32x4*>(src);
 }
 
+unsigned long long* g_trace = nullptr;
 }  // namespace ffs
 }  // namespace pp
+
+#if FFS_DBG & 512
+extern "C" void pp_ffs_set_trace(void* buf) { pp::ffs::g_trace = reinterpret_cast<unsigned long long*>(buf); }
+#endif
 
 extern "C" long long pp_ffn_split_packed_bytes(int E, int F) {
     using namespace pp;
@@ -554,6 +621,7 @@ extern "C" int pp_ffn_split_residual_layernorm(const void* h_in, const void* w_p
     p.h_bytes = (unsigned)((size_t)M * E * 4);
     p.w_bytes = (unsigned)((size_t)(F / ffs::CHUNK) * ffs::CHUNK_BYTES);
     p.eps = eps;
+    p.trace = ffs::g_trace;
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ffs::ffn_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ffs::LDS));
     hipLaunchKernelGGL(ffs::ffn_split_kernel, dim3((M + ffs::BM - 1) / ffs::BM), dim3(ffs::THREADS), ffs::LDS,
                        reinterpret_cast<hipStream_t>(stream), p);

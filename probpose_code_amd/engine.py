@@ -38,7 +38,7 @@ class ProbPoseEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], num_heads: int, img_size=(256, 192), patch_size: int = 16,
                  patch_padding: int = 2, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375),
                  bgr_to_rgb: bool = True, temperature: float = 0.5, normalize: Optional[float] = 1.0,
-                 input_size: Optional[Sequence[int]] = None, ln_eps: float = 1e-6, precision: str = "bf16",
+                 input_size: Optional[Sequence[int]] = None, ln_eps: float = 1e-6, precision: str = "f16x3",
                  device="cuda"):
         if precision not in PREC:
             raise ValueError(f"precision must be one of {list(PREC)}, got {precision!r}")
@@ -92,6 +92,18 @@ class ProbPoseEngine:
         self.fuse_resln = env != "0"
         self._resln_768 = env == "1"
         self.fuse_pool = os.environ.get("PP_FUSE_POOL", "1") != "0"  # first tower stage: conv + pool + ReLU in one launch
+        # f16x3: fc1 - GELU - fc2 + residual + LayerNorm of a layer in one launch (pp_ffn_split.hip; the hidden activation stays
+        # on the CU). The kernel takes W1 / W2 as one buffer in its consumption order, packed here once per layer.
+        self._ffn_packed: Dict[int, torch.Tensor] = {}
+        if precision == "f16x3" and self.fuse_mlp and _lib.lib.pp_ffn_split_packed_bytes(self.E, self.w.ffn_dims) > 0:
+            nbytes = _lib.lib.pp_ffn_split_packed_bytes(self.E, self.w.ffn_dims)
+            with torch.cuda.device(self.device):
+                for i in range(self.w.num_layers):
+                    buf = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+                    _lib.call("pp_ffn_split_pack_weights", self.w[f"l{i}.fc1.w"].data_ptr(), self.w[f"l{i}.fc2.w"].data_ptr(),
+                              buf.data_ptr(), self.E, self.w.ffn_dims, _lib.stream_ptr(self.device))
+                    self._ffn_packed[i] = buf
+                torch.cuda.synchronize(self.device)
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
         self.stage_hook = None  # callable(name) invoked between stages of the launch plan ("embed", "layer<i>", "backbone"); dev / scheduling experiments
@@ -242,7 +254,12 @@ class ProbPoseEngine:
                 qkv_done = nq is not None
                 continue
             res_ln(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])
-            if fuse_ffn:
+            if i in self._ffn_packed:
+                # f16x3: whole FFN + residual + next LayerNorm in one kernel, hidden activation on the CU
+                self._call("ffn_split", "pp_ffn_split_residual_layernorm", ws["h"].data_ptr(), self._ffn_packed[i].data_ptr(),
+                           w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(), ws["x"].data_ptr(), ws["x"].data_ptr(),
+                           gn.data_ptr(), bn.data_ptr(), self.ln_eps, h_next.data_ptr(), M, E, Fd, st)
+            elif fuse_ffn:
                 # whole FFN + residual + next LayerNorm in one kernel: the 4x-wide hidden activation stays on the CU
                 self._call("mlp_res_ln", "pp_mlp_residual_layernorm", ws["h"].data_ptr(), w[f"l{i}.fc1.w"].data_ptr(),
                            w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.w"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(),

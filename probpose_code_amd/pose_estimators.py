@@ -332,15 +332,16 @@ class ProbMapHead(nn.Module):
 @register(MODELS, reference_name="TopdownPoseEstimator", mi355x_name="TopdownPoseEstimatorMI355X")
 class TopdownPoseEstimator(nn.Module):
     """topdown.py:12-194 / base.py:17-243 for inference. Extra keyword: ``precision`` in {"bf16", "f16x3", "f32"}
-    (operand precision of the MFMA kernels: "bf16" = throughput mode; "f16x3" = split-fp16 operands, three fp16 MFMAs per
-    product, meets the reference's 1e-3 tolerance; "f32" = exact fp32 products, bit-for-bit an fmaf chain, slowest)."""
+    (operand precision of the MFMA kernels: "f16x3" (the default) = split-fp16 operands, three fp16 MFMAs per product, meets
+    the reference's 1e-3 tolerance; "bf16" = throughput mode, 0.3 - 0.45 px and a few % argmax flips away from the fp32
+    reference - opt-in only; "f32" = exact fp32 products, bit-for-bit an fmaf chain, slowest)."""
 
     _version = 2
 
     def __init__(self, backbone: dict, neck: Optional[dict] = None, head: Optional[dict] = None,
                  train_cfg: Optional[dict] = None, test_cfg: Optional[dict] = None,
                  data_preprocessor: Optional[dict] = None, init_cfg=None, metainfo: Optional[dict] = None,
-                 precision: str = "bf16"):
+                 precision: str = "f16x3"):
         super().__init__()
         if neck is not None:
             raise NotImplementedError("the ProbPose config has no neck")
