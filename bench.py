@@ -129,6 +129,7 @@ def kernel_work_per_step(eng, B, passes, tag):
     fused_mlp = fused_ln and not wide and eng.fuse_mlp and Fd % 128 == 0
     fused_proj = fused_mlp and eng.fuse_proj
     ffn_split = bool(getattr(eng, "_ffn_packed", None))  # f16x3: fc1 + GELU + fc2 + residual + LN in one launch (pp_ffn_split.hip)
+    proj_split = bool(getattr(eng, "_proj_packed", None))  # f16x3: ... with projection + residual + ln2 in front, same launch
     c_last = eng.w.deconv_channels[-1]
     final_fl, final_b = 2.0 * (B * passes * P) * eng.K * c_last, B * passes * P * (c_last * esz + eng.K * 4)
     if tag == "vit_layer":  # attention + proj + residual + ln2 + fc1 + GELU + fc2 + residual + LN (+ the next layer's qkv)
@@ -154,11 +155,14 @@ def kernel_work_per_step(eng, B, passes, tag):
         return L * 4.0 * M * E * Fd, L * (M * E * 2 + 2 * M * E * 4 + M * E * 2), L, "_ZN2pp3mlp17mlp_res_ln_kernelILb0ELb0ELb0EEEvNS0_6ParamsE"
     if tag == "ffn_split":  # f16x3: fc1 + GELU + fc2 + residual + LN per layer; h in, residual in, x out, h out (4 bytes each)
         return L * 4.0 * M * E * Fd, L * 4 * M * E * 4, L, "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE"
+    if tag == "proj_ffn_split":  # f16x3: proj + residual + ln2 + fc1 + GELU + fc2 + residual + LN per layer; attention rows in,
+        # residual in, x out, h out (4 bytes each); the ln2 rows a workgroup parks in L2 and streams back are not algorithmic bytes
+        return L * (4.0 * M * E * Fd + 2.0 * M * E * E), L * 4 * M * E * 4, L, "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE"
     if tag == "gemm_res_ln":  # patch embed, proj (and fc2 when the FFN is not fused) + residual + LN
         fl = 2.0 * M * E * 768
         by = M * 768 * esz + M * E * (4 + esz)
         n = 1
-        if not fused_proj:
+        if not fused_proj and not proj_split:
             fl += L * 2.0 * M * E * E
             by += L * (M * E * esz + 2 * M * E * 4 + M * E * esz)
             n += L
@@ -198,7 +202,8 @@ def pmc_traffic(kernel_mangled, precision, B):
     if B != 64:
         return None, None
     short = {"_ZN2pp4lovl17linear_ovl_kernelENS_10GemmParamsE": "pp::lovl::linear_ovl_kernel(",
-             "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE": "pp::ffs::ffn_split_kernel("}.get(kernel_mangled)
+             "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE": "pp::ffs::ffn_split_kernel(",
+             "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE": "pp::ffs::proj_ffn_split_kernel("}.get(kernel_mangled)
     for name in (f"r03_{precision}_bs64_hbm_traffic.json", f"r02_{precision}_bs64_hbm_traffic.json", f"r01_{precision}_bs64_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:

@@ -259,6 +259,25 @@ int pp_ffn_split_residual_layernorm(const void* h_in, const void* w_packed, cons
                                     const float* residual, float* x_out, const float* gamma, const float* beta,
                                     float eps, void* h_out, int M, int E, int F, void* stream);
 
+/* The second half of a ViT layer in ONE launch in the parity precision (PP_PREC_F16X3): attention output projection +
+ * residual, ln2, the feed-forward block + residual, and the LayerNorm that follows the layer:
+ *   x_mid = residual + att Wp^T + bp ;  h = LayerNorm(x_mid; gamma2, beta2, eps)
+ *   x_out = x_mid + GELU(h W1^T + b1) W2^T + b2 ;  h_out = LayerNorm(x_out; gamma, beta, eps)
+ * (mmpretrain TransformerEncoderLayer.forward [3P]: x = x + attn(ln1(x)); x = ffn(ln2(x), identity=x); call site
+ * mmpose/models/pose_estimators/base.py:206, ctor args td-pm_ProbPose-small_8xb64-210e_coco-256x192.py:56-67).
+ * x_mid and the hidden activation never leave the CU; h (the ln2 rows) passes through h_scratch (M, E; PP_OUT_SPLIT), which
+ * each workgroup writes and streams back for its own 96 rows (it stays in L2) - h_scratch must not alias att or h_out.
+ * att, h_out (M, E) PP_OUT_SPLIT; wproj_packed from pp_proj_split_pack_weights (Wp (E, E) in the split format;
+ * pp_proj_split_packed_bytes(E) bytes, -1 if unsupported), w_packed from pp_ffn_split_pack_weights. E must be 384, F a
+ * multiple of 128. residual may alias x_out, att may alias h_out. */
+long long pp_proj_split_packed_bytes(int E);
+int pp_proj_split_pack_weights(const void* wp_split, void* packed, int E, void* stream);
+int pp_proj_ffn_split_residual_layernorm(const void* att, const void* wproj_packed, const float* bproj,
+                                         const float* gamma2, const float* beta2, void* h_scratch, const void* w_packed,
+                                         const float* b1, const float* b2, const float* residual, float* x_out,
+                                         const float* gamma, const float* beta, float eps, void* h_out, int M, int E,
+                                         int F, void* stream);
+
 /* Last deconvolution of the heatmap branch fused with the 1x1 convolution that follows it (bf16 operands):
  *   ConvTranspose2d(Cin -> 256, k4, s2, p1) + BN + ReLU  ->  Conv2d(256 -> K, k1)
  * (probmap_head.py:435-472 and :244-249; reshaped to (B, K, H'W') at :627-648). weight / bias as PP_DECONV4X4S2 of

@@ -89,6 +89,14 @@ struct Params {
     unsigned h_bytes, w_bytes;
     float eps;
     unsigned long long* trace;  // dev only (FFS_DBG & 512): s_memtime at every barrier of block 0, waves 0 and 4
+    // PROJ form (attention output projection + residual + ln2 in front of the FFN): h is then a scratch tensor this kernel
+    // writes (ln2 output) before it streams it back
+    const void* att;       // [M, 384] split: attention output (heads concatenated)
+    const void* wproj;     // pre-packed Wp stream (pp_proj_split_pack_weights)
+    const float* bp;       // [384]
+    const float* gamma2;   // ln2
+    const float* beta2;
+    unsigned att_bytes, wproj_bytes;
 };
 
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
@@ -101,6 +109,8 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
 __host__ __device__ constexpr bool is_a(int t) { return ((t % STEPS) + STEPS) % STEPS < NA; }
 __host__ __device__ constexpr int n_ops(int t, int rg) { return is_a(t) ? (rg == 0 ? 4 : 3) : 3; }
 
+#define FFS_WAIT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (0 << 8) | (((N) >> 4) << 14))  // vmcnt(N) lgkmcnt(0)
+
 template <int N0, int N1>
 __device__ __forceinline__ void wait_and_barrier(int rg) {
     // vmcnt(N) lgkmcnt(0) as a builtin (the compiler's wait-count bookkeeping sees it), N by wave half; then the barrier
@@ -112,7 +122,10 @@ __device__ __forceinline__ void wait_and_barrier(int rg) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(THREADS, 2) void ffn_split_kernel(const Params p) {
+// (the body is a __device__ function template and the two kernels below plain functions: a KERNEL template with
+// value-returning lambdas inside loses its host stub in the host pass)
+template <bool PROJ>
+__device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: behind a reference `rg == 0 ? p.wpack : p.h` became an indexed scratch load)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -320,7 +333,6 @@ __global__ __launch_bounds__(THREADS, 2) void ffn_split_kernel(const Params p) {
         stamp();
         __builtin_amdgcn_sched_barrier(0);
     };
-#define FFS_WAIT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (0 << 8) | (((N) >> 4) << 14))
     // allowed outstanding at the wait for step S + 1: pieces of steps S + 2, S + 3 (own share) + the extra loads of L(S - 1), L(S)
     // L segments: this wave's DMA pieces alternate with its fragment reads - four waves issue at the same time, the texture
     // path takes one piece per 16 cycles, and whoever finds its queue full stands still: the reads go out in those gaps
@@ -394,16 +406,179 @@ __global__ __launch_bounds__(THREADS, 2) void ffn_split_kernel(const Params p) {
             for (int rf = 0; rf < 3; ++rf) acc[rf][half * 3 + nf] = mma(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
     };
 
+    // rows past M read row M - 1; nothing of them is ever stored (computed where it is used: as an array it ended up in scratch)
+    auto mrow = [&](int rf) { const int m = m0 + rows0 + rf * 16; return m < p.M ? m : p.M - 1; };
+    // LayerNorm of the 96 x 384 block in the accumulators (row statistics in registers, one LDS exchange between the column
+    // quarters through the G region, which must be out of use): h_dst <- LN(acc) gamma + beta in the split format; x_dst (or
+    // NULL) <- acc
+    auto layernorm_rows = [&](const float* gamma, const float* beta, float* x_dst, void* h_dst) {
+        float* stat = reinterpret_cast<float*>(smem + OFF_G);
+        float mean[3], rstd[3];
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            float sm = 0.f;
+#pragma unroll
+            for (int cf = 0; cf < 6; ++cf) {
+                const f32x4 v = acc[rf][cf];
+                sm += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            if (f_kg == 0) stat[cg * BM + rows0 + rf * 16] = sm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            const int r = rows0 + rf * 16;
+            mean[rf] = ((stat[r] + stat[BM + r]) + (stat[2 * BM + r] + stat[3 * BM + r])) * (1.0f / E);
+            float q = 0.f;
+#pragma unroll
+            for (int cf = 0; cf < 6; ++cf)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = acc[rf][cf][k] - mean[rf];
+                    q = __builtin_fmaf(d, d, q);
+                }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            if (f_kg == 0) stat[(4 + cg) * BM + r] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            const int r = rows0 + rf * 16;
+            const float var = ((stat[4 * BM + r] + stat[5 * BM + r]) + (stat[6 * BM + r] + stat[7 * BM + r])) * (1.0f / E);
+            rstd[rf] = 1.0f / sqrtf(var + p.eps);
+        }
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) {
+            const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n), b = *reinterpret_cast<const f32x4*>(beta + n);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) {
+                const bool live = m0 + rows0 + rf * 16 < p.M;
+                const size_t off = (size_t)(m0 + rows0 + rf * 16) * E + n;
+                const f32x4 v = acc[rf][cf];
+                const float mu = mean[rf], rs = rstd[rf];
+                const f32x4 hv = {(v[0] - mu) * rs * g[0] + b[0], (v[1] - mu) * rs * g[1] + b[1], (v[2] - mu) * rs * g[2] + b[2],
+                                  (v[3] - mu) * rs * g[3] + b[3]};
+                if (x_dst && live) *reinterpret_cast<f32x4*>(x_dst + off) = v;
+#ifndef FFS_PAIR_STORE
+#define FFS_PAIR_STORE 1  // dev A/B switch: 0 two 8-byte stores per lane and fragment
+#endif
+                if (FFS_PAIR_STORE) split_store4_rowpair(h_dst, off, hv, live);  // (lanes f_kg, f_kg ^ 1 hold the halves of a 16-byte chunk)
+                else if (live) split_store4(h_dst, off, hv);
+            }
+        }
+    };
+
+    if constexpr (PROJ) {
+        stamp();
+        stamp();
+        // ================= attention output projection + residual, then ln2:  acc <- x + att Wp^T + bp ;  h <- LN2(acc).
+        // 24 steps shaped like the B-steps (wave tile 48 rows x 48 outputs of one column half, 27 MFMAs): step s = 2 kb + half
+        // takes the Wp half block (192 lines, pre-packed like the W2 blocks) from ring slot s & 3 and the k-block kb of the
+        // attention rows from G buffer kb & 3 (96 lines, fetched with the even steps by waves 0-3). Two steps in flight, one
+        // barrier per step, all waves in the same phase: the phase is ~6 % of the launch, the FFN machinery below is not spent
+        // on it. The ln2 rows then go out to `h` (global, L2) and come back as the streamed row operand of the A-steps.
+        // The residual rows (147 KB per workgroup, 37.7 MB over the chip: ~9 us when every workgroup asks at once) are not needed
+        // before the end of the phase: they trickle in, one 16-byte load per step behind that step's pieces from step 4 on, into
+        // registers the FFN phase has not claimed yet, and are added after the last step.
+#ifndef FFS_RES_LATE
+#define FFS_RES_LATE 1  // dev A/B switch: 0 all residual loads in front of the first step
+#endif
+        f32x4 rres[3][6];
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int cf = 0; cf < 6; ++cf) {
+                acc[rf][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!FFS_RES_LATE) {
+                    const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
+                    rres[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow(rf) * E + n);
+                }
+            }
+        auto issue_p = [&](int s) {
+            if (DBG & 8) return;
+            const bool live = s < 2 * KB;
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wproj), 0, live ? p.wproj_bytes : 0u, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ring + (s & 3) * SLOTB + (3 * wv + u) * 1024), 16, v_w,
+                                                         (live ? s : 0) * B_BLOCK + (3 * wv + u) * 1024, 0, 0);
+            if ((s & 1) == 0 && rg == 0) {
+                const int kb = s >> 1;
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.att), 0, live ? p.att_bytes : 0u, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(smem + OFF_G + (kb & 3) * G_KB + (3 * wv + u) * 1024), 16, v_x,
+                                                             (live ? kb : 0) * 128 + u * 8 * E * 4, 0, 0);
+            }
+        };
+        issue_p(0);
+        issue_p(1);
+#pragma unroll
+        for (int kp = 0; kp < 2 * KB / 4; ++kp) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = 4 * kp + q;
+                // step s has landed when only this wave's pieces of step s + 1 and the residual loads issued in steps s - 2, s - 1
+                // are outstanding (issue order: pieces(s) L(s - 2) pieces(s + 1) L(s - 1); loads exist in steps 4 .. 21)
+                constexpr int R0 = FFS_RES_LATE ? 4 : 1000;
+                const int nl = ((s - 2 >= R0 && s - 2 < R0 + 18) ? 1 : 0) + ((s - 1 >= R0 && s - 1 < R0 + 18) ? 1 : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                stamp();
+                if (rg == 0) {
+                    if (q & 1) { if (nl == 2) FFS_WAIT(8); else if (nl == 1) FFS_WAIT(7); else FFS_WAIT(6); }
+                    else { if (nl == 2) FFS_WAIT(5); else if (nl == 1) FFS_WAIT(4); else FFS_WAIT(3); }
+                } else { if (nl == 2) FFS_WAIT(5); else if (nl == 1) FFS_WAIT(4); else FFS_WAIT(3); }
+                __builtin_amdgcn_s_barrier();
+                stamp();
+                __builtin_amdgcn_sched_barrier(0);
+                issue_p(s + 2);
+                if (s >= R0 && s < R0 + 18) {
+                    const int i = s - R0, rf = i / 6, cf = i % 6;
+                    const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
+                    rres[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow(rf) * E + n);
+                }
+                const int so = slot_off(q);
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf) { bwh[nf] = b_w(so, nf, 0); bwl[nf] = b_w(so, nf, 1); }
+                if ((q & 1) == 0) {
+                    const int j = (s >> 1) & 3;
+#pragma unroll
+                    for (int rf = 0; rf < 3; ++rf) { bgh[rf] = b_g(j, rf, 0); bgl[rf] = b_g(j, rf, 1); }
+                }
+                b_compute(q & 1);
+            }
+        }
+        // + bp (after the sums, as residual + (sum + bias) rounds closest to the reference's x + proj(...))
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bp + (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
+        }
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));  // vmcnt(0) lgkmcnt(0): the zero fillers of steps 24, 25 have landed too
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int cf = 0; cf < 6; ++cf) acc[rf][cf] += rres[rf][cf];
+        __syncthreads();
+        stamp();
+        layernorm_rows(p.gamma2, p.beta2, nullptr, const_cast<void*>(p.h));
+        stamp();
+        // the rows must be in L2 before any wave's DMA asks for them (a store counts in vmcnt until the L2 has acknowledged it)
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));
+        __syncthreads();
+        stamp();
+        stamp();
+    }
+
     // ---- prologue: b1 of the first chunk, the DMA of steps 0 - 2; the residual rows trickle in under the peeled A-steps
     load_b1(0);  // (older than every DMA piece: landed at the first counted wait)
 #pragma unroll
     for (int t = 0; t < 3; ++t) issue_step(0, t - NA);
-    int mrow[3];
-#pragma unroll
-    for (int rf = 0; rf < 3; ++rf) {
-        const int m = m0 + rows0 + rf * 16;
-        mrow[rf] = m < p.M ? m : p.M - 1;  // rows past M read row M - 1; nothing of them is ever stored
-    }
 #pragma unroll
     for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
@@ -417,17 +592,17 @@ __global__ __launch_bounds__(THREADS, 2) void ffn_split_kernel(const Params p) {
     for (int kt = 0; kt < NA; ++kt) {
         constexpr int NX = 2;
         // L: two residual loads (steps 0-8; plain loads into the accumulators, in front of the pieces), the pieces of step kt + 3
-        if (kt <= 8) {
+        if (!PROJ && kt <= 8) {
 #pragma unroll
             for (int u = 0; u < NX; ++u) {
                 const int i = kt * NX + u, rf = i / 6, cf = i % 6;
                 const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
-                acc[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow[rf] * E + n);
+                acc[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow(rf) * E + n);
             }
         }
         a_load(kt & 3, [&](int u) { issue_piece(0, kt - NA + 3, u); });
         // extra loads of L(kt - 1), L(kt) are allowed to be outstanding at the wait for step kt + 1
-        const int e = ((kt >= 1 && kt <= 9) ? NX : 0) + (kt <= 8 ? NX : 0);
+        const int e = PROJ ? 0 : ((kt >= 1 && kt <= 9) ? NX : 0) + (kt <= 8 ? NX : 0);
         sync_l([&]() { if (e == 0) FFS_WAIT(2 * 3); else if (e == NX) FFS_WAIT(2 * 3 + NX); else FFS_WAIT(2 * 3 + 2 * NX); });
         a_compute();
         sync_c([&]() { if (e == 0) FFS_WAIT(2 * 4); else if (e == NX) FFS_WAIT(2 * 4 + NX); else FFS_WAIT(2 * 4 + 2 * NX); });
@@ -490,61 +665,11 @@ __global__ __launch_bounds__(THREADS, 2) void ffn_split_kernel(const Params p) {
     // out-of-bounds fillers issued past the last chunk
     __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));  // vmcnt(0) lgkmcnt(0)
     __syncthreads();
-    float* stat = reinterpret_cast<float*>(smem + OFF_G);
-    float mean[3], rstd[3];
-#pragma unroll
-    for (int rf = 0; rf < 3; ++rf) {
-        float sm = 0.f;
-#pragma unroll
-        for (int cf = 0; cf < 6; ++cf) {
-            const f32x4 v = acc[rf][cf];
-            sm += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-        sm += __shfl_xor(sm, 16);
-        sm += __shfl_xor(sm, 32);
-        if (f_kg == 0) stat[cg * BM + rows0 + rf * 16] = sm;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int rf = 0; rf < 3; ++rf) {
-        const int r = rows0 + rf * 16;
-        mean[rf] = ((stat[r] + stat[BM + r]) + (stat[2 * BM + r] + stat[3 * BM + r])) * (1.0f / E);
-        float q = 0.f;
-#pragma unroll
-        for (int cf = 0; cf < 6; ++cf)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float d = acc[rf][cf][k] - mean[rf];
-                q = __builtin_fmaf(d, d, q);
-            }
-        q += __shfl_xor(q, 16);
-        q += __shfl_xor(q, 32);
-        if (f_kg == 0) stat[(4 + cg) * BM + r] = q;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int rf = 0; rf < 3; ++rf) {
-        const int r = rows0 + rf * 16;
-        const float var = ((stat[4 * BM + r] + stat[5 * BM + r]) + (stat[6 * BM + r] + stat[7 * BM + r])) * (1.0f / E);
-        rstd[rf] = 1.0f / sqrtf(var + p.eps);
-    }
-#pragma unroll
-    for (int cf = 0; cf < 6; ++cf) {
-        const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
-        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + n), b = *reinterpret_cast<const f32x4*>(p.beta + n);
-#pragma unroll
-        for (int rf = 0; rf < 3; ++rf) {
-            if (m0 + rows0 + rf * 16 >= p.M) continue;
-            const size_t off = (size_t)(m0 + rows0 + rf * 16) * E + n;
-            const f32x4 v = acc[rf][cf];
-            const float mu = mean[rf], rs = rstd[rf];
-            const f32x4 hv = {(v[0] - mu) * rs * g[0] + b[0], (v[1] - mu) * rs * g[1] + b[1], (v[2] - mu) * rs * g[2] + b[2],
-                              (v[3] - mu) * rs * g[3] + b[3]};
-            *reinterpret_cast<f32x4*>(p.x_out + off) = v;
-            split_store4(p.h_out, off, hv);
-        }
-    }
+    layernorm_rows(p.gamma, p.beta, p.x_out, p.h_out);
 }
+
+__global__ __launch_bounds__(THREADS, 2) void ffn_split_kernel(const Params p) { ffn_split_body<false>(p); }
+__global__ __launch_bounds__(THREADS, 2) void proj_ffn_split_kernel(const Params p) { ffn_split_body<true>(p); }
 
 // Packs W1 (F, 384) and W2 (384, F), both split row-major, into the stream the kernel consumes: per hidden chunk c of 128
 // units 12 blocks [128 units][128 B] (k-block kb of W1 rows 128 c ..) followed by 8 blocks [192 outputs][128 B] (block
@@ -569,7 +694,27 @@ __global__ void pack_kernel(const char* __restrict__ w1, const char* __restrict_
     *reinterpret_cast<u32x4*>(out + idx * 16) = *reinterpret_cast<const u32x4*>(src);
 }
 
+// Packs Wp (384, 384), split row-major, into the stream of the projection phase: 24 blocks [192 outputs][128 B], block
+// s = 2 kb + half = rows 192 half .. of k-block kb, lines swizzled like the W2 blocks.
+__global__ void pack_proj_kernel(const char* __restrict__ wp, char* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // 16-byte chunk of the output
+    if (idx >= 2 * KB * (B_BLOCK / 16)) return;
+    const int s = idx / (B_BLOCK / 16), q = idx % (B_BLOCK / 16), line = q >> 3, pc = q & 7;
+    const int n = (s & 1) * (E / 2) + line, kb = s >> 1;
+    *reinterpret_cast<u32x4*>(out + (size_t)idx * 16) =
+        *reinterpret_cast<const u32x4*>(wp + ((size_t)n * E + kb * 32) * 4 + ((pc ^ (line & 7)) << 4));
+}
+
 unsigned long long* g_trace = nullptr;
+
+template <bool PROJ>
+static int launch(const Params& p, hipStream_t s) {
+    auto kern = PROJ ? proj_ffn_split_kernel : ffn_split_kernel;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    hipLaunchKernelGGL(kern, dim3((p.M + BM - 1) / BM), dim3(THREADS), LDS, s, p);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
 }  // namespace ffs
 }  // namespace pp
 
@@ -622,9 +767,63 @@ extern "C" int pp_ffn_split_residual_layernorm(const void* h_in, const void* w_p
     p.w_bytes = (unsigned)((size_t)(F / ffs::CHUNK) * ffs::CHUNK_BYTES);
     p.eps = eps;
     p.trace = ffs::g_trace;
-    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ffs::ffn_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ffs::LDS));
-    hipLaunchKernelGGL(ffs::ffn_split_kernel, dim3((M + ffs::BM - 1) / ffs::BM), dim3(ffs::THREADS), ffs::LDS,
-                       reinterpret_cast<hipStream_t>(stream), p);
+    return ffs::launch<false>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" long long pp_proj_split_packed_bytes(int E) {
+    using namespace pp;
+    return E == ffs::E ? (long long)2 * ffs::KB * ffs::B_BLOCK : -1;
+}
+
+extern "C" int pp_proj_split_pack_weights(const void* wp, void* packed, int E, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(wp && packed, PP_ERR_INVALID_ARG, "pp_proj_split_pack_weights: NULL argument");
+    PP_REQUIRE(E == ffs::E, PP_ERR_UNSUPPORTED, "pp_proj_split_pack_weights: built for embed dim 384 (ViT-S)");
+    const int total = 2 * ffs::KB * (ffs::B_BLOCK / 16);
+    hipLaunchKernelGGL(ffs::pack_proj_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const char*>(wp), reinterpret_cast<char*>(packed));
     PP_LAUNCH_CHECK();
     return PP_OK;
+}
+
+extern "C" int pp_proj_ffn_split_residual_layernorm(const void* att, const void* wproj_packed, const float* bproj,
+                                                    const float* gamma2, const float* beta2, void* h_scratch,
+                                                    const void* w_packed, const float* b1, const float* b2,
+                                                    const float* residual, float* x_out, const float* gamma, const float* beta,
+                                                    float eps, void* h_out, int M, int E, int F, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(att && wproj_packed && bproj && gamma2 && beta2 && h_scratch && w_packed && b1 && b2 && residual && x_out && gamma &&
+                   beta && h_out,
+               PP_ERR_INVALID_ARG, "pp_proj_ffn_split_residual_layernorm: NULL argument");
+    PP_REQUIRE(E == ffs::E, PP_ERR_UNSUPPORTED, "pp_proj_ffn_split_residual_layernorm: built for embed dim 384 (ViT-S)");
+    PP_REQUIRE(M > 0 && F > 0 && F % ffs::CHUNK == 0, PP_ERR_UNSUPPORTED,
+               "pp_proj_ffn_split_residual_layernorm: hidden width must be a positive multiple of 128");
+    PP_REQUIRE((size_t)M * E * 4 < ffs::OOB && (size_t)(F / ffs::CHUNK) * ffs::CHUNK_BYTES < ffs::OOB, PP_ERR_UNSUPPORTED,
+               "pp_proj_ffn_split_residual_layernorm: operand exceeds 2 GiB");
+    PP_REQUIRE(h_scratch != att && h_scratch != h_out, PP_ERR_INVALID_ARG,
+               "pp_proj_ffn_split_residual_layernorm: h_scratch must not alias the attention rows or h_out");
+    ffs::Params p{};
+    p.h = h_scratch;
+    p.wpack = w_packed;
+    p.b1 = b1;
+    p.b2 = b2;
+    p.residual = residual;
+    p.x_out = x_out;
+    p.gamma = gamma;
+    p.beta = beta;
+    p.h_out = h_out;
+    p.M = M;
+    p.F = F;
+    p.h_bytes = (unsigned)((size_t)M * E * 4);
+    p.w_bytes = (unsigned)((size_t)(F / ffs::CHUNK) * ffs::CHUNK_BYTES);
+    p.eps = eps;
+    p.trace = ffs::g_trace;
+    p.att = att;
+    p.wproj = wproj_packed;
+    p.bp = bproj;
+    p.gamma2 = gamma2;
+    p.beta2 = beta2;
+    p.att_bytes = p.h_bytes;
+    p.wproj_bytes = (unsigned)(2 * ffs::KB * ffs::B_BLOCK);
+    return ffs::launch<true>(p, reinterpret_cast<hipStream_t>(stream));
 }

@@ -94,15 +94,24 @@ class ProbPoseEngine:
         self.fuse_pool = os.environ.get("PP_FUSE_POOL", "1") != "0"  # first tower stage: conv + pool + ReLU in one launch
         # f16x3: fc1 - GELU - fc2 + residual + LayerNorm of a layer in one launch (pp_ffn_split.hip; the hidden activation stays
         # on the CU). The kernel takes W1 / W2 as one buffer in its consumption order, packed here once per layer.
+        # With fuse_proj the attention output projection + residual + ln2 run in front of it in the same launch
+        # (pp_proj_ffn_split_residual_layernorm): the intermediate residual stream never leaves the CU either.
         self._ffn_packed: Dict[int, torch.Tensor] = {}
+        self._proj_packed: Dict[int, torch.Tensor] = {}
         if precision == "f16x3" and self.fuse_mlp and _lib.lib.pp_ffn_split_packed_bytes(self.E, self.w.ffn_dims) > 0:
             nbytes = _lib.lib.pp_ffn_split_packed_bytes(self.E, self.w.ffn_dims)
+            pbytes = _lib.lib.pp_proj_split_packed_bytes(self.E) if self.fuse_proj else -1
             with torch.cuda.device(self.device):
                 for i in range(self.w.num_layers):
                     buf = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
                     _lib.call("pp_ffn_split_pack_weights", self.w[f"l{i}.fc1.w"].data_ptr(), self.w[f"l{i}.fc2.w"].data_ptr(),
                               buf.data_ptr(), self.E, self.w.ffn_dims, _lib.stream_ptr(self.device))
                     self._ffn_packed[i] = buf
+                    if pbytes > 0:
+                        pbuf = torch.empty(pbytes // 4, dtype=torch.float32, device=self.device)
+                        _lib.call("pp_proj_split_pack_weights", self.w[f"l{i}.proj.w"].data_ptr(), pbuf.data_ptr(), self.E,
+                                  _lib.stream_ptr(self.device))
+                        self._proj_packed[i] = pbuf
                 torch.cuda.synchronize(self.device)
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
@@ -135,6 +144,7 @@ class ProbPoseEngine:
         ws = dict(
             patches=e(M, 3 * self.P * self.P), x=e(M, E, dt=f32), h=e(M, E), qkv=e(M, 3 * E), qkv2=e(M, 3 * E), f=e(M, Fd),
             feat=e(M, E), logits=e(nb, self.K, self.Hh * self.Wh, dt=f32),
+            hs=e(M, E) if self._proj_packed else None,  # ln2 rows of the fused projection + FFN launch (scratch, L2-resident per workgroup)
             scalars=e(4, B, self.K, dt=f32), locs=e(B, self.K, 2, dt=f32),
             keypoints=e(B, self.K, 2, dt=torch.float64), scores=e(B, self.K, dt=f32),
             heatmaps=e(B, self.K, self.Hh, self.Wh, dt=f32),
@@ -252,6 +262,14 @@ class ProbPoseEngine:
                            None if nq else h_next.data_ptr(), nq[0].data_ptr() if nq else None,
                            nq[1].data_ptr() if nq else None, qcur.data_ptr() if nq else None, M, E, Fd, st)
                 qkv_done = nq is not None
+                continue
+            if i in self._proj_packed:
+                # f16x3: projection + residual, ln2, FFN + residual, next LayerNorm in one kernel
+                self._call("proj_ffn_split", "pp_proj_ffn_split_residual_layernorm", ws["h"].data_ptr(), self._proj_packed[i].data_ptr(),
+                           w[f"l{i}.proj.b"].data_ptr(), w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(), ws["hs"].data_ptr(),
+                           self._ffn_packed[i].data_ptr(), w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(),
+                           ws["x"].data_ptr(), ws["x"].data_ptr(), gn.data_ptr(), bn.data_ptr(), self.ln_eps, h_next.data_ptr(),
+                           M, E, Fd, st)
                 continue
             res_ln(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])
             if i in self._ffn_packed:

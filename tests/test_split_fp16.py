@@ -400,3 +400,49 @@ def test_ffn_split_fused_in_place_and_errors():
     with pytest.raises(L.ProbPoseLibraryError):
         L.call("pp_ffn_split_residual_layernorm", None, packed.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(),
                xd.data_ptr(), xd.data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), 1e-6, hd.data_ptr(), M, E, F_, None)
+
+
+def _proj_inputs(M, E=384, seed=80):
+    att = _rand(M, E, seed=seed)
+    wp, bp = _rand(E, E, seed=seed + 1, scale=1 / math.sqrt(E)), _rand(E, seed=seed + 2, scale=0.2)
+    g2, be2 = 1 + 0.1 * _rand(E, seed=seed + 3), _rand(E, seed=seed + 4, scale=0.1)
+    return att, wp, bp, g2, be2
+
+
+@gpu
+@pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (24576, 1536)])
+def test_proj_ffn_split_fused_vs_fp64(M, F_):
+    """pp_proj_ffn_split_residual_layernorm (projection + residual + ln2 + FFN + residual + LayerNorm in one launch) against
+    torch fp64 on the unrounded fp32 inputs, called the way the engine calls it (residual aliases x_out, the attention rows
+    alias h_out); repeated launches bit-identical; a ragged last tile; the bs 64 shape."""
+    L = _lib()
+    E = 384
+    _, r, w1, b1, w2, b2, g, be = _ffn_inputs(M, F_)
+    att, wp, bp, g2, be2 = _proj_inputs(M)
+    x_mid = r.double() + att.double() @ wp.double().t() + bp.double()
+    h_mid = F.layer_norm(x_mid, (E,), g2.double(), be2.double(), 1e-6)
+    x_ref = x_mid + F.gelu(h_mid @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    h_ref = F.layer_norm(x_ref, (E,), g.double(), be.double(), 1e-6)
+    packed = _ffn_pack(L, w1, w2, E, F_)
+    nb = L.lib.pp_proj_split_packed_bytes(E)
+    assert nb == E * E * 4 and L.lib.pp_proj_split_packed_bytes(768) == -1
+    wpp = torch.empty(nb // 4, dtype=torch.float32, device="cuda")
+    L.call("pp_proj_split_pack_weights", _sp(wp).data_ptr(), wpp.data_ptr(), E, None)
+    dev = [t.cuda() for t in (bp, g2, be2, b1, b2, g, be)]
+    outs = []
+    for _ in range(3):
+        ad, xd = _sp(att), r.cuda()
+        scratch = torch.full((M, E), float("nan"), device="cuda")
+        L.call("pp_proj_ffn_split_residual_layernorm", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(),
+               dev[2].data_ptr(), scratch.data_ptr(), packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), xd.data_ptr(),
+               xd.data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(), 1e-6, ad.data_ptr(), M, E, F_, None)
+        outs.append((xd.cpu(), ad.cpu(), scratch.cpu()))
+    torch.testing.assert_close(_unsp(outs[0][2]), h_mid, **TOL)
+    torch.testing.assert_close(outs[0][0].double(), x_ref, rtol=3e-5, atol=3e-5)
+    torch.testing.assert_close(_unsp(outs[0][1]), h_ref, rtol=3e-5, atol=3e-5)
+    for x_o, h_o, _ in outs[1:]:
+        assert torch.equal(x_o, outs[0][0]) and torch.equal(h_o.view(torch.int32), outs[0][1].view(torch.int32))
+    with pytest.raises(L.ProbPoseLibraryError):  # scratch aliasing the attention rows
+        L.call("pp_proj_ffn_split_residual_layernorm", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(),
+               dev[2].data_ptr(), ad.data_ptr(), packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), xd.data_ptr(),
+               xd.data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(), 1e-6, ad.data_ptr(), M, E, F_, None)
