@@ -158,6 +158,9 @@ def kernel_work_per_step(eng, B, passes, tag):
     if tag == "proj_ffn_split":  # f16x3: proj + residual + ln2 + fc1 + GELU + fc2 + residual + LN per layer; attention rows in,
         # residual in, x out, h out (4 bytes each); the ln2 rows a workgroup parks in L2 and streams back are not algorithmic bytes
         return L * (4.0 * M * E * Fd + 2.0 * M * E * E), L * 4 * M * E * 4, L, "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE"
+    if tag == "qkv_attention":  # f16x3: qkv Linear + attention per (sequence, head); LayerNorm rows in, attention rows out
+        att_fl = 4.0 * (B * passes) * eng.heads * eng.Np * eng.Np * eng.hd
+        return L * (2.0 * M * 3 * E * E + att_fl), L * 2 * M * E * 4, L, "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE"
     if tag == "gemm_res_ln":  # patch embed, proj (and fc2 when the FFN is not fused) + residual + LN
         fl = 2.0 * M * E * 768
         by = M * 768 * esz + M * E * (4 + esz)
@@ -175,7 +178,7 @@ def kernel_work_per_step(eng, B, passes, tag):
         return None
     # plain dense layers: qkv (+ fc1 when the FFN is not fused) write the operand dtype; the final 1x1 conv (+ the
     # residual GEMMs when E != 384) write fp32
-    nq = 1 if (fused_proj and eng.fuse_qkv) else L  # qkv Linears left to the plain GEMM
+    nq = 0 if getattr(eng, "fuse_qkv_attn", False) else (1 if (fused_proj and eng.fuse_qkv) else L)  # qkv Linears left to the plain GEMM
     act_fl, act_by, act_n = nq * 2.0 * M * 3 * E * E, nq * (M * E * esz + M * 3 * E * esz), nq
     if not fused_mlp and not ffn_split:
         act_fl += L * 2.0 * M * E * Fd
@@ -203,7 +206,8 @@ def pmc_traffic(kernel_mangled, precision, B):
         return None, None
     short = {"_ZN2pp4lovl17linear_ovl_kernelENS_10GemmParamsE": "pp::lovl::linear_ovl_kernel(",
              "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE": "pp::ffs::ffn_split_kernel(",
-             "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE": "pp::ffs::proj_ffn_split_kernel("}.get(kernel_mangled)
+             "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE": "pp::ffs::proj_ffn_split_kernel(",
+             "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE": "pp::qka::qkv_attention_split_kernel("}.get(kernel_mangled)
     for name in (f"r03_{precision}_bs64_hbm_traffic.json", f"r02_{precision}_bs64_hbm_traffic.json", f"r01_{precision}_bs64_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
@@ -329,7 +333,24 @@ def secondary_rooflines(eng, B, prof, reps):
     #    cycles per wave64 instruction -> ~870 cycles per task; 72 tasks per 96-row workgroup over 4 SIMDs (round-robin);
     #  * HBM: the bytes the phase has to pull (q, k, v; in the fused layer kernel also the fp32 residual rows that load under
     #    it) at the ~5 TB/s the chip sustains on reads when all 256 CUs ask at once (ATT_DBG ablations).
-    if S == 192 and hd == 32:
+    if "qkv_attention" in per_tag:
+        # f16x3: the attention of a (sequence, head) runs in the workgroup that has just computed that head's q, k, v rows
+        # (pp_qkv_attn_split.hip); there is no attention-only kernel to time. Priced as one kernel against the matrix pipe:
+        # three fp16 MFMAs per algorithmic product.
+        ms, n = per_tag["qkv_attention"]
+        M_ = nseq * S
+        qkv_fl = 2.0 * M_ * 3 * heads * hd * heads * hd
+        ach = (qkv_fl + att_fl) / (ms / n * 1e-3) / 1e12
+        ceil_tf = PEAK_TFLOPS["f16x3"] / MFMA_PER_PRODUCT["f16x3"]
+        out["attention"] = {
+            "bound": "mfma", "kernel": "qkv_attention (qkv Linear + attention, one workgroup per (sequence, head))", "avg_launch_ms": ms / n,
+            "algorithmic_gflop_per_layer": (qkv_fl + att_fl) / 1e9, "attention_share_of_flops": att_fl / (qkv_fl + att_fl),
+            "achieved": ach, "peak": PEAK_TFLOPS["f16x3"], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS["f16x3"],
+            "algorithmic_mbytes_per_launch": 2 * M_ * heads * hd * 4 / 1e6,
+            "derived_ceiling": {"TFLOPs": ceil_tf, "frac_of_ceiling": ach / ceil_tf,
+                                "why": "3 fp16 MFMAs per algorithmic product; q, k, v never leave the CU, so the phase's HBM floor of the "
+                                       "stand-alone kernels (113 MB of qkv written and read back per layer) is gone"}}
+    elif S == 192 and hd == 32:
         valu_cycles, clk, hbm_read_bps = 870.0, 2.1e9, 5.0e12
         rounds = max(1, -(-(nseq * S // 96) // 256))  # 96-row workgroups over 256 CUs (bs 64 + flip test: exactly one round)
         t_valu = heads * 6 * valu_cycles / 4 / clk * rounds

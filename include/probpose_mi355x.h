@@ -259,6 +259,18 @@ int pp_ffn_split_residual_layernorm(const void* h_in, const void* w_packed, cons
                                     const float* residual, float* x_out, const float* gamma, const float* beta,
                                     float eps, void* h_out, int M, int E, int F, void* stream);
 
+/* The first half of a ViT layer in ONE launch in the parity precision (PP_PREC_F16X3): the qkv Linear layer and the
+ * multi-head self-attention behind it; the (M, 3E) qkv tensor never reaches HBM:
+ *   qkv = h_in Wqkv^T + bqkv ;  out[:, head] = softmax(q_head k_head^T * scale) v_head   per sequence
+ * (mmpretrain MultiheadAttention.forward [3P]: self.qkv(x).reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4), scaled dot-product
+ * attention, heads concatenated; call site mmpose/models/pose_estimators/base.py:206, ctor args
+ * td-pm_ProbPose-small_8xb64-210e_coco-256x192.py:56-67). One workgroup per (sequence, head). h_in, out (n_seq * seq_len, E)
+ * PP_OUT_SPLIT; wqkv (3E, E) in the split format, rows [q | k | v] as mmpretrain packs them; bqkv (3E) fp32 or NULL.
+ * Built for seq_len 192, head_dim 32, heads * head_dim = 384 (ViT-S at 256x192); PP_ERR_UNSUPPORTED otherwise (callers then
+ * use pp_gemm + pp_attention). out must not alias h_in. */
+int pp_qkv_attention_split(const void* h_in, const void* wqkv, const float* bqkv, void* out, int n_seq, int seq_len, int heads,
+                           int head_dim, float scale, void* stream);
+
 /* The second half of a ViT layer in ONE launch in the parity precision (PP_PREC_F16X3): attention output projection +
  * residual, ln2, the feed-forward block + residual, and the LayerNorm that follows the layer:
  *   x_mid = residual + att Wp^T + bp ;  h = LayerNorm(x_mid; gamma2, beta2, eps)

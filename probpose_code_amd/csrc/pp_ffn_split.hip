@@ -30,8 +30,9 @@
 //   * W1 / W2 come PRE-PACKED in consumption order (pp_ffn_split_pack_weights: per chunk 12 W1 blocks of 16 KiB, then
 //     8 W2 half blocks of 24 KiB, 128-byte lines with the LDS XOR swizzle already applied), so a weight DMA instruction
 //     is a linear 1 KiB copy; the x lines are 128-byte segments of the row-major split tensor, swizzled at the source;
-//   * the 96 x 384 accumulators start from residual + b2 (loaded under the first chunk's A-steps) and end in the LayerNorm
-//     epilogue (row statistics in registers, one LDS exchange between the column quarters).
+//   * the 96 x 384 accumulators start from residual + b2 (requested ahead of the first DMA piece - never between pieces: plain
+//     loads and LDS-DMA pieces do not retire in order with respect to each other, see the projection phase) and end in the
+//     LayerNorm epilogue (row statistics in registers, one LDS exchange between the column quarters).
 // LDS: 48 KiB G + 4 x 28 KiB ring = 160 KiB.
 //
 // Measured at bs 64 (M = 24 576, F = 1536; scripts/micro/ffs_variants.sh + ffs_variants_bench.py, round-robin minima):
@@ -481,22 +482,21 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         // attention rows from G buffer kb & 3 (96 lines, fetched with the even steps by waves 0-3). Two steps in flight, one
         // barrier per step, all waves in the same phase: the phase is ~6 % of the launch, the FFN machinery below is not spent
         // on it. The ln2 rows then go out to `h` (global, L2) and come back as the streamed row operand of the A-steps.
-        // The residual rows (147 KB per workgroup, 37.7 MB over the chip: ~9 us when every workgroup asks at once) are not needed
-        // before the end of the phase: they trickle in, one 16-byte load per step behind that step's pieces from step 4 on, into
-        // registers the FFN phase has not claimed yet, and are added after the last step.
-#ifndef FFS_RES_LATE
-#define FFS_RES_LATE 1  // dev A/B switch: 0 all residual loads in front of the first step
-#endif
+        // The residual rows (147 KB per workgroup) are requested FIRST, ahead of every DMA piece, into registers the FFN phase
+        // has not claimed yet, and added after the last step. They must not trickle in between the pieces: a plain load that
+        // is YOUNGER than an LDS-DMA piece can retire before that piece's LDS write does (the vmcnt decrements of the two
+        // kinds are not ordered with respect to each other), so a counted wait that allows "the loads issued since" to be
+        // outstanding lets a piece through that has not landed - measured: 5 - 26 of 80 launches wrong when a second stream
+        // shares the chip (scripts/micro/ffs_stress_two_streams.py), none alone. Older plain loads are safe: the first counted
+        // wait covers them.
         f32x4 rres[3][6];
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int cf = 0; cf < 6; ++cf) {
                 acc[rf][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (!FFS_RES_LATE) {
-                    const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
-                    rres[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow(rf) * E + n);
-                }
+                const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
+                rres[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow(rf) * E + n);
             }
         auto issue_p = [&](int s) {
             if (DBG & 8) return;
@@ -522,25 +522,14 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int s = 4 * kp + q;
-                // step s has landed when only this wave's pieces of step s + 1 and the residual loads issued in steps s - 2, s - 1
-                // are outstanding (issue order: pieces(s) L(s - 2) pieces(s + 1) L(s - 1); loads exist in steps 4 .. 21)
-                constexpr int R0 = FFS_RES_LATE ? 4 : 1000;
-                const int nl = ((s - 2 >= R0 && s - 2 < R0 + 18) ? 1 : 0) + ((s - 1 >= R0 && s - 1 < R0 + 18) ? 1 : 0);
+                // step s has landed when only this wave's pieces of step s + 1 are outstanding
                 __builtin_amdgcn_sched_barrier(0);
                 stamp();
-                if (rg == 0) {
-                    if (q & 1) { if (nl == 2) FFS_WAIT(8); else if (nl == 1) FFS_WAIT(7); else FFS_WAIT(6); }
-                    else { if (nl == 2) FFS_WAIT(5); else if (nl == 1) FFS_WAIT(4); else FFS_WAIT(3); }
-                } else { if (nl == 2) FFS_WAIT(5); else if (nl == 1) FFS_WAIT(4); else FFS_WAIT(3); }
+                if (rg == 0) { if (q & 1) FFS_WAIT(6); else FFS_WAIT(3); } else FFS_WAIT(3);
                 __builtin_amdgcn_s_barrier();
                 stamp();
                 __builtin_amdgcn_sched_barrier(0);
                 issue_p(s + 2);
-                if (s >= R0 && s < R0 + 18) {
-                    const int i = s - R0, rf = i / 6, cf = i % 6;
-                    const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
-                    rres[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow(rf) * E + n);
-                }
                 const int so = slot_off(q);
 #pragma unroll
                 for (int nf = 0; nf < 3; ++nf) { bwh[nf] = b_w(so, nf, 0); bwl[nf] = b_w(so, nf, 1); }
@@ -570,13 +559,28 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         stamp();
         // the rows must be in L2 before any wave's DMA asks for them (a store counts in vmcnt until the L2 has acknowledged it)
         __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));
+#ifndef FFS_HS_FENCE
+#define FFS_HS_FENCE 0
+#endif
+        if (FFS_HS_FENCE & 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
+        if (FFS_HS_FENCE & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         stamp();
         stamp();
     }
 
-    // ---- prologue: b1 of the first chunk, the DMA of steps 0 - 2; the residual rows trickle in under the peeled A-steps
-    load_b1(0);  // (older than every DMA piece: landed at the first counted wait)
+    // ---- prologue: b1 of the first chunk and (without the projection phase) the residual rows, all OLDER than every DMA piece:
+    // landed at the first counted wait; then the DMA of steps 0 - 2
+    load_b1(0);
+    if constexpr (!PROJ) {
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int cf = 0; cf < 6; ++cf) {
+                const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
+                acc[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow(rf) * E + n);
+            }
+    }
 #pragma unroll
     for (int t = 0; t < 3; ++t) issue_step(0, t - NA);
 #pragma unroll
@@ -590,22 +594,10 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
     // ---- peeled A-steps of the first chunk
 #pragma unroll
     for (int kt = 0; kt < NA; ++kt) {
-        constexpr int NX = 2;
-        // L: two residual loads (steps 0-8; plain loads into the accumulators, in front of the pieces), the pieces of step kt + 3
-        if (!PROJ && kt <= 8) {
-#pragma unroll
-            for (int u = 0; u < NX; ++u) {
-                const int i = kt * NX + u, rf = i / 6, cf = i % 6;
-                const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
-                acc[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow(rf) * E + n);
-            }
-        }
         a_load(kt & 3, [&](int u) { issue_piece(0, kt - NA + 3, u); });
-        // extra loads of L(kt - 1), L(kt) are allowed to be outstanding at the wait for step kt + 1
-        const int e = PROJ ? 0 : ((kt >= 1 && kt <= 9) ? NX : 0) + (kt <= 8 ? NX : 0);
-        sync_l([&]() { if (e == 0) FFS_WAIT(2 * 3); else if (e == NX) FFS_WAIT(2 * 3 + NX); else FFS_WAIT(2 * 3 + 2 * NX); });
+        sync_l([&]() { FFS_WAIT(2 * 3); });
         a_compute();
-        sync_c([&]() { if (e == 0) FFS_WAIT(2 * 4); else if (e == NX) FFS_WAIT(2 * 4 + NX); else FFS_WAIT(2 * 4 + 2 * NX); });
+        sync_c([&]() { FFS_WAIT(2 * 4); });
     }
     // + b2; the first chunk's GELU has no other wave half's MFMAs... it runs beside the OTHER half's segments all the same,
     // but this half's next L segment waits for it (once per launch)
@@ -654,7 +646,9 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             b_load(sb, t & 3, [&](int u) { issue_piece(it, t + 3, u); });
             gelu_pairs(sb, 1, false);
             // pieces of steps t + 2, t + 3: B B up to t = 16, B A' at 17, A' A' at 18, 19
-            const int ex = (t == 12 || t == 13) ? 2 : 0;
+            // (the two b1 loads of step 12 get NO slack in the counts: as younger plain loads they may retire before the pieces
+            // these waits are for - see the projection phase)
+            const int ex = 0;
             sync_l([&]() { if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 3); else FFS_WAIT(2 * 3); });
             b_compute(sb);
             sync_c([&]() { if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 4); else FFS_WAIT(2 * 4); });

@@ -113,6 +113,10 @@ class ProbPoseEngine:
                                   _lib.stream_ptr(self.device))
                         self._proj_packed[i] = pbuf
                 torch.cuda.synchronize(self.device)
+        # f16x3, 192-token sequences of 32-dim heads: qkv Linear + attention of a layer in one launch, one workgroup per
+        # (sequence, head); the qkv tensor never reaches HBM (pp_qkv_attn_split.hip). PP_FUSE_QKV_ATTN=0: pp_gemm + pp_attention
+        self.fuse_qkv_attn = (precision == "f16x3" and os.environ.get("PP_FUSE_QKV_ATTN", "1") != "0" and self.Np == 192
+                              and self.hd == 32 and self.E == 384)
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
         self.stage_hook = None  # callable(name) invoked between stages of the launch plan ("embed", "layer<i>", "backbone"); dev / scheduling experiments
@@ -144,6 +148,7 @@ class ProbPoseEngine:
         ws = dict(
             patches=e(M, 3 * self.P * self.P), x=e(M, E, dt=f32), h=e(M, E), qkv=e(M, 3 * E), qkv2=e(M, 3 * E), f=e(M, Fd),
             feat=e(M, E), logits=e(nb, self.K, self.Hh * self.Wh, dt=f32),
+            att=e(M, E) if self.fuse_qkv_attn else None,  # attention output of the fused qkv + attention launch
             hs=e(M, E) if self._proj_packed else None,  # ln2 rows of the fused projection + FFN launch (scratch, L2-resident per workgroup)
             scalars=e(4, B, self.K, dt=f32), locs=e(B, self.K, 2, dt=f32),
             keypoints=e(B, self.K, 2, dt=torch.float64), scores=e(B, self.K, dt=f32),
@@ -222,8 +227,9 @@ class ProbPoseEngine:
         one_launch = (fused and E == 384 and self.precision == "bf16" and Fd % 128 == 0 and self.fuse_mlp and self.fuse_proj and self.fuse_attn
                       and self.Np == 192 and self.hd == 32)
         qcur, qnext = ws["qkv"], ws["qkv2"]
+        att = ws["att"] if self.fuse_qkv_attn else ws["h"]  # where a layer's attention output goes
         for i in range(L):
-            if not qkv_done:
+            if not qkv_done and not self.fuse_qkv_attn:
                 self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], qcur, M, 3 * E, E)
             if self.stage_hook is not None:
                 self.stage_hook("embed" if i == 0 else f"layer{i - 1}")
@@ -243,8 +249,12 @@ class ProbPoseEngine:
                 qcur, qnext = qnext, qcur
                 continue
             qkv_done = False
-            self._call("attention", "pp_attention", self.prec, qcur.data_ptr(), ws["h"].data_ptr(), B * passes,
-                       self.Np, self.heads, self.hd, scale, st)
+            if self.fuse_qkv_attn:
+                self._call("qkv_attention", "pp_qkv_attention_split", ws["h"].data_ptr(), w[f"l{i}.qkv.w"].data_ptr(),
+                           w[f"l{i}.qkv.b"].data_ptr(), att.data_ptr(), B * passes, self.Np, self.heads, self.hd, scale, st)
+            else:
+                self._call("attention", "pp_attention", self.prec, qcur.data_ptr(), ws["h"].data_ptr(), B * passes,
+                           self.Np, self.heads, self.hd, scale, st)
             last = i + 1 == L
             gn, bn = (w["ln_f.w"], w["ln_f.b"]) if last else (w[f"l{i + 1}.ln1.w"], w[f"l{i + 1}.ln1.b"])
             h_next = ws["feat"] if last else ws["h"]
@@ -265,13 +275,13 @@ class ProbPoseEngine:
                 continue
             if i in self._proj_packed:
                 # f16x3: projection + residual, ln2, FFN + residual, next LayerNorm in one kernel
-                self._call("proj_ffn_split", "pp_proj_ffn_split_residual_layernorm", ws["h"].data_ptr(), self._proj_packed[i].data_ptr(),
+                self._call("proj_ffn_split", "pp_proj_ffn_split_residual_layernorm", att.data_ptr(), self._proj_packed[i].data_ptr(),
                            w[f"l{i}.proj.b"].data_ptr(), w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(), ws["hs"].data_ptr(),
                            self._ffn_packed[i].data_ptr(), w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(),
                            ws["x"].data_ptr(), ws["x"].data_ptr(), gn.data_ptr(), bn.data_ptr(), self.ln_eps, h_next.data_ptr(),
                            M, E, Fd, st)
                 continue
-            res_ln(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])
+            res_ln(att, w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])
             if i in self._ffn_packed:
                 # f16x3: whole FFN + residual + next LayerNorm in one kernel, hidden activation on the CU
                 self._call("ffn_split", "pp_ffn_split_residual_layernorm", ws["h"].data_ptr(), self._ffn_packed[i].data_ptr(),

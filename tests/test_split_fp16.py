@@ -446,3 +446,79 @@ def test_proj_ffn_split_fused_vs_fp64(M, F_):
         L.call("pp_proj_ffn_split_residual_layernorm", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(),
                dev[2].data_ptr(), ad.data_ptr(), packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), xd.data_ptr(),
                xd.data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(), 1e-6, ad.data_ptr(), M, E, F_, None)
+
+
+@gpu
+@pytest.mark.parametrize("n_seq,bias", [(3, True), (16, False), (128, True)])
+def test_qkv_attention_split_fused_vs_fp64(n_seq, bias):
+    """pp_qkv_attention_split (qkv Linear + attention of a (sequence, head) per workgroup, qkv never in HBM) against torch fp64
+    on the unrounded fp32 inputs, with mmpretrain's packing of the qkv rows; an odd number of sequences (no XCD remap), the
+    bs 64 shape; repeated launches bit-identical."""
+    L = _lib()
+    S, E, H, hd = 192, 384, 12, 32
+    M = n_seq * S
+    h = _rand(M, E, seed=90)
+    w, b = _rand(3 * E, E, seed=91, scale=1 / math.sqrt(E)), _rand(3 * E, seed=92, scale=0.3)
+    qkv = h.double() @ w.double().t() + (b.double() if bias else 0.0)
+    q, k, v = qkv.reshape(n_seq, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v
+    ref = att.transpose(1, 2).reshape(M, E)
+    hd_, wd = _sp(h), _sp(w)
+    bd = b.cuda() if bias else None
+    outs = []
+    for _ in range(3):
+        out = torch.full((M, E), float("nan"), device="cuda")
+        L.call("pp_qkv_attention_split", hd_.data_ptr(), wd.data_ptr(), bd.data_ptr() if bias else None, out.data_ptr(), n_seq, S, H,
+               hd, hd ** -0.5, None)
+        outs.append(out.cpu())
+    torch.testing.assert_close(_unsp(outs[0]), ref, **TOL)
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int32), outs[0].view(torch.int32))
+    for bad in ((n_seq, 432, H, hd), (n_seq, S, 6, 64)):
+        with pytest.raises(L.ProbPoseLibraryError):
+            L.call("pp_qkv_attention_split", hd_.data_ptr(), wd.data_ptr(), None, out.data_ptr(), bad[0], bad[1], bad[2], bad[3], 0.1, None)
+    with pytest.raises(L.ProbPoseLibraryError):
+        L.call("pp_qkv_attention_split", hd_.data_ptr(), wd.data_ptr(), None, hd_.data_ptr(), n_seq, S, H, hd, 0.1, None)
+
+
+@gpu
+def test_proj_ffn_split_two_streams_under_contention():
+    """Two independent problems through pp_proj_ffn_split_residual_layernorm on two streams at once must each give the result
+    they give alone, bit for bit. This is the condition bench.py's two steps in flight create; it caught counted vmcnt waits
+    that allowed plain loads issued between LDS-DMA pieces to be outstanding (the two kinds do not retire in order with
+    respect to each other): correct alone, a few 48- / 96-row blocks wrong in 5 - 26 of 80 contended launches."""
+    L = _lib()
+    M, E, F_ = 24576, 384, 1536
+    probs = []
+    for seed in (100, 200):
+        _, r, w1, b1, w2, b2, g, be = _ffn_inputs(M, F_, seed=seed)
+        att, wp, bp, g2, be2 = _proj_inputs(M, seed=seed + 20)
+        wpp = torch.empty(E * E, dtype=torch.float32, device="cuda")
+        L.call("pp_proj_split_pack_weights", _sp(wp).data_ptr(), wpp.data_ptr(), E, None)
+        d = dict(att=_sp(att), x=r.cuda(), wpp=wpp, packed=_ffn_pack(L, w1, w2, E, F_), dev=[t.cuda() for t in (bp, g2, be2, b1, b2, g, be)],
+                 xo=torch.empty(M, E, device="cuda"), ho=torch.empty(M, E, device="cuda"), hs=torch.empty(M, E, device="cuda"))
+        probs.append(d)
+
+    def run(d, stream):
+        v = d["dev"]
+        L.call("pp_proj_ffn_split_residual_layernorm", d["att"].data_ptr(), d["wpp"].data_ptr(), v[0].data_ptr(), v[1].data_ptr(),
+               v[2].data_ptr(), d["hs"].data_ptr(), d["packed"].data_ptr(), v[3].data_ptr(), v[4].data_ptr(), d["x"].data_ptr(),
+               d["xo"].data_ptr(), v[5].data_ptr(), v[6].data_ptr(), 1e-6, d["ho"].data_ptr(), M, E, F_,
+               None if stream is None else stream.cuda_stream)
+
+    want = []
+    for d in probs:
+        run(d, None)
+        torch.cuda.synchronize()
+        want.append((d["xo"].clone(), d["ho"].clone()))
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    for it in range(25):
+        for d in probs:
+            d["xo"].fill_(float("nan")), d["ho"].fill_(float("nan")), d["hs"].fill_(float("nan"))
+        torch.cuda.synchronize()
+        for _ in range(3):
+            run(probs[0], s0), run(probs[1], s1)
+        torch.cuda.synchronize()
+        for k, (d, (xo, ho)) in enumerate(zip(probs, want)):
+            assert torch.equal(d["xo"], xo), f"iteration {it}, stream {k}: x_out differs from the solo launch"
+            assert torch.equal(d["ho"].view(torch.int32), ho.view(torch.int32)), f"iteration {it}, stream {k}: h_out differs"
