@@ -300,6 +300,14 @@ int pp_proj_ffn_split_residual_layernorm(const void* att, const void* wproj_pack
 int pp_deconv_head(const void* act_nhwc, const void* weight, const float* bias, const void* head_w, const float* head_b,
                    float* logits_phased, int B, int H, int W, int Cin, int Cout, int K, void* stream);
 
+/* pp_deconv_head in the parity precision (PP_PREC_F16X3): act_nhwc, weight in the split format; head_w_packed = the 1x1
+ * kernel (K <= 28 maps x 256 channels, zero-padded to 32 rows) as the 32 KiB register image the kernel's waves load
+ * (probpose_code_amd/weights.py::pack_head_split: [column group 4][K block 2][map fragment 2][hi | lo][lane 64][8 halves]).
+ * The ReLU'd tile is split in registers and contracted with it in the epilogue; same logits_phased layout. Needs
+ * 4 * ceil(B H W / 192) >= 192 tiles (PP_ERR_UNSUPPORTED below that: use pp_conv_gemm + pp_gemm). */
+int pp_deconv_head_split(const void* act_nhwc, const void* weight, const float* bias, const void* head_w_packed,
+                         const float* head_b, float* logits_phased, int B, int H, int W, int Cin, int Cout, int K, void* stream);
+
 /* pp_probmap_head_decode for logits in the phase-separated layout of pp_deconv_head (H, W = the heatmap size). */
 int pp_probmap_head_decode_phased(const float* logits, const float* logits_flip, const int32_t* flip_indices,
                                   const double* taps, const int32_t* radius, int B, int K, int H, int W, double in_w,

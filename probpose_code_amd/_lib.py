@@ -65,6 +65,7 @@ SIGNATURES = {
         [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_float, c_float, _P, _P, _P, _P, _P, _P],
     ),
     "pp_deconv_head": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pp_deconv_head_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pp_gemm": (
         c_int,
         [c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],

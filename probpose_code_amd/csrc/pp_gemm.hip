@@ -601,3 +601,27 @@ extern "C" int pp_deconv_head(const void* act_nhwc, const void* weight, const fl
     p.strideA_z = 0; p.strideW_z = (long long)Cout * 4 * Cin; p.strideC_z = 0; p.strideBias_z = 0;
     return panel_gemm(p, 4, reinterpret_cast<hipStream_t>(stream));
 }
+
+extern "C" int pp_deconv_head_split(const void* act_nhwc, const void* weight, const float* bias, const void* head_w_packed,
+                                    const float* head_b, float* logits_phased, int B, int H, int W, int Cin, int Cout, int K,
+                                    void* stream) {
+    using namespace pp;
+    PP_REQUIRE(act_nhwc && weight && head_w_packed && head_b && logits_phased, PP_ERR_INVALID_ARG, "pp_deconv_head_split: NULL argument");
+    PP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0, PP_ERR_INVALID_ARG, "pp_deconv_head_split: bad shape");
+    PP_REQUIRE(Cout == 256 && K >= 1 && K <= 28 && Cin % 32 == 0, PP_ERR_UNSUPPORTED,
+               "pp_deconv_head_split: built for 256 deconvolution channels, at most 28 output maps, Cin % 32 == 0");
+    GemmParams p{};
+    p.A = act_nhwc; p.W = weight; p.C = logits_phased; p.bias = bias; p.residual = nullptr;
+    p.M = B * H * W; p.N = Cout; p.K = 4 * Cin;
+    p.lda = Cin; p.ldw = p.K; p.ldc = Cout;
+    p.H = H; p.Wd = W; p.Cin = Cin; p.py = -1; p.px = -1;
+    p.act = ACT_RELU; p.out_bf16 = 2; p.gather = G_DECONV; p.ldres = Cout;
+    p.head_w = head_w_packed; p.head_b = head_b; p.head_out = logits_phased; p.head_n = K;
+    const size_t ab = (size_t)B * H * W * Cin * 4, wb = (size_t)Cout * p.K * 4;
+    PP_REQUIRE(ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_deconv_head_split: operands must be smaller than 2 GiB");
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    p.strideA_z = 0; p.strideW_z = (long long)Cout * 4 * Cin; p.strideC_z = 0; p.strideBias_z = 0;
+    PP_REQUIRE(panel_split_supported(p, PP_PREC_F16X3, 4), PP_ERR_UNSUPPORTED,
+               "pp_deconv_head_split: needs at least 192 tiles of 192 pixels x 256 channels over the four phases");
+    return panel_split_gemm(p, PP_PREC_F16X3, 4, reinterpret_cast<hipStream_t>(stream));
+}

@@ -75,7 +75,14 @@ __device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.
 // issue). Three stages keep two in flight (wait vmcnt(NI) instead of vmcnt(0)); they only fit with smaller stages
 // (192 x 192 / 128 x 256 tiles: 48 KiB), and the epilogue staging then borrows the buffer of the last stage consumed -
 // its refill is deferred until the epilogue is through.
-template <int GATHER, int RF, int CF, bool SPLIT, int NST>
+// HEAD (round 3; split-fp16 deconvolution with N == BN == 256 only): the 1x1 convolution behind the last deconvolution
+// (probmap_head.py:244-249) runs in the epilogue - ReLU'd accumulators are split in registers and ARE the MFMA operand (the
+// contraction index of a K = 32 block is taken in the order the accumulator layout provides: channels 4 fg + i of two
+// neighbouring 16-channel fragments; the 1x1 weights come pre-permuted to match, weights.py), every wave contracts its 64
+// channels, the four column-group waves' partial sums meet in LDS (<= 28 maps x 96 pixels per pass), and the tile leaves as
+// phase-separated fp32 logits: 13 KB instead of 196 KB per tile, the 403 MB feature map of bs 64 is neither written nor read
+// back, the 1x1 launch disappears.
+template <int GATHER, int RF, int CF, bool SPLIT, int NST, bool HEAD = false>
 __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParams p) {
     constexpr int ESZ = SPLIT ? 4 : 2;   // bytes per operand element
     constexpr int KS = 128 / ESZ;        // elements of K per stage: one 128-byte line per row
@@ -200,6 +207,24 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
     // (tried: every other workgroup of an XCD starting 8 / 16 us late so that the epilogue store bursts of the two groups
     // fall into each other's main loops - qkv 90 -> 96 / 103 us: the delay just adds, the lockstep stores are not the limit)
 
+    // HEAD: this wave's share of the 1x1 weights (channels 64 cg .. + 63: two K = 32 blocks x two 16-map fragments x (hi, lo))
+    // stays in registers for the whole launch; the 1x1 bias goes to LDS behind the partial sums (a vector load in the epilogue
+    // would queue behind the next tile's stages: vmcnt retires in order). Requested before the first DMA piece.
+    constexpr int HP_PITCH = 100, HP_MAXN = 28;                    // partial sums: [4 column groups][head_n][96 pixels], pitch 100
+    constexpr int OFF_HEADB = 4 * HP_MAXN * HP_PITCH * 4;          // 44 800 B into the staging region
+    static_assert(!HEAD || (SPLIT && GATHER == G_DECONV && RF == 6 && CF == 4 && NST == 2 && OFF_HEADB + 128 <= CST_BYTES), "fused 1x1 head");
+    u32x4 hw[HEAD ? 2 : 1][2][2];
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+                    hw[kb2][nf][hl] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.head_w) +
+                                                                      ((size_t)(((cg * 2 + kb2) * 2 + nf) * 2 + hl) * 64 + lane) * 16);
+        if (tid < HP_MAXN) reinterpret_cast<float*>(smem + OFF_CST + OFF_HEADB)[tid] = tid < p.head_n ? p.head_b[tid] : 0.f;
+    }
     setup_issue_tile();
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
@@ -308,6 +333,57 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
         const int e_row = lane_e & 15, e_kg = lane_e >> 4, tid_e = (tid & ~63) | lane_e;
         int z, m0, n0;
         decode_tile(tile, z, m0, n0);
+        if constexpr (HEAD) {
+            float* part = reinterpret_cast<float*>(smem + OFF_CST);
+            const float* hb = reinterpret_cast<const float*>(smem + OFF_CST + OFF_HEADB);
+            const int hwp = p.H * p.Wd;
+            const int phase = p.py < 0 ? z : 2 * p.py + p.px;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (rg == r) {
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf) {
+                        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kb2 = 0; kb2 < 2; ++kb2) {
+                            f32x4 v0 = acc[2 * kb2][rf] + bias_r[2 * kb2], v1 = acc[2 * kb2 + 1][rf] + bias_r[2 * kb2 + 1];
+                            f16x8 ph, pl;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float a0 = fmaxf(v0[j], 0.f), a1 = fmaxf(v1[j], 0.f);
+                                ph[j] = split_hi(a0);
+                                pl[j] = split_lo(a0, ph[j]);
+                                ph[4 + j] = split_hi(a1);
+                                pl[4 + j] = split_lo(a1, ph[4 + j]);
+                            }
+                            o0 = split_mma(__builtin_bit_cast(f16x8, hw[kb2][0][0]), __builtin_bit_cast(f16x8, hw[kb2][0][1]), ph, pl, o0);
+                            o1 = split_mma(__builtin_bit_cast(f16x8, hw[kb2][1][0]), __builtin_bit_cast(f16x8, hw[kb2][1][1]), ph, pl, o1);
+                        }
+                        const int px = rf * 16 + e_row;  // lane: pixel px of the row half, maps 4 fg + i (o0) and 16 + 4 fg + i (o1)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int n0_ = 4 * e_kg + i, n1_ = 16 + 4 * e_kg + i;
+                            if (n0_ < p.head_n) part[(cg * HP_MAXN + n0_) * HP_PITCH + px] = o0[i];
+                            if (n1_ < p.head_n) part[(cg * HP_MAXN + n1_) * HP_PITCH + px] = o1[i];
+                        }
+                    }
+                }
+                wait_vm_lgkm<63>();  // LDS writes only
+                __builtin_amdgcn_s_barrier();
+                for (int idx = tid_e; idx < p.head_n * 96; idx += THREADS) {
+                    const int n = idx / 96, px = idx - n * 96;
+                    const int m = m0 + r * 96 + px;
+                    if (m >= p.M) continue;
+                    const float sum = ((part[(0 * HP_MAXN + n) * HP_PITCH + px] + part[(1 * HP_MAXN + n) * HP_PITCH + px]) +
+                                       (part[(2 * HP_MAXN + n) * HP_PITCH + px] + part[(3 * HP_MAXN + n) * HP_PITCH + px])) + hb[n];
+                    const int b = m / hwp, rr = m - b * hwp;
+                    p.head_out[(((size_t)b * p.head_n + n) * 4 + phase) * hwp + rr] = sum;
+                }
+                wait_vm_lgkm<63>();
+                __builtin_amdgcn_s_barrier();  // the partial sums are rewritten by the other row half / the next tile
+            }
+            continue;
+        }
         char* cst = NST == 2 ? smem + OFF_CST : smem + last_buf * STAGE;
         constexpr int ROWB = BN * 4;            // bytes per staged fp32 row
         constexpr int LPR = BN / 8;             // lanes per row, 8 elements each (32 or 24)
@@ -444,7 +520,7 @@ static int psplit_nst() {  // 0 (default): by shape, see panel_split_shape; 2 / 
 }
 static int panel_split_shape(const GemmParams& p, int groups) {
     const bool three = psplit_nst() == 3;
-    if (p.gather == G_DECONV) return p.N % 256 == 0 ? (three ? 3 : 1) : 0;
+    if (p.gather == G_DECONV) return p.N % 256 == 0 ? ((three && !p.head_w) ? 3 : 1) : 0;
     if (p.N % 192 != 0) return 0;
     if (three) return 4;
     // Linear layers: the persistent grid walks whole rounds of tiles (one per CU); the 192 x 192 three-stage form wins where
@@ -479,6 +555,7 @@ static void shape_dims(int shape, int& BM, int& BN) {
 bool panel_split_supported(const GemmParams& p, int prec, int groups) {
     if (p.planar_P > 0 || p.ksplit > 1) return false;
     if (prec == PP_PREC_F16X3) {
+        if (p.head_w && !(p.gather == G_DECONV && p.N == 256 && p.head_n >= 1 && p.head_n <= 28)) return false;
         if (p.out_bf16 != 0 && p.out_bf16 != 2) return false;
         if (p.K % 64 != 0 || p.Cin % 32 != 0 || p.ldc % 32 != 0 || p.lda % 32 != 0 || p.ldw % 32 != 0) return false;
         if (p.strideA_z % 32 != 0 || p.strideW_z % 32 != 0 || p.strideC_z % 32 != 0) return false;
@@ -513,7 +590,14 @@ int panel_split_gemm(const GemmParams& p_in, int prec, int groups, hipStream_t s
     const bool sp = prec != PP_PREC_BF16;
 #define PP_PS(G, RF, CF, NST) (sp ? panel_split_kernel<G, RF, CF, true, NST> : panel_split_kernel<G, RF, CF, false, NST>)
     switch (p.gather) {
-        case G_DECONV: kern = shape == 3 ? PP_PS(G_DECONV, 4, 4, 3) : PP_PS(G_DECONV, 6, 4, 2); break;
+        case G_DECONV:
+            if (p.head_w) {
+                PP_REQUIRE(sp && shape == 1, PP_ERR_UNSUPPORTED, "pp panel split gemm: the fused 1x1 head needs the split-fp16 192 x 256 form");
+                kern = panel_split_kernel<G_DECONV, 6, 4, true, 2, true>;
+            } else {
+                kern = shape == 3 ? PP_PS(G_DECONV, 4, 4, 3) : PP_PS(G_DECONV, 6, 4, 2);
+            }
+            break;
         case G_CONV3: kern = shape == 4 ? PP_PS(G_CONV3, 6, 3, 3) : PP_PS(G_CONV3, 8, 3, 2); break;
         default: kern = shape == 4 ? PP_PS(G_LINEAR, 6, 3, 3) : PP_PS(G_LINEAR, 8, 3, 2); break;
     }

@@ -317,6 +317,14 @@ class ProbPoseEngine:
                            self.K, st)
                 self._logits_phased = True
                 return ws["logits"]
+            if (j == nd - 1 and self.fuse_head and ob == 2 and cout == 256 and w.has("final.w_head") and cin % 32 == 0
+                    and ww % 4 == 0 and self.K <= 28 and nb * hh * ww * 4 >= 192 * 192):
+                # f16x3: the same fusion, the 1x1 weights as a register image (weights.pack_head_split)
+                self._call("deconv_head", "pp_deconv_head_split", src.data_ptr(), wj.data_ptr(), w[f"deconv{j}.b"].data_ptr(),
+                           w["final.w_head"].data_ptr(), w["final.b"].data_ptr(), ws["logits"].data_ptr(), nb, hh, ww, cin, cout,
+                           self.K, st)
+                self._logits_phased = True
+                return ws["logits"]
             # all four output phases of the transposed conv in one persistent launch
             self._call("deconv", "pp_conv_gemm", self.prec, DECONV, src.data_ptr(), wj.data_ptr(),
                        w[f"deconv{j}.b"].data_ptr(), dst.data_ptr(), nb, hh, ww, cin, cout, -1, -1, 1, 0, 0, 0, 0, cout,

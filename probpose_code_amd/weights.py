@@ -80,6 +80,30 @@ def _bn_fold(sd, name):
     return scale, shift
 
 
+def pack_head_split(w32: torch.Tensor) -> torch.Tensor:
+    """(32, 256) fp32 1x1-conv weights (rows >= K zero) -> the register image the fused deconvolution + 1x1 kernel loads
+    (csrc/pp_panel_split.hip, HEAD): [column group 4][K block 2][map fragment 2][hi | lo][lane 64][8 halves]. Lane (fr, fg) of
+    map fragment nf holds map 16 nf + fr and the channels 64 cg + 32 kb + {4 fg + i, 16 + 4 fg + i : i < 4} - the order in
+    which a lane's accumulators of two neighbouring 16-channel fragments become the other operand."""
+    assert tuple(w32.shape) == (32, 256)
+    w32 = w32.float()
+    hi = w32.half()
+    lo = (w32 - hi.float()).half()
+    lane = torch.arange(64)
+    fr, fg = lane % 16, lane // 16
+    j = torch.arange(8)
+    ch_in_blk = torch.where(j < 4, 4 * fg[:, None] + j[None, :], 16 + 4 * fg[:, None] + (j[None, :] - 4))  # (64, 8)
+    out = torch.empty((4, 2, 2, 2, 64, 8), dtype=torch.float16)
+    for cg in range(4):
+        for kb in range(2):
+            ch = 64 * cg + 32 * kb + ch_in_blk
+            for nf in range(2):
+                rows = (16 * nf + fr)[:, None].expand(64, 8)
+                out[cg, kb, nf, 0] = hi[rows, ch]
+                out[cg, kb, nf, 1] = lo[rows, ch]
+    return out.reshape(-1).view(torch.float32).contiguous()
+
+
 def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = False) -> PackedWeights:
     """``dtype``: operand dtype of the MFMA kernels (bf16 / fp32); ``split=True``: split-fp16 operands in a float32
     container (``to_split``)."""
@@ -141,6 +165,8 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
         wpad = torch.zeros((32, t["final.w"].shape[1]), dtype=torch.float32)
         wpad[:K] = sd["head.final_layer.weight"].reshape(K, -1).float()
         t["final.w_pad"] = op(wpad)
+        if split and wpad.shape[1] == 256:
+            t["final.w_head"] = pack_head_split(wpad).to(device)
 
     # ---- scalar towers
     for c in range(3):

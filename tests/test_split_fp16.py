@@ -522,3 +522,44 @@ def test_proj_ffn_split_two_streams_under_contention():
         for k, (d, (xo, ho)) in enumerate(zip(probs, want)):
             assert torch.equal(d["xo"], xo), f"iteration {it}, stream {k}: x_out differs from the solo launch"
             assert torch.equal(d["ho"].view(torch.int32), ho.view(torch.int32)), f"iteration {it}, stream {k}: h_out differs"
+
+
+@gpu
+@pytest.mark.parametrize("B,K", [(12, 17), (13, 28)])
+def test_deconv_head_split_vs_fp64(B, K):
+    """pp_deconv_head_split (last deconvolution + BN + ReLU with the 1x1 conv in its epilogue, split-fp16 operands) against
+    ConvTranspose2d + ReLU + Conv1x1 in torch fp64 on the unrounded inputs; phase-separated logits rearranged to planar; a
+    ragged last tile (13 x 768 pixels), the largest map count; too few tiles are refused."""
+    from probpose_code_amd.weights import pack_head_split
+
+    L = _lib()
+    H, W, Cin, Cout = 32, 24, 256, 256
+    x = _rand(B, Cin, H, W, seed=120)
+    w = _rand(Cin, Cout, 4, 4, seed=121, scale=1 / math.sqrt(4 * Cin))
+    b = _rand(Cout, seed=122, scale=0.2)
+    wf, bf = _rand(K, Cout, seed=123, scale=4 / math.sqrt(Cout)), _rand(K, seed=124)
+    mid = F.relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+    ref = F.conv2d(mid, wf.double()[:, :, None, None], bf.double())  # (B, K, 2H, 2W)
+    ph = torch.empty((2, 2, Cout, 4 * Cin))
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    t = ty * 2 + tx
+                    ph[py, px, :, t * Cin:(t + 1) * Cin] = w[:, :, 3 - 2 * ty - py, 3 - 2 * tx - px].t()
+    wpad = torch.zeros(32, Cout)
+    wpad[:K] = wf
+    xd, phd, bd, bfd = _sp(x.permute(0, 2, 3, 1).contiguous()), _sp(ph), b.cuda(), bf.cuda()
+    hwd = pack_head_split(wpad).cuda()
+    outs = []
+    for _ in range(2):
+        lg = torch.full((B, K, 4, H * W), float("nan"), device="cuda")
+        L.call("pp_deconv_head_split", xd.data_ptr(), phd.data_ptr(), bd.data_ptr(), hwd.data_ptr(), bfd.data_ptr(), lg.data_ptr(), B, H, W,
+               Cin, Cout, K, None)
+        outs.append(lg.cpu())
+    planar = outs[0].reshape(B, K, 2, 2, H, W).permute(0, 1, 4, 2, 5, 3).reshape(B, K, 2 * H, 2 * W)
+    torch.testing.assert_close(planar.double(), ref, rtol=3e-5, atol=3e-5)
+    assert torch.equal(outs[0], outs[1])
+    with pytest.raises(L.ProbPoseLibraryError):
+        L.call("pp_deconv_head_split", xd.data_ptr(), phd.data_ptr(), bd.data_ptr(), hwd.data_ptr(), bfd.data_ptr(), lg.data_ptr(), 2, H, W,
+               Cin, Cout, K, None)
