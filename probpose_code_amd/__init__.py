@@ -19,7 +19,7 @@ from .pose_estimators import (  # noqa: F401
     VisionTransformer,
     build_pose_estimator,
 )
-from .registry import KEYPOINT_CODECS, MODELS  # noqa: F401
+from .registry import KEYPOINT_CODECS, MODELS, TRANSFORMS  # noqa: F401
 from .structures import InstanceData, PixelData, PoseDataSample  # noqa: F401
 
 __version__ = "0.1.0"

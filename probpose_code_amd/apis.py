@@ -126,34 +126,61 @@ def inference_topdown(model, img: Union[np.ndarray, torch.Tensor], bboxes=None, 
         return model.test_step(batch)
 
 
+DEFAULT_VAL_PIPELINE = [
+    dict(type="LoadImage"),
+    dict(type="GetBBoxCenterScale"),
+    dict(type="TopdownAffine", input_size=(192, 256), use_udp=True),
+    dict(type="PackPoseInputs"),
+]
+
+
+def _val_pipeline(model) -> T.Compose:
+    """``Compose(model.cfg.test_dataloader.dataset.pipeline)`` (apis/inference.py:159), built once per model. Configs without a
+    test dataloader (a bare model dict) get the ProbPose val pipeline at the decoder's input size."""
+    pipe = getattr(model, "_val_pipeline", None)
+    if pipe is None:
+        cfg = getattr(model, "cfg", None)
+        steps = None
+        if cfg is not None:
+            try:
+                steps = cfg["test_dataloader"]["dataset"]["pipeline"]
+            except (KeyError, TypeError):
+                steps = cfg.get("val_pipeline", None) if hasattr(cfg, "get") else None
+        if not steps:
+            steps = [dict(t) for t in DEFAULT_VAL_PIPELINE]
+            steps[2]["input_size"] = tuple(int(v) for v in model.head.decoder.input_size)
+        pipe = T.Compose([dict(t) for t in steps])
+        for t in pipe.transforms:
+            if isinstance(t, T.TopdownAffine) and t.device is None:
+                t.device = str(next(model.parameters()).device)
+        model._val_pipeline = pipe
+    return pipe
+
+
 def _frame_batch(model, img, bboxes, bbox_format):
-    """(image, boxes) -> the ``test_step`` batch dict of ``inference_topdown`` (box arithmetic on the host, one warp launch)."""
-    if isinstance(img, str):
-        img = load_image_bgr(img)
-    h, w = img.shape[:2]
+    """(image, boxes) -> the ``test_step`` batch dict of ``inference_topdown``: one ``data_info`` per box through the config's
+    val pipeline (box arithmetic on the host, ONE warp launch for all boxes of the image), then ``pseudo_collate``."""
+    pipeline = _val_pipeline(model)
     if bboxes is None or len(bboxes) == 0:
+        if isinstance(img, str):
+            img = load_image_bgr(img)  # (the reference opens the file for its size, then LoadImage reads it again per box)
+        h, w = img.shape[:2]
         bboxes = np.array([[0, 0, w, h]], dtype=np.float32)
     else:
         bboxes = np.array(bboxes) if isinstance(bboxes, list) else np.asarray(bboxes)
         assert bbox_format in {"xyxy", "xywh"}, f'Invalid bbox_format "{bbox_format}".'
         if bbox_format == "xywh":
             bboxes = T.bbox_xywh2xyxy(bboxes)
-    bboxes = np.asarray(bboxes, np.float32)[:, :4]
-    input_size = tuple(model.head.decoder.input_size)  # (w, h)
-    pipeline = model.cfg.get("val_pipeline", None) if hasattr(model, "cfg") else None
-    pad = 1.25
-    if pipeline:
-        for t in pipeline:
-            if t.get("type") == "TopdownAffine":
-                pad = float(t.get("input_padding", pad))
-    centers, scales, mats = T.topdown_affine_params(bboxes, input_size, input_padding=pad)
-    dev = next(model.parameters()).device
-    img_t = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
-    crops = T.warp_affine_crops(img_t.to(dev), mats, input_size)
-    batch = pack_crops(crops, centers, scales, model.dataset_meta, bboxes=bboxes)
-    for ds in batch["data_samples"]:
-        ds.set_metainfo(dict(ori_shape=(h, w), img_shape=(h, w)))
-    return batch
+        if isinstance(img, str):
+            img = load_image_bgr(img)  # decoded once for all boxes
+    data_list = []
+    for bbox in bboxes:
+        data_info = dict(img=img)
+        data_info["bbox"] = np.asarray(bbox, np.float32)[None, :4]  # shape (1, 4)
+        data_info["bbox_score"] = np.ones(1, dtype=np.float32)  # shape (1,)
+        data_info.update(model.dataset_meta)
+        data_list.append(data_info)
+    return T.pseudo_collate(pipeline.batched(data_list))
 
 
 def inference_topdown_stream(model, frames, bbox_format: str = "xyxy", depth: int = 2, max_persons: int = 64):

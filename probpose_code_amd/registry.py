@@ -99,7 +99,11 @@ def _real_registries():
         from mmpose.registry import KEYPOINT_CODECS as KC  # type: ignore
         from mmpose.registry import MODELS as M  # type: ignore
 
-        return M, KC
+        try:
+            from mmpose.registry import TRANSFORMS as T  # type: ignore
+        except ImportError:  # an MMPose without the transform registry: the val pipeline uses this package's own
+            T = None
+        return M, KC, T
     except Exception:  # noqa: BLE001 -- mmpose / mmengine absent or broken: use the shim
         return None
 
@@ -107,10 +111,13 @@ def _real_registries():
 _real = _real_registries()
 USING_MMENGINE = _real is not None
 if USING_MMENGINE:
-    MODELS, KEYPOINT_CODECS = _real
+    MODELS, KEYPOINT_CODECS, TRANSFORMS = _real
+    if TRANSFORMS is None:
+        TRANSFORMS = Registry("transform")
 else:
     MODELS = Registry("model")
     KEYPOINT_CODECS = Registry("KEYPOINT_CODECS")
+    TRANSFORMS = Registry("transform")  # mmpose/registry.py:36: the val pipeline's LoadImage / GetBBoxCenterScale / TopdownAffine / PackPoseInputs
 
 # Under a real MMPose, registering under the reference's own names needs force=True.
 OVERRIDE_REFERENCE_NAMES = (not USING_MMENGINE) or os.environ.get("PROBPOSE_MI355X_OVERRIDE", "0") == "1"

@@ -4,25 +4,25 @@
 # Kernel timing (--kernel-trace --stats) and the HBM counters (--pmc FETCH_SIZE, --pmc WRITE_SIZE) are separate runs;
 # PMC runs never carry another trace domain.
 set -u
-tag=${1:-r02_bf16_bs64}
-prec=${2:-bf16}
+tag=${1:-r03_f16x3_bs64}
+prec=${2:-f16x3}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/profiles
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_stats /tmp/prof_fetch /tmp/prof_write
 python $root/bench.py --steps 50 --warmup 10 --precision $prec > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --precision $prec \
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec \
     > $out/${tag}_bench_under_rocprof.json 2> /tmp/prof_stats.log
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 # the same with strictly one step at a time on one stream (bench.py's default keeps two steps in flight: kernels of two steps
 # then share the chip and the per-kernel durations of the trace include that)
 rm -rf /tmp/prof_stats1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- python $root/bench.py --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --precision $prec \
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- python $root/bench.py --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec \
     > $out/${tag}_bench_under_rocprof_one_in_flight.json 2> /tmp/prof_stats1.log
 cp $(find /tmp/prof_stats1 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_one_in_flight.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --precision $prec > /dev/null 2> /tmp/prof_fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --precision $prec > /dev/null 2> /tmp/prof_write.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_write.log
 python3 - "$out/${tag}_hbm_traffic.json" <<'PY'
 import csv, glob, json, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -44,5 +44,42 @@ for k, d in acc.items():
                          "hbm_bytes_per_launch": int((2 * fa + wa) * 1024)}
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print("kernels with traffic:", len(out["kernels"]))
+PY
+# SQ counters (three more separate --pmc passes, kernel-trace only): MFMA pipe busy, waiting share, LDS bank conflicts per kernel
+for i in 1 2 3; do rm -rf /tmp/prof_sq$i; done
+i=0
+for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
+           "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d /tmp/prof_sq$i -- python $root/bench.py --no-graph --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_sq$i.log
+done
+python3 - "$out/${tag}_sq_counters.txt" "$prec" <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("/tmp/prof_sq*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+m = lambda d, k: (sum(d[k]) / len(d[k])) if d.get(k) else float("nan")
+with open(sys.argv[1], "w") as fo:
+    fo.write("SQ counters per launch, rocprofv3 --pmc (separate passes, kernel-trace only) on `python bench.py --no-graph --in-flight 1 --steps 3 "
+             f"--warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision {sys.argv[2]}`, bs64, 1x MI355X (scripts/collect_profiles.sh). "
+             "Derived: MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); SQ_BUSY_CU_CYCLES / 256 = cycles per CU; "
+             "LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES.\n\n")
+    rows = sorted(acc.items(), key=lambda kv: -m(kv[1], "SQ_BUSY_CU_CYCLES") * len(kv[1].get("SQ_BUSY_CU_CYCLES", [])))
+    for k, d in rows:
+        if not d.get("SQ_BUSY_CU_CYCLES") or m(d, "SQ_BUSY_CU_CYCLES") < 256 * 2000:
+            continue
+        busy = m(d, "SQ_VALU_MFMA_BUSY_CYCLES") / (4 * m(d, "SQ_BUSY_CU_CYCLES"))
+        conf = m(d, "SQ_LDS_BANK_CONFLICT") / m(d, "SQ_LDS_IDX_ACTIVE") if m(d, "SQ_LDS_IDX_ACTIVE") > 0 else float("nan")
+        fo.write(f"{k}\n    launches {len(d['SQ_BUSY_CU_CYCLES'])}   MFMA pipe busy {100 * busy:.1f} %   cycles per CU {m(d, 'SQ_BUSY_CU_CYCLES') / 256:,.0f}   "
+                 f"LDS bank-conflict share {100 * conf:.1f} %   waiting share of wave cycles {100 * m(d, 'SQ_WAIT_ANY') / m(d, 'SQ_WAVE_CYCLES'):.0f} %\n")
+    fo.write("\n")
+    for k, d in rows:
+        if not d.get("SQ_BUSY_CU_CYCLES") or m(d, "SQ_BUSY_CU_CYCLES") < 256 * 2000:
+            continue
+        fo.write(k + "\n")
+        for c, v in sorted(d.items()):
+            fo.write(f"  {c:34s} n={len(v):4d} mean={sum(v) / len(v):16.1f}\n")
+print(open(sys.argv[1]).read()[:3000])
 PY
 tail -2 /tmp/prof_stats.log; ls -la $out
