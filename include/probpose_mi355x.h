@@ -50,6 +50,45 @@ const char* pp_status_string(int status);
 /* Number of compute units of the current device (for callers sizing batches); <0 on error. */
 int pp_device_cu_count(void);
 
+/* Explicit process-wide options. The library NEVER reads the environment: kernel selection depends only on the arguments of a
+ * call and on these switches, which exist for A/B timing and default to the shipped plan:
+ *   "panel" (1)              0: every GEMM / convolution on the 128 x 128-tile kernel
+ *   "conv_halo" (1)          0: first tower convolution (bf16) on the implicit-GEMM kernel
+ *   "linear_ovl" (1)         0: split-fp16 Linear layers without the overlapped-epilogue kernel
+ *   "psplit_nst" (0)         2 / 3: force the two- / three-stage form of the wide-tile split kernel
+ *   "panel_linear_mink" (0)  > 0: shortest K of a bf16 Linear layer that takes the wide-tile kernel
+ *   "psplit_bf16_conv" (0)   1: bf16 convolutions through the split kernel's bf16 instantiation
+ * Unknown names return PP_ERR_INVALID_ARG. Not thread-safe against concurrent launches (set them before the first call).
+ * (probpose_code_amd/_lib.py forwards PP_OPT_<NAME>=<int> environment variables here at import - host-side convenience.) */
+int pp_set_option(const char* name, int value);
+int pp_get_option(const char* name, int* value);
+
+/* Bytes of the caller-allocated buffers of one step of the launch plan (the library never allocates). `shape`
+ * describes the step: prec = PP_PREC_*; n_img = crops x flip passes; n_tokens per image; embed / ffn widths; patch_k = 3 * patch
+ * * patch; feat_h x feat_w = the backbone's output grid; heat_h x heat_w = the heatmap; deconv_channels = channels of the
+ * deconvolution outputs. `buffer` = PP_WS_*; `index` selects the deconvolution (PP_WS_DECONV: 0, 1 ...) or the tower stage
+ * (PP_WS_TOWER*: 0..2), 0 otherwise. Operand-format buffers are 2 bytes per element in PP_PREC_BF16 and 4 in PP_PREC_F32 /
+ * PP_PREC_F16X3 (the split format is a 4-byte container). Returns < 0 (PP_ERR_INVALID_ARG) for an unknown buffer / bad shape. */
+typedef struct {
+    int prec, n_img, n_tokens, embed, ffn, patch_k, n_keypoints, feat_h, feat_w, heat_h, heat_w, deconv_channels;
+} pp_plan_shape;
+enum {
+    PP_WS_PATCHES = 0,       /* (M, patch_k) operand format: im2col of the preprocessed crops, M = n_img * n_tokens        */
+    PP_WS_X = 1,             /* (M, embed) fp32: the residual stream                                                       */
+    PP_WS_H = 2,             /* (M, embed) operand format: LayerNorm output feeding qkv                                    */
+    PP_WS_QKV = 3,           /* (M, 3 embed) operand format (unfused qkv + attention only)                                 */
+    PP_WS_ATT = 4,           /* (M, embed) operand format: attention output of pp_qkv_attention_split                      */
+    PP_WS_LN2 = 5,           /* (M, embed) operand format: ln2 rows parked by pp_proj_ffn_split_residual_layernorm         */
+    PP_WS_FFN = 6,           /* (M, ffn) operand format: hidden activation (unfused FFN only)                              */
+    PP_WS_FEAT = 7,          /* (M, embed) operand format: final LayerNorm = NHWC feature map                              */
+    PP_WS_LOGITS = 8,        /* (n_img, K, heat_h * heat_w) fp32                                                           */
+    PP_WS_DECONV = 9,        /* output of deconvolution `index`, NHWC operand format                                       */
+    PP_WS_TOWER = 10,        /* (4, n_img, h, w, embed) operand format: convolution output of tower stage `index`         */
+    PP_WS_TOWER_PARTIAL = 11,/* (3, 4, n_img, h, w, embed) fp32: split-K partial sums of tower stage `index`               */
+    PP_WS_TOWER_POOLED = 12  /* (4, n_img, h / ph, w / pw, embed) operand format: pooled output of tower stage `index`     */
+};
+long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* shape);
+
 /* ------------------------------------------------------------------------------------
  * ProbMap decode, fused with the flip-test average.
  *

@@ -52,6 +52,9 @@ SIGNATURES = {
     "pp_last_error": (c_char_p, []),
     "pp_status_string": (c_char_p, [c_int]),
     "pp_device_cu_count": (c_int, []),
+    "pp_set_option": (c_int, [c_char_p, c_int]),
+    "pp_get_option": (c_int, [c_char_p, _P]),
+    "pp_workspace_bytes": (c_longlong, [c_int, c_int, _P]),
     "pp_probmap_decode": (
         c_int,
         [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P, _P, _P, _P, _P, _P],
@@ -121,6 +124,40 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 
+class PlanShape(ctypes.Structure):
+    """pp_plan_shape of include/probpose_mi355x.h."""
+    _fields_ = [(n, c_int) for n in ("prec", "n_img", "n_tokens", "embed", "ffn", "patch_k", "n_keypoints", "feat_h", "feat_w",
+                                     "heat_h", "heat_w", "deconv_channels")]
+
+
+# PP_WS_* of the header
+WS = dict(patches=0, x=1, h=2, qkv=3, att=4, ln2=5, ffn=6, feat=7, logits=8, deconv=9, tower=10, tower_partial=11, tower_pooled=12)
+
+
+def workspace_bytes(buffer: str, shape: "PlanShape", index: int = 0) -> int:
+    n = lib.pp_workspace_bytes(WS[buffer], index, ctypes.byref(shape))
+    if n < 0:
+        raise ProbPoseLibraryError("pp_workspace_bytes", lib.pp_status_string(int(n)).decode(), last_error())
+    return int(n)
+
+
+def set_option(name: str, value: int) -> None:
+    check("pp_set_option", lib.pp_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = c_int(0)
+    check("pp_get_option", lib.pp_get_option(name.encode(), ctypes.byref(v)))
+    return v.value
+
+
+def _options_from_env() -> None:
+    """Host-side convenience (the C library itself never reads the environment): PP_OPT_<NAME>=<int> -> pp_set_option."""
+    for k, v in os.environ.items():
+        if k.startswith("PP_OPT_"):
+            set_option(k[len("PP_OPT_"):].lower(), int(v))
+
+
 def last_error() -> str:
     return lib.pp_last_error().decode("utf-8", "replace")
 
@@ -148,3 +185,6 @@ def stream_ptr(device=None):
 
 def call(fn_name: str, *args):
     check(fn_name, getattr(lib, fn_name)(*args))
+
+
+_options_from_env()

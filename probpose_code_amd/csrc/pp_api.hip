@@ -14,9 +14,96 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- explicit process-wide options (dev A/B switches of kernel selection). The library never reads the environment.
+struct Option { const char* name; int value; };
+static Option g_options[] = {
+    {"panel", 1},              // 0: every GEMM / convolution on the 128 x 128 kernel (pp_gemm.hip)
+    {"conv_halo", 1},          // 0: first tower convolution (bf16) on the implicit-GEMM kernel instead of pp_conv_halo.hip
+    {"linear_ovl", 1},         // 0: split-fp16 Linear layers on pp_panel_split.hip instead of pp_linear_ovl.hip
+    {"psplit_nst", 0},         // 2 / 3: force the two- / three-stage form of pp_panel_split.hip (0: by shape)
+    {"panel_linear_mink", 0},  // > 0: shortest K of a bf16 Linear layer that takes the wide-tile kernel (0: built-in thresholds)
+    {"psplit_bf16_conv", 0},   // 1: bf16 convolutions through pp_panel_split.hip instead of pp_panel_gemm.hip
+};
+
+int option(const char* name) {
+    for (const Option& o : g_options)
+        if (std::strcmp(o.name, name) == 0) return o.value;
+    return 0;
+}
+
 }  // namespace pp
 
 extern "C" {
+
+int pp_set_option(const char* name, int value) {
+    using namespace pp;
+    PP_REQUIRE(name, PP_ERR_INVALID_ARG, "pp_set_option: NULL name");
+    for (Option& o : g_options)
+        if (std::strcmp(o.name, name) == 0) {
+            o.value = value;
+            return PP_OK;
+        }
+    set_error("pp_set_option: unknown option '%s'", name);
+    return PP_ERR_INVALID_ARG;
+}
+
+int pp_get_option(const char* name, int* value) {
+    using namespace pp;
+    PP_REQUIRE(name && value, PP_ERR_INVALID_ARG, "pp_get_option: NULL argument");
+    for (const Option& o : g_options)
+        if (std::strcmp(o.name, name) == 0) {
+            *value = o.value;
+            return PP_OK;
+        }
+    set_error("pp_get_option: unknown option '%s'", name);
+    return PP_ERR_INVALID_ARG;
+}
+
+long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* sh) {
+    using namespace pp;
+    if (!sh || sh->n_img <= 0 || sh->n_tokens <= 0 || sh->embed <= 0 || sh->ffn <= 0 || sh->n_keypoints <= 0 || sh->feat_h <= 0 || sh->feat_w <= 0 ||
+        (sh->prec != PP_PREC_BF16 && sh->prec != PP_PREC_F32 && sh->prec != PP_PREC_F16X3)) {
+        set_error("pp_workspace_bytes: bad plan shape");
+        return PP_ERR_INVALID_ARG;
+    }
+    const long long esz = sh->prec == PP_PREC_BF16 ? 2 : 4;  // operand element: bf16, or fp32 / split fp16 (4 bytes each)
+    const long long M = (long long)sh->n_img * sh->n_tokens, E = sh->embed;
+    auto tower_hw = [&](int j, long long& h, long long& w, long long& ph, long long& pw) {  // pooling schedule (4,3), (2,2), (2,2): probmap_head.py:264
+        h = sh->feat_h;
+        w = sh->feat_w;
+        for (int i = 0;; ++i) {
+            ph = i == 0 ? 4 : 2;
+            pw = i == 0 ? 3 : 2;
+            if (i == j) return;
+            h /= ph;
+            w /= pw;
+        }
+    };
+    switch (buffer) {
+        case PP_WS_PATCHES: return M * sh->patch_k * esz;
+        case PP_WS_X: return M * E * 4;                     // residual stream, fp32
+        case PP_WS_H: case PP_WS_FEAT: case PP_WS_ATT: case PP_WS_LN2: return M * E * esz;
+        case PP_WS_QKV: return M * 3 * E * esz;
+        case PP_WS_FFN: return M * (long long)sh->ffn * esz;
+        case PP_WS_LOGITS: return (long long)sh->n_img * sh->n_keypoints * sh->heat_h * sh->heat_w * 4;
+        case PP_WS_DECONV: {                                 // output of deconvolution `index`: (n_img, 2^(i+1) feat_h, 2^(i+1) feat_w, channels)
+            if (index < 0 || index >= 8 || sh->deconv_channels <= 0) break;
+            const long long up = 2ll << index;
+            return (long long)sh->n_img * sh->feat_h * up * sh->feat_w * up * sh->deconv_channels * esz;
+        }
+        case PP_WS_TOWER: case PP_WS_TOWER_PARTIAL: case PP_WS_TOWER_POOLED: {
+            if (index < 0 || index > 2) break;
+            long long h, w, ph, pw;
+            tower_hw(index, h, w, ph, pw);
+            if (buffer == PP_WS_TOWER) return 4ll * sh->n_img * h * w * E * esz;
+            if (buffer == PP_WS_TOWER_PARTIAL) return 3ll * 4 * sh->n_img * h * w * E * 4;   // three K-slices, fp32
+            return 4ll * sh->n_img * (h / ph) * (w / pw) * E * esz;
+        }
+        default: break;
+    }
+    set_error("pp_workspace_bytes: unknown buffer %d (index %d)", buffer, index);
+    return PP_ERR_INVALID_ARG;
+}
 
 int pp_abi_version(void) { return PP_ABI_VERSION; }
 

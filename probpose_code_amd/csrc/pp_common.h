@@ -12,6 +12,7 @@
 namespace pp {
 
 void set_error(const char* fmt, ...);
+int option(const char* name);  // explicit dev switches (pp_set_option); the library never reads the environment
 
 inline int fail(int code, const char* what) {
     set_error("%s", what);

@@ -377,14 +377,7 @@ static int device_cus() {
     return cus;
 }
 
-static bool enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = std::getenv("PP_CONV_HALO");  // dev A/B switch: 0 = implicit-GEMM kernel of pp_panel_gemm.hip
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    return on == 1;
-}
+static bool enabled() { return option("conv_halo") != 0; }  // dev A/B switch (pp_set_option): 0 = implicit-GEMM kernel of pp_panel_gemm.hip
 
 }  // namespace halo
 

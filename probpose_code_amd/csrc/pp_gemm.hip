@@ -492,7 +492,7 @@ int gemm(const GemmParams& p, int prec, int groups, hipStream_t s) {
 }  // namespace pp
 
 static bool panel_enabled() {
-    static const bool use_panel = !(getenv("PP_PANEL") && atoi(getenv("PP_PANEL")) == 0);  // dev switch for A/B timing
+    const bool use_panel = pp::option("panel") != 0;  // dev switch for A/B timing (pp_set_option)
     return use_panel;
 }
 

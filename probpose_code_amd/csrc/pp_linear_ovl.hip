@@ -316,7 +316,7 @@ static int device_cus() {
 }  // namespace lovl
 
 static bool linear_ovl_enabled() {
-    static const bool on = !(getenv("PP_LINEAR_OVL") && atoi(getenv("PP_LINEAR_OVL")) == 0);  // dev switch for A/B timing
+    const bool on = option("linear_ovl") != 0;  // dev switch for A/B timing (pp_set_option)
     return on;
 }
 

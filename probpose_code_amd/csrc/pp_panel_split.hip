@@ -515,7 +515,7 @@ static int device_cus() {
 // which tile shape serves this problem, or 0: 1 = 192 x 256 (deconvolutions, N % 256), 2 = 256 x 192 (N % 192);
 // three-stage forms (PP_PSPLIT_NST=3, dev): 3 = 128 x 256, 4 = 192 x 192
 static int psplit_nst() {  // 0 (default): by shape, see panel_split_shape; 2 / 3 force the two- / three-stage forms (dev)
-    static const int v = getenv("PP_PSPLIT_NST") ? atoi(getenv("PP_PSPLIT_NST")) : 0;
+    const int v = option("psplit_nst");
     return v;
 }
 static int panel_split_shape(const GemmParams& p, int groups) {
@@ -539,11 +539,11 @@ static int panel_split_shape(const GemmParams& p, int groups) {
 // with another's main loop (dev: PP_PANEL_LINEAR_MINK). Measured on ViT-B at bs 64 (scripts/bench_base.py): K = 768 with bf16
 // output (qkv, fc1) 8.66 ms on the 128 x 128 kernel vs 9.83 ms here; K = 768 with fp32 output + residual (proj) 6.65 vs 6.28 ms
 static int panel_linear_min_k(bool out_bf16) {
-    static const int v = getenv("PP_PANEL_LINEAR_MINK") ? atoi(getenv("PP_PANEL_LINEAR_MINK")) : 0;
+    const int v = option("panel_linear_mink");
     return v > 0 ? v : (out_bf16 ? 1536 : 768);
 }
 static bool panel_bf16_conv() {  // dev: bf16 convolutions through this kernel instead of pp_panel_gemm.hip
-    static const bool v = getenv("PP_PSPLIT_BF16_CONV") && atoi(getenv("PP_PSPLIT_BF16_CONV")) != 0;
+    const bool v = option("psplit_bf16_conv") != 0;
     return v;
 }
 

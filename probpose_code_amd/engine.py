@@ -34,12 +34,27 @@ ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 CONV3X3, DECONV = 1, 2
 
 
+# launch-plan switches and their shipped values (fuse_resln: None = on for E = 384 only, True = also the E = 768 row-owner kernel)
+PLAN_DEFAULTS = dict(fuse_mlp=True, fuse_proj=True, fuse_qkv=True, split_k=True, fuse_attn=True, fuse_head=True, fuse_resln=None,
+                     fuse_pool=True, fuse_qkv_attn=True)
+
+
+def plan_from_env() -> Dict[str, object]:
+    """PP_FUSE_MLP=0 ... -> {fuse_mlp: False, ...}; PP_FUSE_RESLN=1 / 0 -> True / False. Dev convenience only."""
+    out: Dict[str, object] = {}
+    for k in PLAN_DEFAULTS:
+        v = os.environ.get("PP_" + k.upper())
+        if v is not None:
+            out[k] = (v == "1") if k == "fuse_resln" else (v != "0")
+    return out
+
+
 class ProbPoseEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], num_heads: int, img_size=(256, 192), patch_size: int = 16,
                  patch_padding: int = 2, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375),
                  bgr_to_rgb: bool = True, temperature: float = 0.5, normalize: Optional[float] = 1.0,
                  input_size: Optional[Sequence[int]] = None, ln_eps: float = 1e-6, precision: str = "f16x3",
-                 device="cuda"):
+                 device="cuda", plan: Optional[Dict[str, object]] = None):
         if precision not in PREC:
             raise ValueError(f"precision must be one of {list(PREC)}, got {precision!r}")
         self.device = torch.device(device)
@@ -75,23 +90,26 @@ class ProbPoseEngine:
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._flip: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}
-        self.fuse_mlp = os.environ.get("PP_FUSE_MLP", "1") != "0"
-        self.fuse_proj = os.environ.get("PP_FUSE_PROJ", "1") != "0"
-        self.fuse_qkv = os.environ.get("PP_FUSE_QKV", "1") != "0"
-        self.split_k = os.environ.get("PP_SPLIT_K", "1") != "0"
-        # attention inside the layer kernel (pp_vit_layer, one launch per layer; 192-token sequences, head dim 32): about 2 %
-        # faster per step than pp_attention + the fused rest since the residual rows load under its attention phase
-        # (DESIGN.md 4); PP_FUSE_ATTN=0 switches back to two launches per layer
-        self.fuse_attn = os.environ.get("PP_FUSE_ATTN", "1") != "0"
-        self.fuse_head = os.environ.get("PP_FUSE_HEAD", "1") != "0"
-        # residual GEMM + LayerNorm in one launch (pp_gemm_ln.hip; 0: GEMM, then LayerNorm). Default on for E = 384. At E = 768
-        # (ViT-B) the row-owner kernel exists and is tested, but is OFF unless PP_FUSE_RESLN=1: measured at 384x288 bs 32 it saves
+        # Launch-plan switches: every fusion below is on in the shipped plan; `plan` (constructor argument) turns single ones off
+        # for A/B timing and for the tests of the unfused kernels, PP_FUSE_* environment variables do the same from outside a
+        # script (read HERE, in the host-side mirror - the C library reads no environment, include/probpose_mi355x.h).
+        pl = dict(PLAN_DEFAULTS)
+        pl.update(plan_from_env())
+        pl.update(plan or {})
+        unknown = set(pl) - set(PLAN_DEFAULTS)
+        if unknown:
+            raise ValueError(f"unknown launch-plan switch(es) {sorted(unknown)}; known: {sorted(PLAN_DEFAULTS)}")
+        self.plan = pl
+        self.fuse_mlp, self.fuse_proj, self.fuse_qkv, self.split_k = pl["fuse_mlp"], pl["fuse_proj"], pl["fuse_qkv"], pl["split_k"]
+        # attention inside the bf16 layer kernel (pp_vit_layer, one launch per layer; 192-token sequences, head dim 32): about 2 %
+        # faster per step than pp_attention + the fused rest since the residual rows load under its attention phase (DESIGN.md 4)
+        self.fuse_attn, self.fuse_head, self.fuse_pool = pl["fuse_attn"], pl["fuse_head"], pl["fuse_pool"]
+        # residual GEMM + LayerNorm in one launch (pp_gemm_ln.hip; False: GEMM, then LayerNorm). Default on for E = 384. At E = 768
+        # (ViT-B) the row-owner kernel exists and is tested, but is OFF unless fuse_resln is True: measured at 384x288 bs 32 it saves
         # the LayerNorm launches one step at a time (10.72 -> 10.47 ms) and loses with two steps in flight (9.64 -> 10.01 ms: one
         # 124 KiB workgroup per CU cannot share a CU with the other step's kernels, the 128 x 128 GEMM tiles can)
-        env = os.environ.get("PP_FUSE_RESLN")
-        self.fuse_resln = env != "0"
-        self._resln_768 = env == "1"
-        self.fuse_pool = os.environ.get("PP_FUSE_POOL", "1") != "0"  # first tower stage: conv + pool + ReLU in one launch
+        self.fuse_resln = pl["fuse_resln"] is not False
+        self._resln_768 = pl["fuse_resln"] is True
         # f16x3: fc1 - GELU - fc2 + residual + LayerNorm of a layer in one launch (pp_ffn_split.hip; the hidden activation stays
         # on the CU). The kernel takes W1 / W2 as one buffer in its consumption order, packed here once per layer.
         # With fuse_proj the attention output projection + residual + ln2 run in front of it in the same launch
@@ -115,8 +133,7 @@ class ProbPoseEngine:
                 torch.cuda.synchronize(self.device)
         # f16x3, 192-token sequences of 32-dim heads: qkv Linear + attention of a layer in one launch, one workgroup per
         # (sequence, head); the qkv tensor never reaches HBM (pp_qkv_attn_split.hip). PP_FUSE_QKV_ATTN=0: pp_gemm + pp_attention
-        self.fuse_qkv_attn = (precision == "f16x3" and os.environ.get("PP_FUSE_QKV_ATTN", "1") != "0" and self.Np == 192
-                              and self.hd == 32 and self.E == 384)
+        self.fuse_qkv_attn = precision == "f16x3" and pl["fuse_qkv_attn"] and self.Np == 192 and self.hd == 32 and self.E == 384
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
         self.stage_hook = None  # callable(name) invoked between stages of the launch plan ("embed", "layer<i>", "backbone"); dev / scheduling experiments
@@ -144,26 +161,44 @@ class ProbPoseEngine:
         nb = B * passes
         M = nb * self.Np
         E, Fd = self.E, self.w.ffn_dims
-        e = lambda *s, dt=T: torch.empty(s, dtype=dt, device=dev)  # noqa: E731
+        dc = self.w.deconv_channels
+        shape = _lib.PlanShape(prec=self.prec, n_img=nb, n_tokens=self.Np, embed=E, ffn=Fd, patch_k=3 * self.P * self.P, n_keypoints=self.K,
+                               feat_h=self.Hp, feat_w=self.Wp, heat_h=self.Hh, heat_w=self.Wh, deconv_channels=dc[0] if dc else 0)
+
+        def buf(which, dims, dt=T, index=0):
+            """One buffer of the plan, sized by the library (pp_workspace_bytes): the C side owns the formats' byte sizes."""
+            nbytes = _lib.workspace_bytes(which, shape, index)
+            t = torch.empty(nbytes, dtype=torch.uint8, device=dev).view(dt)
+            assert t.numel() == math.prod(dims), (which, index, nbytes, dims)
+            return t.view(*dims)
+
+        e = lambda *s, dt=T: torch.empty(s, dtype=dt, device=dev)  # noqa: E731  (results: sizes fixed by the output contract)
+        fused_layer = self.precision == "f16x3" and self.fuse_qkv_attn and bool(self._proj_packed)
         ws = dict(
-            patches=e(M, 3 * self.P * self.P), x=e(M, E, dt=f32), h=e(M, E), qkv=e(M, 3 * E), qkv2=e(M, 3 * E), f=e(M, Fd),
-            feat=e(M, E), logits=e(nb, self.K, self.Hh * self.Wh, dt=f32),
-            att=e(M, E) if self.fuse_qkv_attn else None,  # attention output of the fused qkv + attention launch
-            hs=e(M, E) if self._proj_packed else None,  # ln2 rows of the fused projection + FFN launch (scratch, L2-resident per workgroup)
+            patches=buf("patches", (M, 3 * self.P * self.P)), x=buf("x", (M, E), f32), h=buf("h", (M, E)),
+            feat=buf("feat", (M, E)), logits=buf("logits", (nb, self.K, self.Hh * self.Wh), f32),
+            # qkv / hidden activation only where a launch plan without the fused layer kernels needs them
+            qkv=None if fused_layer else buf("qkv", (M, 3 * E)), qkv2=None if fused_layer else buf("qkv", (M, 3 * E)),
+            f=None if (fused_layer or self._ffn_packed) else buf("ffn", (M, Fd)),
+            att=buf("att", (M, E)) if self.fuse_qkv_attn else None,  # attention output of the fused qkv + attention launch
+            hs=buf("ln2", (M, E)) if self._proj_packed else None,  # ln2 rows of the fused projection + FFN launch (scratch, parked in L2 / MALL)
             scalars=e(4, B, self.K, dt=f32), locs=e(B, self.K, 2, dt=f32),
             keypoints=e(B, self.K, 2, dt=torch.float64), scores=e(B, self.K, dt=f32),
             heatmaps=e(B, self.K, self.Hh, self.Wh, dt=f32),
         )
         hh, ww = self.Hp, self.Wp
-        for j, c in enumerate(self.w.deconv_channels):
+        for j, c in enumerate(dc):
             hh, ww = hh * 2, ww * 2
-            ws[f"d{j}"] = e(nb, hh, ww, c)
+            if c == dc[0]:
+                ws[f"d{j}"] = buf("deconv", (nb, hh, ww, c), index=j)
+            else:
+                ws[f"d{j}"] = e(nb, hh, ww, c)
         for j, (th, tw) in enumerate(self.tower_hw):
             ph, pw_ = self.pools[j]
-            ws[f"t{j}"] = e(4, nb, th, tw, E)
+            ws[f"t{j}"] = buf("tower", (4, nb, th, tw, E), index=j)
             if nb * th * tw * 4 < 128 * 128:
-                ws[f"tp{j}"] = e(3, 4, nb, th, tw, E, dt=f32)  # split-K partial sums of the small tower stages
-            ws[f"p{j}"] = e(4, nb, th // ph, tw // pw_, E)
+                ws[f"tp{j}"] = buf("tower_partial", (3, 4, nb, th, tw, E), f32, index=j)  # split-K partial sums of the small tower stages
+            ws[f"p{j}"] = buf("tower_pooled", (4, nb, th // ph, tw // pw_, E), index=j)
         self._ws[key] = ws
         return ws
 

@@ -37,3 +37,37 @@ def test_argument_validation_without_gpu(lib_built):
                                     None, None, None, None, None, None)
     assert st == _lib.PP_ERR_INVALID_ARG
     assert b"non-NULL" in _lib.lib.pp_last_error()
+
+
+def test_options_and_workspace_query_without_gpu(lib_built):
+    """pp_set_option / pp_get_option (the library reads no environment: kernel selection switches are explicit) and
+    pp_workspace_bytes (the caller sizes every buffer from the library's answer) are host-only entry points."""
+    from probpose_code_amd import _lib
+
+    assert _lib.get_option("panel") == 1 and _lib.get_option("psplit_nst") == 0
+    _lib.set_option("panel", 0)
+    assert _lib.get_option("panel") == 0
+    _lib.set_option("panel", 1)
+    import pytest
+
+    with pytest.raises(_lib.ProbPoseLibraryError, match="unknown option"):
+        _lib.set_option("no_such_switch", 1)
+    text = open(os.path.join(ROOT, "probpose_code_amd", "csrc", "pp_gemm.hip")).read()
+    for f in os.listdir(os.path.join(ROOT, "probpose_code_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "probpose_code_amd", "csrc", f)).read(), f"{f} reads the environment"
+    assert "getenv" not in text
+    sh = _lib.PlanShape(prec=2, n_img=128, n_tokens=192, embed=384, ffn=1536, patch_k=768, n_keypoints=17, feat_h=16, feat_w=12,
+                        heat_h=64, heat_w=48, deconv_channels=256)
+    M = 128 * 192
+    assert _lib.workspace_bytes("x", sh) == M * 384 * 4 and _lib.workspace_bytes("h", sh) == M * 384 * 4  # split fp16: 4-byte container
+    assert _lib.workspace_bytes("logits", sh) == 128 * 17 * 64 * 48 * 4
+    assert _lib.workspace_bytes("deconv", sh, 1) == 128 * 64 * 48 * 256 * 4
+    assert _lib.workspace_bytes("tower_pooled", sh, 0) == 4 * 128 * 4 * 4 * 384 * 4
+    sh.prec = 0
+    assert _lib.workspace_bytes("h", sh) == M * 384 * 2 and _lib.workspace_bytes("x", sh) == M * 384 * 4  # bf16 operands, fp32 stream
+    with pytest.raises(_lib.ProbPoseLibraryError):
+        _lib.workspace_bytes("tower", sh, 5)
+    sh.n_img = 0
+    with pytest.raises(_lib.ProbPoseLibraryError):
+        _lib.workspace_bytes("x", sh)
