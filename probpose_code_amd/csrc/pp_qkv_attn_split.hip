@@ -45,9 +45,9 @@ constexpr int A_LINES = S, W_LINES = 3 * HD;
 constexpr int STAGE = (A_LINES + W_LINES) * 128;  // 36 KiB
 constexpr int KB = E / 32;                        // 12 K-steps
 constexpr int OFF_Q = 0, OFF_K = S * 128, OFF_V = 2 * S * 128;
-constexpr int SPV = S + 8;                        // V^T row pitch in halves
+constexpr int SPV = S + 4;                        // V^T row pitch in halves: 98 dwords - the 16 rows a ds_read2_b64 group touches fall on 16 distinct bank pairs (mod 32)
 constexpr int V_PLANE = HD * SPV * 2;             // bytes of one plane
-constexpr int LDS = OFF_V + 2 * V_PLANE;          // 74 752 B
+constexpr int LDS = OFF_V + 2 * V_PLANE;          // 74 240 B
 constexpr unsigned OOB = 0x7ffffff0u;
 static_assert(LDS >= 2 * STAGE && 2 * LDS <= 160 * 1024, "two workgroups per CU");
 
