@@ -181,7 +181,13 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         const int blk = chunk_of(live ? ci : 0) * CHUNK_BYTES + kb * A_BLOCK;
         if (u < 3) {
             const int so = (rg == 0 ? blk + 3 * wv * 1024 : kb * 128) + u * a_stride;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a(live), (lds_ptr_t)(ring + slot * SLOTB + a_dst + u * 1024), 16, v_a, so, 0, 0);
+#ifndef FFS_X_AUX
+#define FFS_X_AUX 0  // dev: cache policy bits of the x pieces (2 = nt: the rows are private to the workgroup, no reuse in L2 to protect)
+#endif
+            if (FFS_X_AUX != 0 && rg == 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a(live), (lds_ptr_t)(ring + slot * SLOTB + a_dst + u * 1024), 16, v_a, so, 0, FFS_X_AUX);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a(live), (lds_ptr_t)(ring + slot * SLOTB + a_dst + u * 1024), 16, v_a, so, 0, 0);
         } else if (rg == 0) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w(live), (lds_ptr_t)(ring + slot * SLOTB + (12 + wv) * 1024), 16, v_w, blk + (12 + wv) * 1024, 0, 0);
         }
@@ -337,8 +343,12 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
     // allowed outstanding at the wait for step S + 1: pieces of steps S + 2, S + 3 (own share) + the extra loads of L(S - 1), L(S)
     // L segments: this wave's DMA pieces alternate with its fragment reads - four waves issue at the same time, the texture
     // path takes one piece per 16 cycles, and whoever finds its queue full stands still: the reads go out in those gaps
+#ifndef FFS_DMA_IN_C
+#define FFS_DMA_IN_C 0  // dev A/B: 1 = the DMA pieces of step s + 3 are issued in the MFMA segment C(s), between the MFMAs, not in L(s)
+#endif
     auto pin = [&]() { __builtin_amdgcn_sched_barrier(0); };
-    auto a_load = [&](int slot_i, auto issue_fn) {
+    auto a_load = [&](int slot_i, auto issue_fn_) {
+        auto issue_fn = [&](int u) { if (!FFS_DMA_IN_C) issue_fn_(u); };
         const int so = slot_off(slot_i);
         issue_fn(0);
         pin();
@@ -357,21 +367,30 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         pin();
         issue_fn(3);
     };
-    auto a_compute = [&]() {
+    auto a_compute = [&](auto issue_fn_) {
+        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C) { pin(); issue_fn_(u); pin(); } };
 #pragma unroll
-        for (int rf = 0; rf < 3; ++rf)
+        for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(awh[nf], axh[rf], pacc[rf][nf]);
+            if (rf == 1) issue_fn(0);
+        }
 #pragma unroll
-        for (int rf = 0; rf < 3; ++rf)
+        for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(awl[nf], axh[rf], pacc[rf][nf]);
+            if (rf == 0) issue_fn(1);
+            if (rf == 2) issue_fn(2);
+        }
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf)
+        for (int nf = 0; nf < 2; ++nf) {
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) pacc[rf][nf] = mma(awh[nf], axl[rf], pacc[rf][nf]);
+            if (nf == 0) issue_fn(3);
+        }
     };
-    auto b_load = [&](int sb, int slot_i, auto issue_fn) {
+    auto b_load = [&](int sb, int slot_i, auto issue_fn_) {
+        auto issue_fn = [&](int u) { if (!FFS_DMA_IN_C) issue_fn_(u); };
         const int so = slot_off(slot_i);
         issue_fn(0);
         pin();
@@ -391,20 +410,27 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         }
         issue_fn(3);
     };
-    auto b_compute = [&](int sb) {
+    auto b_compute = [&](int sb, auto issue_fn_) {
+        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C) { pin(); issue_fn_(u); pin(); } };
         const int half = sb & 1;
 #pragma unroll
-        for (int rf = 0; rf < 3; ++rf)
+        for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(bwh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+            if (rf == 1) issue_fn(0);
+        }
 #pragma unroll
-        for (int rf = 0; rf < 3; ++rf)
+        for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(bwl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+            if (rf == 1) issue_fn(1);
+        }
 #pragma unroll
-        for (int nf = 0; nf < 3; ++nf)
+        for (int nf = 0; nf < 3; ++nf) {
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) acc[rf][half * 3 + nf] = mma(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+            if (nf == 0) { issue_fn(2); issue_fn(3); }
+        }
     };
 
     // rows past M read row M - 1; nothing of them is ever stored (computed where it is used: as an array it ended up in scratch)
@@ -467,7 +493,11 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
 #ifndef FFS_PAIR_STORE
 #define FFS_PAIR_STORE 1  // dev A/B switch: 0 two 8-byte stores per lane and fragment
 #endif
-                if (FFS_PAIR_STORE) split_store4_rowpair(h_dst, off, hv, live);  // (lanes f_kg, f_kg ^ 1 hold the halves of a 16-byte chunk)
+#ifndef FFS_HS_NT
+#define FFS_HS_NT 0  // dev: ln2 rows (x_dst == nullptr) stored non-temporally
+#endif
+                if (FFS_HS_NT && !x_dst) split_store4_rowpair_nt(h_dst, off, hv, live);
+                else if (FFS_PAIR_STORE) split_store4_rowpair(h_dst, off, hv, live);  // (lanes f_kg, f_kg ^ 1 hold the halves of a 16-byte chunk)
                 else if (live) split_store4(h_dst, off, hv);
             }
         }
@@ -482,21 +512,19 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         // attention rows from G buffer kb & 3 (96 lines, fetched with the even steps by waves 0-3). Two steps in flight, one
         // barrier per step, all waves in the same phase: the phase is ~6 % of the launch, the FFN machinery below is not spent
         // on it. The ln2 rows then go out to `h` (global, L2) and come back as the streamed row operand of the A-steps.
-        // The residual rows (147 KB per workgroup) are requested FIRST, ahead of every DMA piece, into registers the FFN phase
-        // has not claimed yet, and added after the last step. They must not trickle in between the pieces: a plain load that
-        // is YOUNGER than an LDS-DMA piece can retire before that piece's LDS write does (the vmcnt decrements of the two
-        // kinds are not ordered with respect to each other), so a counted wait that allows "the loads issued since" to be
-        // outstanding lets a piece through that has not landed - measured: 5 - 26 of 80 launches wrong when a second stream
-        // shares the chip (scripts/micro/ffs_stress_two_streams.py), none alone. Older plain loads are safe: the first counted
-        // wait covers them.
-        f32x4 rres[3][6];
+        // The residual rows (147 KB per workgroup) are requested FIRST, ahead of every DMA piece, straight into the accumulators
+        // (the projection adds onto them). They must not trickle in between the pieces: a plain load that is YOUNGER than an
+        // LDS-DMA piece can retire before that piece's LDS write does (the vmcnt decrements of the two kinds are not ordered
+        // with respect to each other), so a counted wait that allows "the loads issued since" to be outstanding lets a piece
+        // through that has not landed - measured: 5 - 26 of 80 launches wrong when a second stream shares the chip
+        // (scripts/micro/ffs_stress_two_streams.py), none alone. Older plain loads are safe: the first counted wait covers them.
+        // (Held in a second register set until the end of the phase they cost 72 registers: 34 spilled.)
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int cf = 0; cf < 6; ++cf) {
-                acc[rf][cf] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int n = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4;
-                rres[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow(rf) * E + n);
+                acc[rf][cf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mrow(rf) * E + n);
             }
         auto issue_p = [&](int s) {
             if (DBG & 8) return;
@@ -517,8 +545,8 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         };
         issue_p(0);
         issue_p(1);
-#pragma unroll
-        for (int kp = 0; kp < 2 * KB / 4; ++kp) {
+#pragma unroll 1
+        for (int kp = 0; kp < 2 * KB / 4; ++kp) {  // (rolled: fully unrolled the 24 steps cost 34 spilled registers)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int s = 4 * kp + q;
@@ -538,7 +566,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
 #pragma unroll
                     for (int rf = 0; rf < 3; ++rf) { bgh[rf] = b_g(j, rf, 0); bgl[rf] = b_g(j, rf, 1); }
                 }
-                b_compute(q & 1);
+                b_compute(q & 1, [](int) {});
             }
         }
         // + bp (after the sums, as residual + (sum + bias) rounds closest to the reference's x + proj(...))
@@ -549,10 +577,6 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
         }
         __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));  // vmcnt(0) lgkmcnt(0): the zero fillers of steps 24, 25 have landed too
-#pragma unroll
-        for (int rf = 0; rf < 3; ++rf)
-#pragma unroll
-            for (int cf = 0; cf < 6; ++cf) acc[rf][cf] += rres[rf][cf];
         __syncthreads();
         stamp();
         layernorm_rows(p.gamma2, p.beta2, nullptr, const_cast<void*>(p.h));
@@ -595,8 +619,8 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
 #pragma unroll
     for (int kt = 0; kt < NA; ++kt) {
         a_load(kt & 3, [&](int u) { issue_piece(0, kt - NA + 3, u); });
-        sync_l([&]() { FFS_WAIT(2 * 3); });
-        a_compute();
+        sync_l([&]() { if (FFS_DMA_IN_C) FFS_WAIT(3); else FFS_WAIT(2 * 3); });
+        a_compute([&](int u) { issue_piece(0, kt - NA + 3, u); });
         sync_c([&]() { FFS_WAIT(2 * 4); });
     }
     // + b2; the first chunk's GELU has no other wave half's MFMAs... it runs beside the OTHER half's segments all the same,
@@ -634,8 +658,8 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             }
             // pieces of steps kt + 2, kt + 3: A A up to 8, A B at 9, B B at 10, 11 (the first iteration's vmcnt(0) above makes
             // every count an upper bound there)
-            sync_l([&]() { if (kt <= 8) FFS_WAIT(2 * 3); else if (kt == 9) FFS_WAIT(3 + 3); else FFS_WAIT(6); });
-            a_compute();
+            sync_l([&]() { if (FFS_DMA_IN_C) FFS_WAIT(3); else if (kt <= 8) FFS_WAIT(2 * 3); else if (kt == 9) FFS_WAIT(3 + 3); else FFS_WAIT(6); });
+            a_compute([&](int u) { issue_piece(it, kt + 3, u); });
             sync_c([&]() { if (kt <= 8) FFS_WAIT(2 * 4); else if (kt == 9) FFS_WAIT(4 + 3); else FFS_WAIT(6); });
         }
         // ================= B-steps of chunk it; their L segments carry one GELU pair of chunk it + 1 each (pairs 0..7)
@@ -649,8 +673,8 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             // (the two b1 loads of step 12 get NO slack in the counts: as younger plain loads they may retire before the pieces
             // these waits are for - see the projection phase)
             const int ex = 0;
-            sync_l([&]() { if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 3); else FFS_WAIT(2 * 3); });
-            b_compute(sb);
+            sync_l([&]() { if (FFS_DMA_IN_C) FFS_WAIT(3); else if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 3); else FFS_WAIT(2 * 3); });
+            b_compute(sb, [&](int u) { issue_piece(it, t + 3, u); });
             sync_c([&]() { if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 4); else FFS_WAIT(2 * 4); });
         }
     }

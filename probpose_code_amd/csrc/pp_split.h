@@ -69,6 +69,23 @@ __device__ __forceinline__ void split_store4_rowpair(void* base, size_t idx, spl
     char* p = split_addr(base, idx & ~(size_t)7) + (odd ? 64 : 0);
     if (store) *reinterpret_cast<u32x4_t*>(p) = q;
 }
+__device__ __forceinline__ void split_store4_rowpair_nt(void* base, size_t idx, split_f32x4 v, bool store) {  // dev: the same, non-temporal
+    f16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = split_hi(v[j]);
+        l[j] = split_lo(v[j], h[j]);
+    }
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x2_t hu = __builtin_bit_cast(u32x2_t, h), lu = __builtin_bit_cast(u32x2_t, l);
+    const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(hu[1], lu[1], false, false);
+    const u32x4_t q = {s0[0], s1[0], s0[1], s1[1]};
+    const bool odd = (threadIdx.x & 16) != 0;
+    char* p = split_addr(base, idx & ~(size_t)7) + (odd ? 64 : 0);
+    if (store) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t*>(p));
+}
 __device__ __forceinline__ split_f32x4 split_load4(const void* base, size_t idx) {
     const char* p = split_addr(base, idx);
     const f16x4 h = *reinterpret_cast<const f16x4*>(p), l = *reinterpret_cast<const f16x4*>(p + 64);

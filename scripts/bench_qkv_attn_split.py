@@ -13,9 +13,11 @@ def fused():
 def two():
     L.call("pp_gemm", 2, h.data_ptr(), w.data_ptr(), b.data_ptr(), None, 0, qkv.data_ptr(), M, 3 * E, E, E, E, 3 * E, 0, 2, 0, None)
     L.call("pp_attention", 2, qkv.data_ptr(), out.data_ptr(), n_seq, S, H, hd, hd ** -0.5, None)
-times = {"fused": [], "qkv + attention": []}
+def fused2():
+    L.set_option("qkv_attn_pair", 1); fused(); L.set_option("qkv_attn_pair", 0)
+times = {"fused (one head)": [], "fused (head pair)": [], "qkv + attention": []}
 for rep in range(5):
-    for name, run in (("fused", fused), ("qkv + attention", two)):
+    for name, run in (("fused (one head)", fused), ("fused (head pair)", fused2), ("qkv + attention", two)):
         for _ in range(3): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
