@@ -19,7 +19,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef WAVES
 #define WAVES 12
 #endif
-#ifndef ABL  // timing-only ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA
+#ifndef PIPE
+#define PIPE 0  // 1: fragments of step t + 1 read under the MFMAs of step t (two register sets)
+#endif
+#ifndef ABL  // timing-only ablations: 1 no DMA traffic, 2 no fragment reads, 4 no MFMA, 8 no DMA instructions, 16 no barrier (PIPE form)
 #define ABL 0
 #endif
 constexpr int BM = 96, E = 384, CHUNK = 128, NCH = 12;
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12_kernel(const char* _
     const int c_rot = (int)(blockIdx.x & 7);
     auto chunk_of = [&](int i) { const int c = (i + c_rot) % NCH; return c; };
     auto issue = [&](int ci, int t) {  // step t (0..19) of chunk ci into slot (t & 3)
+        if (ABL & 8) return;  // no DMA instructions at all
         char* dst = ring + (t & 3) * SLOTB;
         const int base = chunk_of(ci % NCH) * CHUNK_BYTES;
         if (t < NA) {
@@ -94,7 +98,15 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12_kernel(const char* _
     const int rows0 = rg * (16 * RF) + f_row;
     auto rd = [&](int off) -> u32x4 {
         if (ABL & 2) return u32x4{(unsigned)off, 1u, 2u, 3u};
+#if PIPE
+        // as asm: the compiler puts `s_waitcnt vmcnt(0)` in front of an ordinary LDS read that follows an LDS-DMA instruction
+        // (it cannot tell the ring slots apart); the step's own `lgkmcnt(0)` at its top covers these reads one step later
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(off));
+        return v;
+#else
         return *reinterpret_cast<const u32x4*>(smem + off);
+#endif
     };
 
     f32x4 acc[RF][6], pacc[RF][2];
@@ -109,6 +121,95 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12_kernel(const char* _
     issue(0, 0);
     issue(0, 1);
     issue(0, 2);
+#if PIPE
+    // software-pipelined form: the fragments of step t + 1 are read (into the other register set) under the MFMAs of step t
+    u32x4 fw[2][6], fx[2][2 * RF], gb[2][2 * RF];
+    auto load = [&](int t, int set) {  // t in 0..19
+        const int so = OFF_RING + (t & 3) * SLOTB;
+        if (t < NA) {
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                fw[set][nf] = rd(so + (cg * 32 + nf * 16 + f_row) * 128 + ch_hi);
+                fw[set][2 + nf] = rd(so + (cg * 32 + nf * 16 + f_row) * 128 + ch_lo);
+            }
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf) {
+                fx[set][rf] = rd(so + X_OFF + (rows0 + rf * 16) * 128 + ch_hi);
+                fx[set][RF + rf] = rd(so + X_OFF + (rows0 + rf * 16) * 128 + ch_lo);
+            }
+        } else {
+            const int sb = t - NA;
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) {
+                fw[set][nf] = rd(so + (cg * 48 + nf * 16 + f_row) * 128 + ch_hi);
+                fw[set][3 + nf] = rd(so + (cg * 48 + nf * 16 + f_row) * 128 + ch_lo);
+            }
+            if ((sb & 1) == 0) {
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) {
+                    gb[(sb >> 1) & 1][rf] = rd((sb >> 1) * G_KB + (rows0 + rf * 16) * 128 + ch_hi);
+                    gb[(sb >> 1) & 1][RF + rf] = rd((sb >> 1) * G_KB + (rows0 + rf * 16) * 128 + ch_lo);
+                }
+            }
+        }
+    };
+    auto compute = [&](int t, int set) {
+        if (t < NA) {
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(fw[set][nf], fx[set][rf], pacc[rf][nf]);
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(fw[set][2 + nf], fx[set][rf], pacc[rf][nf]);
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(fw[set][nf], fx[set][RF + rf], pacc[rf][nf]);
+        } else {
+            const int sb = t - NA, half = sb & 1, g = (sb >> 1) & 1;
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(fw[set][nf], gb[g][rf], acc[rf][half * 3 + nf]);
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(fw[set][3 + nf], gb[g][rf], acc[rf][half * 3 + nf]);
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(fw[set][nf], gb[g][RF + rf], acc[rf][half * 3 + nf]);
+        }
+    };
+#define WAITVM_ONLY(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (0 << 8) | (((N) >> 4) << 14))  // vmcnt(N) lgkmcnt(0): the asm reads of the previous step (this step's fragments) are in
+    auto waitn2 = [](int n) {
+        switch (n) {
+            case 2: WAITVM_ONLY(2); break;
+            case 3: WAITVM_ONLY(3); break;
+            case 4: WAITVM_ONLY(4); break;
+            default: WAITVM_ONLY(0); break;
+        }
+    };
+    WAITVM(0);
+    __builtin_amdgcn_s_barrier();
+    load(0, 0);
+    for (int ci = 0; ci < NCH; ++ci) {
+#pragma unroll
+        for (int t = 0; t < STEPS; ++t) {
+            const int t2 = (t + 2) % STEPS;
+            __builtin_amdgcn_sched_barrier(0);
+            if (wv < 4) waitn2(t2 < NA ? n_a(0) : n_b(0)); else waitn2(t2 < NA ? n_a(4) : n_b(4));  // step t + 1 has landed
+            if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            { const int t3 = t + 3; if (t3 < STEPS) issue(ci, t3); else issue(ci + 1, t3 - STEPS); }
+            load((t + 1) % STEPS, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);  // the reads go out first, the MFMAs of this step cover their latency
+            compute(t, t & 1);
+        }
+    }
+#else
     for (int ci = 0; ci < NCH; ++ci) {
 #pragma unroll
         for (int t = 0; t < STEPS; ++t) {
@@ -185,6 +286,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12_kernel(const char* _
             }
         }
     }
+#endif
     __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | 0);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -224,6 +326,6 @@ int main() {
         if (ms / 20 < best) best = ms / 20;
     }
     hipError_t err = hipGetLastError();
-    printf("WAVES=%d ABL=%d: %.1f us per launch (240 steps: %.0f ns per step), err=%s\n", WAVES, ABL, best * 1e3, best * 1e6 / 240, hipGetErrorString(err));
+    printf("WAVES=%d PIPE=%d ABL=%d: %.1f us per launch (240 steps: %.0f ns per step), err=%s\n", WAVES, PIPE, ABL, best * 1e3, best * 1e6 / 240, hipGetErrorString(err));
     return 0;
 }
