@@ -439,6 +439,23 @@ extern "C" int pp_conv3x3_maxpool_relu(int prec, const void* act_nhwc, const voi
             if (conv_halo_supported(p, prec, groups)) return conv_halo(p, groups, reinterpret_cast<hipStream_t>(stream));
         }
     }
+    if (prec == PP_PREC_F16X3 && fmt == PP_OUT_SPLIT && pp::option("panel") != 0 && pp::option("conv_pool_split") != 0) {
+        // split-fp16: pooling in the epilogue of the wide-tile kernel (pp_panel_split.hip, POOL)
+        GemmParams p{};
+        p.A = act_nhwc; p.W = weight; p.C = out_pooled; p.bias = bias;
+        p.M = B * H * W; p.N = Cout; p.K = 9 * Cin;
+        p.lda = Cin; p.ldw = p.K; p.ldc = Cout; p.ldres = Cout;
+        p.H = H; p.Wd = W; p.Cin = Cin;
+        p.act = ACT_NONE; p.out_bf16 = 2; p.gather = G_CONV3;
+        p.pool_h = ph; p.pool_w = pw;
+        const size_t ab = (size_t)B * H * W * Cin * 4, wb = (size_t)Cout * p.K * 4;
+        if (ab < 0x70000000u && wb < 0x70000000u) {
+            p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+            p.strideA_z = stride_act_g; p.strideW_z = stride_w_g; p.strideBias_z = stride_bias_g;
+            p.strideC_z = (long long)B * Ho * Wo * Cout;
+            if (panel_split_supported(p, prec, groups)) return panel_split_gemm(p, prec, groups, reinterpret_cast<hipStream_t>(stream));
+        }
+    }
     PP_REQUIRE(scratch_full, PP_ERR_UNSUPPORTED,
                "pp_conv3x3_maxpool_relu: this shape / precision takes the two-launch path and needs scratch_full (groups, B, H, W, Cout)");
     const int st = pp_conv_gemm(prec, PP_CONV3X3, act_nhwc, weight, bias, scratch_full, B, H, W, Cin, Cout, 0, 0, groups, stride_act_g,

@@ -82,7 +82,11 @@ __device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.
 // channels, the four column-group waves' partial sums meet in LDS (<= 28 maps x 96 pixels per pass), and the tile leaves as
 // phase-separated fp32 logits: 13 KB instead of 196 KB per tile, the 403 MB feature map of bs 64 is neither written nor read
 // back, the 1x1 launch disappears.
-template <int GATHER, int RF, int CF, bool SPLIT, int NST, bool HEAD = false>
+// POOL (round 3; split-fp16 3x3 convolution on 16 x 12 maps, 192 x 192 three-stage form: a tile = one image x 192 channels): the
+// stage's MaxPool2d(4, 3) + ReLU (probmap_head.py:261-294: Conv - BN - MaxPool - ReLU) runs on the staged quarter - a quarter
+// is four image rows = one row of pooling windows - and only the pooled (4, 4) map leaves: 12.6 MB instead of 151 MB at bs 64,
+// the pooling launch and its re-read disappear.
+template <int GATHER, int RF, int CF, bool SPLIT, int NST, bool HEAD = false, bool POOL = false>
 __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParams p) {
     constexpr int ESZ = SPLIT ? 4 : 2;   // bytes per operand element
     constexpr int KS = 128 / ESZ;        // elements of K per stage: one 128-byte line per row
@@ -434,7 +438,42 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
             wait_vm_lgkm<63>();  // LDS writes only: the DMA of the next tile stays in flight
             __builtin_amdgcn_s_barrier();
             const int cl = tid_e % LPR, rl = tid_e / LPR;
-            if (rl < RPP) {
+            if constexpr (POOL) {
+                static_assert(!POOL || (SPLIT && GATHER == G_CONV3 && RF == 6 && NST == 3), "fused pooling: split-fp16 3x3 conv, 192-row tiles");
+                // quarter q = image rows pool_h q .. (QR = pool_h * W pixels); thread (window j of the row, 8 channels): max over the
+                // pool_h x pool_w staged pixels, then ReLU (bias is already in: max and + commute)
+                const int Wo = p.Wd / p.pool_w;
+                if (rl < Wo) {
+                    f32x4 v0 = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, v1 = v0;
+                    for (int r = 0; r < p.pool_h; ++r)
+                        for (int c = 0; c < p.pool_w; ++c) {
+                            const int ml = r * p.Wd + rl * p.pool_w + c;
+                            const f32x4 a0 = *reinterpret_cast<const f32x4*>(cst + ml * ROWB + (((2 * cl) ^ (ml & 7)) << 4));
+                            const f32x4 a1 = *reinterpret_cast<const f32x4*>(cst + ml * ROWB + (((2 * cl + 1) ^ (ml & 7)) << 4));
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                v0[i] = fmaxf(v0[i], a0[i]);
+                                v1[i] = fmaxf(v1[i], a1[i]);
+                            }
+                        }
+                    f16x8 hv, lv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float b0 = fmaxf(v0[i], 0.f), b1 = fmaxf(v1[i], 0.f);
+                        hv[i] = split_hi(b0);
+                        lv[i] = split_lo(b0, hv[i]);
+                        hv[4 + i] = split_hi(b1);
+                        lv[4 + i] = split_lo(b1, hv[4 + i]);
+                    }
+                    const int b_img = m0 / (p.H * p.Wd);
+                    const size_t eoff = (size_t)z * p.strideC_z + (((size_t)b_img * 4 + q) * Wo + rl) * p.ldc + n0 + cl * 8;
+                    if (m0 < p.M) {
+                        char* o = split_addr(p.C, eoff);
+                        *reinterpret_cast<f16x8*>(o) = hv;
+                        *reinterpret_cast<f16x8*>(o + 64) = lv;
+                    }
+                }
+            } else if (rl < RPP) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int ml = it * RPP + rl;
@@ -522,7 +561,7 @@ static int panel_split_shape(const GemmParams& p, int groups) {
     const bool three = psplit_nst() == 3;
     if (p.gather == G_DECONV) return p.N % 256 == 0 ? ((three && !p.head_w) ? 3 : 1) : 0;
     if (p.N % 192 != 0) return 0;
-    if (three) return 4;
+    if (three || p.pool_h > 0) return 4;
     // Linear layers: the persistent grid walks whole rounds of tiles (one per CU); the 192 x 192 three-stage form wins where
     // it turns a ragged last round into full ones (qkv at bs 64: 576 tiles of 256 x 192 = 2.25 rounds -> 768 tiles of
     // 192 x 192 = 3.0: 91 -> 79 us) and loses otherwise (fc1: 3 rounds either way but 12 % more fill per FLOP: 117 -> 125 us)
@@ -554,6 +593,11 @@ static void shape_dims(int shape, int& BM, int& BN) {
 
 bool panel_split_supported(const GemmParams& p, int prec, int groups) {
     if (p.planar_P > 0 || p.ksplit > 1) return false;
+    if (p.pool_h > 0) {  // fused MaxPool + ReLU: one 16 x 12 image per 192-row tile, a quarter of the tile = one row of windows
+        if (prec != PP_PREC_F16X3 || p.gather != G_CONV3 || p.out_bf16 != 2 || p.residual || p.head_w) return false;
+        if (p.H * p.Wd != 192 || p.pool_h * p.Wd != 48 || p.H != 4 * p.pool_h || p.Wd % p.pool_w != 0 || p.M % 192 != 0 || p.N % 192 != 0) return false;
+        if (p.act != ACT_NONE) return false;
+    }
     if (prec == PP_PREC_F16X3) {
         if (p.head_w && !(p.gather == G_DECONV && p.N == 256 && p.head_n >= 1 && p.head_n <= 28)) return false;
         if (p.out_bf16 != 0 && p.out_bf16 != 2) return false;
@@ -598,7 +642,14 @@ int panel_split_gemm(const GemmParams& p_in, int prec, int groups, hipStream_t s
                 kern = shape == 3 ? PP_PS(G_DECONV, 4, 4, 3) : PP_PS(G_DECONV, 6, 4, 2);
             }
             break;
-        case G_CONV3: kern = shape == 4 ? PP_PS(G_CONV3, 6, 3, 3) : PP_PS(G_CONV3, 8, 3, 2); break;
+        case G_CONV3:
+            if (p.pool_h > 0) {
+                PP_REQUIRE(sp && shape == 4, PP_ERR_UNSUPPORTED, "pp panel split gemm: fused pooling needs the split-fp16 192 x 192 form");
+                kern = panel_split_kernel<G_CONV3, 6, 3, true, 3, false, true>;
+            } else {
+                kern = shape == 4 ? PP_PS(G_CONV3, 6, 3, 3) : PP_PS(G_CONV3, 8, 3, 2);
+            }
+            break;
         default: kern = shape == 4 ? PP_PS(G_LINEAR, 6, 3, 3) : PP_PS(G_LINEAR, 8, 3, 2); break;
     }
 #undef PP_PS

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12_kernel(const char* _
     const int rows0 = rg * (16 * RF) + f_row;
     auto rd = [&](int off) -> u32x4 {
         if (ABL & 2) return u32x4{(unsigned)off, 1u, 2u, 3u};
-#if PIPE
+#if PIPE == 2
         // as asm: the compiler puts `s_waitcnt vmcnt(0)` in front of an ordinary LDS read that follows an LDS-DMA instruction
         // (it cannot tell the ring slots apart); the step's own `lgkmcnt(0)` at its top covers these reads one step later
         u32x4 v;

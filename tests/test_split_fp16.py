@@ -566,3 +566,36 @@ def test_deconv_head_split_vs_fp64(B, K):
     with pytest.raises(L.ProbPoseLibraryError):
         L.call("pp_deconv_head_split", xd.data_ptr(), phd.data_ptr(), bd.data_ptr(), hwd.data_ptr(), bfd.data_ptr(), lg.data_ptr(), 2, H, W,
                Cin, Cout, K, None)
+
+
+@gpu
+@pytest.mark.parametrize("B", [24, 33])
+def test_conv3x3_maxpool_relu_split_fused_vs_two_launches(B):
+    """pp_conv3x3_maxpool_relu in the split-fp16 mode: MaxPool(4, 3) + ReLU in the epilogue of the wide-tile convolution (one
+    16 x 12 image per 192-row tile) against torch fp64 on the unrounded inputs, and against the two-launch route
+    (pp_set_option("conv_pool_split", 0): pp_conv_gemm + pp_maxpool_relu_nhwc - another tile shape, so another fp32 summation
+    order: equal to fp32 accumulation noise, not bit for bit); the scratch tensor stays untouched. (Below 24
+    images the launch has fewer than 192 tiles and takes the two-launch route by itself.)"""
+    L = _lib()
+    G, C, H, W, ph, pw = 4, 384, 16, 12, 4, 3
+    x = _rand(B, C, H, W, seed=234)
+    w = _rand(G, C, C, 3, 3, seed=235, scale=1 / math.sqrt(9 * C))
+    b = _rand(G, C, seed=236)
+    ref = torch.stack([F.max_pool2d(F.conv2d(x.double(), w[g].double(), b[g].double(), padding=1), (ph, pw)).clamp_min(0) for g in range(G)])
+    xd = _sp(x.permute(0, 2, 3, 1).contiguous())
+    wd = _sp(w.permute(0, 1, 3, 4, 2).reshape(G, C, 9 * C).contiguous())
+    bd = b.cuda()
+    outs = []
+    for fused in (1, 0):
+        L.set_option("conv_pool_split", fused)
+        pooled = torch.full((G, B, H // ph, W // pw, C), float("nan"), device="cuda")
+        scratch = torch.zeros((G, B, H, W, C), device="cuda")
+        L.call("pp_conv3x3_maxpool_relu", F16X3, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), pooled.data_ptr(), scratch.data_ptr(),
+               B, H, W, C, C, ph, pw, G, 0, C * 9 * C, C, SPLIT, None)
+        torch.cuda.synchronize()
+        if fused:
+            assert not scratch.any(), "the one-launch form must not touch the scratch tensor"
+        outs.append(pooled.cpu())
+    L.set_option("conv_pool_split", 1)
+    torch.testing.assert_close(_unsp(outs[0]).permute(0, 1, 4, 2, 3), ref, **TOL)
+    torch.testing.assert_close(_unsp(outs[0]), _unsp(outs[1]), **TOL)
