@@ -543,6 +543,10 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
                                                              (live ? kb : 0) * 128 + u * 8 * E * 4, 0, 0);
             }
         };
+#ifndef FFS_PPRIO
+#define FFS_PPRIO 1  // 1 = waves 4-7 (the younger half, which loses the matrix-pipe arbitration) at priority 1 during the projection steps: 201.9 -> 200.2 us; 2 = for the whole kernel (no further gain); 0 = off
+#endif
+        if (FFS_PPRIO && rg == 1) __builtin_amdgcn_s_setprio(1);
         issue_p(0);
         issue_p(1);
 #pragma unroll 1
@@ -576,6 +580,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
         }
+        if (FFS_PPRIO == 1 && rg == 1) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));  // vmcnt(0) lgkmcnt(0): the zero fillers of steps 24, 25 have landed too
         __syncthreads();
         stamp();

@@ -150,6 +150,13 @@ class ProbPoseEngine:
                 "reshapes them to (B, 1, K) (probmap_head.py:780-783), which needs 1x1"
             )
 
+    def ksplit(self, rows: int) -> int:
+        """K-slices of a small tower convolution with `rows` output pixels over the batch (3 = one kernel row of taps per slice,
+        9 = one tap). Stages with fewer than 1024 rows (the 2 x 2 maps at bs 64: 144 tiles for 256 CUs with three slices) take nine:
+        split-K launch 48 -> 27 us, the nine-way sum costs 5 us more (dev override: PP_KSPLIT9_BELOW=<rows>)."""
+        thr = int(os.environ.get("PP_KSPLIT9_BELOW", "1024"))
+        return 9 if rows < thr else 3
+
     # ------------------------------------------------------------------ workspace
     def _workspace(self, B: int, passes: int, slot: int = 0) -> Dict[str, torch.Tensor]:
         """Buffers of one step at batch size B. ``slot`` > 0: a second (third ...) independent set, so that consecutive
@@ -197,7 +204,9 @@ class ProbPoseEngine:
             ph, pw_ = self.pools[j]
             ws[f"t{j}"] = buf("tower", (4, nb, th, tw, E), index=j)
             if nb * th * tw * 4 < 128 * 128:
-                ws[f"tp{j}"] = buf("tower_partial", (3, 4, nb, th, tw, E), f32, index=j)  # split-K partial sums of the small tower stages
+                ks = self.ksplit(nb * th * tw)
+                ws[f"tp{j}"] = (buf("tower_partial", (3, 4, nb, th, tw, E), f32, index=j) if ks == 3  # split-K partial sums of the small tower stages
+                                else e(ks, 4, nb, th, tw, E, dt=f32))
             ws[f"p{j}"] = buf("tower_pooled", (4, nb, th // ph, tw // pw_, E), index=j)
         self._ws[key] = ws
         return ws
@@ -383,9 +392,10 @@ class ProbPoseEngine:
                 # few output rows: one workgroup per 128 x 128 tile would leave most CUs idle for a 54-step K loop;
                 # cut K in three (one kernel row of taps each), reduce + bias in the pooling kernel
                 part = ws[f"tp{j}"]
+                ks = part.shape[0]
                 self._call("conv3x3_splitk", "pp_conv3x3_splitk", self.prec, src.data_ptr(), w[f"tower{j}.w"].data_ptr(),
-                           part.data_ptr(), nb, th, tw, E, E, 4, stride_src, E * 9 * E, 3, st)
-                self._call("maxpool", "pp_sum_maxpool_relu_nhwc", part.data_ptr(), 3, 4 * rows * E, w[f"tower{j}.b"].data_ptr(),
+                           part.data_ptr(), nb, th, tw, E, E, 4, stride_src, E * 9 * E, ks, st)
+                self._call("maxpool", "pp_sum_maxpool_relu_nhwc", part.data_ptr(), ks, 4 * rows * E, w[f"tower{j}.b"].data_ptr(),
                            nb, ws[f"p{j}"].data_ptr(), ob, 4 * nb, th, tw, E, ph, pw_, st)
                 src = ws[f"p{j}"]
                 stride_src = nb * (th // ph) * (tw // pw_) * E
