@@ -19,6 +19,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef WAVES
 #define WAVES 12
 #endif
+#ifndef ROT
+#define ROT 0
+#endif
+#ifndef OPAQUE
+#define OPAQUE 0
+#endif
 #ifndef PIPE
 #define PIPE 0  // 1: fragments of step t + 1 read under the MFMAs of step t (two register sets)
 #endif
@@ -70,18 +76,26 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12_kernel(const char* _
         char* dst = ring + (t & 3) * SLOTB;
         const int base = chunk_of(ci % NCH) * CHUNK_BYTES;
         if (t < NA) {
-            const int blk = base + t * A_BLOCK;
+#if ROT
+            // the workgroups of an XCD (rank blockIdx.x >> 3) walk the k-blocks of a chunk in different rotations: at any moment
+            // they ask the L2 for different lines instead of the same 1 KiB piece
+            int tk = t + (int)((blockIdx.x >> 3) % NA);
+            tk = tk >= NA ? tk - NA : tk;
+#else
+            const int tk = t;
+#endif
+            const int blk = base + tk * A_BLOCK;
             if (WAVES == 12) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + wv * 1024), 16, v_w, blk + wv * 1024, 0, 0);
                 if (wv < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + (12 + wv) * 1024), 16, v_w, blk + (12 + wv) * 1024, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(dst + X_OFF + wv * 1024), 16, v_x(wv), t * 128, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(dst + X_OFF + wv * 1024), 16, v_x(wv), tk * 128, 0, 0);
             } else {
                 if (wv < 4) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + (4 * wv + u) * 1024), 16, v_w, blk + (4 * wv + u) * 1024, 0, 0);
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(dst + X_OFF + (3 * (wv - 4) + u) * 1024), 16, v_x(3 * (wv - 4) + u), t * 128, 0, 0);
+                    for (int u = 0; u < 3; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(dst + X_OFF + (3 * (wv - 4) + u) * 1024), 16, v_x(3 * (wv - 4) + u), tk * 128, 0, 0);
                 }
             }
         } else {
@@ -125,7 +139,10 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12_kernel(const char* _
     // software-pipelined form: the fragments of step t + 1 are read (into the other register set) under the MFMAs of step t
     u32x4 fw[2][6], fx[2][2 * RF], gb[2][2 * RF];
     auto load = [&](int t, int set) {  // t in 0..19
-        const int so = OFF_RING + (t & 3) * SLOTB;
+        int so = OFF_RING + (t & 3) * SLOTB;
+#if OPAQUE
+        asm volatile("" : "+s"(so));  // (as pp_ffn_split.hip's slot_off(): the slot offset is opaque to the compiler)
+#endif
         if (t < NA) {
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
