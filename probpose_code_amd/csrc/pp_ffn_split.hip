@@ -344,11 +344,11 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
     // L segments: this wave's DMA pieces alternate with its fragment reads - four waves issue at the same time, the texture
     // path takes one piece per 16 cycles, and whoever finds its queue full stands still: the reads go out in those gaps
 #ifndef FFS_DMA_IN_C
-#define FFS_DMA_IN_C 0  // dev A/B: 1 = the DMA pieces of step s + 3 are issued in the MFMA segment C(s), between the MFMAs, not in L(s)
+#define FFS_DMA_IN_C 2  // 0 = all DMA pieces of step s + 3 in the load segment L(s); 1 = the DMA pieces of step s + 3 are issued in the MFMA segment C(s), between the MFMAs, not in L(s); 2 (shipped) = two in L(s), the rest in C(s): 181.6 -> 179.4 us (FFN), 215.2 -> 211.9 (with projection)
 #endif
     auto pin = [&]() { __builtin_amdgcn_sched_barrier(0); };
     auto a_load = [&](int slot_i, auto issue_fn_) {
-        auto issue_fn = [&](int u) { if (!FFS_DMA_IN_C) issue_fn_(u); };
+        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C == 0 || (FFS_DMA_IN_C == 2 && u < 2)) issue_fn_(u); };
         const int so = slot_off(slot_i);
         issue_fn(0);
         pin();
@@ -368,7 +368,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         issue_fn(3);
     };
     auto a_compute = [&](auto issue_fn_) {
-        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C) { pin(); issue_fn_(u); pin(); } };
+        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C == 1 || (FFS_DMA_IN_C == 2 && u >= 2)) { pin(); issue_fn_(u); pin(); } };
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
@@ -390,7 +390,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         }
     };
     auto b_load = [&](int sb, int slot_i, auto issue_fn_) {
-        auto issue_fn = [&](int u) { if (!FFS_DMA_IN_C) issue_fn_(u); };
+        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C == 0 || (FFS_DMA_IN_C == 2 && u < 2)) issue_fn_(u); };
         const int so = slot_off(slot_i);
         issue_fn(0);
         pin();
@@ -411,7 +411,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         issue_fn(3);
     };
     auto b_compute = [&](int sb, auto issue_fn_) {
-        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C) { pin(); issue_fn_(u); pin(); } };
+        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C == 1 || (FFS_DMA_IN_C == 2 && u >= 2)) { pin(); issue_fn_(u); pin(); } };
         const int half = sb & 1;
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
@@ -624,7 +624,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
 #pragma unroll
     for (int kt = 0; kt < NA; ++kt) {
         a_load(kt & 3, [&](int u) { issue_piece(0, kt - NA + 3, u); });
-        sync_l([&]() { if (FFS_DMA_IN_C) FFS_WAIT(3); else FFS_WAIT(2 * 3); });
+        sync_l([&]() { if (FFS_DMA_IN_C == 1) FFS_WAIT(3); else if (FFS_DMA_IN_C == 2) FFS_WAIT(3 + 2); else FFS_WAIT(2 * 3); });
         a_compute([&](int u) { issue_piece(0, kt - NA + 3, u); });
         sync_c([&]() { FFS_WAIT(2 * 4); });
     }
@@ -663,7 +663,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             }
             // pieces of steps kt + 2, kt + 3: A A up to 8, A B at 9, B B at 10, 11 (the first iteration's vmcnt(0) above makes
             // every count an upper bound there)
-            sync_l([&]() { if (FFS_DMA_IN_C) FFS_WAIT(3); else if (kt <= 8) FFS_WAIT(2 * 3); else if (kt == 9) FFS_WAIT(3 + 3); else FFS_WAIT(6); });
+            sync_l([&]() { if (FFS_DMA_IN_C == 1) FFS_WAIT(3); else if (FFS_DMA_IN_C == 2) FFS_WAIT(3 + 2); else if (kt <= 8) FFS_WAIT(2 * 3); else if (kt == 9) FFS_WAIT(3 + 3); else FFS_WAIT(6); });
             a_compute([&](int u) { issue_piece(it, kt + 3, u); });
             sync_c([&]() { if (kt <= 8) FFS_WAIT(2 * 4); else if (kt == 9) FFS_WAIT(4 + 3); else FFS_WAIT(6); });
         }
@@ -678,7 +678,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             // (the two b1 loads of step 12 get NO slack in the counts: as younger plain loads they may retire before the pieces
             // these waits are for - see the projection phase)
             const int ex = 0;
-            sync_l([&]() { if (FFS_DMA_IN_C) FFS_WAIT(3); else if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 3); else FFS_WAIT(2 * 3); });
+            sync_l([&]() { if (FFS_DMA_IN_C == 1) FFS_WAIT(3); else if (FFS_DMA_IN_C == 2) FFS_WAIT(3 + 2); else if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 3); else FFS_WAIT(2 * 3); });
             b_compute(sb, [&](int u) { issue_piece(it, t + 3, u); });
             sync_c([&]() { if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 4); else FFS_WAIT(2 * 4); });
         }
