@@ -326,6 +326,46 @@ def secondary_rooflines(eng, B, prof, reps):
                        f"LDS) = {rounds} rounds -> >= {rounds * chain_us:.0f} us per launch",
             },
         }
+        # the same kernel at bs 512 (BASELINE config 3's global batch on one GPU; SURVEY H6: where the HBM fraction becomes meaningful):
+        # the step's own logits tiled eight times (same sparse maps), timed alone
+        try:
+            from probpose_code_amd import _lib
+            from probpose_code_amd import synthetic as S_
+
+            ws = eng._workspace(B, 2)
+            if getattr(eng, "_logits_phased", False) and B * 8 <= 512:
+                rep8 = 512 // B
+                lg = ws["logits"][:B].repeat(rep8, 1, 1).contiguous()
+                lgf = ws["logits"][B:].repeat(rep8, 1, 1).contiguous()
+                nb = rep8 * B
+                kp = torch.empty((nb, eng.K, 2), dtype=torch.float64, device=eng.device)
+                lo, sc = torch.empty((nb, eng.K, 2), device=eng.device), torch.empty((nb, eng.K), device=eng.device)
+                fi = eng._flip_indices(S_.COCO_FLIP_INDICES)
+
+                def run512():
+                    _lib.call("pp_probmap_head_decode_phased", lg.data_ptr(), lgf.data_ptr(), fi.data_ptr(), eng.taps.data_ptr(), eng.radius.data_ptr(),
+                              nb, eng.K, eng.Hh, eng.Wh, float(eng.input_size[0]), float(eng.input_size[1]), eng.temperature,
+                              -1.0 if eng.normalize is None else float(eng.normalize), None, None, lo.data_ptr(), kp.data_ptr(), sc.data_ptr(),
+                              _lib.stream_ptr(eng.device))
+
+                for _ in range(3):
+                    run512()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    run512()
+                e1.record()
+                torch.cuda.synchronize()
+                ms512 = e0.elapsed_time(e1) / 10
+                by512 = 2 * nb * eng.K * eng.Hh * eng.Wh * 4
+                out["head_decode_bs512"] = {"bound": "hbm", "crops": nb, "avg_launch_ms": ms512, "algorithmic_mbytes_per_launch": by512 / 1e6,
+                                            "achieved": by512 / (ms512 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": by512 / (ms512 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "why": f"{nb * eng.K} workgroups on 768 slots = {-(-nb * eng.K // 768)} rounds of the ~15 us chain: the launch is "
+                                                   "latency-bound at every batch size; the logits are read exactly once"}
+        except Exception as exc:  # noqa: BLE001 -- a secondary record must not take the bench line down
+            out["head_decode_bs512"] = {"error": str(exc)[:200]}
     att_fl = 4.0 * nseq * heads * S * S * hd  # QK^T + PV per layer
     # Two ceilings for softmax(q k^T) v at 192 tokens x head dim 32, both far under the MFMA peak (128 FLOP per v_exp_f32):
     #  * VALU: per (16-query tile, head) task 48 v_exp_f32 + ~50 v_fma + 24 v_max3 + 28 v_cvt_pk + ~30 others; SIMD retire rates
