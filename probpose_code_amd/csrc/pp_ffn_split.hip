@@ -108,7 +108,10 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
 // DMA instructions of one step by wave half: A-steps 16 W1 pieces by waves 0-3 (4 each) + 12 x pieces by waves 4-7 (3 each),
 // B-steps 24 pieces, 3 per wave
 __host__ __device__ constexpr bool is_a(int t) { return ((t % STEPS) + STEPS) % STEPS < NA; }
-__host__ __device__ constexpr int n_ops(int t, int rg) { return is_a(t) ? (rg == 0 ? 4 : 3) : 3; }
+#ifndef FFS_ONEHALF
+#define FFS_ONEHALF 0  // dev A/B: 1 = waves 0-3 issue ALL DMA pieces (7 per A-step, 6 per B-step), waves 4-7 none
+#endif
+__host__ __device__ constexpr int n_ops(int t, int rg) { return FFS_ONEHALF ? (rg == 0 ? (is_a(t) ? 7 : 6) : 0) : (is_a(t) ? (rg == 0 ? 4 : 3) : 3); }
 
 #define FFS_WAIT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (0 << 8) | (((N) >> 4) << 14))  // vmcnt(N) lgkmcnt(0)
 
@@ -179,6 +182,18 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         if (DBG & 8) return;
         const bool live = ci < nchunks;
         const int blk = chunk_of(live ? ci : 0) * CHUNK_BYTES + kb * A_BLOCK;
+        if (FFS_ONEHALF) {  // wave w < 4: W1 pieces 4 w .. 4 w + 3 (u < 4), x pieces 3 w .. 3 w + 2 (u = 4 .. 6)
+            if (rg != 0 || u > 6) return;
+            if (u < 4) {
+                const int q = 4 * wv + u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w(live), (lds_ptr_t)(ring + slot * SLOTB + q * 1024), 16, v_w, blk + q * 1024, 0, 0);
+            } else {
+                const int xq = 3 * wv + (u - 4);
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.h), 0, (live && FFS_XSRC != 3 && FFS_XSRC != 2) ? p.h_bytes : 0u, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(ring + slot * SLOTB + X_OFF + xq * 1024), 16, v_x, kb * 128 + (u - 4) * 8 * E * 4, 0, 0);
+            }
+            return;
+        }
         if (u < 3) {
             const int so = (rg == 0 ? blk + 3 * wv * 1024 : kb * 128) + u * a_stride;
 #ifndef FFS_X_AUX
@@ -195,6 +210,13 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
     auto issue_b = [&](int ci, int sb, int slot, int u) {
         if (DBG & 8) return;
         const bool live = ci >= 0 && ci < nchunks;
+        if (FFS_ONEHALF) {  // wave w < 4: W2 pieces 6 w .. 6 w + 5
+            if (rg != 0 || u > 5) return;
+            const int q = 6 * wv + u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w(live), (lds_ptr_t)(ring + slot * SLOTB + q * 1024), 16, v_w,
+                                                     chunk_of(live ? ci : 0) * CHUNK_BYTES + B_PART + sb * B_BLOCK + q * 1024, 0, 0);
+            return;
+        }
         const int so = chunk_of(live ? ci : 0) * CHUNK_BYTES + B_PART + sb * B_BLOCK + 3 * wv * 1024;
         if (u < 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w(live), (lds_ptr_t)(ring + slot * SLOTB + (3 * wv + u) * 1024), 16, v_w, so + u * 1024, 0, 0);
     };
@@ -209,7 +231,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
     };
     auto issue_step = [&](int it, int t) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) issue_piece(it, t, u);
+        for (int u = 0; u < (FFS_ONEHALF ? 7 : 4); ++u) issue_piece(it, t, u);
     };
 
     // ---- fragment reads: hi halves in 16-byte chunk f_kg, lo halves in chunk 4 + f_kg of a line, swizzled by line & 7.
@@ -348,7 +370,10 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
 #endif
     auto pin = [&]() { __builtin_amdgcn_sched_barrier(0); };
     auto a_load = [&](int slot_i, auto issue_fn_) {
-        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C == 0 || (FFS_DMA_IN_C == 2 && u < 2)) issue_fn_(u); };
+        auto issue_fn = [&](int u) {
+            if (FFS_ONEHALF) { issue_fn_(2 * u); if (u < 3) issue_fn_(2 * u + 1); return; }  // 0 1 | 2 3 | 4 5 | 6
+            if (FFS_DMA_IN_C == 0 || (FFS_DMA_IN_C == 2 && u < 2)) issue_fn_(u);
+        };
         const int so = slot_off(slot_i);
         issue_fn(0);
         pin();
@@ -368,7 +393,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         issue_fn(3);
     };
     auto a_compute = [&](auto issue_fn_) {
-        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C == 1 || (FFS_DMA_IN_C == 2 && u >= 2)) { pin(); issue_fn_(u); pin(); } };
+        auto issue_fn = [&](int u) { if (!FFS_ONEHALF && (FFS_DMA_IN_C == 1 || (FFS_DMA_IN_C == 2 && u >= 2))) { pin(); issue_fn_(u); pin(); } };
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
@@ -390,7 +415,10 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         }
     };
     auto b_load = [&](int sb, int slot_i, auto issue_fn_) {
-        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C == 0 || (FFS_DMA_IN_C == 2 && u < 2)) issue_fn_(u); };
+        auto issue_fn = [&](int u) {
+            if (FFS_ONEHALF) { if (u < 3) { issue_fn_(2 * u); issue_fn_(2 * u + 1); } else issue_fn_(6); return; }  // 0 1 | 2 3 | 4 5 | 6 (a seventh piece exists when step s + 3 is an A-step)
+            if (FFS_DMA_IN_C == 0 || (FFS_DMA_IN_C == 2 && u < 2)) issue_fn_(u);
+        };
         const int so = slot_off(slot_i);
         issue_fn(0);
         pin();
@@ -411,7 +439,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         issue_fn(3);
     };
     auto b_compute = [&](int sb, auto issue_fn_) {
-        auto issue_fn = [&](int u) { if (FFS_DMA_IN_C == 1 || (FFS_DMA_IN_C == 2 && u >= 2)) { pin(); issue_fn_(u); pin(); } };
+        auto issue_fn = [&](int u) { if (!FFS_ONEHALF && (FFS_DMA_IN_C == 1 || (FFS_DMA_IN_C == 2 && u >= 2))) { pin(); issue_fn_(u); pin(); } };
         const int half = sb & 1;
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
@@ -624,9 +652,9 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
 #pragma unroll
     for (int kt = 0; kt < NA; ++kt) {
         a_load(kt & 3, [&](int u) { issue_piece(0, kt - NA + 3, u); });
-        sync_l([&]() { if (FFS_DMA_IN_C == 1) FFS_WAIT(3); else if (FFS_DMA_IN_C == 2) FFS_WAIT(3 + 2); else FFS_WAIT(2 * 3); });
+        sync_l([&]() { if (FFS_ONEHALF) FFS_WAIT(63); else if (FFS_DMA_IN_C == 1) FFS_WAIT(3); else if (FFS_DMA_IN_C == 2) FFS_WAIT(3 + 2); else FFS_WAIT(2 * 3); });
         a_compute([&](int u) { issue_piece(0, kt - NA + 3, u); });
-        sync_c([&]() { FFS_WAIT(2 * 4); });
+        sync_c([&]() { if (FFS_ONEHALF) FFS_WAIT(14); else FFS_WAIT(2 * 4); });
     }
     // + b2; the first chunk's GELU has no other wave half's MFMAs... it runs beside the OTHER half's segments all the same,
     // but this half's next L segment waits for it (once per launch)
@@ -663,9 +691,9 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             }
             // pieces of steps kt + 2, kt + 3: A A up to 8, A B at 9, B B at 10, 11 (the first iteration's vmcnt(0) above makes
             // every count an upper bound there)
-            sync_l([&]() { if (FFS_DMA_IN_C == 1) FFS_WAIT(3); else if (FFS_DMA_IN_C == 2) FFS_WAIT(3 + 2); else if (kt <= 8) FFS_WAIT(2 * 3); else if (kt == 9) FFS_WAIT(3 + 3); else FFS_WAIT(6); });
+            sync_l([&]() { if (FFS_ONEHALF) FFS_WAIT(63); else if (FFS_DMA_IN_C == 1) FFS_WAIT(3); else if (FFS_DMA_IN_C == 2) FFS_WAIT(3 + 2); else if (kt <= 8) FFS_WAIT(2 * 3); else if (kt == 9) FFS_WAIT(3 + 3); else FFS_WAIT(6); });
             a_compute([&](int u) { issue_piece(it, kt + 3, u); });
-            sync_c([&]() { if (kt <= 8) FFS_WAIT(2 * 4); else if (kt == 9) FFS_WAIT(4 + 3); else FFS_WAIT(6); });
+            sync_c([&]() { if (FFS_ONEHALF) { if (kt <= 8) FFS_WAIT(14); else if (kt == 9) FFS_WAIT(13); else FFS_WAIT(12); } else if (kt <= 8) FFS_WAIT(2 * 4); else if (kt == 9) FFS_WAIT(4 + 3); else FFS_WAIT(6); });
         }
         // ================= B-steps of chunk it; their L segments carry one GELU pair of chunk it + 1 each (pairs 0..7)
 #pragma unroll
@@ -678,9 +706,9 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             // (the two b1 loads of step 12 get NO slack in the counts: as younger plain loads they may retire before the pieces
             // these waits are for - see the projection phase)
             const int ex = 0;
-            sync_l([&]() { if (FFS_DMA_IN_C == 1) FFS_WAIT(3); else if (FFS_DMA_IN_C == 2) FFS_WAIT(3 + 2); else if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 3); else FFS_WAIT(2 * 3); });
+            sync_l([&]() { if (FFS_ONEHALF) FFS_WAIT(63); else if (FFS_DMA_IN_C == 1) FFS_WAIT(3); else if (FFS_DMA_IN_C == 2) FFS_WAIT(3 + 2); else if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 3); else FFS_WAIT(2 * 3); });
             b_compute(sb, [&](int u) { issue_piece(it, t + 3, u); });
-            sync_c([&]() { if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 4); else FFS_WAIT(2 * 4); });
+            sync_c([&]() { if (FFS_ONEHALF) { if (t <= 16) FFS_WAIT(12); else if (t == 17) FFS_WAIT(13); else FFS_WAIT(14); } else if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 4); else FFS_WAIT(2 * 4); });
         }
     }
     if (rg == 0) __builtin_amdgcn_s_barrier();  // waves 0-3 are one segment ahead
