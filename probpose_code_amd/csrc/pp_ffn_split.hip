@@ -27,6 +27,9 @@
 //   * GELU(P + b1) of a finished chunk (fp32 -> erfc form -> (hi, lo)) rides in the L segments of the NEXT twenty steps: one
 //     value pair per B-step (held in registers: the G tile is still being read), the last four pairs and the stores into
 //     the G tile (48 KiB, operand of the B-steps) in the following A-steps;
+//   * odd chunk visits walk the k-blocks of their A-steps backwards (FFS_SAWTOOTH): the rows a workgroup re-streams per chunk are
+//     then found in L2 where the previous pass left off - cyclic re-reads of a working set larger than the cache never hit
+//     (HBM-side traffic 730 -> 456 MB per launch);
 //   * W1 / W2 come PRE-PACKED in consumption order (pp_ffn_split_pack_weights: per chunk 12 W1 blocks of 16 KiB, then
 //     8 W2 half blocks of 24 KiB, 128-byte lines with the LDS XOR swizzle already applied), so a weight DMA instruction
 //     is a linear 1 KiB copy; the x lines are 128-byte segments of the row-major split tensor, swizzled at the source;
@@ -178,9 +181,16 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
     auto rsrc_w = [&](bool live) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wpack), 0, (live && FFS_XSRC != 3) ? p.w_bytes : 0u, 0x00020000); };
     // piece u (0..2; 3 = the extra W1 piece of waves 0-3) of A-step kb of the chunk visited ci-th into ring slot `slot`; past the
     // last chunk the descriptor has no extent: the DMA writes zeros, every wave's vmcnt arithmetic stays the same
-    auto issue_a = [&](int ci, int kb, int slot, int u) {
+#ifndef FFS_SAWTOOTH
+#define FFS_SAWTOOTH 1  // 0 = every chunk walks the k-blocks 0 .. 11 (dev A/B)
+#endif
+    auto issue_a = [&](int ci, int kb_, int slot, int u) {
         if (DBG & 8) return;
         const bool live = ci < nchunks;
+        // Odd visits walk the k-blocks backwards. A workgroup re-reads its 144 KB of rows once per chunk, the 32 workgroups of an
+        // XCD hold 4.6 MB of them beside the weights: more than the 4 MB L2, and walked in the same direction every time an LRU
+        // cache never hits. Turning round at the end of every pass finds the blocks read last still resident.
+        const int kb = (FFS_SAWTOOTH && (ci & 1)) ? NA - 1 - kb_ : kb_;
         const int blk = chunk_of(live ? ci : 0) * CHUNK_BYTES + kb * A_BLOCK;
         if (FFS_ONEHALF) {  // wave w < 4: W1 pieces 4 w .. 4 w + 3 (u < 4), x pieces 3 w .. 3 w + 2 (u = 4 .. 6)
             if (rg != 0 || u > 6) return;
