@@ -113,6 +113,16 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
     // XCD-aware tile order as in pp_panel_gemm.hip: row panel -> group -> column tile, contiguous runs per XCD
     auto decode_tile = [&](int t, int& z, int& m0, int& n0) {
         if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);
+        if (p.tile_order == 1) {
+            // weight-major: a contiguous run of tiles (= what one XCD works on at a time) shares ONE (group, column tile) weight set
+            // and walks the row panels - for the 3x3 convolutions of the split-fp16 mode, whose weight sets (2.65 MB per 192
+            // columns) no longer fit the 4 MB L2 eight at a time
+            m0 = (t % ntm) * BM;
+            const int r = t / ntm;
+            n0 = (r % ntn) * BN;
+            z = r / ntn;
+            return;
+        }
         n0 = (t % ntn) * BN;
         const int r = t / ntn;
         z = r % p.groups;
@@ -624,6 +634,7 @@ int panel_split_gemm(const GemmParams& p_in, int prec, int groups, hipStream_t s
     using namespace psplit;
     GemmParams p = p_in;
     p.groups = groups;
+    p.tile_order = (p.gather == G_CONV3 && option("psplit_conv_weight_major") != 0) ? 1 : 0;
     if (p.gather == G_LINEAR) p.Cin = p.K;
     PP_REQUIRE(p.a_bytes > 0 && p.w_bytes > 0 && p.a_bytes < OOB && p.w_bytes < OOB, PP_ERR_UNSUPPORTED,
                "pp panel split gemm: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
