@@ -59,6 +59,7 @@ int pp_device_cu_count(void);
  *   "panel_linear_mink" (0)  > 0: shortest K of a bf16 Linear layer that takes the wide-tile kernel
  *   "psplit_bf16_conv" (0)   1: bf16 convolutions through the split kernel's bf16 instantiation
  *   "psplit_conv_weight_major" (0)  1: tiles of the split-fp16 3x3 convolutions weight-set-major (measured slower)
+ *   "attn_dma" (1)           0: split-fp16 attention of 432-token sequences with the register-staged kernel
  *   "conv_pool_split" (1)    0: split-fp16 first tower stage as two launches (conv, then pooling)
  *   "qkv_attn_pair" (0)      1: pp_qkv_attention_split with a head pair per workgroup (measured slower; kept for A/B)
  * Unknown names return PP_ERR_INVALID_ARG. Not thread-safe against concurrent launches (set them before the first call).

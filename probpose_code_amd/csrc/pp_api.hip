@@ -24,6 +24,7 @@ static Option g_options[] = {
     {"panel_linear_mink", 0},  // > 0: shortest K of a bf16 Linear layer that takes the wide-tile kernel (0: built-in thresholds)
     {"psplit_bf16_conv", 0},   // 1: bf16 convolutions through pp_panel_split.hip instead of pp_panel_gemm.hip
     {"psplit_conv_weight_major", 0},  // 1: split-fp16 3x3 convolution tiles weight-set-major (one weight set per XCD at a time; measured 625 vs 612 us: slower)
+    {"attn_dma", 1},           // 0: split-fp16 attention of 432-token sequences with the register-staged kernel of round 2
     {"conv_pool_split", 1},    // 0: split-fp16 first tower stage as conv + pooling launches instead of pooling in the conv epilogue
     {"qkv_attn_pair", 0},      // 1: pp_qkv_attention_split with a head PAIR per workgroup (one workgroup per CU; measured slower)
 };

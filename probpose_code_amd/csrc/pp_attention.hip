@@ -752,6 +752,8 @@ static int launch_attention_split_stream(const void* qkv, void* out, int n_seq, 
     return PP_OK;
 }
 
+int attention_split_dma(const void* qkv, void* out, int n_seq, int heads, int head_dim, float scale, hipStream_t s);  // pp_attention_dma.hip
+
 }  // namespace pp
 
 extern "C" int pp_attention(int prec, const void* qkv, void* out, int n_seq, int seq_len, int heads, int head_dim,
@@ -774,6 +776,8 @@ extern "C" int pp_attention(int prec, const void* qkv, void* out, int n_seq, int
     } else if (prec == PP_PREC_F16X3) {
         if (head_dim == 32 && seq_len == 192) return launch_attention_split<32, 12>(qkv, out, n_seq, heads, scale, s);
         if (head_dim == 64 && seq_len == 192) return launch_attention_split<64, 12>(qkv, out, n_seq, heads, scale, s);
+        if (seq_len == 432 && (head_dim == 32 || head_dim == 64) && option("attn_dma") != 0)  // K / V by LDS-DMA, V^T by transposing reads
+            return attention_split_dma(qkv, out, n_seq, heads, head_dim, scale, s);
         if (head_dim == 32 && seq_len == 432) return launch_attention_split_stream<32, 27, 2>(qkv, out, n_seq, heads, scale, s);
         if (head_dim == 64 && seq_len == 432) return launch_attention_split_stream<64, 27, 2>(qkv, out, n_seq, heads, scale, s);
     } else {

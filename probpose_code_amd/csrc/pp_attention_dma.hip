@@ -1,0 +1,249 @@
+// Multi-head self-attention for 432-token sequences (384x288 crops: BASELINE config 4) in the parity precision (PP_PREC_F16X3,
+// split-fp16 operands): softmax(q k^T * scale) v per (sequence, head), from the packed (M, 3E) qkv tensor of the split format.
+// (mmpretrain MultiheadAttention.forward [3P]: scaled dot-product attention on qkv.reshape(B, N, 3, H, hd); call site
+// mmpose/models/pose_estimators/base.py:206; nearest reference config td-hm_ViTPose-base_8xb64-210e_coco-256x192.py:46-61.)
+//
+// Round 2's kernel for this shape (pp_attention.hip, attention_split_stream_kernel) stages K and V^T of half the keys through
+// registers - V with a 2-byte transposing scatter - into 115 KiB of LDS: one workgroup per CU, 337 us per ViT-B layer at bs 32
+// for 54 us of MFMA issue. Here K and V stay ROW-MAJOR by key and come in by LDS-DMA:
+//   * a workgroup = (sequence, head, query quarter): seven waves, one 16-query tile each (27 tiles = 7 + 7 + 7 + 6); q
+//     fragments from global memory once;
+//   * the keys stream through a ring of four 32-key stages: per stage K and V as HD / 32 sub-tiles of [32 keys][128 B] (the
+//     raw split blocks: 32 hi halves | 32 lo halves, 16-byte chunks XOR-swizzled by key & 7 at the source) = 16 KiB at head
+//     dim 64, three stages ahead; 64 KiB of LDS and < 128 registers: two workgroups per CU;
+//   * S^T = K Q^T (a query's scores lane-local), online softmax over the stages (running maximum / sum, O rescaled when the
+//     maximum moves), P split in registers, O^T = V^T P^T with the V^T fragments read by ds_read_b64_tr_b16 - the gfx950
+//     transposing LDS read (within 16 lanes, lane 4 r + q supplies the address of four consecutive halves M[r][4 q ..], lane i
+//     receives M[0..3][i]: four keys of one head dim per lane) - for the hi and the lo plane; no register staging, no scatter.
+#include "pp_common.h"
+#include "pp_split.h"
+
+namespace pp {
+namespace adma {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+
+constexpr int S = 432, NT = S / 16, QSPLIT = 4, TPW = (NT + QSPLIT - 1) / QSPLIT, THREADS = 64 * TPW;  // 7 waves
+constexpr int SK = 32;                         // keys per stage
+constexpr int NSTG = (S + SK - 1) / SK;        // 14 stages (the last one holds 16 keys)
+constexpr int RING = 4;
+
+template <int HD>
+struct Cfg {
+    static constexpr int NB = HD / 32;                   // 128-byte blocks per key and operand
+    static constexpr int SUB = SK * 128;                 // one sub-tile: 32 keys x 128 B
+    static constexpr int STAGE = 2 * NB * SUB;           // K sub-tiles, then V sub-tiles
+    static constexpr int PIECES = STAGE / 1024;          // DMA instructions per stage (8 keys x 128 B each)
+    static constexpr int LDS = RING * STAGE;
+    static constexpr int DT = HD / 16;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));  // vmcnt(N) only
+}
+
+template <int HD>
+__global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const char* __restrict__ qkv, char* __restrict__ out, int n_seq,
+                                                                         int heads, unsigned qkv_bytes, float scale_log2e) {
+    using C = Cfg<HD>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+
+    int id = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);  // the query quarters and heads of a sequence on one XCD
+    const int qs = id % QSPLIT;
+    id /= QSPLIT;
+    const int seq = id / heads, head = id - seq * heads;
+    const int E = heads * HD;
+    const unsigned row_bytes = (unsigned)(3 * E * 4);
+    const unsigned base = (unsigned)(seq * S) * row_bytes + (unsigned)(head * HD * 4);  // q block 0 of the sequence's first token
+    const int qt = qs * TPW + wv;       // this wave's query tile
+    const bool live = qt < NT;          // (the last quarter has six tiles: its seventh wave only helps with the DMA)
+
+    // ---- DMA: piece j of a stage = sub-tile j / 4 (K blocks 0 .. NB - 1, then V blocks), keys 8 (j % 4) .. + 7; lane (l = lane >> 3,
+    // pc = lane & 7) fetches the logical 16-byte chunk pc ^ l of key 8 (j % 4) + l
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qkv), 0, qkv_bytes, 0x00020000);
+    const int d_l = lane >> 3;
+    const unsigned d_sw = (unsigned)(((lane & 7) ^ d_l) << 4);
+    auto issue_stage = [&](int st) {
+        char* dst = smem + (st & (RING - 1)) * C::STAGE;
+#pragma unroll
+        for (int u = 0; u < (C::PIECES + TPW - 1) / TPW; ++u) {
+            const int j = wv + u * TPW;
+            if (j < C::PIECES) {
+                const int sub = j >> 2, kq = j & 3;
+                const int which = sub / C::NB, blk = sub - which * C::NB;  // 0 = K, 1 = V
+                const unsigned vo = base + (unsigned)(st * SK + kq * 8 + d_l) * row_bytes + (unsigned)((1 + which) * E * 4 + blk * 128) + d_sw;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + j * 1024), 16, vo, 0, 0, 0);
+            }
+        }
+    };
+    // pieces this wave issues per stage (wave-uniform): for the counted waits
+    const int my_pieces = (C::PIECES - wv + TPW - 1) / TPW;
+
+    // ---- q fragments of this wave's tile: lane (query fr, chunk fg) of block g
+    f16x8 qh[C::NB], ql[C::NB];
+    {
+        const char* qrow = qkv + base + (size_t)((live ? qt : 0) * 16 + fr) * row_bytes;
+#pragma unroll
+        for (int g = 0; g < C::NB; ++g) {
+            qh[g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + fg * 16);
+            ql[g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + 64 + fg * 16);
+        }
+    }
+    issue_stage(0);
+    issue_stage(1);
+    issue_stage(2);
+
+    f32x4 o[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -__builtin_inff(), l_run = 0.f;
+
+    const int sw = fr & 7;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte address of the dynamic region (0)
+    // V^T fragments through the transposing read: lane fr = 4 r + q of the 16-lane group fg addresses key 4 fg + r, halves 4 q ..
+    const int tr_r = fr >> 2, tr_q = fr & 3;
+    const int vkey = 4 * fg + tr_r;  // (+ 16 for the second read: same key & 7)
+
+    for (int st = 0; st < NSTG; ++st) {
+        // stage st has landed when only this wave's pieces of the (up to two) younger stages are outstanding
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int younger = min(NSTG - 1 - st, 2) * my_pieces;  // wave-uniform, small: a switch keeps the immediates literal
+            if (younger == 0) wait_vm<0>();
+            else if (younger == 1) wait_vm<1>();
+            else if (younger == 2) wait_vm<2>();
+            else if (younger == 3) wait_vm<3>();
+            else if (younger == 4) wait_vm<4>();
+            else if (younger == 5) wait_vm<5>();
+            else wait_vm<6>();
+        }
+        __builtin_amdgcn_s_barrier();  // every wave's pieces of stage st are in; every wave is done with stage st - 1 (its buffer is refilled next)
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 3 < NSTG) issue_stage(st + 3);
+        if (!live) continue;
+        const char* Ks = smem + (st & (RING - 1)) * C::STAGE;
+        const bool tail = st == NSTG - 1 && (S % SK) != 0;  // the last stage holds S % 32 = 16 keys: its second key tile does not exist
+
+        // ---- scores of the stage's two key tiles: s[kt][i] = q . k for key 32 st + 16 kt + 4 fg + i of query fr
+        f32x4 sc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int r = kt * 16 + fr;
+#pragma unroll
+            for (int g = 0; g < C::NB; ++g) {
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(Ks + g * C::SUB + r * 128 + ((fg ^ sw) << 4));
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(Ks + g * C::SUB + r * 128 + (((4 + fg) ^ sw) << 4));
+                acc = split_mma(kh, kl, qh[g], ql[g], acc);
+            }
+            sc[kt] = acc;
+        }
+        if (tail) sc[1] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        // ---- online softmax
+        float mx = m_run;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sc[kt][i]);
+        {  // max over the four lane groups of a query: the gfx950 row swaps (plain VALU) instead of two trips through the LDS queue
+            const unsigned mu = __builtin_bit_cast(unsigned, mx);
+            const auto s16 = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+            const unsigned mv = __builtin_bit_cast(unsigned, mx);
+            const auto s32 = __builtin_amdgcn_permlane32_swap(mv, mv, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
+        }
+        const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);  // (first stage: exp2(-inf) = 0, nothing to rescale)
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) o[dt] *= alpha;
+        m_run = mx;
+        const float mb = mx * scale_log2e;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], scale_log2e, -mb));  // masked keys: exp2(-inf) = 0
+                sc[kt][i] = e;
+                sum += e;
+            }
+        l_run += sum;  // this lane's keys only; the four lanes of a query are added up at the end
+        // ---- O^T += V^T P^T: the K = 32 block takes keys 4 fg + i and 16 + 4 fg + i per lane on both operands
+        f16x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ph[j] = split_hi(sc[0][j]);
+            pl[j] = split_lo(sc[0][j], ph[j]);
+            ph[4 + j] = split_hi(sc[1][j]);
+            pl[4 + j] = split_lo(sc[1][j], ph[4 + j]);
+        }
+        // two head-dim tiles (16 dims each) per group: eight transposing reads in flight, one wait, six MFMAs.
+        // As asm: the BUILTIN carries no memory operand, so the compiler waits for every LDS-DMA in flight (vmcnt(0)) in front of
+        // it - the three stages ahead included. The explicit lgkmcnt(0) covers the group's reads.
+#pragma unroll
+        for (int d2 = 0; d2 < C::DT / 2; ++d2) {
+            u32x2 h0[2], h1[2], l0[2], l1[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int dt = 2 * d2 + e;
+                const int g = dt >> 1, c0 = 2 * (dt & 1) + (tr_q >> 1);  // logical hi chunk of dims 16 dt + 4 q ..
+                const unsigned vb = lds_base + (unsigned)((st & (RING - 1)) * C::STAGE + C::NB * C::SUB + g * C::SUB + vkey * 128 + (tr_q & 1) * 8);
+                const unsigned a_hi = vb + (unsigned)((c0 ^ (vkey & 7)) << 4), a_lo = vb + (unsigned)(((4 + c0) ^ (vkey & 7)) << 4);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h0[e]) : "v"(a_hi));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(h1[e]) : "v"(a_hi));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(l0[e]) : "v"(a_lo));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(l1[e]) : "v"(a_lo));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0[0]), "+v"(h1[0]), "+v"(l0[0]), "+v"(l1[0]), "+v"(h0[1]), "+v"(h1[1]), "+v"(l0[1]), "+v"(l1[1]));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const u32x4 vh = {h0[e][0], h0[e][1], h1[e][0], h1[e][1]}, vl = {l0[e][0], l0[e][1], l1[e][0], l1[e][1]};
+                o[2 * d2 + e] = split_mma(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, vl), ph, pl, o[2 * d2 + e]);
+            }
+        }
+    }
+    if (!live) return;
+    float sum = l_run;
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    const size_t oidx = ((size_t)seq * S + qt * 16 + fr) * E + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) split_store4_rowpair(out, oidx + dt * 16 + 4 * fg, o[dt] * inv, true);
+}
+
+template <int HD>
+static int launch(const void* qkv, void* out, int n_seq, int heads, float scale, hipStream_t s) {
+    using C = Cfg<HD>;
+    auto kern = attention_split_dma_kernel<HD>;
+    const size_t bytes = (size_t)n_seq * S * 3 * heads * HD * 4;
+    PP_REQUIRE(bytes < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_attention: qkv tensor exceeds 2 GiB (32-bit buffer offsets)");
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    hipLaunchKernelGGL(kern, dim3(n_seq * heads * QSPLIT), dim3(THREADS), C::LDS, s, reinterpret_cast<const char*>(qkv),
+                       reinterpret_cast<char*>(out), n_seq, heads, (unsigned)bytes, scale * 1.44269504088896340736f);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // namespace adma
+
+// 432-token sequences in the split format, head dim 32 or 64 (called from pp_attention)
+int attention_split_dma(const void* qkv, void* out, int n_seq, int heads, int head_dim, float scale, hipStream_t s) {
+    if (head_dim == 64) return adma::launch<64>(qkv, out, n_seq, heads, scale, s);
+    if (head_dim == 32) return adma::launch<32>(qkv, out, n_seq, heads, scale, s);
+    return fail(PP_ERR_UNSUPPORTED, "pp_attention (LDS-DMA form): head dim 32 or 64");
+}
+
+}  // namespace pp
