@@ -312,18 +312,20 @@ def secondary_rooflines(eng, B, prof, reps):
         by = 2 * B * eng.K * eng.Hh * eng.Wh * 4  # both logit maps of every (crop, keypoint), read once (417 792 B / crop)
         wgs, slots = B * eng.K, 3 * 256
         rounds = -(-wgs // slots)
-        chain_us = 15.0  # one workgroup's dependent chain, measured: scripts/bench_decode.py (17-workgroup launch 18.9 us - ~4 us launch)
+        chain_us = 17.0  # one workgroup's dependent chain: the 17-workgroup launch (one crop) in a rocprofv3 kernel trace, scripts/micro/decode_pmc.sh
         ceil_gbs = by / (rounds * chain_us * 1e-6) / 1e9
         out["head_decode"] = {
             "bound": "hbm", "achieved": by / (ms / n * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": by / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms / n, "algorithmic_mbytes_per_launch": by / 1e6,
             "derived_ceiling": {
                 "GBps": ceil_gbs, "frac_of_ceiling": by / (ms / n * 1e-3) / 1e9 / ceil_gbs,
-                "why": f"latency-bound, not bandwidth-bound: the {by / 1e6:.1f} MB are L2 / MALL resident and each (crop, keypoint) "
-                       f"workgroup runs a dependent chain - loads, block max, ~5 Michelot threshold iterations (a block reduction + "
-                       f"barrier each), flip merge, bounding box, fp64 row pass, fp64 column pass, block argmax: a dozen barriers, "
-                       f"~{chain_us:.0f} us measured for one workgroup alone; {wgs} workgroups on {slots} slots (3 per CU at 49 KiB "
-                       f"LDS) = {rounds} rounds -> >= {rounds * chain_us:.0f} us per launch",
+                "why": f"instruction- and latency-bound, not bandwidth-bound: the {by / 1e6:.1f} MB are L2 / MALL resident; each (crop, keypoint) "
+                       f"workgroup issues ~2 550 VALU instructions per wave (Sparsemax of two 3072-pixel rows in registers, flip merge, "
+                       f"support box, fp64 row and column passes over the box dilated by a radius of up to 9, argmax) behind a dozen "
+                       f"barriers: ~{chain_us:.0f} us for one workgroup alone, 40 % of it issuing; {wgs} workgroups = {wgs / 256:.2f} per CU x 4 waves "
+                       f"x 2 550 VALU x 4 cycles = 23 us of VALU issue per SIMD at best balance; the band buffer is sized for 3 workgroups per "
+                       f"CU ({slots} slots, {rounds} rounds -> >= {rounds * chain_us:.0f} us) - 4 and 5 per CU measured SLOWER (40 / 46 us vs 36: "
+                       f"4.25 workgroups per CU are balanced by the dispatcher handing out work, not by residency)",
             },
         }
         # the same kernel at bs 512 (BASELINE config 3's global batch on one GPU; SURVEY H6: where the HBM fraction becomes meaningful):
@@ -362,8 +364,8 @@ def secondary_rooflines(eng, B, prof, reps):
                 out["head_decode_bs512"] = {"bound": "hbm", "crops": nb, "avg_launch_ms": ms512, "algorithmic_mbytes_per_launch": by512 / 1e6,
                                             "achieved": by512 / (ms512 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": by512 / (ms512 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            "why": f"{nb * eng.K} workgroups on 768 slots = {-(-nb * eng.K // 768)} rounds of the ~15 us chain: the launch is "
-                                                   "latency-bound at every batch size; the logits are read exactly once"}
+                                            "why": f"{nb * eng.K} workgroups = {nb * eng.K / 256:.0f} per CU x 4 waves x ~2 550 VALU instructions: the launch is "
+                                                   "instruction-bound at every batch size; the logits are read exactly once"}
         except Exception as exc:  # noqa: BLE001 -- a secondary record must not take the bench line down
             out["head_decode_bs512"] = {"error": str(exc)[:200]}
     att_fl = 4.0 * nseq * heads * S * S * hd  # QK^T + PV per layer

@@ -61,6 +61,7 @@ int pp_device_cu_count(void);
  *   "psplit_conv_weight_major" (0)  1: tiles of the split-fp16 3x3 convolutions weight-set-major (measured slower)
  *   "attn_dma" (1)           0: split-fp16 attention of 432-token sequences with the register-staged kernel
  *   "conv_pool_split" (1)    0: split-fp16 first tower stage as two launches (conv, then pooling)
+ *   "decode_wgs_per_cu" (3)  pp_probmap_(head_)decode: workgroups per CU its LDS band buffer is sized for (5 .. 1)
  *   "qkv_attn_pair" (0)      1: pp_qkv_attention_split with a head pair per workgroup (measured slower; kept for A/B)
  * Unknown names return PP_ERR_INVALID_ARG. Not thread-safe against concurrent launches (set them before the first call).
  * (probpose_code_amd/_lib.py forwards PP_OPT_<NAME>=<int> environment variables here at import - host-side convenience.) */

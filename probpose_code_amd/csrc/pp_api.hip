@@ -26,6 +26,7 @@ static Option g_options[] = {
     {"psplit_conv_weight_major", 0},  // 1: split-fp16 3x3 convolution tiles weight-set-major (one weight set per XCD at a time; measured 625 vs 612 us: slower)
     {"attn_dma", 1},           // 0: split-fp16 attention of 432-token sequences with the register-staged kernel of round 2
     {"conv_pool_split", 1},    // 0: split-fp16 first tower stage as conv + pooling launches instead of pooling in the conv epilogue
+    {"decode_wgs_per_cu", 3},  // most workgroups per CU the decode kernel sizes its band buffer for (5 .. 1): more than 3 measured slower at bs 64 (4.25 workgroups per CU are balanced by the dispatcher, not by residency; smaller buffers mean more bands)
     {"qkv_attn_pair", 0},      // 1: pp_qkv_attention_split with a head PAIR per workgroup (one workgroup per CU; measured slower)
 };
 

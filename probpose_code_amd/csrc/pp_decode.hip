@@ -23,6 +23,14 @@ constexpr int GX = 6;  // outputs per work item in the row pass (sliding registe
 constexpr int GY = 4;  // outputs per work item in the column pass
 constexpr int RED_BYTES = 512;  // cross-wave reduction scratch at the head of the dynamic LDS region
 
+// i / d for 0 <= i < 2^20, 1 <= d <= 2^12 in three VALU instructions (the integer division is ~25, and the kernel did some forty
+// of them per thread): (i + 0.5) / d is at least 0.5 / d away from an integer, the float product is off by < q 2^-22.
+struct FastDiv {
+    float r;
+    __device__ __forceinline__ explicit FastDiv(int d) : r(1.0f / (float)d) {}
+    __device__ __forceinline__ int operator()(int i) const { return (int)(((float)i + 0.5f) * r); }
+};
+
 struct ArgBest {
     float v;
     int idx;
@@ -42,81 +50,139 @@ struct Box {
     int y0, y1, x0, x1;  // inclusive; empty when y1 < y0
 };
 
+// One BAND of output rows at a time. The row-pass results a band needs - its own rows and R rows either side, mirrored at the
+// map's top / bottom edge (scipy 'reflect'), exact zeros where the source row lies outside the support box - go to `rowd`
+// (NR row slots of W doubles); the column pass of the band reads nothing else. A Sparsemax map's dilated box fits one band;
+// a dense map takes several (the R rows either side are then computed again for the next band). With NR slots instead of
+// H + 2 RM rows the workgroup's LDS is 31 KiB instead of 49 at 64 x 48: five workgroups per CU, the bs 64 launch (1088
+// workgroups) is one occupancy round instead of two.
+//
+// The convolved map takes the place of the averaged map (convf == mapf, pitch W < Wp: output rows <= y only ever cover
+// map rows <= y), and later bands still read the map. So only the LAST band writes its outputs in place; an earlier band
+// parks them behind its row slots (a third of the slots then: band = 2/3 (NR - 2R) rows) until the NEXT band's row pass
+// is through - that pass needs map rows >= (first row of the next band) - R, all of them below the outputs flushed by
+// then (band > R - 1: decode_row_slots keeps NR >= 2 RM + 16). Every thread flushes exactly the cells it parks (same
+// item -> thread map in every band), so the park needs no barrier of its own.
 template <int R>
-__device__ __forceinline__ void row_pass(const float* __restrict__ mapf, double* __restrict__ rowd,
-                                         const double* __restrict__ tap_g, int H, int W, int Wp, int tid, Box bx) {
+__device__ __forceinline__ ArgBest conv_banded(float* __restrict__ mapf, double* __restrict__ rowd,
+                                               const double* __restrict__ tap_g, int H, int W, int Wp, int NR, int tid,
+                                               Box bx) {
     double tap[R + 1];  // the kernel is symmetric bit for bit (exp(-t^2/2s) / sum): R + 1 distinct factors, in SGPRs
 #pragma unroll
     for (int j = 0; j <= R; ++j) tap[j] = tap_g[j];
     const int xa = max(bx.x0 - R, 0), xb = min(bx.x1 + R, W - 1);  // columns the support reaches through the row kernel
-    const int nxg = (xb - xa + GX) / GX, ny = bx.y1 - bx.y0 + 1;
-    for (int it = tid; it < ny * nxg; it += DEC_THREADS) {
-        const int yr = it / nxg, y = bx.y0 + yr, x0 = xa + (it - yr * nxg) * GX;
-        const float* p = mapf + y * Wp + x0 + (RM - R);  // window starts R samples left of output x0
-        double win[GX + 2 * R];
-#pragma unroll
-        for (int c = 0; c < GX + 2 * R; ++c) win[c] = (double)p[c];
-        double acc[GX];
-#pragma unroll
-        for (int g = 0; g < GX; ++g) acc[g] = 0.0;
-#pragma unroll
-        for (int j = 0; j <= 2 * R; ++j)  // t ascending, one fused multiply-add per tap
-#pragma unroll
-            for (int g = 0; g < GX; ++g) acc[g] = fma(win[g + j], tap[j <= R ? j : 2 * R - j], acc[g]);
-#pragma unroll
-        for (int g = 0; g < GX; ++g)
-            if (x0 + g <= xb) rowd[(y + RM) * W + x0 + g] = acc[g];
-    }
-}
-
-template <int R>
-__device__ __forceinline__ ArgBest col_pass(const double* __restrict__ rowd, float* __restrict__ convf,
-                                            const double* __restrict__ tap_g, int H, int W, int tid, Box bx) {
-    double tap[R + 1];
-#pragma unroll
-    for (int j = 0; j <= R; ++j) tap[j] = tap_g[j];
-    ArgBest best{-__builtin_inff(), 0x7fffffff};
-    const int xa = max(bx.x0 - R, 0), xb = min(bx.x1 + R, W - 1);
     const int ya = max(bx.y0 - R, 0), yb = min(bx.y1 + R, H - 1);
-    const int nyg = (yb - ya + GY) / GY, nx = xb - xa + 1;
-    for (int it = tid; it < nx * nyg; it += DEC_THREADS) {
-        const int yg = it / nx, x = xa + it - yg * nx, y0 = ya + yg * GY;
-        const double* p = rowd + (y0 + RM - R) * W + x;
-        double win[GY + 2 * R];
+    const int nx = xb - xa + 1, nxg = (nx + GX - 1) / GX;
+    const FastDiv div_nx(nx), div_nxg(nxg);
+    const bool one_band = yb - ya + 1 <= NR - 2 * R;
+    const int band = one_band ? yb - ya + 1 : ((NR - 2 * R) * 2) / 3;
+    float* convf = mapf;
+    float* park = reinterpret_cast<float*>(rowd + (band + 2 * R) * W);  // [band][nx], several bands only
+    ArgBest best{-__builtin_inff(), 0x7fffffff};
+    for (int by0 = ya; by0 <= yb; by0 += band) {
+        const int by1 = min(by0 + band - 1, yb);
+        const bool last = by1 == yb;
+        // ---- row pass: slot s <- sum_t map[reflect(by0 - R + s)][x + t] * tap[t], f64
+        const int nslot = by1 - by0 + 1 + 2 * R;
+        for (int it = tid; it < nslot * nxg; it += DEC_THREADS) {
+            const int s = div_nxg(it), x0 = xa + (it - s * nxg) * GX;
+            int y = by0 - R + s;
+            y = y < 0 ? -1 - y : (y >= H ? 2 * H - 1 - y : y);  // half-sample symmetric: -1 -> 0, H -> H - 1
+            double acc[GX];
 #pragma unroll
-        for (int c = 0; c < GY + 2 * R; ++c) win[c] = (y0 + RM - R + c < H + 2 * RM) ? p[c * W] : 0.0;
-        double acc[GY];
+            for (int g = 0; g < GX; ++g) acc[g] = 0.0;
+            if (y >= bx.y0 && y <= bx.y1) {
+                const float* p = mapf + y * Wp + x0 + (RM - R);  // window starts R samples left of output x0
+                double win[GX + 2 * R];
 #pragma unroll
-        for (int g = 0; g < GY; ++g) acc[g] = 0.0;
+                for (int c = 0; c < GX + 2 * R; ++c) win[c] = (double)p[c];
 #pragma unroll
-        for (int j = 0; j <= 2 * R; ++j)
+                for (int j = 0; j <= 2 * R; ++j)  // t ascending, one fused multiply-add per tap
 #pragma unroll
-            for (int g = 0; g < GY; ++g) acc[g] = fma(win[g + j], tap[j <= R ? j : 2 * R - j], acc[g]);
+                    for (int g = 0; g < GX; ++g) acc[g] = fma(win[g + j], tap[j <= R ? j : 2 * R - j], acc[g]);
+            }
 #pragma unroll
-        for (int g = 0; g < GY; ++g) {
-            if (y0 + g <= yb) {
-                const float v = (float)acc[g];  // the single rounding scipy does on output
-                const int idx = (y0 + g) * W + x;
-                convf[idx] = v;
-                if (better(v, idx, best.v, best.idx)) best = ArgBest{v, idx};
+            for (int g = 0; g < GX; ++g)
+                if (x0 + g <= xb) rowd[s * W + x0 + g] = acc[g];
+        }
+        __syncthreads();
+        // ---- column pass + running argmax. Before a thread parks a cell it flushes what the previous band left there.
+        const int nyg = (by1 - by0 + GY) / GY;
+        for (int it = tid; it < nx * (one_band ? nyg : (band + GY - 1) / GY); it += DEC_THREADS) {
+            const int yg = div_nx(it), xo = it - yg * nx, x = xa + xo, s0 = yg * GY;
+            if (by0 > ya) {
+#pragma unroll
+                for (int g = 0; g < GY; ++g)
+                    if (s0 + g < band) convf[(by0 - band + s0 + g) * W + x] = park[(s0 + g) * nx + xo];
+            }
+            if (yg >= nyg) continue;  // (a shorter last band: flush only)
+            const double* p = rowd + s0 * W + x;
+            double win[GY + 2 * R];
+#pragma unroll
+            for (int c = 0; c < GY + 2 * R; ++c) win[c] = (s0 + c < NR) ? p[c * W] : 0.0;  // (slots past the band's last feed only outputs that are dropped)
+            double acc[GY];
+#pragma unroll
+            for (int g = 0; g < GY; ++g) acc[g] = 0.0;
+#pragma unroll
+            for (int j = 0; j <= 2 * R; ++j)
+#pragma unroll
+                for (int g = 0; g < GY; ++g) acc[g] = fma(win[g + j], tap[j <= R ? j : 2 * R - j], acc[g]);
+#pragma unroll
+            for (int g = 0; g < GY; ++g) {
+                if (by0 + s0 + g <= by1) {
+                    const float v = (float)acc[g];  // the single rounding scipy does on output
+                    const int idx = (by0 + s0 + g) * W + x;
+                    if (last) convf[idx] = v;
+                    else park[(s0 + g) * nx + xo] = v;
+                    if (better(v, idx, best.v, best.idx)) best = ArgBest{v, idx};
+                }
             }
         }
+        if (!last) __syncthreads();  // the slots are written again
     }
     return best;
+}
+
+// ---- lane exchanges of the xor butterfly (32, 16, 8, 4, 2, 1 - the pairing order __shfl_xor loops have, so sums keep their
+// bits) without the LDS queue: the gfx950 row swaps for 32 / 16 (each lane ends up with its own and its partner's value: any
+// commutative op takes them in either order), DPP row rotate / shifts / quad permutes below that.
+__device__ __forceinline__ int dpp_xor8(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); }  // row_ror:8
+__device__ __forceinline__ int dpp_xor4(int v) {
+    const int t = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0x5, false);  // row_shl:4 into lanes 0-3, 8-11 of a row
+    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);         // row_shr:4 into lanes 4-7, 12-15
+}
+__device__ __forceinline__ int dpp_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
+
+template <class T, class Op>
+__device__ __forceinline__ T wave_allreduce(T v, Op op) {
+    static_assert(sizeof(T) == 4, "one dword");
+    auto I = [](T x) { return __builtin_bit_cast(int, x); };
+    auto V = [](int x) { return __builtin_bit_cast(T, x); };
+    {
+        const auto s = __builtin_amdgcn_permlane32_swap((unsigned)I(v), (unsigned)I(v), false, false);
+        v = op(V((int)s[0]), V((int)s[1]));
+    }
+    {
+        const auto s = __builtin_amdgcn_permlane16_swap((unsigned)I(v), (unsigned)I(v), false, false);
+        v = op(V((int)s[0]), V((int)s[1]));
+    }
+    v = op(v, V(dpp_xor8(I(v))));
+    v = op(v, V(dpp_xor4(I(v))));
+    v = op(v, V(dpp_xor2(I(v))));
+    v = op(v, V(dpp_xor1(I(v))));
+    return v;
 }
 
 // ---- block-wide reductions for the in-register Sparsemax (4 waves)
 struct SmxStat {
     float s0, s1;
-    int n0, n1;
+    int n;  // candidates of the two rows, n0 | n1 << 16 (a row has at most 12 288 pixels)
 };
 
 __device__ __forceinline__ void block_max2(float& a, float& b, float* scratch) {
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) {
-        a = fmaxf(a, __shfl_xor(a, off));
-        b = fmaxf(b, __shfl_xor(b, off));
-    }
+    a = wave_allreduce(a, [](float x, float y) { return fmaxf(x, y); });
+    b = wave_allreduce(b, [](float x, float y) { return fmaxf(x, y); });
     if (lane_id() == 0) {
         scratch[2 * wave_id()] = a;
         scratch[2 * wave_id() + 1] = b;
@@ -129,13 +195,12 @@ __device__ __forceinline__ void block_max2(float& a, float& b, float* scratch) {
     }
 }
 
-__device__ __forceinline__ SmxStat block_sum_stat(SmxStat v, SmxStat* scratch) {
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) {
-        v.s0 += __shfl_xor(v.s0, off);
-        v.s1 += __shfl_xor(v.s1, off);
-        v.n0 += __shfl_xor(v.n0, off);
-        v.n1 += __shfl_xor(v.n1, off);
+// `quiet`: no lane of this wave has a candidate left (wave-uniform) - its partial sums are zeros without the exchanges
+__device__ __forceinline__ SmxStat block_sum_stat(SmxStat v, bool quiet, SmxStat* scratch) {
+    if (!quiet) {
+        v.s0 = wave_allreduce(v.s0, [](float x, float y) { return x + y; });
+        v.s1 = wave_allreduce(v.s1, [](float x, float y) { return x + y; });
+        v.n = wave_allreduce(v.n, [](int x, int y) { return x + y; });
     }
     if (lane_id() == 0) scratch[wave_id()] = v;
     __syncthreads();
@@ -144,8 +209,7 @@ __device__ __forceinline__ SmxStat block_sum_stat(SmxStat v, SmxStat* scratch) {
     for (int w = 1; w < DEC_THREADS / WAVE; ++w) {  // fixed order: every thread gets the same bits
         r.s0 += scratch[w].s0;
         r.s1 += scratch[w].s1;
-        r.n0 += scratch[w].n0;
-        r.n1 += scratch[w].n1;
+        r.n += scratch[w].n;
     }
     return r;
 }
@@ -158,21 +222,22 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     const float* __restrict__ hm, const float* __restrict__ hm_flip, const int32_t* __restrict__ flip_indices,
     const double* __restrict__ taps, const int32_t* __restrict__ radius, int K, int H, int W, double in_w,
     double in_h, float temperature, float normalize, float* __restrict__ avg_out, float* __restrict__ conv_out,
-    float* __restrict__ locs, double* __restrict__ keypoints, float* __restrict__ scores, int phased) {
+    float* __restrict__ locs, double* __restrict__ keypoints, float* __restrict__ scores, int phased, int NR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int bk = blockIdx.x;
     const int b = bk / K, k = bk - b * K;
     const int Wp = W + 2 * RM;
     const int HW = H * W, HW4 = HW >> 2, W4 = W >> 2;
+    const FastDiv div_w(W), div_w4(W4), div_w2(W >> 1), div_q(HW4);
 
     // all LDS in the one dynamic region (16-B aligned carve offsets)
     ArgBest* red = reinterpret_cast<ArgBest*>(smem);                                         // [4] cross-wave argmax
     float* mapf = reinterpret_cast<float*>(smem + RED_BYTES);                                // [H][Wp] (+ slack) averaged map, x-padded
-    double* rowd = reinterpret_cast<double*>(smem + RED_BYTES + (((H * Wp + 32) * 4 + 15) & ~15));  // [H+2RM][W] row pass, y-padded
-    // [H][W] convolved map (f32): it takes the place of the averaged map, which is dead once the row pass is through - except
-    // for the one value at the final argmax (the score), so every thread parks its share of the map (4 NV values) in
-    // registers first. 49 KiB instead of 61 at 64 x 48: three workgroups per CU.
+    double* rowd = reinterpret_cast<double*>(smem + RED_BYTES + (((H * Wp + 32) * 4 + 15) & ~15));  // [NR][W] row pass of one band (conv_banded)
+    // [H][W] convolved map (f32): it takes the place of the averaged map, which is dead once the last row pass is through -
+    // except for the one value at the final argmax (the score), so every thread parks its share of the map (4 NV values) in
+    // registers first.
     float* convf = mapf;
 
     const f32x4* src = reinterpret_cast<const f32x4*>(hm + (size_t)bk * HW);
@@ -185,7 +250,7 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         for (int e = 0; e < NV; ++e) {
             const int i4 = tid + e * DEC_THREADS;
             if (i4 < HW4) {
-                const int y = i4 / W4, x = (i4 - y * W4) * 4;
+                const int y = div_w4(i4), x = (i4 - y * W4) * 4;
                 f32x4 v = src[i4];
                 if (HAS_FLIP) {
                     const f32x4 f = srcf[y * W4 + (W4 - 1 - (x >> 2))];
@@ -205,6 +270,10 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         SmxStat* sscr = reinterpret_cast<SmxStat*>(smem + 64);
         f32x4 z0[NV], z1[NV];
         float m0 = -__builtin_inff(), m1 = -__builtin_inff();
+        // a division costs nine VALU instructions, the row has 24 per thread: multiply when the temperature is a normal power of two
+        const unsigned t_bits = __builtin_bit_cast(unsigned, temperature);
+        const bool t_pow2 = (t_bits & 0x007fffffu) == 0 && (t_bits >> 23) >= 2 && (t_bits >> 23) <= 252;
+        const float t_inv = __builtin_bit_cast(float, (254u << 23) - t_bits);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             const int i4 = tid + e * DEC_THREADS;
@@ -212,8 +281,13 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
             z0[e] = f32x4{ninf, ninf, ninf, ninf};
             z1[e] = z0[e];
             if (i4 < HW4) {
-                z0[e] = src[i4] / temperature;
-                if (HAS_FLIP) z1[e] = srcf[i4] / temperature;
+                if (t_pow2) {  // x / 2^k == x * 2^-k bit for bit
+                    z0[e] = src[i4] * t_inv;
+                    if (HAS_FLIP) z1[e] = srcf[i4] * t_inv;
+                } else {
+                    z0[e] = src[i4] / temperature;
+                    if (HAS_FLIP) z1[e] = srcf[i4] / temperature;
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -235,32 +309,35 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
             z1[e] -= m1;
         }
         float tau0 = smx ? -1.0f : 0.f, tau1 = tau0;
-        int prev0 = -1, prev1 = -1;
+        int prev = -1;
+        bool alive = true;  // the thresholds only rise: a thread without a candidate now has none in any later round
         for (int iter = 0; iter < (smx ? 64 : 0); ++iter) {
-            SmxStat st{0.f, 0.f, 0, 0};
+            SmxStat st{0.f, 0.f, 0};
+            if (alive) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e)
+                for (int e = 0; e < NV; ++e)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float d0 = z0[e][j] - tau0;
-                    if (d0 > 0.f) {
-                        st.s0 += d0;
-                        st.n0 += 1;
-                    }
-                    if (HAS_FLIP) {
-                        const float d1 = z1[e][j] - tau1;
-                        if (d1 > 0.f) {
-                            st.s1 += d1;
-                            st.n1 += 1;
+                    for (int j = 0; j < 4; ++j) {
+                        const float d0 = z0[e][j] - tau0;
+                        if (d0 > 0.f) {
+                            st.s0 += d0;
+                            st.n += 1;
+                        }
+                        if (HAS_FLIP) {
+                            const float d1 = z1[e][j] - tau1;
+                            if (d1 > 0.f) {
+                                st.s1 += d1;
+                                st.n += 1 << 16;
+                            }
                         }
                     }
-                }
-            st = block_sum_stat(st, sscr + (iter & 1) * (DEC_THREADS / WAVE));
-            if (st.n0 == prev0 && (!HAS_FLIP || st.n1 == prev1)) break;
-            prev0 = st.n0;
-            prev1 = st.n1;
-            tau0 = tau0 + (st.s0 - 1.0f) / (float)st.n0;
-            if (HAS_FLIP) tau1 = tau1 + (st.s1 - 1.0f) / (float)st.n1;
+                alive = st.n != 0;
+            }
+            st = block_sum_stat(st, __builtin_amdgcn_ballot_w64(alive) == 0, sscr + (iter & 1) * (DEC_THREADS / WAVE));
+            if (st.n == prev) break;
+            prev = st.n;
+            tau0 = tau0 + (st.s0 - 1.0f) / (float)(st.n & 0xffff);
+            if (HAS_FLIP) tau1 = tau1 + (st.s1 - 1.0f) / (float)(st.n >> 16);
         }
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
@@ -268,9 +345,9 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
             if (i4 < HW4) {
                 // memory order of the four values -> pixel (y, x0 + j * dx): row-major, or (logits written by the fused
                 // deconvolution head) the four 2x2 output phases one after the other, each a (H/2, W/2) row-major block
-                int y = i4 / W4, x0 = (i4 - y * W4) * 4, dx = 1;
+                int y = div_w4(i4), x0 = (i4 - y * W4) * 4, dx = 1;
                 if (phased) {
-                    const int e0 = i4 * 4, q = HW >> 2, z = e0 / q, rr = e0 - z * q, yy = rr / (W >> 1);
+                    const int e0 = i4 * 4, q = HW >> 2, z = div_q(e0), rr = e0 - z * q, yy = div_w2(rr);
                     y = 2 * yy + (z >> 1);
                     x0 = 2 * (rr - yy * (W >> 1)) + (z & 1);
                     dx = 2;
@@ -286,9 +363,9 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
             for (int e = 0; e < NV; ++e) {
                 const int i4 = tid + e * DEC_THREADS;
                 if (i4 < HW4) {
-                    int y = i4 / W4, xf = (i4 - y * W4) * 4, dx = 1;
+                    int y = div_w4(i4), xf = (i4 - y * W4) * 4, dx = 1;
                     if (phased) {
-                        const int e0 = i4 * 4, q = HW >> 2, z = e0 / q, rr = e0 - z * q, yy = rr / (W >> 1);
+                        const int e0 = i4 * 4, q = HW >> 2, z = div_q(e0), rr = e0 - z * q, yy = div_w2(rr);
                         y = 2 * yy + (z >> 1);
                         xf = 2 * (rr - yy * (W >> 1)) + (z & 1);
                         dx = 2;
@@ -305,7 +382,7 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         if (avg_out) {
             __syncthreads();
             for (int i = tid; i < HW; i += DEC_THREADS) {
-                const int y = i / W, x = i - y * W;
+                const int y = div_w(i), x = i - y * W;
                 avg_out[(size_t)bk * HW + i] = mapf[y * Wp + RM + x];
             }
         }
@@ -322,7 +399,7 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
 #pragma unroll
     for (int i = 0; i < 4 * NV; ++i) {
         const int px = tid + i * DEC_THREADS;
-        const int y = px / W, x = px - y * W;
+        const int y = div_w(px), x = px - y * W;
         mine[i] = px < HW ? mapf[y * Wp + RM + x] : 0.f;
         if (px < HW && mine[i] != 0.f) {  // (NaN counts as non-zero)
             bx.y0 = min(bx.y0, y); bx.y1 = max(bx.y1, y);
@@ -330,19 +407,15 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         }
     }
     {
-#pragma unroll
-        for (int off = WAVE / 2; off > 0; off >>= 1) {
-            bx.y0 = min(bx.y0, __shfl_xor(bx.y0, off)); bx.y1 = max(bx.y1, __shfl_xor(bx.y1, off));
-            bx.x0 = min(bx.x0, __shfl_xor(bx.x0, off)); bx.x1 = max(bx.x1, __shfl_xor(bx.x1, off));
-        }
+        bx.y0 = wave_allreduce(bx.y0, [](int a, int b) { return min(a, b); });
+        bx.y1 = wave_allreduce(bx.y1, [](int a, int b) { return max(a, b); });
+        bx.x0 = wave_allreduce(bx.x0, [](int a, int b) { return min(a, b); });
+        bx.x1 = wave_allreduce(bx.x1, [](int a, int b) { return max(a, b); });
         int* bscr = reinterpret_cast<int*>(smem + 256);  // (the Sparsemax scratch below it is out of use past the barrier above)
         if (lane_id() == 0) {
             bscr[4 * wave_id() + 0] = bx.y0; bscr[4 * wave_id() + 1] = bx.y1;
             bscr[4 * wave_id() + 2] = bx.x0; bscr[4 * wave_id() + 3] = bx.x1;
         }
-        // the row-pass result starts from zeros: rows outside the box feed the column pass as exact zeros
-        double* rz = rowd;
-        for (int i = tid; i < (H + 2 * RM) * W; i += DEC_THREADS) rz[i] = 0.0;
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < DEC_THREADS / WAVE; ++w) {
@@ -354,8 +427,8 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     }
     const bool empty = bx.y1 < bx.y0;
     // half-sample symmetric x-padding (scipy.ndimage 'reflect'): -1 -> 0, -2 -> 1, W -> W-1, ...
-    for (int i = tid; i < H * 2 * RM; i += DEC_THREADS) {
-        const int y = i / (2 * RM), p = i - y * (2 * RM);
+    for (int i = tid; i < (empty ? 0 : (bx.y1 - bx.y0 + 1) * 2 * RM); i += DEC_THREADS) {  // (the row pass reads no other row)
+        const int yr = i / (2 * RM), y = bx.y0 + yr, p = i - yr * (2 * RM);
         if (p < RM)
             mapf[y * Wp + (RM - 1 - p)] = mapf[y * Wp + RM + p];
         else
@@ -365,52 +438,47 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
 
     const int r = __builtin_amdgcn_readfirstlane(radius[k]);
     const double* tap_g = taps + k * PP_MAX_TAPS;
-    // ---- row pass: rowd[y][x] = sum_t map[y][x+t] * tap[t], f64
-    if (!empty) switch (r) {
-        case 0: row_pass<0>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
-        case 1: row_pass<1>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
-        case 2: row_pass<2>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
-        case 3: row_pass<3>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
-        case 4: row_pass<4>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
-        case 5: row_pass<5>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
-        case 6: row_pass<6>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
-        case 7: row_pass<7>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
-        case 8: row_pass<8>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
-        default: row_pass<9>(mapf, rowd, tap_g, H, W, Wp, tid, bx); break;
-    }
-    __syncthreads();
-    // symmetric y-padding of the row-pass result
-    for (int i = tid; i < 2 * RM * W; i += DEC_THREADS) {
-        const int p = i / W, x = i - p * W;
-        if (p < RM)
-            rowd[(RM - 1 - p) * W + x] = rowd[(RM + p) * W + x];
-        else
-            rowd[(RM + H + (p - RM)) * W + x] = rowd[(RM + H - 1 - (p - RM)) * W + x];
-    }
-    __syncthreads();  // the row pass has read the map for the last time: its region becomes the convolved map,
-    for (int i = tid; i < HW; i += DEC_THREADS) convf[i] = 0.0f;  // zero outside the box
-    __syncthreads();
-
-    // ---- column pass + running argmax
+    // ---- separable convolution over the dilated box, band by band; the outputs land in convf, the rest of it is 0.0f
     ArgBest best{-__builtin_inff(), 0x7fffffff};
     if (!empty) switch (r) {
-        case 0: best = col_pass<0>(rowd, convf, tap_g, H, W, tid, bx); break;
-        case 1: best = col_pass<1>(rowd, convf, tap_g, H, W, tid, bx); break;
-        case 2: best = col_pass<2>(rowd, convf, tap_g, H, W, tid, bx); break;
-        case 3: best = col_pass<3>(rowd, convf, tap_g, H, W, tid, bx); break;
-        case 4: best = col_pass<4>(rowd, convf, tap_g, H, W, tid, bx); break;
-        case 5: best = col_pass<5>(rowd, convf, tap_g, H, W, tid, bx); break;
-        case 6: best = col_pass<6>(rowd, convf, tap_g, H, W, tid, bx); break;
-        case 7: best = col_pass<7>(rowd, convf, tap_g, H, W, tid, bx); break;
-        case 8: best = col_pass<8>(rowd, convf, tap_g, H, W, tid, bx); break;
-        default: best = col_pass<9>(rowd, convf, tap_g, H, W, tid, bx); break;
+        case 0: best = conv_banded<0>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+        case 1: best = conv_banded<1>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+        case 2: best = conv_banded<2>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+        case 3: best = conv_banded<3>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+        case 4: best = conv_banded<4>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+        case 5: best = conv_banded<5>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+        case 6: best = conv_banded<6>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+        case 7: best = conv_banded<7>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+        case 8: best = conv_banded<8>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+        default: best = conv_banded<9>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+    }
+    const int cxa = max(bx.x0 - r, 0), cxb = min(bx.x1 + r, W - 1), cya = max(bx.y0 - r, 0), cyb = min(bx.y1 + r, H - 1);
+    if (conv_out) {  // zero outside the box (every read of the map is behind a barrier by now; disjoint from the band outputs)
+        const int xa = cxa, xb = cxb, ya = cya, yb = cyb;
+        for (int i = tid; i < HW; i += DEC_THREADS) {
+            const int y = div_w(i), x = i - y * W;
+            if (empty || y < ya || y > yb || x < xa || x > xb) convf[i] = 0.0f;
+        }
     }
     // wave-level then block-level argmax
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(best.v, off);
-        const int oi = __shfl_xor(best.idx, off);
-        if (better(ov, oi, best.v, best.idx)) best = ArgBest{ov, oi};
+    {
+        auto F = [](int x) { return __builtin_bit_cast(float, x); };
+        auto I = [](float x) { return __builtin_bit_cast(int, x); };
+        auto pick = [](ArgBest a, ArgBest b) { return better(a.v, a.idx, b.v, b.idx) ? a : b; };  // (a strict order: symmetric)
+        {
+            const auto sv = __builtin_amdgcn_permlane32_swap((unsigned)I(best.v), (unsigned)I(best.v), false, false);
+            const auto si = __builtin_amdgcn_permlane32_swap((unsigned)best.idx, (unsigned)best.idx, false, false);
+            best = pick(ArgBest{F((int)sv[0]), (int)si[0]}, ArgBest{F((int)sv[1]), (int)si[1]});
+        }
+        {
+            const auto sv = __builtin_amdgcn_permlane16_swap((unsigned)I(best.v), (unsigned)I(best.v), false, false);
+            const auto si = __builtin_amdgcn_permlane16_swap((unsigned)best.idx, (unsigned)best.idx, false, false);
+            best = pick(ArgBest{F((int)sv[0]), (int)si[0]}, ArgBest{F((int)sv[1]), (int)si[1]});
+        }
+        best = pick(ArgBest{F(dpp_xor8(I(best.v))), dpp_xor8(best.idx)}, best);
+        best = pick(ArgBest{F(dpp_xor4(I(best.v))), dpp_xor4(best.idx)}, best);
+        best = pick(ArgBest{F(dpp_xor2(I(best.v))), dpp_xor2(best.idx)}, best);
+        best = pick(ArgBest{F(dpp_xor1(I(best.v))), dpp_xor1(best.idx)}, best);
     }
     if (lane_id() == 0) red[wave_id()] = best;
     __syncthreads();
@@ -445,9 +513,11 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         float lx = (float)xi, ly = (float)yi;
         // post_processing.py:384-430 -- interior peaks only, f32, zero curvature -> 1e-6, no clamp
         if (xi > 0 && xi < W - 1 && yi > 0 && yi < H - 1) {
-            const float c = convf[yi * W + xi];
-            const float xp = convf[yi * W + xi + 1], xm = convf[yi * W + xi - 1];
-            const float yp = convf[(yi + 1) * W + xi], ym = convf[(yi - 1) * W + xi];
+            // (outside the convolved box the map is 0.0f; only written there when the caller asked for the map)
+            auto cv = [&](int y, int x) { return (empty || y < cya || y > cyb || x < cxa || x > cxb) ? 0.0f : convf[y * W + x]; };
+            const float c = cv(yi, xi);
+            const float xp = cv(yi, xi + 1), xm = cv(yi, xi - 1);
+            const float yp = cv(yi + 1, xi), ym = cv(yi - 1, xi);
             const float dx = (xp - xm) / 2.0f;
             const float dy = (yp - ym) / 2.0f;
             float dxx = xp + xm - 2.0f * c;
@@ -466,13 +536,26 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     }
 }
 
-static size_t decode_lds_bytes(int H, int W) {
-    const size_t mapf = (((size_t)H * (W + 2 * RM) + 32) * 4 + 15) & ~(size_t)15;
-    return RED_BYTES + mapf + (size_t)(H + 2 * RM) * W * 8;  // (the convolved map reuses the averaged map's region)
+static size_t decode_fixed_bytes(int H, int W) {
+    return RED_BYTES + ((((size_t)H * (W + 2 * RM) + 32) * 4 + 15) & ~(size_t)15);  // (the convolved map reuses the averaged map's region)
+}
+
+// Row slots of the band buffer: as many workgroups per CU as the map allows (five at 64 x 48, two at 96 x 72), a band never
+// lower than 16 output rows at the largest radius. 1.5 KiB of every share stay free for the allocation granule.
+static int decode_row_slots(int H, int W) {
+    const size_t fixed = decode_fixed_bytes(H, W);
+    const int full = H + 2 * RM;
+    for (int n = std::min(5, std::max(1, pp::option("decode_wgs_per_cu"))); n >= 1; --n) {
+        const size_t budget = (size_t)160 * 1024 / n - 1536;
+        if (budget <= fixed) continue;
+        const int nr = (int)std::min<size_t>((size_t)full, (budget - fixed) / ((size_t)W * 8));
+        if (nr == full || nr >= 2 * RM + 16) return nr;
+    }
+    return -1;
 }
 
 typedef void (*DecodeKernel)(const float*, const float*, const int32_t*, const double*, const int32_t*, int, int, int,
-                             double, double, float, float, float*, float*, float*, double*, float*, int);
+                             double, double, float, float, float*, float*, float*, double*, float*, int, int);
 
 template <int NV>
 static DecodeKernel pick_kernel(bool from_logits, bool flip) {
@@ -498,8 +581,9 @@ static int decode_launch(bool from_logits, const float* hm, const float* hm_flip
     PP_REQUIRE(H >= RM && W >= RM, PP_ERR_UNSUPPORTED,
                "pp_probmap_decode: heatmap smaller than the largest OKS-kernel radius (9)");
     PP_REQUIRE(W % 4 == 0, PP_ERR_UNSUPPORTED, "pp_probmap_decode: heatmap width must be a multiple of 4");
-    const size_t lds = decode_lds_bytes(H, W);
-    PP_REQUIRE(lds <= 160 * 1024, PP_ERR_UNSUPPORTED, "pp_probmap_decode: heatmap too large for one CU's LDS");
+    const int nr = decode_row_slots(H, W);
+    PP_REQUIRE(nr > 0, PP_ERR_UNSUPPORTED, "pp_probmap_decode: heatmap too large for one CU's LDS");
+    const size_t lds = decode_fixed_bytes(H, W) + (size_t)nr * W * 8;
     if (from_logits)
         PP_REQUIRE(temperature > 0.f, PP_ERR_INVALID_ARG, "pp_probmap_head_decode: temperature must be positive");
     const int nv = (H * W / 4 + DEC_THREADS - 1) / DEC_THREADS;
@@ -512,7 +596,7 @@ static int decode_launch(bool from_logits, const float* hm, const float* hm_flip
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * K), dim3(DEC_THREADS), lds, s, hm, hm_flip, flip_indices, taps, radius, K, H,
-                       W, in_w, in_h, temperature, normalize, avg_out, conv_out, locs, keypoints, scores, phased);
+                       W, in_w, in_h, temperature, normalize, avg_out, conv_out, locs, keypoints, scores, phased, nr);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }

@@ -18,7 +18,10 @@ fi = eng._flip_indices(S.COCO_FLIP_INDICES)
 def run(lg, T, nb=B):
     _lib.call("pp_probmap_head_decode", lg.data_ptr(), lg[B:].data_ptr(), fi.data_ptr(), eng.taps.data_ptr(), eng.radius.data_ptr(), nb, 17, 64, 48,
               192.0, 256.0, T, 1.0, None, None, ws["locs"].data_ptr(), ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), None)
-for name, lg, T in (("model logits, T=0.5 (sparse)", logits, 0.5), ("noise logits, T=50 (dense support)", torch.randn_like(logits), 50.0)):
+for wgs in (5, 4, 3, 2):
+  _lib.set_option("decode_wgs_per_cu", wgs)
+  print("decode_wgs_per_cu", wgs)
+  for name, lg, T in (("model logits, T=0.5 (sparse)", logits, 0.5), ("noise logits, T=50 (dense support)", torch.randn_like(logits), 50.0)):
     for _ in range(3): run(lg, T)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,6 +30,7 @@ for name, lg, T in (("model logits, T=0.5 (sparse)", logits, 0.5), ("noise logit
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     print(f"{name:36s} {us:7.1f} us   {2 * B * 17 * 3072 * 4 / us / 1e3:7.1f} GB/s of logits")
+_lib.set_option("decode_wgs_per_cu", 5)
 # the dependent chain of ONE workgroup (17 workgroups on 256 CUs: nothing queues): loads -> max -> threshold iterations -> map ->
 # box -> row pass -> column pass -> argmax, a dozen barriers; the bs64 launch is 1088 workgroups on 768 slots (3 per CU: 49 KiB LDS)
 for _ in range(3): run(logits, 0.5, 1)
