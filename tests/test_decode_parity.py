@@ -130,6 +130,46 @@ def test_convolved_map_stress_vs_scipy_direct_sum():
     assert mism_kp == 0, f"{mism_kp} keypoint coordinates differ"
 
 
+@pytest.mark.parametrize("hw", [(64, 48), (96, 72)])
+def test_banded_row_pass_matches_one_band(hw):
+    """The fp64 row pass lives in a BAND of row slots (pp_decode.hip conv_banded). With the buffer sized for five workgroups
+    per CU (option decode_wgs_per_cu) a dense 64 x 48 map takes several bands - outputs of one band parked while the
+    next band's row pass still reads the map they will overwrite, mirrored rows at both edges recomputed per band - and
+    must give the same bits as the one-band run, which the golden cases and the scipy stress test pin. Maps: dense
+    noise (every band full), a dense top half / bottom half (boxes that start or end inside a band), and sparse blobs."""
+    from probpose_code_amd import _lib
+
+    H, W = hw
+    K = 17
+    rng = np.random.default_rng(7)
+    codec = _codec(hw)
+    dense = rng.random((6, K, H, W), dtype=np.float32) ** 4
+    top, bot = dense.copy(), dense.copy()
+    top[:, :, H // 2 + 3:] = 0
+    bot[:, :, : H // 2 - 5] = 0
+    hm = np.concatenate([dense, top, bot, _sparse_batch(rng, 6, H, W)])
+    x = torch.from_numpy(hm).cuda()
+    default = _lib.get_option("decode_wgs_per_cu")
+    try:
+        _lib.set_option("decode_wgs_per_cu", 1)  # the whole map's rows in one band
+        ref = codec.decode_device(x, return_conv=True)
+        ref = {k: ref[k].cpu().numpy() for k in ("conv", "locs", "keypoints", "scores")}
+        kerns = D.oks_kernels(K, H, W)
+        for b in (0, 7, 13):  # and the one-band run against scipy's direct sum
+            want = np.stack([D.convolve_scipy(hm[b, k], kerns[k]) for k in range(K)])
+            assert np.array_equal(ref["conv"][b], want)
+        for wgs in (5, 4, 3, 2):
+            _lib.set_option("decode_wgs_per_cu", wgs)
+            out = codec.decode_device(x, return_conv=True)
+            for k in ref:
+                assert np.array_equal(out[k].cpu().numpy(), ref[k], equal_nan=True), f"{k} differs with the band buffer sized for {wgs} workgroups per CU"
+            out = codec.decode_device(x)  # without the convolved map (no zero fill: the sub-pixel step reads through the box)
+            for k in ("locs", "keypoints", "scores"):
+                assert np.array_equal(out[k].cpu().numpy(), ref[k], equal_nan=True)
+    finally:
+        _lib.set_option("decode_wgs_per_cu", default)
+
+
 def test_single_hot_pixel_property():
     """Size-independent property at the full bs=64 shape: an isolated interior hot pixel decodes
     to exactly its own location (symmetric kernel => zero Newton step), scaled by
