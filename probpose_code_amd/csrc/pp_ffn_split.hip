@@ -335,6 +335,58 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             asm volatile("" : "+v"(gq_hi[first + c]), "+v"(gq_lo[first + c]));
         }
     };
+#ifndef FFS_GELU_IN_C
+#define FFS_GELU_IN_C 0  // 1 = the B-steps' GELU pair runs in the MFMA segment C(s), two or three VALU instructions behind each MFMA (gelu_stage), not in L(s): measured 200.0 vs 198.7 us, same bits - the VALU work is not what the L segments wait for
+#endif
+    // The same pair, cut into 24 stages of two or three VALU instructions (a transcendental has a stage to itself): stage k sits
+    // behind the k-th MFMA of a B-step's C segment - a 16x16x32 MFMA holds the matrix pipe for 16 cycles and takes 4 to issue,
+    // which leaves the wave three plain VALU issue slots per MFMA at no cost to the pipe. Same operations in the same order per
+    // value as gelu_pairs.
+    float sx[2], sz[2], st[2], se[2], sq[2], sg[2];
+    _Float16 sh[2], sl[2];
+    auto gelu_stage = [&](int k, int pair) {
+        const int f = pair >> 1, i0 = 2 * (pair & 1);
+        if (DBG & 2) {
+            if (k == 0) {
+                sg[0] = pacc[f >> 1][f & 1][i0]; sg[1] = pacc[f >> 1][f & 1][i0 + 1];
+            }
+        } else switch (k) {
+            case 0: sx[0] = pacc[f >> 1][f & 1][i0]; sx[1] = pacc[f >> 1][f & 1][i0 + 1];
+                    sz[0] = fabsf(sx[0]) * 0.70710678118654752440f; sz[1] = fabsf(sx[1]) * 0.70710678118654752440f; break;
+            case 1: st[0] = __builtin_fmaf(0.3275911f, sz[0], 1.0f); st[1] = __builtin_fmaf(0.3275911f, sz[1], 1.0f); break;
+            case 2: st[0] = __builtin_amdgcn_rcpf(st[0]); break;
+            case 3: st[1] = __builtin_amdgcn_rcpf(st[1]); break;
+            case 4: se[0] = sz[0] * sz[0]; se[1] = sz[1] * sz[1]; break;
+            case 5: se[0] = -se[0] * 1.44269504088896340736f; se[1] = -se[1] * 1.44269504088896340736f; break;
+            case 6: se[0] = __builtin_amdgcn_exp2f(se[0]); break;
+            case 7: se[1] = __builtin_amdgcn_exp2f(se[1]); break;
+            case 8: sq[0] = __builtin_fmaf(st[0], 1.061405429f, -1.453152027f); sq[1] = __builtin_fmaf(st[1], 1.061405429f, -1.453152027f); break;
+            case 9: sq[0] = __builtin_fmaf(st[0], sq[0], 1.421413741f); sq[1] = __builtin_fmaf(st[1], sq[1], 1.421413741f); break;
+            case 10: sq[0] = __builtin_fmaf(st[0], sq[0], -0.284496736f); sq[1] = __builtin_fmaf(st[1], sq[1], -0.284496736f); break;
+            case 11: sq[0] = __builtin_fmaf(st[0], sq[0], 0.254829592f); sq[1] = __builtin_fmaf(st[1], sq[1], 0.254829592f); break;
+            case 12: sq[0] = st[0] * sq[0]; sq[1] = st[1] * sq[1]; break;
+            case 13: sq[0] = sq[0] * se[0]; sq[1] = sq[1] * se[1]; break;                       // erfc(z)
+            case 14: se[0] = 2.0f - sq[0]; se[1] = 2.0f - sq[1]; break;
+            case 15: sq[0] = sx[0] < 0.f ? sq[0] : se[0]; break;
+            case 16: sq[1] = sx[1] < 0.f ? sq[1] : se[1]; break;
+            case 17: sg[0] = 0.5f * sx[0]; sg[1] = 0.5f * sx[1]; break;
+            case 18: sg[0] = sg[0] * sq[0]; sg[1] = sg[1] * sq[1]; break;
+            default: break;
+        }
+        switch (k) {
+            case 19: sh[0] = split_hi(sg[0]); sh[1] = split_hi(sg[1]); break;
+            case 20: sz[0] = (float)sh[0]; sz[1] = (float)sh[1]; break;
+            case 21: sz[0] = sg[0] - sz[0]; sz[1] = sg[1] - sz[1]; break;
+            case 22: sl[0] = (_Float16)sz[0]; sl[1] = (_Float16)sz[1]; break;
+            case 23: {
+                gq_hi[pair] = f16x2{sh[0], sh[1]};
+                gq_lo[pair] = f16x2{sl[0], sl[1]};
+                asm volatile("" : "+v"(gq_hi[pair]), "+v"(gq_lo[pair]));
+                break;
+            }
+            default: break;
+        }
+    };
     auto write_g = [&](int f0, int f1) {
 #pragma unroll
         for (int f = f0; f < f1; ++f) {
@@ -358,7 +410,10 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
     auto sync_l = [&](auto wait_rg1) {  // after L(s)
         __builtin_amdgcn_sched_barrier(0);
         stamp();
-        if (rg == 0) __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));  // lgkmcnt(0): the fragments are in
+#ifndef FFS_RG0_NOWAIT
+#define FFS_RG0_NOWAIT 1  // 1 (shipped) = waves 0-3 do not wait for their fragment reads at the end of L(s): their slot is refilled two time slots later, and the MFMAs of C(s) get the compiler's own partial waits (211.1 -> 207.1 us, same bits); 0 = lgkmcnt(0) there
+#endif
+        if (rg == 0) { if (!FFS_RG0_NOWAIT) __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14)); }  // lgkmcnt(0): the fragments are in
         else wait_rg1();
         __builtin_amdgcn_s_barrier();
         stamp();
@@ -448,25 +503,26 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         }
         issue_fn(3);
     };
-    auto b_compute = [&](int sb, auto issue_fn_) {
+    auto b_compute = [&](int sb, auto issue_fn_, auto side) {  // side(k): VALU work behind the k-th MFMA (k = 0 .. 26)
         auto issue_fn = [&](int u) { if (!FFS_ONEHALF && (FFS_DMA_IN_C == 1 || (FFS_DMA_IN_C == 2 && u >= 2))) { pin(); issue_fn_(u); pin(); } };
         const int half = sb & 1;
+        int k = 0;
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
-            for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(bwh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+            for (int nf = 0; nf < 3; ++nf) { acc[rf][half * 3 + nf] = mma(bwh[nf], bgh[rf], acc[rf][half * 3 + nf]); side(k++); }
             if (rf == 1) issue_fn(0);
         }
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
-            for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(bwl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+            for (int nf = 0; nf < 3; ++nf) { acc[rf][half * 3 + nf] = mma(bwl[nf], bgh[rf], acc[rf][half * 3 + nf]); side(k++); }
             if (rf == 1) issue_fn(1);
         }
 #pragma unroll
         for (int nf = 0; nf < 3; ++nf) {
 #pragma unroll
-            for (int rf = 0; rf < 3; ++rf) acc[rf][half * 3 + nf] = mma(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+            for (int rf = 0; rf < 3; ++rf) { acc[rf][half * 3 + nf] = mma(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]); side(k++); }
             if (nf == 0) { issue_fn(2); issue_fn(3); }
         }
     };
@@ -608,7 +664,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
 #pragma unroll
                     for (int rf = 0; rf < 3; ++rf) { bgh[rf] = b_g(j, rf, 0); bgl[rf] = b_g(j, rf, 1); }
                 }
-                b_compute(q & 1, [](int) {});
+                b_compute(q & 1, [](int) {}, [](int) {});
             }
         }
         // + bp (after the sums, as residual + (sum + bias) rounds closest to the reference's x + proj(...))
@@ -711,13 +767,13 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             const int t = NA + sb;
             if (sb == 0) load_b1(it + 2);  // (in front of this segment's pieces: two more operations outstanding at steps 12, 13)
             b_load(sb, t & 3, [&](int u) { issue_piece(it, t + 3, u); });
-            gelu_pairs(sb, 1, false);
+            if (!FFS_GELU_IN_C) gelu_pairs(sb, 1, false);
             // pieces of steps t + 2, t + 3: B B up to t = 16, B A' at 17, A' A' at 18, 19
             // (the two b1 loads of step 12 get NO slack in the counts: as younger plain loads they may retire before the pieces
             // these waits are for - see the projection phase)
             const int ex = 0;
             sync_l([&]() { if (FFS_ONEHALF) FFS_WAIT(63); else if (FFS_DMA_IN_C == 1) FFS_WAIT(3); else if (FFS_DMA_IN_C == 2) FFS_WAIT(3 + 2); else if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 3); else FFS_WAIT(2 * 3); });
-            b_compute(sb, [&](int u) { issue_piece(it, t + 3, u); });
+            b_compute(sb, [&](int u) { issue_piece(it, t + 3, u); }, [&](int k) { if (FFS_GELU_IN_C && k < 24) { pin(); gelu_stage(k, sb); pin(); } });
             sync_c([&]() { if (FFS_ONEHALF) { if (t <= 16) FFS_WAIT(12); else if (t == 17) FFS_WAIT(13); else FFS_WAIT(14); } else if (t <= 16) { if (ex) FFS_WAIT(6 + 2); else FFS_WAIT(6); } else if (t == 17) FFS_WAIT(3 + 4); else FFS_WAIT(2 * 4); });
         }
     }
