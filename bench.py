@@ -84,6 +84,8 @@ def parse(argv=None):
     ap.add_argument("--no-second-mode", "--no-parity-mode", dest="no_second_mode", action="store_true",
                     help="skip the second bench in the other precision (bf16 `throughput_mode` beside an f16x3 headline and vice versa)")
     ap.add_argument("--no-config4", action="store_true", help="skip the bounded ViT-B 384x288 record")
+    ap.add_argument("--no-bs512-decode", action="store_true",
+                    help="skip roofline_targets.head_decode_bs512 (counter passes: its launches would mix into the step's decode kernel)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="steps in flight (StepPipeline slots: own HIP stream, workspace and graph each); 1 = strictly one batch "
                          "at a time on one stream")
@@ -300,7 +302,7 @@ def roofline_record(eng, B, prof, reps):
     return kernel_ms, rec
 
 
-def secondary_rooflines(eng, B, prof, reps):
+def secondary_rooflines(eng, B, prof, reps, bs512=True):
     """The two kernels BASELINE.json's `north_star` sets targets for - ViT attention (>= 70 % MFMA) and the ProbMap decode
     (>= 60 % HBM) - with the datasheet fraction AND the ceiling their arithmetic allows at this shape, with the
     instruction-count derivation. Measured live from the same instrumented pass."""
@@ -335,7 +337,7 @@ def secondary_rooflines(eng, B, prof, reps):
             from probpose_code_amd import synthetic as S_
 
             ws = eng._workspace(B, 2)
-            if getattr(eng, "_logits_phased", False) and B * 8 <= 512:
+            if bs512 and getattr(eng, "_logits_phased", False) and B * 8 <= 512:
                 rep8 = 512 // B
                 lg = ws["logits"][:B].repeat(rep8, 1, 1).contiguous()
                 lgf = ws["logits"][B:].repeat(rep8, 1, 1).contiguous()
@@ -748,7 +750,7 @@ def main(argv=None):
             print(json.dumps(line))
         else:
             line["kernel_ms_per_step"], line["roofline"] = roofline_record(eng, B, *prof)
-            line["roofline_targets"] = secondary_rooflines(eng, B, *prof)
+            line["roofline_targets"] = secondary_rooflines(eng, B, *prof, bs512=not args.no_bs512_decode)
             ref = None
             if world == 1 and not args.no_cpu_baseline:
                 threads = min(16, len(os.sched_getaffinity(0)))

@@ -21,8 +21,8 @@ rm -rf /tmp/prof_stats1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- python $root/bench.py --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec \
     > $out/${tag}_bench_under_rocprof_one_in_flight.json 2> /tmp/prof_stats1.log
 cp $(find /tmp/prof_stats1 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_one_in_flight.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_write.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-bs512-decode --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-bs512-decode --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_write.log
 python3 - "$out/${tag}_hbm_traffic.json" <<'PY'
 import csv, glob, json, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -51,7 +51,7 @@ i=0
 for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d /tmp/prof_sq$i -- python $root/bench.py --no-graph --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_sq$i.log
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d /tmp/prof_sq$i -- python $root/bench.py --no-graph --in-flight 1 --steps 3 --warmup 1 --no-bs512-decode --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_sq$i.log
 done
 python3 - "$out/${tag}_sq_counters.txt" "$prec" <<'PY'
 import csv, glob, sys, collections
