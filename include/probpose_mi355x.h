@@ -58,7 +58,9 @@ int pp_device_cu_count(void);
  *   "psplit_nst" (0)         2 / 3: force the two- / three-stage form of the wide-tile split kernel
  *   "panel_linear_mink" (0)  > 0: shortest K of a bf16 Linear layer that takes the wide-tile kernel
  *   "psplit_bf16_conv" (0)   1: bf16 convolutions through the split kernel's bf16 instantiation
- *   "psplit_conv_weight_major" (0)  1: tiles of the split-fp16 3x3 convolutions weight-set-major (measured slower)
+ *   "psplit_tap_inner" (1)          K walk of the gathered split-fp16 convolutions: 1 = 3x3 convolutions channel-block-major
+ *                                   (the nine shifted re-reads of a block hit L2), 2 = deconvolutions too, 0 = tap-major
+ *   "psplit_conv_weight_major" (1)  tiles of those 3x3 convolutions weight-set-major (with taps inner only): half the HBM-side fetch
  *   "attn_dma" (1)           0: split-fp16 attention of 432-token sequences with the register-staged kernel
  *   "conv_pool_split" (1)    0: split-fp16 first tower stage as two launches (conv, then pooling)
  *   "decode_wgs_per_cu" (3)  pp_probmap_(head_)decode: workgroups per CU its LDS band buffer is sized for (5 .. 1)

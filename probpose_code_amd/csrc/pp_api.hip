@@ -23,7 +23,8 @@ static Option g_options[] = {
     {"psplit_nst", 0},         // 2 / 3: force the two- / three-stage form of pp_panel_split.hip (0: by shape)
     {"panel_linear_mink", 0},  // > 0: shortest K of a bf16 Linear layer that takes the wide-tile kernel (0: built-in thresholds)
     {"psplit_bf16_conv", 0},   // 1: bf16 convolutions through pp_panel_split.hip instead of pp_panel_gemm.hip
-    {"psplit_conv_weight_major", 0},  // 1: split-fp16 3x3 convolution tiles weight-set-major (one weight set per XCD at a time; measured 625 vs 612 us: slower)
+    {"psplit_tap_inner", 1},          // K walk of the gathered convolutions of pp_panel_split.hip channel-block-major (taps inner): 1 = 3x3 convolutions, 2 = deconvolutions too, 0 = tap-major
+    {"psplit_conv_weight_major", 1},  // 3x3 convolution tiles weight-set-major (one weight set per XCD at a time); only together with taps inner
     {"attn_dma", 1},           // 0: split-fp16 attention of 432-token sequences with the register-staged kernel of round 2
     {"conv_pool_split", 1},    // 0: split-fp16 first tower stage as conv + pooling launches instead of pooling in the conv epilogue
     {"decode_wgs_per_cu", 3},  // most workgroups per CU the decode kernel sizes its band buffer for (5 .. 1): more than 3 measured slower at bs 64 (4.25 workgroups per CU are balanced by the dispatcher, not by residency; smaller buffers mean more bands)

@@ -30,6 +30,7 @@ struct GemmParams {
                             // K is the length of one slice, ldw the full row; conv gathers start at tap slice * K / Cin
     int groups;             // independent problems in one launch (the four towers); tiles of all groups share the persistent grid
     int pool_h, pool_w;     // pp_conv_halo.hip only, > 0: C is the MaxPool2d(pool_h, pool_w) + ReLU of the convolution, (N, H / pool_h, W / pool_w, Cout)
+    int tap_inner;          // pp_panel_split.hip: 1 = the K walk of a gathered convolution runs tap-inner (channel block -> taps) instead of tap -> channel blocks
     int tile_order;         // pp_panel_split.hip: 0 row panel -> group -> column tile (activations shared per XCD), 1 weight set -> row panels
     int planar_P;           // >0: store planar, out[((m / P) * N + n) * P + m % P]  (NHWC rows -> (B, N, P) planes)
     unsigned a_bytes, w_bytes;  // extent of the activation / weight tensor of ONE group (buffer-descriptor bound)

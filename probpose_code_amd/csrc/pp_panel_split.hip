@@ -193,11 +193,21 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, i_live ? w_voff + kb : OOB, 0, 0, 0);
         }
     };
+    const int ntaps = p.K / p.Cin;
     auto advance_cursor = [&]() {
-        i_c0 += KS;
-        if (i_c0 == p.Cin) {
-            i_c0 = 0;
-            ++i_tap;
+        if (p.tap_inner) {
+            // channel block -> taps: the nine (four) shifted reads of a 128-byte column block of the tile's pixels follow each
+            // other directly - the re-reads of the gather hit in L2 whatever else the XCD's workgroups stream meanwhile
+            if (++i_tap == ntaps) {
+                i_tap = 0;
+                i_c0 += KS;
+            }
+        } else {
+            i_c0 += KS;
+            if (i_c0 == p.Cin) {
+                i_c0 = 0;
+                ++i_tap;
+            }
         }
         if (++i_step == nsteps) {
             i_tile += gridDim.x;
@@ -634,7 +644,12 @@ int panel_split_gemm(const GemmParams& p_in, int prec, int groups, hipStream_t s
     using namespace psplit;
     GemmParams p = p_in;
     p.groups = groups;
-    p.tile_order = (p.gather == G_CONV3 && option("psplit_conv_weight_major") != 0) ? 1 : 0;
+    // 3x3 convolutions: taps inner + weight-set-major tiles (first tower stage at bs 64: 765 -> 371 MB fetched per launch, 635 ->
+    // 630 us). Weight-major WITHOUT taps inner is the worst of the four (2.46 GB: 32 row panels live per XCD, the nine shifted
+    // re-reads of each miss L2), so it is only honoured together. Deconvolutions measured 1 - 3 % slower taps-inner: off.
+    const int ti = option("psplit_tap_inner");
+    p.tap_inner = (p.gather == G_CONV3 && ti >= 1) || (p.gather == G_DECONV && ti >= 2) ? 1 : 0;
+    p.tile_order = (p.gather == G_CONV3 && p.tap_inner && option("psplit_conv_weight_major") != 0) ? 1 : 0;
     if (p.gather == G_LINEAR) p.Cin = p.K;
     PP_REQUIRE(p.a_bytes > 0 && p.w_bytes > 0 && p.a_bytes < OOB && p.w_bytes < OOB, PP_ERR_UNSUPPORTED,
                "pp panel split gemm: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -643,6 +658,7 @@ int panel_split_gemm(const GemmParams& p_in, int prec, int groups, hipStream_t s
     int BM, BN;
     shape_dims(shape, BM, BN);
     const bool sp = prec != PP_PREC_BF16;
+    if ((long long)p.K * BN * (sp ? 4 : 2) > 3 * 1024 * 1024) p.tile_order = 0;  // a weight set must stay in the XCD's 4 MB L2 beside the streamed rows (ViT-B towers: 5.3 MB)
 #define PP_PS(G, RF, CF, NST) (sp ? panel_split_kernel<G, RF, CF, true, NST> : panel_split_kernel<G, RF, CF, false, NST>)
     switch (p.gather) {
         case G_DECONV:
