@@ -131,15 +131,21 @@ def test_gemm_residual_layernorm_split(K, res_mod, E):
 
 
 @gpu
-@pytest.mark.parametrize("hd,S", [(32, 192), (64, 192), (32, 432), (64, 432)])
-def test_attention_split(hd, S):
+@pytest.mark.parametrize("hd,S,dma", [(32, 192, 1), (64, 192, 1), (32, 432, 1), (64, 432, 1), (32, 432, 0), (64, 432, 0)])
+def test_attention_split(hd, S, dma):
+    """432-token sequences: the LDS-DMA kernel (pp_attention_dma.hip, option attn_dma = 1, the default) and the register-staged
+    kernel it replaced (attn_dma = 0), both against fp64."""
     L = _lib()
     n_seq, heads = 3, 4
     E = heads * hd
     qkv = _rand(n_seq * S, 3 * E, seed=16, scale=1.3)
     qd = _sp(qkv)
     out = torch.empty((n_seq * S, E), device="cuda")
-    L.call("pp_attention", F16X3, qd.data_ptr(), out.data_ptr(), n_seq, S, heads, hd, hd ** -0.5, None)
+    L.set_option("attn_dma", dma)
+    try:
+        L.call("pp_attention", F16X3, qd.data_ptr(), out.data_ptr(), n_seq, S, heads, hd, hd ** -0.5, None)
+    finally:
+        L.set_option("attn_dma", 1)
     x = qkv.double().reshape(n_seq, S, 3, heads, hd).permute(2, 0, 3, 1, 4)
     att = ((x[0] @ x[1].transpose(-2, -1)) * hd ** -0.5).softmax(-1)
     ref = (att @ x[2]).transpose(1, 2).reshape(n_seq * S, E)
