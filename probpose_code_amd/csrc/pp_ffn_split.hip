@@ -457,8 +457,12 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         pin();
         issue_fn(3);
     };
+#ifndef FFS_CPRIO
+#define FFS_CPRIO 0  // dev A/B: n > 0 = a wave raises its priority to n for its MFMA segments C(s) (the partner wave of the SIMD is in a load segment then): 207.9 / 207.6 us (n = 1 / 3) against 205.8 - the matrix pipe does not wait for issue slots
+#endif
     auto a_compute = [&](auto issue_fn_) {
         auto issue_fn = [&](int u) { if (!FFS_ONEHALF && (FFS_DMA_IN_C == 1 || (FFS_DMA_IN_C == 2 && u >= 2))) { pin(); issue_fn_(u); pin(); } };
+        if (FFS_CPRIO) __builtin_amdgcn_s_setprio(FFS_CPRIO);
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
@@ -478,6 +482,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             for (int rf = 0; rf < 3; ++rf) pacc[rf][nf] = mma(awh[nf], axl[rf], pacc[rf][nf]);
             if (nf == 0) issue_fn(3);
         }
+        if (FFS_CPRIO) { pin(); __builtin_amdgcn_s_setprio(0); }
     };
     auto b_load = [&](int sb, int slot_i, auto issue_fn_) {
         auto issue_fn = [&](int u) {
@@ -507,6 +512,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         auto issue_fn = [&](int u) { if (!FFS_ONEHALF && (FFS_DMA_IN_C == 1 || (FFS_DMA_IN_C == 2 && u >= 2))) { pin(); issue_fn_(u); pin(); } };
         const int half = sb & 1;
         int k = 0;
+        if (FFS_CPRIO) __builtin_amdgcn_s_setprio(FFS_CPRIO);
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
@@ -525,6 +531,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             for (int rf = 0; rf < 3; ++rf) { acc[rf][half * 3 + nf] = mma(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]); side(k++); }
             if (nf == 0) { issue_fn(2); issue_fn(3); }
         }
+        if (FFS_CPRIO) { pin(); __builtin_amdgcn_s_setprio(0); }
     };
 
     // rows past M read row M - 1; nothing of them is ever stored (computed where it is used: as an array it ended up in scratch)
