@@ -1,0 +1,53 @@
+"""Parity sweep of the full path (f16x3, the product's precision) against the CPU oracle (oracle.model_ref, test infrastructure)
+over weight seeds, crop seeds and batch sizes - the same comparison as bench.py's `parity_vs_oracle`, more inputs. Run on the
+GPU box: python scripts/parity_sweep.py [out.json]. ProbPose-small at 256x192 with flip test; ViT-B at 384x288 with B = 4."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from oracle import model_ref as M
+from probpose_code_amd import ProbPoseEngine
+from probpose_code_amd import synthetic as S
+
+
+def compare(out, ref):
+    kp = out["keypoints"].cpu().numpy()
+    sc = out["scalars"].cpu().numpy()
+    d = np.abs(kp[:, None] - ref["keypoints_input_space"]).max(-1)
+    same = d < 2.0
+    return {"keypoint_linf_px_same_argmax": float(d[same].max()), "argmax_flips": int((~same).sum()), "keypoints": int(same.size),
+            "probs_linf": float(np.abs(sc[0][:, None] - ref["keypoints_probs"]).max()),
+            "visible_linf": float(np.abs(sc[1][:, None] - ref["keypoints_visible"]).max()),
+            "oks_linf": float(np.abs(sc[2][:, None] - ref["keypoints_oks"]).max())}
+
+
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+rows = []
+for wseed, cseed, B, scale in ((0, 100, 64, 2.0), (1, 101, 64, 2.0), (2, 102, 64, 1.0), (3, 103, 33, 3.0), (4, 104, 7, 2.0), (5, 105, 1, 2.0)):
+    sd = S.synthetic_state_dict("small", seed=wseed, logit_scale=scale)
+    crops = S.synthetic_crops(B, seed=cseed)
+    ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD)
+    eng = ProbPoseEngine(sd, 12, precision="f16x3")
+    out = eng.forward(crops.cuda(), True, S.COCO_FLIP_INDICES)
+    torch.cuda.synchronize()
+    r = dict(model="ProbPose-small 256x192", weight_seed=wseed, crop_seed=cseed, batch=B, logit_scale=scale, **compare(out, ref))
+    rows.append(r)
+    print(r, flush=True)
+    del eng
+img = (384, 288)
+sd = S.synthetic_state_dict("base", img_size=img, seed=0, logit_scale=2.0)
+crops = S.synthetic_crops(4, img_size=img, seed=1)
+ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD, input_size=(288, 384))
+eng = ProbPoseEngine(sd, 12, img_size=img, precision="f16x3", input_size=(288, 384))
+out = eng.forward(crops.cuda(), True, S.COCO_FLIP_INDICES)
+torch.cuda.synchronize()
+r = dict(model="ProbPose-base (ViT-B) 384x288", weight_seed=0, crop_seed=1, batch=4, logit_scale=2.0, **compare(out, ref))
+rows.append(r)
+print(r, flush=True)
+worst = max(x["keypoint_linf_px_same_argmax"] for x in rows)
+summary = {"precision": "f16x3", "against": "oracle/model_ref.py (fp32 CPU restatement of the reference path)", "runs": rows,
+           "worst_keypoint_linf_px": worst, "total_argmax_flips": sum(x["argmax_flips"] for x in rows),
+           "total_keypoints": sum(x["keypoints"] for x in rows), "within_1e-3": bool(worst <= 1e-3 and sum(x["argmax_flips"] for x in rows) == 0)}
+print(json.dumps({k: v for k, v in summary.items() if k != "runs"}))
+if len(sys.argv) > 1:
+    json.dump(summary, open(sys.argv[1], "w"), indent=1)
