@@ -10,7 +10,8 @@
 //     fragments from global memory once;
 //   * the keys stream through a ring of four 32-key stages: per stage K and V as HD / 32 sub-tiles of [32 keys][128 B] (the
 //     raw split blocks: 32 hi halves | 32 lo halves, 16-byte chunks XOR-swizzled by key & 7 at the source) = 16 KiB at head
-//     dim 64, three stages ahead; 64 KiB of LDS and < 128 registers: two workgroups per CU;
+//     dim 64; the stages go in PAIRS (one barrier, one running-maximum update and one rescale of O per 64 keys: 149 -> 145 us),
+//     the next pair requested while this one is worked on; 64 KiB of LDS and < 128 registers: two workgroups per CU;
 //   * S^T = K Q^T (a query's scores lane-local), online softmax over the stages (running maximum / sum, O rescaled when the
 //     maximum moves), P split in registers, O^T = V^T P^T with the V^T fragments read by ds_read_b64_tr_b16 - the gfx950
 //     transposing LDS read (within 16 lanes, lane 4 r + q supplies the address of four consecutive halves M[r][4 q ..], lane i
@@ -87,8 +88,6 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
             }
         }
     };
-    // pieces this wave issues per stage (wave-uniform): for the counted waits
-    const int my_pieces = (C::PIECES - wv + TPW - 1) / TPW;
 
     // ---- q fragments of this wave's tile: lane (query fr, chunk fg) of block g
     f16x8 qh[C::NB], ql[C::NB];
@@ -102,7 +101,6 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
     }
     issue_stage(0);
     issue_stage(1);
-    issue_stage(2);
 
     f32x4 o[C::DT];
 #pragma unroll
@@ -115,32 +113,28 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
     const int tr_r = fr >> 2, tr_q = fr & 3;
     const int vkey = 4 * fg + tr_r;  // (+ 16 for the second read: same key & 7)
 
-    for (int st = 0; st < NSTG; ++st) {
-        // stage st has landed when only this wave's pieces of the (up to two) younger stages are outstanding
+    // Two stages (64 keys) between barriers: one running-maximum update, one rescale of O and one barrier per 48 MFMAs instead
+    // of per 24. The pair p + 1 is requested at the top of pair p, into the two slots pair p - 1 has just left.
+    static_assert(NSTG % 2 == 0 && RING == 4, "stage pairs on a ring of four");
+    for (int pr = 0; pr < NSTG / 2; ++pr) {
         __builtin_amdgcn_sched_barrier(0);
-        {
-            const int younger = min(NSTG - 1 - st, 2) * my_pieces;  // wave-uniform, small: a switch keeps the immediates literal
-            if (younger == 0) wait_vm<0>();
-            else if (younger == 1) wait_vm<1>();
-            else if (younger == 2) wait_vm<2>();
-            else if (younger == 3) wait_vm<3>();
-            else if (younger == 4) wait_vm<4>();
-            else if (younger == 5) wait_vm<5>();
-            else wait_vm<6>();
+        wait_vm<0>();                  // this wave's pieces of the pair are in (nothing younger is in flight)
+        __builtin_amdgcn_s_barrier();  // every wave's pieces are in; every wave is done with pair pr - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * pr + 2 < NSTG) {
+            issue_stage(2 * pr + 2);
+            issue_stage(2 * pr + 3);
         }
-        __builtin_amdgcn_s_barrier();  // every wave's pieces of stage st are in; every wave is done with stage st - 1 (its buffer is refilled next)
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 3 < NSTG) issue_stage(st + 3);
         if (!live) continue;
-        const char* Ks = smem + (st & (RING - 1)) * C::STAGE;
-        const bool tail = st == NSTG - 1 && (S % SK) != 0;  // the last stage holds S % 32 = 16 keys: its second key tile does not exist
+        const bool tail = pr == NSTG / 2 - 1 && (S % SK) != 0;  // the last stage holds S % 32 = 16 keys: its second key tile does not exist
 
-        // ---- scores of the stage's two key tiles: s[kt][i] = q . k for key 32 st + 16 kt + 4 fg + i of query fr
-        f32x4 sc[2];
+        // ---- scores of the pair's four key tiles: s[kt][i] = q . k for key 64 pr + 16 kt + 4 fg + i of query fr
+        f32x4 sc[4];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < 4; ++kt) {
+            const char* Ks = smem + ((2 * pr + (kt >> 1)) & (RING - 1)) * C::STAGE;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const int r = kt * 16 + fr;
+            const int r = (kt & 1) * 16 + fr;
 #pragma unroll
             for (int g = 0; g < C::NB; ++g) {
                 const f16x8 kh = *reinterpret_cast<const f16x8*>(Ks + g * C::SUB + r * 128 + ((fg ^ sw) << 4));
@@ -149,11 +143,11 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
             }
             sc[kt] = acc;
         }
-        if (tail) sc[1] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        if (tail) sc[3] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
         // ---- online softmax
         float mx = m_run;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sc[kt][i]);
         {  // max over the four lane groups of a query: the gfx950 row swaps (plain VALU) instead of two trips through the LDS queue
@@ -164,7 +158,7 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
             const auto s32 = __builtin_amdgcn_permlane32_swap(mv, mv, false, false);
             mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
         }
-        const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);  // (first stage: exp2(-inf) = 0, nothing to rescale)
+        const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);  // (first pair: exp2(-inf) = 0, nothing to rescale)
         l_run *= alpha;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) o[dt] *= alpha;
@@ -172,7 +166,7 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
         const float mb = mx * scale_log2e;
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], scale_log2e, -mb));  // masked keys: exp2(-inf) = 0
@@ -180,37 +174,41 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
                 sum += e;
             }
         l_run += sum;  // this lane's keys only; the four lanes of a query are added up at the end
-        // ---- O^T += V^T P^T: the K = 32 block takes keys 4 fg + i and 16 + 4 fg + i per lane on both operands
-        f16x8 ph, pl;
+        // ---- O^T += V^T P^T, one K = 32 block per stage of the pair: keys 4 fg + i and 16 + 4 fg + i per lane on both operands
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ph[j] = split_hi(sc[0][j]);
-            pl[j] = split_lo(sc[0][j], ph[j]);
-            ph[4 + j] = split_hi(sc[1][j]);
-            pl[4 + j] = split_lo(sc[1][j], ph[4 + j]);
-        }
-        // two head-dim tiles (16 dims each) per group: eight transposing reads in flight, one wait, six MFMAs.
-        // As asm: the BUILTIN carries no memory operand, so the compiler waits for every LDS-DMA in flight (vmcnt(0)) in front of
-        // it - the three stages ahead included. The explicit lgkmcnt(0) covers the group's reads.
+        for (int h = 0; h < 2; ++h) {
+            const int st = 2 * pr + h;
+            f16x8 ph, pl;
 #pragma unroll
-        for (int d2 = 0; d2 < C::DT / 2; ++d2) {
-            u32x2 h0[2], h1[2], l0[2], l1[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int dt = 2 * d2 + e;
-                const int g = dt >> 1, c0 = 2 * (dt & 1) + (tr_q >> 1);  // logical hi chunk of dims 16 dt + 4 q ..
-                const unsigned vb = lds_base + (unsigned)((st & (RING - 1)) * C::STAGE + C::NB * C::SUB + g * C::SUB + vkey * 128 + (tr_q & 1) * 8);
-                const unsigned a_hi = vb + (unsigned)((c0 ^ (vkey & 7)) << 4), a_lo = vb + (unsigned)(((4 + c0) ^ (vkey & 7)) << 4);
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h0[e]) : "v"(a_hi));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(h1[e]) : "v"(a_hi));
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(l0[e]) : "v"(a_lo));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(l1[e]) : "v"(a_lo));
+            for (int j = 0; j < 4; ++j) {
+                ph[j] = split_hi(sc[2 * h][j]);
+                pl[j] = split_lo(sc[2 * h][j], ph[j]);
+                ph[4 + j] = split_hi(sc[2 * h + 1][j]);
+                pl[4 + j] = split_lo(sc[2 * h + 1][j], ph[4 + j]);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0[0]), "+v"(h1[0]), "+v"(l0[0]), "+v"(l1[0]), "+v"(h0[1]), "+v"(h1[1]), "+v"(l0[1]), "+v"(l1[1]));
+            // two head-dim tiles (16 dims each) per group: eight transposing reads in flight, one wait, six MFMAs.
+            // As asm: the BUILTIN carries no memory operand, so the compiler waits for every LDS-DMA in flight (vmcnt(0)) in front of
+            // it - the stages ahead included. The explicit lgkmcnt(0) covers the group's reads.
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const u32x4 vh = {h0[e][0], h0[e][1], h1[e][0], h1[e][1]}, vl = {l0[e][0], l0[e][1], l1[e][0], l1[e][1]};
-                o[2 * d2 + e] = split_mma(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, vl), ph, pl, o[2 * d2 + e]);
+            for (int d2 = 0; d2 < C::DT / 2; ++d2) {
+                u32x2 h0[2], h1[2], l0[2], l1[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int dt = 2 * d2 + e;
+                    const int g = dt >> 1, c0 = 2 * (dt & 1) + (tr_q >> 1);  // logical hi chunk of dims 16 dt + 4 q ..
+                    const unsigned vb = lds_base + (unsigned)((st & (RING - 1)) * C::STAGE + C::NB * C::SUB + g * C::SUB + vkey * 128 + (tr_q & 1) * 8);
+                    const unsigned a_hi = vb + (unsigned)((c0 ^ (vkey & 7)) << 4), a_lo = vb + (unsigned)(((4 + c0) ^ (vkey & 7)) << 4);
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h0[e]) : "v"(a_hi));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(h1[e]) : "v"(a_hi));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(l0[e]) : "v"(a_lo));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(l1[e]) : "v"(a_lo));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0[0]), "+v"(h1[0]), "+v"(l0[0]), "+v"(l1[0]), "+v"(h0[1]), "+v"(h1[1]), "+v"(l0[1]), "+v"(l1[1]));
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const u32x4 vh = {h0[e][0], h0[e][1], h1[e][0], h1[e][1]}, vl = {l0[e][0], l0[e][1], l1[e][0], l1[e][1]};
+                    o[2 * d2 + e] = split_mma(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, vl), ph, pl, o[2 * d2 + e]);
+                }
             }
         }
     }
