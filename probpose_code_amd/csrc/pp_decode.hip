@@ -54,8 +54,10 @@ struct Box {
 // map's top / bottom edge (scipy 'reflect'), exact zeros where the source row lies outside the support box - go to `rowd`
 // (NR row slots of W doubles); the column pass of the band reads nothing else. A Sparsemax map's dilated box fits one band;
 // a dense map takes several (the R rows either side are then computed again for the next band). With NR slots instead of
-// H + 2 RM rows the workgroup's LDS is 31 KiB instead of 49 at 64 x 48: five workgroups per CU, the bs 64 launch (1088
-// workgroups) is one occupancy round instead of two.
+// H + 2 RM rows a workgroup's LDS can be 31 KiB instead of 49 at 64 x 48 (five workgroups per CU) and 78 KiB instead of 100 at
+// 96 x 72 (two instead of one). At bs 64 five and four per CU measured SLOWER than three (46 / 40 / 36 us: the launch is bound
+// by instructions and the dispatcher balances 4.25 workgroups per CU better than residency does; a 35-slot buffer also
+// splits the box of a radius-9 keypoint): decode_row_slots sizes the buffer for option "decode_wgs_per_cu" (3) per CU.
 //
 // The convolved map takes the place of the averaged map (convf == mapf, pitch W < Wp: output rows <= y only ever cover
 // map rows <= y), and later bands still read the map. So only the LAST band writes its outputs in place; an earlier band
