@@ -19,6 +19,9 @@ FLIP = list(D.COCO_FLIP_INDICES)
 def _codec(name_or_hw):
     from probpose_code_amd import KEYPOINT_CODECS
 
+    if not isinstance(name_or_hw, str) and name_or_hw not in ((64, 48), (96, 72)):
+        H, W = name_or_hw  # any other heatmap size (input = 4 x heatmap, like the two configs)
+        return KEYPOINT_CODECS.build(dict(type="ProbMap", input_size=(4 * W, 4 * H), heatmap_size=(W, H), sigma=-1))
     small = name_or_hw.startswith("s_") if isinstance(name_or_hw, str) else name_or_hw == (64, 48)
     cfg = (
         dict(type="ProbMap", input_size=(192, 256), heatmap_size=(48, 64), sigma=-1)
@@ -130,7 +133,7 @@ def test_convolved_map_stress_vs_scipy_direct_sum():
     assert mism_kp == 0, f"{mism_kp} keypoint coordinates differ"
 
 
-@pytest.mark.parametrize("hw", [(64, 48), (96, 72)])
+@pytest.mark.parametrize("hw", [(64, 48), (96, 72), (128, 96), (36, 28)])
 def test_banded_row_pass_matches_one_band(hw):
     """The fp64 row pass lives in a BAND of row slots (pp_decode.hip conv_banded). With the buffer sized for five workgroups
     per CU (option decode_wgs_per_cu) a dense 64 x 48 map takes several bands - outputs of one band parked while the
@@ -158,6 +161,8 @@ def test_banded_row_pass_matches_one_band(hw):
         for b in (0, 7, 13):  # and the one-band run against scipy's direct sum
             want = np.stack([D.convolve_scipy(hm[b, k], kerns[k]) for k in range(K)])
             assert np.array_equal(ref["conv"][b], want)
+            k_ref, _ = D.probmap_decode(hm[b], tuple(codec.input_size), tuple(codec.heatmap_size))
+            assert np.array_equal(ref["keypoints"][b][None], k_ref, equal_nan=True)
         for wgs in (5, 4, 3, 2):
             _lib.set_option("decode_wgs_per_cu", wgs)
             out = codec.decode_device(x, return_conv=True)
