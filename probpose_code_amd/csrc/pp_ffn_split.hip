@@ -336,7 +336,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
         }
     };
 #ifndef FFS_GELU_IN_C
-#define FFS_GELU_IN_C 0  // 1 = the B-steps' GELU pair runs in the MFMA segment C(s), two or three VALU instructions behind each MFMA (gelu_stage), not in L(s): measured 200.0 vs 198.7 us, same bits - the VALU work is not what the L segments wait for
+#define FFS_GELU_IN_C 0  // 1 = the B-steps' GELU pair runs in the MFMA segment C(s), two or three VALU instructions behind each MFMA (gelu_stage), not in L(s): measured 200.0 vs 198.7 us, same bits. (In that build the compiler sinks the stages to their first use - one clump behind the last MFMAs; with every stage's values pinned by an empty asm the ISA does alternate MFMA / two VALU as intended and measures 198.8 vs 197.6 us: the erfc arithmetic costs its ~17 us per launch wherever it is issued - both waves of a SIMD are short of issue time, not one of them)
 #endif
     // The same pair, cut into 24 stages of two or three VALU instructions (a transcendental has a stage to itself): stage k sits
     // behind the k-th MFMA of a B-step's C segment - a 16x16x32 MFMA holds the matrix pipe for 16 cycles and takes 4 to issue,
