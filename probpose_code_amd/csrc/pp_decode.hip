@@ -18,7 +18,10 @@ namespace pp {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RM = PP_MAX_RADIUS;  // every map is padded by the largest radius
-constexpr int DEC_THREADS = 256;
+#ifndef PP_DEC_THREADS
+#define PP_DEC_THREADS 256  // dev A/B: 128 (two waves per workgroup, 64 x 48 maps only) measured 53 us against 36: the chain gets longer, nothing is saved
+#endif
+constexpr int DEC_THREADS = PP_DEC_THREADS;
 constexpr int GX = 6;  // outputs per work item in the row pass (sliding register window)
 constexpr int GY = 4;  // outputs per work item in the column pass
 constexpr int RED_BYTES = 512;  // cross-wave reduction scratch at the head of the dynamic LDS region

@@ -18,7 +18,7 @@ fi = eng._flip_indices(S.COCO_FLIP_INDICES)
 def run(lg, T, nb=B):
     _lib.call("pp_probmap_head_decode", lg.data_ptr(), lg[B:].data_ptr(), fi.data_ptr(), eng.taps.data_ptr(), eng.radius.data_ptr(), nb, 17, 64, 48,
               192.0, 256.0, T, 1.0, None, None, ws["locs"].data_ptr(), ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), None)
-for wgs in (5, 4, 3, 2):
+for wgs in [int(x) for x in os.environ.get('DECODE_WGS', '5 4 3 2').split()]:
   _lib.set_option("decode_wgs_per_cu", wgs)
   print("decode_wgs_per_cu", wgs)
   for name, lg, T in (("model logits, T=0.5 (sparse)", logits, 0.5), ("noise logits, T=50 (dense support)", torch.randn_like(logits), 50.0)):
