@@ -7,10 +7,11 @@ from probpose_code_amd import ProbPoseEngine
 from probpose_code_amd import synthetic as S
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 img = (384, 288)
 sd = S.synthetic_state_dict("base", img_size=img, seed=0, logit_scale=2.0)
 x = S.synthetic_crops(B, img_size=img, seed=1).cuda()
-eng = ProbPoseEngine(sd, 12, img_size=img, precision="bf16", input_size=(288, 384))
+eng = ProbPoseEngine(sd, 12, img_size=img, precision=PREC, input_size=(288, 384))
 for _ in range(3): eng.forward(x, True, S.COCO_FLIP_INDICES)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
