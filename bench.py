@@ -84,6 +84,7 @@ def parse(argv=None):
     ap.add_argument("--no-second-mode", "--no-parity-mode", dest="no_second_mode", action="store_true",
                     help="skip the second bench in the other precision (bf16 `throughput_mode` beside an f16x3 headline and vice versa)")
     ap.add_argument("--no-config4", action="store_true", help="skip the bounded ViT-B 384x288 record")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the `drop_in` record (model.test_step / test_step_stream timed)")
     ap.add_argument("--no-bs512-decode", action="store_true",
                     help="skip roofline_targets.head_decode_bs512 (counter passes: its launches would mix into the step's decode kernel)")
     ap.add_argument("--in-flight", type=int, default=2,
@@ -249,6 +250,77 @@ def sustained_mfma_rate():
     except (OSError, ValueError):
         pass
     return None
+
+
+
+class ClockProbe:
+    """Average shader clock over the timed loop: pp_clock_probe (one sleeping wavefront that brackets wall time with s_memtime and
+    the 100 MHz s_memrealtime) on a side stream of its own, started with the loop and stopped - through a word in pinned host
+    memory - when the loop's last step has been submitted (the device is then at most `steps in flight` steps from the end)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.words = torch.zeros(3, dtype=torch.int64).pin_memory()  # [cycles, ticks, stop]
+        self.stream = torch.cuda.Stream(device=dev)
+        self.running = False
+
+    def start(self, max_us=4_000_000):
+        from probpose_code_amd import _lib
+
+        self.words.zero_()
+        base = self.words.data_ptr()
+        _lib.call("pp_clock_probe", base, base + 16, int(max_us), self.stream.cuda_stream)
+        self.running = True
+
+    def stop(self):
+        self.words[2] = 1  # plain host store; the wavefront polls it with a system-scope load every few microseconds
+
+    def read(self):
+        if not self.running:
+            return None
+        self.stop()
+        self.stream.synchronize()
+        self.running = False
+        cyc, ticks = int(self.words[0]), int(self.words[1])
+        if ticks <= 0:
+            return None
+        return {"shader_clock_MHz": cyc / ticks * 100.0, "window_ms": ticks / 1e5,
+                "how": "pp_clock_probe: s_memtime cycles / s_memrealtime (100 MHz) ticks of one sleeping wavefront on a side stream, from the "
+                       "start of the timed loop to the submission of its last step"}
+
+
+def device_limits(index=0):
+    """Power cap / clock limits of the GPU the bench ran on, best effort (sysfs first, rocm-smi second; absent on a box without
+    them): lets a driver-side number be normalised for the box-to-box clock spread."""
+    import glob
+
+    out = {}
+    try:
+        out["max_clock_MHz"] = torch.cuda.get_device_properties(index).clock_rate / 1e3
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap"))
+        if cards:
+            out["power_cap_W"] = [int(open(c).read()) / 1e6 for c in cards][min(index, len(cards) - 1)]
+            avg = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"))
+            if avg:
+                out["power_now_W"] = int(open(avg[min(index, len(avg) - 1)]).read()) / 1e6
+    except Exception:  # noqa: BLE001
+        pass
+    if "power_cap_W" not in out:
+        try:
+            r = subprocess.run(["rocm-smi", "-d", str(index), "--showmaxpower", "--showpower", "--json"], capture_output=True, text=True, timeout=20)
+            js = json.loads(r.stdout)
+            card = next(iter(js.values()))
+            for k, v in card.items():
+                if "Max Graphics Package Power" in k:
+                    out["power_cap_W"] = float(v)
+                elif "Package Power" in k and "Max" not in k:
+                    out["power_now_W"] = float(v)
+        except Exception:  # noqa: BLE001
+            pass
+    return out
 
 
 def roofline_record(eng, B, prof, reps):
@@ -480,7 +552,7 @@ class StubEngine:
 
 
 # ------------------------------------------------------------------------------------------ one timed run
-def timed_run(eng, crops, gather, flip, steps, warmup, use_graph, dist_mod, dev, depth=1, world=1):
+def timed_run(eng, crops, gather, flip, steps, warmup, use_graph, dist_mod, dev, depth=1, world=1, probe=None):
     """W untimed + exactly K timed steps bracketed by barrier + synchronize; returns this rank's seconds and host
     copies of the LAST TIMED step's outputs (what the graph replay left in the engine's output buffers).
     ``depth`` > 1: consecutive steps go to consecutive slots of a StepPipeline (own stream, workspace, graph and pinned
@@ -515,9 +587,13 @@ def timed_run(eng, crops, gather, flip, steps, warmup, use_graph, dist_mod, dev,
     for _ in range(warmup):
         step()
     barrier()
+    if probe is not None:
+        probe.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if probe is not None:
+        probe.stop()  # (a host store: the probe's wavefront has left the chip long before the closing synchronize returns)
     barrier()
     dt = time.perf_counter() - t0
     if pipe is not None:
@@ -611,6 +687,65 @@ def config4_record(dev, args):
     return rec
 
 
+
+def drop_in_record(dev, args, sd, B):
+    """The drop-in call timed: `model.test_step(batch)` - what the reference's callers drive (mmpose/apis/inference.py:195-196;
+    tools/test.py:115-136 through mmengine's `Runner.test()`) - on the estimator built from the config through the registry,
+    batches as `apis.pack_crops` makes them (`pseudo_collate` layout: a list of B uint8 CHW crops + B PoseDataSample), the host
+    side included: preprocessor stacking, the engine's graph replay, ONE record copy to pinned host memory, B `InstanceData` /
+    `PoseDataSample` built and mapped to image space. `test_step`: strictly one batch at a time, the host packaging after the
+    device has finished; `test_step_stream(depth=2)`: the packaging of batch n under the device's work on batch n + 1."""
+    from probpose_code_amd import apis
+    from probpose_code_amd import synthetic as S
+
+    cfg = os.path.join(ROOT, "configs", "td-pm_ProbPose-small_mi355x_coco-256x192.py")
+    model = apis.init_model(cfg, {"state_dict": sd}, device=str(dev), cfg_options={"model.precision": args.precision})
+    rng = np.random.default_rng(11)
+    center = np.stack([rng.uniform(80, 400, B), rng.uniform(100, 500, B)], -1).astype(np.float32)
+    scale = (np.array([192, 256], np.float32) * rng.uniform(0.8, 2.5, (B, 1)).astype(np.float32) * 1.25).astype(np.float32)
+    crops = [S.synthetic_crops(B, seed=200 + i).to(dev) for i in range(3)]
+    batches = [apis.pack_crops(c, center, scale, model.dataset_meta) for c in crops]  # three batch dicts: none is in flight twice
+    steps, warm = min(args.steps, 30), 4
+    rec = {"what": "crops/s of the drop-in entry points on the registry-built estimator, host packaging included; inputs = pack_crops batches "
+                   f"(list of {B} device-resident uint8 crops + {B} PoseDataSample); ProbPose-small, flip_test=True, {args.precision}",
+           "steps": steps, "warmup": warm, "batch": B}
+    with torch.no_grad():
+        for i in range(warm):  # (first call of a size: launches one by one; second: graph capture; then replays)
+            model.test_step(batches[i % 3])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            res = model.test_step(batches[i % 3])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rec["test_step"] = {"value": B * steps / dt, "unit": "crops/s", "ms_per_batch": dt / steps * 1e3}
+        kp_sync = np.stack([r.pred_instances.keypoints for r in res])
+        # host-side share of a test_step: the same call with the device work already done is not separable; time the packaging alone
+        t1 = time.perf_counter()
+        for i in range(steps):
+            data = model.data_preprocessor(batches[i % 3], False)
+        torch.cuda.synchronize()
+        rec["test_step"]["preprocessor_ms"] = (time.perf_counter() - t1) / steps * 1e3
+        for depth in (2,):
+            gen = model.test_step_stream((batches[i % 3] for i in range(warm + steps)), depth=depth, max_batch=B)
+            for _ in range(warm):
+                next(gen)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            last = None
+            for last in gen:
+                pass
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            rec[f"test_step_stream_depth{depth}"] = {"value": B * steps / dt, "unit": "crops/s", "ms_per_batch": dt / steps * 1e3}
+            kp_stream = np.stack([r.pred_instances.keypoints for r in last])
+            rec[f"test_step_stream_depth{depth}"]["identical_to_test_step"] = bool(np.array_equal(kp_stream, kp_sync)) \
+                if (warm + steps - 1) % 3 == (steps - 1) % 3 else None
+    del model
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
@@ -670,7 +805,9 @@ def main(argv=None):
     eng = make_engine(args.precision)
     gather = ResultGather(B, eng.K, dev, world)  # fixed-layout result record, pinned host copy, RCCL all_gather
     depth = max(1, args.in_flight)
-    dt_rank, snap = timed_run(eng, crops, gather, flip, args.steps, args.warmup, use_graph, dist, dev, depth, world)
+    probe = ClockProbe(dev) if not args.stub else None
+    dt_rank, snap = timed_run(eng, crops, gather, flip, args.steps, args.warmup, use_graph, dist, dev, depth, world, probe=probe)
+    clock = probe.read() if probe is not None else None
     dt, rank_secs, rank_devs = reduce_times(dt_rank, dist, dev, world, local_rank)
     # the PCIe-inclusive rate: every step's crops start in pinned HOST memory (never `value`: the boundary hands over device
     # buffers); the host-to-device copy rides on a copy stream under the kernels in flight (pipeline.StepPipeline.submit)
@@ -749,6 +886,11 @@ def main(argv=None):
             line["stub_gather_ok"] = bool(all(rec[r, i, 0, 0] == r * 1000 + i for r in range(world) for i in (0, B - 1)))
             print(json.dumps(line))
         else:
+            # the clock the timed loop ran at on this box (rank 0's GPU) and the limits it ran under: the box-to-box spread of
+            # `value` is clock spread, `value / shader_clock_MHz` is the box-independent figure
+            line["clock"] = dict(clock or {}, **device_limits(local_rank))
+            if clock:
+                line["clock"]["crops_per_s_per_GHz"] = line["value"] / (clock["shader_clock_MHz"] / 1e3)
             line["kernel_ms_per_step"], line["roofline"] = roofline_record(eng, B, *prof)
             line["roofline_targets"] = secondary_rooflines(eng, B, *prof, bs512=not args.no_bs512_decode)
             ref = None
@@ -789,6 +931,14 @@ def main(argv=None):
                 if second == THROUGHPUT_PRECISION:
                     line[second_key]["note"] = ("bf16 operands are narrower arithmetic than the fp32 reference: outside the path's 1e-3 "
                                                 "tolerance (see parity_vs_oracle of this record); reported for comparison, never as `value`")
+            if world == 1 and not args.no_drop_in:
+                try:
+                    line["drop_in"] = drop_in_record(dev, args, sd, B)
+                    for k in ("test_step", "test_step_stream_depth2"):
+                        if k in line["drop_in"]:
+                            line["drop_in"][k]["frac_of_headline"] = line["drop_in"][k]["value"] / line["value"]
+                except Exception as exc:  # noqa: BLE001 -- a secondary record must not take the bench line down
+                    line["drop_in"] = {"error": repr(exc)[:300]}
             if world == 1 and not args.no_config4:
                 line["config4"] = config4_record(dev, args)
             print(json.dumps(line))

@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 1
+/* 2: + pp_clock_probe, pp_conv3x3_splitk_slices, option "ksplit9_below"; PP_WS_TOWER_PARTIAL sized for the slice count the
+ *    library itself picks (round 3 added pp_workspace_bytes / pp_set_option / the split-fp16 layer kernels under version 1). */
+#define PP_ABI_VERSION 2
 
 enum {
     PP_OK = 0,
@@ -65,6 +67,7 @@ int pp_device_cu_count(void);
  *   "conv_pool_split" (1)    0: split-fp16 first tower stage as two launches (conv, then pooling)
  *   "decode_wgs_per_cu" (3)  pp_probmap_(head_)decode: workgroups per CU its LDS band buffer is sized for (5 .. 1)
  *   "qkv_attn_pair" (0)      1: pp_qkv_attention_split with a head pair per workgroup (measured slower; kept for A/B)
+ *   "ksplit9_below" (1024)   pp_conv3x3_splitk_slices: output rows under which a small tower stage is cut into nine K-slices
  * Unknown names return PP_ERR_INVALID_ARG. Not thread-safe against concurrent launches (set them before the first call).
  * (probpose_code_amd/_lib.py forwards PP_OPT_<NAME>=<int> environment variables here at import - host-side convenience.) */
 int pp_set_option(const char* name, int value);
@@ -91,10 +94,25 @@ enum {
     PP_WS_LOGITS = 8,        /* (n_img, K, heat_h * heat_w) fp32                                                           */
     PP_WS_DECONV = 9,        /* output of deconvolution `index`, NHWC operand format                                       */
     PP_WS_TOWER = 10,        /* (4, n_img, h, w, embed) operand format: convolution output of tower stage `index`         */
-    PP_WS_TOWER_PARTIAL = 11,/* (3, 4, n_img, h, w, embed) fp32: split-K partial sums of tower stage `index`               */
+    PP_WS_TOWER_PARTIAL = 11,/* (slices, 4, n_img, h, w, embed) fp32: split-K partial sums of tower stage `index`, slices =
+                              * pp_conv3x3_splitk_slices(n_img * h * w)                                                    */
     PP_WS_TOWER_POOLED = 12  /* (4, n_img, h / ph, w / pw, embed) operand format: pooled output of tower stage `index`     */
 };
 long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* shape);
+
+/* K-slices of pp_conv3x3_splitk for a tower stage with `rows` = n_img * h * w output pixels (probmap_head.py:261-294, the 4 x 4
+ * and 2 x 2 stages): 3 = one kernel row of taps per slice, 9 = one tap per slice when the stage has fewer rows than option
+ * "ksplit9_below" (too few tiles to fill the chip otherwise). The caller passes this count to pp_conv3x3_splitk /
+ * pp_sum_maxpool_relu_nhwc; PP_WS_TOWER_PARTIAL is sized for it. */
+int pp_conv3x3_splitk_slices(int rows);
+
+/* Measurement aid (bench hygiene, no reference counterpart): one wavefront that sleeps on `stream` until *stop_flag becomes
+ * non-zero (stop_flag: a word both sides can address - pinned host memory the caller sets with a plain store; NULL = no flag) or
+ * `max_microseconds` (<= 5 000 000) of wall time have passed, then writes out[0] = shader-clock cycles (s_memtime) and out[1] =
+ * ticks of the constant 100 MHz counter (s_memrealtime) it saw meanwhile: out[0] / out[1] * 100 = the average shader clock in
+ * MHz over that window. Launched on a side stream beside a timed loop it records the clock the loop actually ran at (box-to-box
+ * spread is clock spread). `out` may be pinned host memory too. */
+int pp_clock_probe(unsigned long long* out_cycles_ticks, const unsigned long long* stop_flag, unsigned int max_microseconds, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * ProbMap decode, fused with the flip-test average.

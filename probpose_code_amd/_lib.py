@@ -55,6 +55,8 @@ SIGNATURES = {
     "pp_set_option": (c_int, [c_char_p, c_int]),
     "pp_get_option": (c_int, [c_char_p, _P]),
     "pp_workspace_bytes": (c_longlong, [c_int, c_int, _P]),
+    "pp_conv3x3_splitk_slices": (c_int, [c_int]),
+    "pp_clock_probe": (c_int, [_P, _P, ctypes.c_uint, _P]),
     "pp_probmap_decode": (
         c_int,
         [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, _P, _P, _P, _P, _P, _P],
@@ -152,10 +154,17 @@ def get_option(name: str) -> int:
 
 
 def _options_from_env() -> None:
-    """Host-side convenience (the C library itself never reads the environment): PP_OPT_<NAME>=<int> -> pp_set_option."""
+    """Host-side convenience (the C library itself never reads the environment): PP_OPT_<NAME>=<int> -> pp_set_option, once,
+    at import. A stray or malformed variable is reported and skipped - it must not make the package unimportable."""
+    import warnings
+
     for k, v in os.environ.items():
-        if k.startswith("PP_OPT_"):
+        if not k.startswith("PP_OPT_"):
+            continue
+        try:
             set_option(k[len("PP_OPT_"):].lower(), int(v))
+        except (ValueError, ProbPoseLibraryError) as exc:
+            warnings.warn(f"ignoring {k}={v!r}: {exc}", RuntimeWarning, stacklevel=2)
 
 
 def last_error() -> str:

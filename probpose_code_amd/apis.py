@@ -161,6 +161,7 @@ def _frame_batch(model, img, bboxes, bbox_format):
     """(image, boxes) -> the ``test_step`` batch dict of ``inference_topdown``: one ``data_info`` per box through the config's
     val pipeline (box arithmetic on the host, ONE warp launch for all boxes of the image), then ``pseudo_collate``."""
     pipeline = _val_pipeline(model)
+    img_path = img if isinstance(img, str) else None  # kept beside the decoded-once pixels (apis/inference.py:182-186: dict(img_path=img))
     if bboxes is None or len(bboxes) == 0:
         if isinstance(img, str):
             img = load_image_bgr(img)  # (the reference opens the file for its size, then LoadImage reads it again per box)
@@ -176,7 +177,9 @@ def _frame_batch(model, img, bboxes, bbox_format):
     data_list = []
     for bbox in bboxes:
         data_info = dict(img=img)
-        data_info["bbox"] = np.asarray(bbox, np.float32)[None, :4]  # shape (1, 4)
+        if img_path is not None:
+            data_info["img_path"] = img_path  # LoadImage keeps an existing img_path; PackPoseInputs forwards it as metainfo
+        data_info["bbox"] = bbox[None, :4]  # shape (1, 4), dtype as given (:185; a trailing score column is dropped, the reference's bbox_xyxy2cs would choke on it)
         data_info["bbox_score"] = np.ones(1, dtype=np.float32)  # shape (1,)
         data_info.update(model.dataset_meta)
         data_list.append(data_info)

@@ -29,12 +29,32 @@ static Option g_options[] = {
     {"conv_pool_split", 1},    // 0: split-fp16 first tower stage as conv + pooling launches instead of pooling in the conv epilogue
     {"decode_wgs_per_cu", 3},  // most workgroups per CU the decode kernel sizes its band buffer for (5 .. 1): more than 3 measured slower at bs 64 (4.25 workgroups per CU are balanced by the dispatcher, not by residency; smaller buffers mean more bands)
     {"qkv_attn_pair", 0},      // 1: pp_qkv_attention_split with a head PAIR per workgroup (one workgroup per CU; measured slower)
+    {"ksplit9_below", 1024},   // pp_conv3x3_splitk_slices: tower stages with fewer output rows than this take nine K-slices (one tap each) instead of three
 };
 
 int option(const char* name) {
     for (const Option& o : g_options)
         if (std::strcmp(o.name, name) == 0) return o.value;
     return 0;
+}
+
+// One wavefront that brackets a stretch of wall time with the shader-clock counter (s_memtime) and the constant 100 MHz
+// counter (s_memrealtime): cycles / ticks * 100 = the average shader clock in MHz while it ran. It ends when *stop becomes
+// non-zero (a host-visible word the caller sets with a plain store) or after `ticks` of the 100 MHz counter.
+__global__ void clock_probe_kernel(unsigned long long* out, const unsigned long long* stop, unsigned long long ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    for (long long guard = 0; guard < (1ll << 21) && r1 - r0 < ticks; ++guard) {
+        if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+        __builtin_amdgcn_s_sleep(127);  // ~127 x 64 cycles asleep per poll: the wave issues next to nothing
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    __hip_atomic_store(out + 0, c1 - c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(out + 1, r1 - r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace pp
@@ -102,7 +122,8 @@ long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* sh) {
             long long h, w, ph, pw;
             tower_hw(index, h, w, ph, pw);
             if (buffer == PP_WS_TOWER) return 4ll * sh->n_img * h * w * E * esz;
-            if (buffer == PP_WS_TOWER_PARTIAL) return 3ll * 4 * sh->n_img * h * w * E * 4;   // three K-slices, fp32
+            if (buffer == PP_WS_TOWER_PARTIAL)   // K-slices as pp_conv3x3_splitk_slices says for this stage's rows, fp32
+                return (long long)pp_conv3x3_splitk_slices((int)(sh->n_img * h * w)) * 4 * sh->n_img * h * w * E * 4;
             return 4ll * sh->n_img * (h / ph) * (w / pw) * E * esz;
         }
         default: break;
@@ -110,6 +131,8 @@ long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* sh) {
     set_error("pp_workspace_bytes: unknown buffer %d (index %d)", buffer, index);
     return PP_ERR_INVALID_ARG;
 }
+
+int pp_conv3x3_splitk_slices(int rows) { return rows < pp::option("ksplit9_below") ? 9 : 3; }
 
 int pp_abi_version(void) { return PP_ABI_VERSION; }
 
@@ -124,6 +147,16 @@ const char* pp_status_string(int status) {
         case PP_ERR_WORKSPACE: return "PP_ERR_WORKSPACE";
         default: return "PP_ERR_UNKNOWN";
     }
+}
+
+int pp_clock_probe(unsigned long long* out_cycles_ticks, const unsigned long long* stop_flag, unsigned int max_microseconds, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(out_cycles_ticks, PP_ERR_INVALID_ARG, "pp_clock_probe: NULL output");
+    PP_REQUIRE(max_microseconds <= 5000000u, PP_ERR_INVALID_ARG, "pp_clock_probe: at most 5 s");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_cycles_ticks, stop_flag,
+                       (unsigned long long)max_microseconds * 100ull);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
 }
 
 int pp_device_cu_count(void) {

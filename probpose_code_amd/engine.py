@@ -40,12 +40,13 @@ PLAN_DEFAULTS = dict(fuse_mlp=True, fuse_proj=True, fuse_qkv=True, split_k=True,
 
 
 def plan_from_env() -> Dict[str, object]:
-    """PP_FUSE_MLP=0 ... -> {fuse_mlp: False, ...}; PP_FUSE_RESLN=1 / 0 -> True / False. Dev convenience only."""
+    """PP_FUSE_MLP=0 / 1 ... -> {fuse_mlp: False / True, ...}. Dev convenience only, read ONCE per engine, in the constructor;
+    any other value leaves the switch at its default (a stray variable must not change the plan)."""
     out: Dict[str, object] = {}
     for k in PLAN_DEFAULTS:
         v = os.environ.get("PP_" + k.upper())
-        if v is not None:
-            out[k] = (v == "1") if k == "fuse_resln" else (v != "0")
+        if v in ("0", "1"):
+            out[k] = v == "1"
     return out
 
 
@@ -131,6 +132,10 @@ class ProbPoseEngine:
                                   _lib.stream_ptr(self.device))
                         self._proj_packed[i] = pbuf
                 torch.cuda.synchronize(self.device)
+            # the fused launches read only the packed copies: release the plain ones (55 MiB at ViT-S)
+            for i in range(self.w.num_layers):
+                for name in (f"l{i}.fc1.w", f"l{i}.fc2.w") + ((f"l{i}.proj.w",) if i in self._proj_packed else ()):
+                    self.w.t.pop(name, None)
         # f16x3, 192-token sequences of 32-dim heads: qkv Linear + attention of a layer in one launch, one workgroup per
         # (sequence, head); the qkv tensor never reaches HBM (pp_qkv_attn_split.hip). PP_FUSE_QKV_ATTN=0: pp_gemm + pp_attention
         self.fuse_qkv_attn = precision == "f16x3" and pl["fuse_qkv_attn"] and self.Np == 192 and self.hd == 32 and self.E == 384
@@ -152,10 +157,10 @@ class ProbPoseEngine:
 
     def ksplit(self, rows: int) -> int:
         """K-slices of a small tower convolution with `rows` output pixels over the batch (3 = one kernel row of taps per slice,
-        9 = one tap). Stages with fewer than 1024 rows (the 2 x 2 maps at bs 64: 144 tiles for 256 CUs with three slices) take nine:
-        split-K launch 48 -> 27 us, the nine-way sum costs 5 us more (dev override: PP_KSPLIT9_BELOW=<rows>)."""
-        thr = int(os.environ.get("PP_KSPLIT9_BELOW", "1024"))
-        return 9 if rows < thr else 3
+        9 = one tap): the library's own rule (pp_conv3x3_splitk_slices; PP_WS_TOWER_PARTIAL is sized by the same rule). Stages
+        with fewer than 1024 rows (the 2 x 2 maps at bs 64: 144 tiles for 256 CUs with three slices) take nine: split-K launch
+        48 -> 27 us, the nine-way sum costs 5 us more (dev switch: pp_set_option("ksplit9_below", rows))."""
+        return int(_lib.lib.pp_conv3x3_splitk_slices(int(rows)))
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, B: int, passes: int, slot: int = 0) -> Dict[str, torch.Tensor]:
@@ -205,8 +210,7 @@ class ProbPoseEngine:
             ws[f"t{j}"] = buf("tower", (4, nb, th, tw, E), index=j)
             if nb * th * tw * 4 < 128 * 128:
                 ks = self.ksplit(nb * th * tw)
-                ws[f"tp{j}"] = (buf("tower_partial", (3, 4, nb, th, tw, E), f32, index=j) if ks == 3  # split-K partial sums of the small tower stages
-                                else e(ks, 4, nb, th, tw, E, dt=f32))
+                ws[f"tp{j}"] = buf("tower_partial", (ks, 4, nb, th, tw, E), f32, index=j)  # split-K partial sums of the small tower stages
             ws[f"p{j}"] = buf("tower_pooled", (4, nb, th // ph, tw // pw_, E), index=j)
         self._ws[key] = ws
         return ws

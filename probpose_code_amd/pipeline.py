@@ -32,6 +32,11 @@ class StepPipeline:
             raise ValueError("depth must be >= 1")
         self.engine, self.batch, self.depth = engine, batch, depth
         self.flip_test, self.flip_indices = flip_test, flip_indices
+        # True: every batch has exactly ``batch`` rows and replays the slot's captured graph (captured here, up front);
+        # "full": batches of exactly ``batch`` rows replay the slot's graph (captured when the first one arrives in the slot),
+        # smaller ones are launched kernel by kernel; False: always kernel by kernel
+        if use_graph not in (True, False, "full"):
+            raise ValueError(f"use_graph must be True, False or 'full', got {use_graph!r}")
         self.use_graph = use_graph
         dev = torch.device(engine.device)
         self.device = dev
@@ -50,7 +55,7 @@ class StepPipeline:
         self._staged_ev: List[Optional[torch.cuda.Event]] = [None] * depth
         self._consumed_ev: List[Optional[torch.cuda.Event]] = [None] * depth
         self._copy_stream = torch.cuda.Stream(device=dev) if (self.cuda and depth > 1) else None
-        if use_graph and self.cuda:
+        if use_graph is True and self.cuda:
             for j in range(depth):
                 self._dev_in[j] = engine.capture(batch, flip_test, flip_indices, slot=j)
         if self.cuda:
@@ -100,7 +105,8 @@ class StepPipeline:
                 else:  # depth 1: nothing to hide the copy under
                     self._dev_in[j][:n].copy_(crops_u8, non_blocking=True)
                 crops_u8 = self._dev_in[j][:n]
-            if self.use_graph:
+            if self.use_graph is True or (self.use_graph == "full" and self.cuda and crops_u8.shape[0] == self.batch
+                                          and crops_u8.dtype == torch.uint8):
                 out = eng.forward_graph(crops_u8, self.flip_test, self.flip_indices, slot=j)
             else:
                 out = eng.forward(crops_u8, self.flip_test, self.flip_indices, slot=j)

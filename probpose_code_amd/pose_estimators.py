@@ -291,7 +291,8 @@ class ProbMapHead(nn.Module):
         if flip:
             assert isinstance(feats, list) and len(feats) == 2
             if test_cfg.get("flip_mode", "heatmap") != "heatmap" or test_cfg.get("shift_heatmap", False):
-                raise NotImplementedError("MI355X head implements flip_mode='heatmap', shift_heatmap=False (ProbPose config)")
+                raise NotImplementedError("MI355X head implements flip_mode='heatmap', shift_heatmap=False (models/utils/tta.py:35-39; "
+                                          "the ProbPose config): the flip merge is fused into the decode kernel")
             flip_indices = batch_data_samples[0].metainfo["flip_indices"]
             x = torch.cat([self._to_nhwc(feats[0]), self._to_nhwc(feats[1])])
         else:
@@ -301,18 +302,28 @@ class ProbMapHead(nn.Module):
         return self.pack_predictions(out, test_cfg)
 
     def pack_predictions(self, out: Dict[str, Tensor], test_cfg: dict = {}):
-        """probmap_head.py:779-804: device results -> list of InstanceData (+ PixelData)."""
+        """probmap_head.py:779-804: device results -> list of InstanceData (+ PixelData). One ``pp_pack_records`` launch and ONE
+        device-to-host copy bring the whole batch back (the estimator's ``predict`` uses its own pinned buffer for that and
+        calls ``pack_records`` directly)."""
+        from .dist import pack_records as _pack
+
+        rec = _pack(out).cpu().numpy()  # (B, K, 7) float64: x, y, conf, prob, vis, oks, err (raw)
+        return self.pack_records(rec, test_cfg, out.get("heatmaps"))
+
+    def pack_records(self, rec: np.ndarray, test_cfg: dict = {}, heatmaps: Optional[Tensor] = None):
+        """probmap_head.py:779-804 from the batch's host record ``rec`` (B, K, 7) float64 [x, y, conf, prob, vis, oks, raw error]
+        (float32 device results widened exactly, so narrowing them back is exact too). Every field of the batch is cut out of
+        the record ONCE; the per-crop ``InstanceData`` hold (1, K[, 2]) views of those batch arrays - no per-crop copies."""
         eng = self._engine
-        kpts = out["keypoints"].cpu().numpy()
-        conf = out["scores"].cpu().numpy()
-        sc = out["scalars"].cpu().numpy()
-        B, C = conf.shape
-        probabilities, visibilities, oks, errors = (sc[i].reshape((B, 1, C)) for i in range(4))
-        errors = errors / np.sqrt(eng.Hh**2 + eng.Wh**2)  # :786-787
+        B, C = rec.shape[:2]
+        kpts = np.ascontiguousarray(rec[..., :2])  # float64, like the reference's decode (codecs/probmap.py:218)
+        sc = np.ascontiguousarray(np.moveaxis(rec[..., 2:7], -1, 0).astype(np.float32))  # (5, B, K): conf, prob, vis, oks, err
+        conf, probabilities, visibilities, oks, errors = (sc[i].reshape(B, 1, C) for i in range(5))
+        errors = errors / np.sqrt(eng.Hh**2 + eng.Wh**2)  # :786-787, the same expression (its result dtype is numpy's promotion rule's)
         preds = []
         for pi in range(B):
-            p = InstanceData(keypoints=kpts[pi][None], keypoint_scores=conf[pi][None])
-            p.set_field(p["keypoint_scores"], "keypoints_conf")
+            p = InstanceData(keypoints=kpts[pi:pi + 1], keypoint_scores=conf[pi])
+            p.set_field(conf[pi], "keypoints_conf")
             p.set_field(probabilities[pi], "keypoints_probs")
             p.set_field(visibilities[pi], "keypoints_visible")
             p.set_field(oks[pi], "keypoints_oks")
@@ -321,7 +332,8 @@ class ProbMapHead(nn.Module):
                 p.set_field(oks[pi], "keypoint_scores")
             preds.append(p)
         if test_cfg.get("output_heatmaps", False):
-            return preds, [PixelData(heatmaps=hm) for hm in out["heatmaps"].detach().clone()]
+            assert heatmaps is not None, "output_heatmaps needs the engine's heatmaps"
+            return preds, [PixelData(heatmaps=hm) for hm in heatmaps.detach().clone()]
         return preds
 
     def loss(self, *a, **k):
@@ -341,7 +353,7 @@ class TopdownPoseEstimator(nn.Module):
     def __init__(self, backbone: dict, neck: Optional[dict] = None, head: Optional[dict] = None,
                  train_cfg: Optional[dict] = None, test_cfg: Optional[dict] = None,
                  data_preprocessor: Optional[dict] = None, init_cfg=None, metainfo: Optional[dict] = None,
-                 precision: str = "f16x3"):
+                 precision: str = "f16x3", graph_replay: bool = True):
         super().__init__()
         if neck is not None:
             raise NotImplementedError("the ProbPose config has no neck")
@@ -349,6 +361,11 @@ class TopdownPoseEstimator(nn.Module):
         self.train_cfg = train_cfg if train_cfg else {}
         self.test_cfg = test_cfg if test_cfg else {}
         self.precision = precision
+        # ``predict`` replays the engine's captured hipGraph for a batch size it has met before (the first batch of a size runs
+        # the same launches one by one - a one-off size never pays for a capture); False: always kernel by kernel
+        self.graph_replay = bool(graph_replay)
+        self._sizes_seen: Dict[tuple, int] = {}
+        self._gather = None  # ResultGather of ``predict``: pinned host record buffer, grown to the largest batch met
         self.backbone = MODELS.build(backbone)
         self.head = MODELS.build(head) if head is not None else None
         self.data_preprocessor = MODELS.build(data_preprocessor) if data_preprocessor is not None else PoseDataPreprocessor()
@@ -373,6 +390,8 @@ class TopdownPoseEstimator(nn.Module):
     # -- engine lifecycle: (re)built lazily from the module's own state_dict
     def reset_engine(self):
         self._engine = None
+        self._sizes_seen = {}
+        self._gather = None
 
     def _apply(self, fn, *args, **kwargs):  # .to(device) / .cuda() move the parameters -> rebuild
         self.reset_engine()
@@ -442,17 +461,43 @@ class TopdownPoseEstimator(nn.Module):
         x = self.extract_feat(inputs)
         return self.head.forward(x) if self.with_head else x
 
+    def _check_flip_cfg(self) -> bool:
+        flip = bool(self.test_cfg.get("flip_test", False))
+        if flip and self.test_cfg.get("flip_mode", "heatmap") != "heatmap":
+            raise NotImplementedError(
+                f"flip_mode={self.test_cfg.get('flip_mode')!r}: the MI355X path merges the flipped pass as flip_mode='heatmap' "
+                "(models/utils/tta.py:35-39; the ProbPose config); 'udp_combined' / 'offset' belong to other heads' outputs")
+        if flip and self.test_cfg.get("shift_heatmap", False):
+            raise NotImplementedError(
+                "shift_heatmap=True (tta.py:64-66: the flipped map moved one pixel to the right before averaging) is not built into "
+                "the fused flip-merge + decode kernel; the ProbPose config and every UDP config use shift_heatmap=False")
+        return flip
+
     def predict(self, inputs: Tensor, data_samples: list) -> list:
         """topdown.py:86-126, as ONE launch sequence: both flip-test passes are batched through the
-        backbone and the head consumes the features in place."""
+        backbone and the head consumes the features in place. A batch size met before replays the engine's captured
+        hipGraph (bit-identical to the launches one by one, tests/test_estimator_gpu.py); the results come back as ONE
+        fixed-layout record (``pp_pack_records``) through ONE copy into pinned host memory."""
+        from .dist import ResultGather
+
         assert self.with_head, "The model must have head to perform prediction."
-        flip = bool(self.test_cfg.get("flip_test", False))
+        flip = self._check_flip_cfg()
         flip_indices = data_samples[0].metainfo["flip_indices"] if flip else None
-        if flip and (self.test_cfg.get("flip_mode", "heatmap") != "heatmap" or self.test_cfg.get("shift_heatmap", False)):
-            raise NotImplementedError("MI355X path implements flip_mode='heatmap', shift_heatmap=False (ProbPose config)")
-        out = self.engine.forward(inputs, flip, flip_indices,
-                                  return_heatmaps=bool(self.test_cfg.get("output_heatmaps", False)))
-        preds = self.head.pack_predictions(out, self.test_cfg)
+        want_hm = bool(self.test_cfg.get("output_heatmaps", False))
+        eng = self.engine
+        B = int(inputs.shape[0])
+        key = (B, flip, tuple(flip_indices) if flip_indices is not None else None, want_hm)
+        seen = self._sizes_seen.get(key, 0)
+        self._sizes_seen[key] = seen + 1
+        if self.graph_replay and seen >= 1 and inputs.dtype == torch.uint8:
+            out = eng.forward_graph(inputs, flip, flip_indices, return_heatmaps=want_hm)
+        else:
+            out = eng.forward(inputs, flip, flip_indices, return_heatmaps=want_hm)
+        if self._gather is None or self._gather.batch < B:
+            self._gather = ResultGather(max(B, 64), eng.K, eng.device, 1)
+        self._gather(out)
+        rec = self._gather.wait()[0, :B].numpy().copy()  # the pinned buffer is reused by the next batch
+        preds = self.head.pack_records(rec, self.test_cfg, out.get("heatmaps"))
         if isinstance(preds, tuple):
             batch_pred_instances, batch_pred_fields = preds
         else:
@@ -463,27 +508,23 @@ class TopdownPoseEstimator(nn.Module):
         """Generator over an iterable of ``test_step`` batch dicts (``inputs``, ``data_samples``): yields what ``test_step``
         returns for each, in order, while up to ``depth`` batches are in flight on the device (pipeline.StepPipeline: own
         stream and workspace per slot; the loop of tools/test.py / the video loop of demo/topdown_demo_with_mmdet.py finishes
-        one batch before the next starts). Batches may differ in size (persons per frame) up to ``max_batch``: kernel by
-        kernel launches, no graph. Results are bit-identical to ``test_step``: the records that come back are float64
-        images of the same float32 / float64 device results (``output_heatmaps`` is not carried by the record: use
-        ``test_step`` for that)."""
+        one batch before the next starts). Batches may differ in size (persons per frame) up to ``max_batch``: a batch of
+        exactly ``max_batch`` crops replays the slot's captured hipGraph (captured when the first such batch arrives - the
+        fixed-size batches of a test dataloader), smaller ones are launched kernel by kernel. Results are bit-identical to
+        ``test_step``: the records that come back are float64 images of the same float32 / float64 device results
+        (``output_heatmaps`` is not carried by the record: use ``test_step`` for that)."""
         from .pipeline import StepPipeline
 
         assert self.with_head, "The model must have head to perform prediction."
         if bool(self.test_cfg.get("output_heatmaps", False)):
             raise NotImplementedError("test_step_stream returns the per-keypoint records only; output_heatmaps needs test_step")
-        flip = bool(self.test_cfg.get("flip_test", False))
-        if flip and (self.test_cfg.get("flip_mode", "heatmap") != "heatmap" or self.test_cfg.get("shift_heatmap", False)):
-            raise NotImplementedError("MI355X path implements flip_mode='heatmap', shift_heatmap=False (ProbPose config)")
+        flip = self._check_flip_cfg()
         pipe, pending = None, []  # pending: (ticket, n, data_samples)
 
         def collect(entry):
             ticket, n, samples = entry
-            rec = pipe.result(ticket)[0, :n]  # (n, K, 7) float64: x, y, conf, prob, vis, oks, err (raw)
-            out = dict(keypoints=rec[..., :2].clone(), scores=rec[..., 2].to(torch.float32),
-                       scalars=rec[..., 3:7].permute(2, 0, 1).to(torch.float32).contiguous())
-            preds = self.head.pack_predictions(out, self.test_cfg)
-            return self.add_pred_to_datasample(preds, None, samples)
+            rec = pipe.result(ticket)[0, :n].numpy().copy()  # (n, K, 7) float64: x, y, conf, prob, vis, oks, err (raw)
+            return self.add_pred_to_datasample(self.head.pack_records(rec, self.test_cfg), None, samples)
 
         for data in batches:
             data = self.data_preprocessor(data, False)
@@ -495,7 +536,8 @@ class TopdownPoseEstimator(nn.Module):
                     ds.set_metainfo(self.metainfo)
             if pipe is None:
                 fi = samples[0].metainfo["flip_indices"] if flip else None
-                pipe = StepPipeline(self.engine, max_batch, fi, flip_test=flip, depth=depth, use_graph=False)
+                pipe = StepPipeline(self.engine, max_batch, fi, flip_test=flip, depth=depth,
+                                    use_graph="full" if self.graph_replay else False)
             if inputs.shape[0] > max_batch:
                 raise ValueError(f"batch of {inputs.shape[0]} crops exceeds max_batch={max_batch}")
             while len(pending) >= depth:  # the slot about to be reused must have been read
@@ -505,22 +547,27 @@ class TopdownPoseEstimator(nn.Module):
             yield collect(pending.pop(0))
 
     def add_pred_to_datasample(self, batch_pred_instances, batch_pred_fields, batch_data_samples):
-        """topdown.py:128-194."""
+        """topdown.py:128-194. The input -> image space map of the keypoints (:165-167) is evaluated for the whole batch in one
+        numpy expression when the per-crop keypoint arrays are views of one batch array (``ProbMapHead.pack_records``) and the
+        samples' ``input_center`` / ``input_scale`` / ``input_size`` agree in dtype - the same elementwise operations in the same
+        dtypes as the per-sample expression, hence the same bits - and sample by sample otherwise."""
         assert len(batch_pred_instances) == len(batch_data_samples)
         if batch_pred_fields is None:
             batch_pred_fields = []
         output_keypoint_indices = self.test_cfg.get("output_keypoint_indices", None)
+        mapped = self._map_batch_to_image_space(batch_pred_instances, batch_data_samples)
         for pred_instances, pred_fields, data_sample in zip_longest(batch_pred_instances, batch_pred_fields,
                                                                     batch_data_samples):
             if pred_instances is None:
                 continue
             gt_instances = data_sample.gt_instances
-            input_center = data_sample.metainfo["input_center"]
-            input_scale = data_sample.metainfo["input_scale"]
-            input_size = data_sample.metainfo["input_size"]
-            pred_instances.keypoints[..., :2] = (
-                pred_instances.keypoints[..., :2] / input_size * input_scale + input_center - 0.5 * input_scale
-            )
+            if not mapped:
+                input_center = data_sample.metainfo["input_center"]
+                input_scale = data_sample.metainfo["input_scale"]
+                input_size = data_sample.metainfo["input_size"]
+                pred_instances.keypoints[..., :2] = (
+                    pred_instances.keypoints[..., :2] / input_size * input_scale + input_center - 0.5 * input_scale
+                )
             if "keypoints_visible" not in pred_instances:
                 pred_instances.keypoints_visible = pred_instances.keypoint_scores
             if output_keypoint_indices is not None:
@@ -539,6 +586,33 @@ class TopdownPoseEstimator(nn.Module):
                         pred_fields.set_field(value[output_keypoint_indices], key)
                 data_sample.pred_fields = pred_fields
         return batch_data_samples
+
+    @staticmethod
+    def _map_batch_to_image_space(batch_pred_instances, batch_data_samples) -> bool:
+        """One evaluation of topdown.py:165-167 for the batch; False = not applicable (the caller maps sample by sample)."""
+        n = len(batch_pred_instances)
+        if n < 2 or any(p is None for p in batch_pred_instances):
+            return False
+        base = batch_pred_instances[0].keypoints.base
+        if base is None or base.ndim != 3 or base.shape[0] != n or base.dtype != np.float64:
+            return False
+        for i, p in enumerate(batch_pred_instances):
+            k = p.keypoints
+            if k.base is not base or k.shape != (1,) + base.shape[1:] or k.ctypes.data != base[i].ctypes.data:
+                return False
+        try:
+            metas = [ds.metainfo for ds in batch_data_samples]
+            cen = [np.asarray(m["input_center"]) for m in metas]
+            sca = [np.asarray(m["input_scale"]) for m in metas]
+            siz = [np.asarray(m["input_size"]) for m in metas]
+        except KeyError:
+            return False
+        for arrs in (cen, sca, siz):
+            if any(a.shape != (2,) or a.dtype != arrs[0].dtype for a in arrs):
+                return False
+        cen, sca, siz = (np.stack(a)[:, None, :] for a in (cen, sca, siz))  # (B, 1, 2): broadcast over the K keypoints
+        base[..., :2] = base[..., :2] / siz * sca + cen - 0.5 * sca
+        return True
 
 
 def build_pose_estimator(cfg: dict):

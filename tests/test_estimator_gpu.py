@@ -117,6 +117,46 @@ def test_full_path_bs64_within_1e3(precision):
     assert np.abs(out["scores"].cpu().numpy()[:, None] - ref["keypoints_conf"]).max() <= 1e-3
 
 
+def _fields_of(results):
+    out = {}
+    for f in FIELDS + ["keypoints", "bboxes", "bbox_scores"]:
+        out[f] = np.stack([np.asarray(getattr(ds.pred_instances, f)) for ds in results])
+    return out
+
+
+def test_test_step_graph_replay_equals_eager_bit_for_bit(setup):
+    """The drop-in call itself (`model.test_step`, mmpose/apis/inference.py:195-196) on the fast path: the first batch of a size
+    is launched kernel by kernel, the second captures the hipGraph, later ones replay it; the results come back through one
+    record copy. Every `pred_instances` field must equal the kernel-by-kernel estimator's (graph_replay=False) bit for bit, on
+    DIFFERENT batches in a row, and `test_step_stream` (graph for full batches, two in flight) must deliver the same."""
+    from probpose_code_amd import apis
+    from probpose_code_amd import synthetic as S
+
+    sd, _, center, scale, _ = setup
+    fast = apis.init_model(CFG, {"state_dict": sd}, device="cuda:0")
+    slow = apis.init_model(CFG, {"state_dict": sd}, device="cuda:0", cfg_options={"model.graph_replay": False})
+    assert fast.graph_replay and not slow.graph_replay
+    batches = [S.synthetic_crops(B, seed=40 + i) for i in range(4)]
+    got = []
+    with torch.no_grad():
+        for i, crops in enumerate(batches):
+            a = _fields_of(fast.test_step(apis.pack_crops(crops, center, scale, fast.dataset_meta)))
+            b = _fields_of(slow.test_step(apis.pack_crops(crops, center, scale, slow.dataset_meta)))
+            for f in a:
+                assert a[f].dtype == b[f].dtype and np.array_equal(a[f], b[f]), f"{f}: batch {i} differs between replay and eager test_step"
+            got.append(a)
+        key = (B, True, tuple(S.COCO_FLIP_INDICES), False)
+        assert fast._sizes_seen[key] == 4 and any(k[0] == B for k in fast.engine._graphs), "test_step did not reach the graph path"
+        assert not slow.engine._graphs
+        assert not np.array_equal(got[2]["keypoints"], got[3]["keypoints"]), "a replay repeated the previous batch"
+        stream = list(fast.test_step_stream((apis.pack_crops(c, center, scale, fast.dataset_meta) for c in batches), depth=2, max_batch=B))
+        assert any(k[0] == B and k[-1] == 1 for k in fast.engine._graphs), "test_step_stream did not capture its second slot's graph"
+        for i, res in enumerate(stream):
+            c = _fields_of(res)
+            for f in c:
+                assert c[f].dtype == got[i][f].dtype and np.array_equal(c[f], got[i][f]), f"{f}: streamed batch {i} differs from test_step"
+
+
 @pytest.mark.parametrize("precision", ["bf16", "f16x3"])
 def test_graph_replay_equals_eager_bit_for_bit(precision):
     """bench.py times forward_graph (hipGraph replay): it must produce exactly what the eager launch sequence does,
