@@ -17,12 +17,20 @@ namespace pp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RM = PP_MAX_RADIUS;  // every map is padded by the largest radius
+constexpr int RM = PP_MAX_RADIUS;  // largest radius: the x-padding the row pass may read
+constexpr int PAD = 12;            // x-padding of the LDS map either side: >= RM and a multiple of 4, so that a pixel quad (y, 4 q .. 4 q + 3)
+                                   // is a 16-byte aligned slot (ds_write_b128 / ds_read_b128: one conflict-free access per quad)
+constexpr int ROWD_SLACK = 7;      // the fp64 row slots' pitch is W + 0..7, chosen per workgroup (conv_banded)
 #ifndef PP_DEC_THREADS
 #define PP_DEC_THREADS 256  // dev A/B: 128 (two waves per workgroup, 64 x 48 maps only) measured 53 us against 36: the chain gets longer, nothing is saved
 #endif
 constexpr int DEC_THREADS = PP_DEC_THREADS;
-constexpr int GX = 6;  // outputs per work item in the row pass (sliding register window)
+#ifndef PP_DEC_GX
+#define PP_DEC_GX 7
+#endif
+constexpr int GX = PP_DEC_GX;  // outputs per work item in the row pass (sliding register window). Odd: consecutive lanes then read the map at a
+                       // stride of 7 dwords (all 32 banks of a ds_read_b32 lane group distinct) and write the fp64 slots at 14 dwords
+                       // (conflict-free per 16-lane group); 6 was 2-way on both
 constexpr int GY = 4;  // outputs per work item in the column pass
 constexpr int RED_BYTES = 512;  // cross-wave reduction scratch at the head of the dynamic LDS region
 
@@ -60,17 +68,17 @@ struct Box {
 // H + 2 RM rows a workgroup's LDS can be 31 KiB instead of 49 at 64 x 48 (five workgroups per CU) and 78 KiB instead of 100 at
 // 96 x 72 (two instead of one). At bs 64 five and four per CU measured SLOWER than three (46 / 40 / 36 us: the launch is bound
 // by instructions and the dispatcher balances 4.25 workgroups per CU better than residency does; a 35-slot buffer also
-// splits the box of a radius-9 keypoint): decode_row_slots sizes the buffer for option "decode_wgs_per_cu" (3) per CU.
+// splits the box of a radius-9 keypoint): decode_rowd_doubles sizes the buffer for option "decode_wgs_per_cu" (3) per CU.
 //
 // The convolved map takes the place of the averaged map (convf == mapf, pitch W < Wp: output rows <= y only ever cover
 // map rows <= y), and later bands still read the map. So only the LAST band writes its outputs in place; an earlier band
 // parks them behind its row slots (a third of the slots then: band = 2/3 (NR - 2R) rows) until the NEXT band's row pass
 // is through - that pass needs map rows >= (first row of the next band) - R, all of them below the outputs flushed by
-// then (band > R - 1: decode_row_slots keeps NR >= 2 RM + 16). Every thread flushes exactly the cells it parks (same
+// then (band > R - 1: decode_rowd_doubles keeps NR >= 2 RM + 16). Every thread flushes exactly the cells it parks (same
 // item -> thread map in every band), so the park needs no barrier of its own.
 template <int R>
 __device__ __forceinline__ ArgBest conv_banded(float* __restrict__ mapf, double* __restrict__ rowd,
-                                               const double* __restrict__ tap_g, int H, int W, int Wp, int NR, int tid,
+                                               const double* __restrict__ tap_g, int H, int W, int Wp, int cap, int tid,
                                                Box bx) {
     double tap[R + 1];  // the kernel is symmetric bit for bit (exp(-t^2/2s) / sum): R + 1 distinct factors, in SGPRs
 #pragma unroll
@@ -78,11 +86,23 @@ __device__ __forceinline__ ArgBest conv_banded(float* __restrict__ mapf, double*
     const int xa = max(bx.x0 - R, 0), xb = min(bx.x1 + R, W - 1);  // columns the support reaches through the row kernel
     const int ya = max(bx.y0 - R, 0), yb = min(bx.y1 + R, H - 1);
     const int nx = xb - xa + 1, nxg = (nx + GX - 1) / GX;
-    const FastDiv div_nx(nx), div_nxg(nxg);
+    // Column pass: lane -> (output rows 4 yg .. 4 yg + 3, column x), x fastest, nx4 = nx rounded up to a multiple of 4 columns per
+    // row group. The fp64 slots' pitch Wr is picked so that a step of one row group (4 rows = 8 Wr dwords) equals 2 nx4 dwords
+    // mod 64: the lanes' ds_read_b64 addresses are then LINEAR in the lane index mod 64 dwords - no two lanes of a 32-lane
+    // group share a bank whatever the box width (with pitch W = 48 a row group was 384 = 0 mod 64 dwords from the previous one:
+    // every box narrower than 32 columns was 2-way).
+    const int nx4 = (nx + 3) & ~3;
+    int Wr = W + ((((nx4 >> 2) - W) % 8 + 8) & 7);  // 4 Wr == nx4 (mod 32)
+    int NR = cap / Wr;                              // row slots the buffer (`cap` doubles) holds at this pitch
+    if (NR < yb - ya + 1 + 2 * R) {                 // the box would no longer fit ONE band: the plain pitch (bands cost more than conflicts)
+        Wr = W;
+        NR = cap / W;
+    }
+    const FastDiv div_nx(nx4), div_nxg(nxg);
     const bool one_band = yb - ya + 1 <= NR - 2 * R;
     const int band = one_band ? yb - ya + 1 : ((NR - 2 * R) * 2) / 3;
     float* convf = mapf;
-    float* park = reinterpret_cast<float*>(rowd + (band + 2 * R) * W);  // [band][nx], several bands only
+    float* park = reinterpret_cast<float*>(rowd + (band + 2 * R) * Wr);  // [band][nx], several bands only
     ArgBest best{-__builtin_inff(), 0x7fffffff};
     for (int by0 = ya; by0 <= yb; by0 += band) {
         const int by1 = min(by0 + band - 1, yb);
@@ -97,7 +117,7 @@ __device__ __forceinline__ ArgBest conv_banded(float* __restrict__ mapf, double*
 #pragma unroll
             for (int g = 0; g < GX; ++g) acc[g] = 0.0;
             if (y >= bx.y0 && y <= bx.y1) {
-                const float* p = mapf + y * Wp + x0 + (RM - R);  // window starts R samples left of output x0
+                const float* p = mapf + y * Wp + x0 + (PAD - R);  // window starts R samples left of output x0
                 double win[GX + 2 * R];
 #pragma unroll
                 for (int c = 0; c < GX + 2 * R; ++c) win[c] = (double)p[c];
@@ -108,23 +128,24 @@ __device__ __forceinline__ ArgBest conv_banded(float* __restrict__ mapf, double*
             }
 #pragma unroll
             for (int g = 0; g < GX; ++g)
-                if (x0 + g <= xb) rowd[s * W + x0 + g] = acc[g];
+                if (x0 + g <= xb) rowd[s * Wr + x0 + g] = acc[g];
         }
         __syncthreads();
         // ---- column pass + running argmax. Before a thread parks a cell it flushes what the previous band left there.
         const int nyg = (by1 - by0 + GY) / GY;
-        for (int it = tid; it < nx * (one_band ? nyg : (band + GY - 1) / GY); it += DEC_THREADS) {
-            const int yg = div_nx(it), xo = it - yg * nx, x = xa + xo, s0 = yg * GY;
+        for (int it = tid; it < nx4 * (one_band ? nyg : (band + GY - 1) / GY); it += DEC_THREADS) {
+            const int yg = div_nx(it), xo = it - yg * nx4, x = xa + xo, s0 = yg * GY;
+            if (xo >= nx) continue;  // (the up to three lanes that pad a row group to nx4)
             if (by0 > ya) {
 #pragma unroll
                 for (int g = 0; g < GY; ++g)
                     if (s0 + g < band) convf[(by0 - band + s0 + g) * W + x] = park[(s0 + g) * nx + xo];
             }
             if (yg >= nyg) continue;  // (a shorter last band: flush only)
-            const double* p = rowd + s0 * W + x;
+            const double* p = rowd + s0 * Wr + x;
             double win[GY + 2 * R];
 #pragma unroll
-            for (int c = 0; c < GY + 2 * R; ++c) win[c] = (s0 + c < NR) ? p[c * W] : 0.0;  // (slots past the band's last feed only outputs that are dropped)
+            for (int c = 0; c < GY + 2 * R; ++c) win[c] = (s0 + c < NR) ? p[c * Wr] : 0.0;  // (slots past the band's last feed only outputs that are dropped)
             double acc[GY];
 #pragma unroll
             for (int g = 0; g < GY; ++g) acc[g] = 0.0;
@@ -227,19 +248,31 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     const float* __restrict__ hm, const float* __restrict__ hm_flip, const int32_t* __restrict__ flip_indices,
     const double* __restrict__ taps, const int32_t* __restrict__ radius, int K, int H, int W, double in_w,
     double in_h, float temperature, float normalize, float* __restrict__ avg_out, float* __restrict__ conv_out,
-    float* __restrict__ locs, double* __restrict__ keypoints, float* __restrict__ scores, int phased, int NR) {
+    float* __restrict__ locs, double* __restrict__ keypoints, float* __restrict__ scores, int phased, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int bk = blockIdx.x;
     const int b = bk / K, k = bk - b * K;
-    const int Wp = W + 2 * RM;
+    const int Wp = W + 2 * PAD;
     const int HW = H * W, HW4 = HW >> 2, W4 = W >> 2;
-    const FastDiv div_w(W), div_w4(W4), div_w2(W >> 1), div_q(HW4);
+    const FastDiv div_w(W), div_w4(W4);
+    // A thread owns the pixel QUADS q = tid + 256 e (e < NV): pixels (y, x0 .. x0 + 3), y = q / (W / 4), x0 = 4 (q % (W / 4)) - the same
+    // quads whatever the memory layout of the input, so both layouts give the same bits; a quad is one 16-byte aligned LDS slot.
+    // (Measured and dropped, round 4: lane pairs (l, l + 32) sharing an octet, numbered row-parity-major, so that a half-wave reads 512
+    // contiguous bytes of one phase block and two v_permlane32_swap interleave the columns - 39.3 / 37.3 us against 37.8 / 35.8 for the
+    // two 8-byte loads per quad below: the octet order puts the lanes' 16-byte LDS stores 32 bytes apart, 2-way conflicts.)
+    auto quad = [&](int e, int& y, int& x0) -> bool {
+        const int i4 = tid + e * DEC_THREADS;
+        if (i4 >= HW4) return false;
+        y = div_w4(i4);
+        x0 = (i4 - y * W4) * 4;
+        return true;
+    };
 
     // all LDS in the one dynamic region (16-B aligned carve offsets)
     ArgBest* red = reinterpret_cast<ArgBest*>(smem);                                         // [4] cross-wave argmax
     float* mapf = reinterpret_cast<float*>(smem + RED_BYTES);                                // [H][Wp] (+ slack) averaged map, x-padded
-    double* rowd = reinterpret_cast<double*>(smem + RED_BYTES + (((H * Wp + 32) * 4 + 15) & ~15));  // [NR][W] row pass of one band (conv_banded)
+    double* rowd = reinterpret_cast<double*>(smem + RED_BYTES + (((H * Wp + 32) * 4 + 15) & ~15));  // [NR][W + 0..7] row pass of one band (conv_banded)
     // [H][W] convolved map (f32): it takes the place of the averaged map, which is dead once the last row pass is through -
     // except for the one value at the final argmax (the score), so every thread parks its share of the map (4 NV values) in
     // registers first.
@@ -253,17 +286,15 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         // ---- load + flip-back + average: partner of pixels (y, x..x+3) is the reversed vector at (y, W-4-x)
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
-            const int i4 = tid + e * DEC_THREADS;
-            if (i4 < HW4) {
-                const int y = div_w4(i4), x = (i4 - y * W4) * 4;
-                f32x4 v = src[i4];
+            int y, x;
+            if (quad(e, y, x)) {
+                f32x4 v = src[y * W4 + (x >> 2)];
                 if (HAS_FLIP) {
                     const f32x4 f = srcf[y * W4 + (W4 - 1 - (x >> 2))];
                     v = (v + f32x4{f[3], f[2], f[1], f[0]}) * 0.5f;
                 }
-                float* d = mapf + y * Wp + RM + x;
-                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-                if (avg_out) reinterpret_cast<f32x4*>(avg_out + (size_t)bk * HW)[i4] = v;
+                *reinterpret_cast<f32x4*>(mapf + y * Wp + PAD + x) = v;  // 16-byte aligned slot
+                if (avg_out) reinterpret_cast<f32x4*>(avg_out + (size_t)bk * HW)[y * W4 + (x >> 2)] = v;
             }
         }
     } else {
@@ -279,21 +310,34 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         const unsigned t_bits = __builtin_bit_cast(unsigned, temperature);
         const bool t_pow2 = (t_bits & 0x007fffffu) == 0 && (t_bits >> 23) >= 2 && (t_bits >> 23) <= 252;
         const float t_inv = __builtin_bit_cast(float, (254u << 23) - t_bits);
+        // The quad (y, x0 ..) of a row in memory. Row-major: one 16-byte vector. Phase-separated (the fused deconvolution head
+        // writes the four 2x2 output phases one after the other, each a (H/2, W/2) row-major block): two 8-byte pairs - columns
+        // x0 / 2, x0 / 2 + 1 of row y / 2 of the phases (y & 1, 0) and (y & 1, 1) - interleaved.
+        auto load_quad = [&](const f32x4* base, bool ok, int y, int x0) -> f32x4 {
+            const float ninf = -__builtin_inff();
+            f32x4 r{ninf, ninf, ninf, ninf};
+            if (!ok) return r;
+            if (!phased) return base[y * W4 + (x0 >> 2)];
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2* pb = reinterpret_cast<const f32x2*>(base) + ((y & 1) * HW4 + (y >> 1) * W4 + (x0 >> 2));  // (in pairs: a phase block is HW4 / 2 pairs)
+            const f32x2 a = pb[0], c = pb[HW4 >> 1];
+            return f32x4{a[0], c[0], a[1], c[1]};
+        };
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
-            const int i4 = tid + e * DEC_THREADS;
-            const float ninf = -__builtin_inff();
-            z0[e] = f32x4{ninf, ninf, ninf, ninf};
+            int y = 0, x0 = 0;
+            const bool ok = quad(e, y, x0);
+            z0[e] = load_quad(src, ok, y, x0);
             z1[e] = z0[e];
-            if (i4 < HW4) {
-                if (t_pow2) {  // x / 2^k == x * 2^-k bit for bit
-                    z0[e] = src[i4] * t_inv;
-                    if (HAS_FLIP) z1[e] = srcf[i4] * t_inv;
-                } else {
-                    z0[e] = src[i4] / temperature;
-                    if (HAS_FLIP) z1[e] = srcf[i4] / temperature;
-                }
+            if (HAS_FLIP) z1[e] = load_quad(srcf, ok, y, x0);
+            if (t_pow2) {  // x / 2^k == x * 2^-k bit for bit (-inf of a lane without a quad stays -inf)
+                z0[e] = z0[e] * t_inv;
+                if (HAS_FLIP) z1[e] = z1[e] * t_inv;
+            } else {
+                z0[e] = z0[e] / temperature;
+                if (HAS_FLIP) z1[e] = z1[e] / temperature;
             }
+            if (!HAS_FLIP) { const float ninf = -__builtin_inff(); z1[e] = f32x4{ninf, ninf, ninf, ninf}; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 m0 = fmaxf(m0, z0[e][j]);
@@ -346,70 +390,58 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         }
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
-            const int i4 = tid + e * DEC_THREADS;
-            if (i4 < HW4) {
-                // memory order of the four values -> pixel (y, x0 + j * dx): row-major, or (logits written by the fused
-                // deconvolution head) the four 2x2 output phases one after the other, each a (H/2, W/2) row-major block
-                int y = div_w4(i4), x0 = (i4 - y * W4) * 4, dx = 1;
-                if (phased) {
-                    const int e0 = i4 * 4, q = HW >> 2, z = div_q(e0), rr = e0 - z * q, yy = div_w2(rr);
-                    y = 2 * yy + (z >> 1);
-                    x0 = 2 * (rr - yy * (W >> 1)) + (z & 1);
-                    dx = 2;
-                }
-                float* d = mapf + y * Wp + RM + x0;
+            int y, x0;
+            if (quad(e, y, x0)) {
+                f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[j * dx] = clamp01(fmaxf(z0[e][j] - tau0, 0.0f) * normalize);
+                for (int j = 0; j < 4; ++j) v[j] = clamp01(fmaxf(z0[e][j] - tau0, 0.0f) * normalize);
+                *reinterpret_cast<f32x4*>(mapf + y * Wp + PAD + x0) = v;
             }
         }
         if (HAS_FLIP) {
             __syncthreads();
 #pragma unroll
             for (int e = 0; e < NV; ++e) {
-                const int i4 = tid + e * DEC_THREADS;
-                if (i4 < HW4) {
-                    int y = div_w4(i4), xf = (i4 - y * W4) * 4, dx = 1;
-                    if (phased) {
-                        const int e0 = i4 * 4, q = HW >> 2, z = div_q(e0), rr = e0 - z * q, yy = div_w2(rr);
-                        y = 2 * yy + (z >> 1);
-                        xf = 2 * (rr - yy * (W >> 1)) + (z & 1);
-                        dx = 2;
-                    }
-                    float* d = mapf + y * Wp + RM + (W - 1 - xf);  // pixel xf + j dx of the flipped pass lands at W-1-xf-j dx
+                int y, xf;
+                if (quad(e, y, xf)) {
+                    // pixels xf .. xf + 3 of the flipped pass land at W-1-xf .. W-4-xf: the reversed quad at column W-4-xf; exactly
+                    // one thread owns each cell
+                    f32x4* d = reinterpret_cast<f32x4*>(mapf + y * Wp + PAD + (W - 4 - xf));
+                    f32x4 v = *d;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {                // exactly one thread owns each cell
-                        const float p = clamp01(fmaxf(z1[e][j] - tau1, 0.0f) * normalize);
-                        d[-j * dx] = (d[-j * dx] + p) * 0.5f;
-                    }
+                    for (int j = 0; j < 4; ++j) v[3 - j] = (v[3 - j] + clamp01(fmaxf(z1[e][j] - tau1, 0.0f) * normalize)) * 0.5f;
+                    *d = v;
                 }
             }
         }
         if (avg_out) {
             __syncthreads();
-            for (int i = tid; i < HW; i += DEC_THREADS) {
-                const int y = div_w(i), x = i - y * W;
-                avg_out[(size_t)bk * HW + i] = mapf[y * Wp + RM + x];
+            for (int i4 = tid; i4 < HW4; i4 += DEC_THREADS) {
+                const int y = div_w4(i4), x = (i4 - y * W4) * 4;
+                reinterpret_cast<f32x4*>(avg_out + (size_t)bk * HW)[i4] = *reinterpret_cast<const f32x4*>(mapf + y * Wp + PAD + x);
             }
         }
     }
     __syncthreads();
-    // ---- the averaged map is complete. Every thread parks its share (pixels tid + 256 i) in registers - the score is the
+    // ---- the averaged map is complete. Every thread parks its share (its quads) in registers - the score is the
     // RAW map value at the final argmax, and the convolved map will take this region's place - and the workgroup finds
     // the bounding box of the non-zero pixels: a Sparsemax row has 2 - 10 px of support, and an output further than the
     // kernel radius from that box is a sum of exact zeros (fp64 accumulation of +0 terms, reflect padding included: a
     // mirrored sample lies within the radius of the border it mirrors). Only the dilated box is convolved; the rest
     // is written as 0.0f - bit for bit what scipy.ndimage.convolve returns there.
-    float mine[4 * NV];
+    f32x4 mine[NV];
     Box bx{1 << 20, -1, 1 << 20, -1};
 #pragma unroll
-    for (int i = 0; i < 4 * NV; ++i) {
-        const int px = tid + i * DEC_THREADS;
-        const int y = div_w(px), x = px - y * W;
-        mine[i] = px < HW ? mapf[y * Wp + RM + x] : 0.f;
-        if (px < HW && mine[i] != 0.f) {  // (NaN counts as non-zero)
-            bx.y0 = min(bx.y0, y); bx.y1 = max(bx.y1, y);
-            bx.x0 = min(bx.x0, x); bx.x1 = max(bx.x1, x);
-        }
+    for (int e = 0; e < NV; ++e) {
+        int y = 0, x = 0;
+        const bool ok = quad(e, y, x);
+        mine[e] = ok ? *reinterpret_cast<const f32x4*>(mapf + y * Wp + PAD + x) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ok && mine[e][j] != 0.f) {  // (NaN counts as non-zero)
+                bx.y0 = min(bx.y0, y); bx.y1 = max(bx.y1, y);
+                bx.x0 = min(bx.x0, x + j); bx.x1 = max(bx.x1, x + j);
+            }
     }
     {
         bx.y0 = wave_allreduce(bx.y0, [](int a, int b) { return min(a, b); });
@@ -435,9 +467,9 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     for (int i = tid; i < (empty ? 0 : (bx.y1 - bx.y0 + 1) * 2 * RM); i += DEC_THREADS) {  // (the row pass reads no other row)
         const int yr = i / (2 * RM), y = bx.y0 + yr, p = i - yr * (2 * RM);
         if (p < RM)
-            mapf[y * Wp + (RM - 1 - p)] = mapf[y * Wp + RM + p];
+            mapf[y * Wp + (PAD - 1 - p)] = mapf[y * Wp + PAD + p];
         else
-            mapf[y * Wp + RM + W + (p - RM)] = mapf[y * Wp + RM + W - 1 - (p - RM)];
+            mapf[y * Wp + PAD + W + (p - RM)] = mapf[y * Wp + PAD + W - 1 - (p - RM)];
     }
     __syncthreads();
 
@@ -446,16 +478,16 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     // ---- separable convolution over the dilated box, band by band; the outputs land in convf, the rest of it is 0.0f
     ArgBest best{-__builtin_inff(), 0x7fffffff};
     if (!empty) switch (r) {
-        case 0: best = conv_banded<0>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
-        case 1: best = conv_banded<1>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
-        case 2: best = conv_banded<2>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
-        case 3: best = conv_banded<3>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
-        case 4: best = conv_banded<4>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
-        case 5: best = conv_banded<5>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
-        case 6: best = conv_banded<6>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
-        case 7: best = conv_banded<7>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
-        case 8: best = conv_banded<8>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
-        default: best = conv_banded<9>(mapf, rowd, tap_g, H, W, Wp, NR, tid, bx); break;
+        case 0: best = conv_banded<0>(mapf, rowd, tap_g, H, W, Wp, cap, tid, bx); break;
+        case 1: best = conv_banded<1>(mapf, rowd, tap_g, H, W, Wp, cap, tid, bx); break;
+        case 2: best = conv_banded<2>(mapf, rowd, tap_g, H, W, Wp, cap, tid, bx); break;
+        case 3: best = conv_banded<3>(mapf, rowd, tap_g, H, W, Wp, cap, tid, bx); break;
+        case 4: best = conv_banded<4>(mapf, rowd, tap_g, H, W, Wp, cap, tid, bx); break;
+        case 5: best = conv_banded<5>(mapf, rowd, tap_g, H, W, Wp, cap, tid, bx); break;
+        case 6: best = conv_banded<6>(mapf, rowd, tap_g, H, W, Wp, cap, tid, bx); break;
+        case 7: best = conv_banded<7>(mapf, rowd, tap_g, H, W, Wp, cap, tid, bx); break;
+        case 8: best = conv_banded<8>(mapf, rowd, tap_g, H, W, Wp, cap, tid, bx); break;
+        default: best = conv_banded<9>(mapf, rowd, tap_g, H, W, Wp, cap, tid, bx); break;
     }
     const int cxa = max(bx.x0 - r, 0), cxb = min(bx.x1 + r, W - 1), cya = max(bx.y0 - r, 0), cyb = min(bx.y1 + r, H - 1);
     if (conv_out) {  // zero outside the box (every read of the map is behind a barrier by now; disjoint from the band outputs)
@@ -501,10 +533,14 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         for (int w = 1; w < DEC_THREADS / WAVE; ++w)
             if (better(red[w].v, red[w].idx, bb.v, bb.idx)) bb = red[w];
         if (zidx >= 0 && better(0.0f, zidx, bb.v, bb.idx)) bb = ArgBest{0.0f, zidx};
-        if ((bb.idx & (DEC_THREADS - 1)) == tid) {
-            float sv = mine[0];
+        const int wy = div_w(bb.idx), wx = bb.idx - wy * W, wq = wy * W4 + (wx >> 2);  // the winner's quad: its owner and slot
+        const int own_e = wq / DEC_THREADS, own_tid = wq & (DEC_THREADS - 1);
+        if (own_tid == tid) {
+            float sv = mine[0][0];
 #pragma unroll
-            for (int i = 1; i < 4 * NV; ++i) sv = (bb.idx / DEC_THREADS) == i ? mine[i] : sv;
+            for (int e = 0; e < NV; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sv = (own_e == e && (wx & 3) == j) ? mine[e][j] : sv;
             reinterpret_cast<float*>(red + DEC_THREADS / WAVE)[0] = sv;
         }
     }
@@ -542,19 +578,20 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
 }
 
 static size_t decode_fixed_bytes(int H, int W) {
-    return RED_BYTES + ((((size_t)H * (W + 2 * RM) + 32) * 4 + 15) & ~(size_t)15);  // (the convolved map reuses the averaged map's region)
+    return RED_BYTES + ((((size_t)H * (W + 2 * PAD) + 32) * 4 + 15) & ~(size_t)15);  // (the convolved map reuses the averaged map's region)
 }
 
-// Row slots of the band buffer: as many workgroups per CU as the map allows (five at 64 x 48, two at 96 x 72), a band never
-// lower than 16 output rows at the largest radius. 1.5 KiB of every share stay free for the allocation granule.
-static int decode_row_slots(int H, int W) {
+// Capacity of the band buffer in doubles: as many workgroups per CU as the map allows (five at 64 x 48, two at 96 x 72), never
+// more than every row of the map at the widest pitch, a band never lower than 16 output rows at the largest radius and the
+// widest pitch. 1.5 KiB of every share stay free for the allocation granule.
+static long decode_rowd_doubles(int H, int W) {
     const size_t fixed = decode_fixed_bytes(H, W);
-    const int full = H + 2 * RM;
+    const size_t full = (size_t)(H + 2 * RM) * (W + ROWD_SLACK);
     for (int n = std::min(5, std::max(1, pp::option("decode_wgs_per_cu"))); n >= 1; --n) {
         const size_t budget = (size_t)160 * 1024 / n - 1536;
         if (budget <= fixed) continue;
-        const int nr = (int)std::min<size_t>((size_t)full, (budget - fixed) / ((size_t)W * 8));
-        if (nr == full || nr >= 2 * RM + 16) return nr;
+        const size_t cap = std::min(full, (budget - fixed) / 8);
+        if (cap == full || cap >= (size_t)(2 * RM + 16) * (W + ROWD_SLACK)) return (long)cap;
     }
     return -1;
 }
@@ -586,9 +623,9 @@ static int decode_launch(bool from_logits, const float* hm, const float* hm_flip
     PP_REQUIRE(H >= RM && W >= RM, PP_ERR_UNSUPPORTED,
                "pp_probmap_decode: heatmap smaller than the largest OKS-kernel radius (9)");
     PP_REQUIRE(W % 4 == 0, PP_ERR_UNSUPPORTED, "pp_probmap_decode: heatmap width must be a multiple of 4");
-    const int nr = decode_row_slots(H, W);
-    PP_REQUIRE(nr > 0, PP_ERR_UNSUPPORTED, "pp_probmap_decode: heatmap too large for one CU's LDS");
-    const size_t lds = decode_fixed_bytes(H, W) + (size_t)nr * W * 8;
+    const long cap = decode_rowd_doubles(H, W);
+    PP_REQUIRE(cap > 0, PP_ERR_UNSUPPORTED, "pp_probmap_decode: heatmap too large for one CU's LDS");
+    const size_t lds = decode_fixed_bytes(H, W) + (size_t)cap * 8;
     if (from_logits)
         PP_REQUIRE(temperature > 0.f, PP_ERR_INVALID_ARG, "pp_probmap_head_decode: temperature must be positive");
     const int nv = (H * W / 4 + DEC_THREADS - 1) / DEC_THREADS;
@@ -601,7 +638,7 @@ static int decode_launch(bool from_logits, const float* hm, const float* hm_flip
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * K), dim3(DEC_THREADS), lds, s, hm, hm_flip, flip_indices, taps, radius, K, H,
-                       W, in_w, in_h, temperature, normalize, avg_out, conv_out, locs, keypoints, scores, phased, nr);
+                       W, in_w, in_h, temperature, normalize, avg_out, conv_out, locs, keypoints, scores, phased, (int)cap);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
