@@ -68,6 +68,7 @@ int pp_device_cu_count(void);
  *   "decode_wgs_per_cu" (3)  pp_probmap_(head_)decode: workgroups per CU its LDS band buffer is sized for (5 .. 1)
  *   "qkv_attn_pair" (0)      1: pp_qkv_attention_split with a head pair per workgroup (measured slower; kept for A/B)
  *   "ksplit9_below" (1024)   pp_conv3x3_splitk_slices: output rows under which a small tower stage is cut into nine K-slices
+ *   "ksplit_channels" (1)    pp_conv3x3_splitk_slices: 0 = whole-tap slices only (never the four channel ranges of the wide-tile kernel)
  * Unknown names return PP_ERR_INVALID_ARG. Not thread-safe against concurrent launches (set them before the first call).
  * (probpose_code_amd/_lib.py forwards PP_OPT_<NAME>=<int> environment variables here at import - host-side convenience.) */
 int pp_set_option(const char* name, int value);
@@ -95,16 +96,18 @@ enum {
     PP_WS_DECONV = 9,        /* output of deconvolution `index`, NHWC operand format                                       */
     PP_WS_TOWER = 10,        /* (4, n_img, h, w, embed) operand format: convolution output of tower stage `index`         */
     PP_WS_TOWER_PARTIAL = 11,/* (slices, 4, n_img, h, w, embed) fp32: split-K partial sums of tower stage `index`, slices =
-                              * pp_conv3x3_splitk_slices(n_img * h * w)                                                    */
+                              * pp_conv3x3_splitk_slices(prec, n_img, h, w, embed, embed, 4)                                                    */
     PP_WS_TOWER_POOLED = 12  /* (4, n_img, h / ph, w / pw, embed) operand format: pooled output of tower stage `index`     */
 };
 long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* shape);
 
-/* K-slices of pp_conv3x3_splitk for a tower stage with `rows` = n_img * h * w output pixels (probmap_head.py:261-294, the 4 x 4
- * and 2 x 2 stages): 3 = one kernel row of taps per slice, 9 = one tap per slice when the stage has fewer rows than option
- * "ksplit9_below" (too few tiles to fill the chip otherwise). The caller passes this count to pp_conv3x3_splitk /
- * pp_sum_maxpool_relu_nhwc; PP_WS_TOWER_PARTIAL is sized for it. */
-int pp_conv3x3_splitk_slices(int rows);
+/* K-slices of pp_conv3x3_splitk for a small tower stage (probmap_head.py:261-294, the 4 x 4 and 2 x 2 stages; `groups` = the four
+ * towers): 3 = one kernel row of taps per slice, 9 = one tap per slice when the stage has fewer than option "ksplit9_below" output
+ * rows B * H * W (too few tiles to fill the chip otherwise); 4 = four CHANNEL ranges (all nine taps each) on the split-fp16
+ * wide-tile kernel, when the stage has enough rows for its 256 x 192 tiles to fill the chip (PP_PREC_F16X3, Cin % 128 == 0,
+ * Cout % 192 == 0; option "ksplit_channels"). The caller passes this count to pp_conv3x3_splitk / pp_sum_maxpool_relu_nhwc;
+ * PP_WS_TOWER_PARTIAL is sized for it. */
+int pp_conv3x3_splitk_slices(int prec, int B, int H, int W, int Cin, int Cout, int groups);
 
 /* Measurement aid (bench hygiene, no reference counterpart): one wavefront that sleeps on `stream` until *stop_flag becomes
  * non-zero (stop_flag: a word both sides can address - pinned host memory the caller sets with a plain store; NULL = no flag) or
@@ -378,8 +381,10 @@ int pp_probmap_head_decode_phased(const float* logits, const float* logits_flip,
                                   double in_h, float temperature, float normalize, float* avg_out, float* conv_out,
                                   float* locs, double* keypoints, float* scores, void* stream);
 
-/* Split-K form of the towers' 3x3 convolution for stages with few output pixels: the nine taps are cut into ksplit
- * (1, 3 or 9) slices, every (slice, group) pair is its own set of output tiles, and the fp32 partial sums go to
+/* Split-K form of the towers' 3x3 convolution for stages with few output pixels: the contraction is cut into ksplit slices -
+ * 1, 3 or 9: whole taps (any precision); any other count with Cin % (32 ksplit) == 0: channel ranges [s Cin / ksplit, ...) of all nine
+ * taps (PP_PREC_F16X3 on the wide-tile kernel only, needs >= 192 tiles of 256 x 192; pp_conv3x3_splitk_slices returns such a
+ * count only where it applies) - every (slice, group) pair is its own set of output tiles, and the fp32 partial sums go to
  * partials (ksplit, groups, B*H*W, Cout) WITHOUT bias. Weight layout as PP_CONV3X3 of pp_conv_gemm. Followed by
  * pp_sum_maxpool_relu_nhwc, which reduces the slices, adds the (folded BatchNorm) bias, pools and applies ReLU
  * (probmap_head.py:261-294). */

@@ -55,7 +55,7 @@ SIGNATURES = {
     "pp_set_option": (c_int, [c_char_p, c_int]),
     "pp_get_option": (c_int, [c_char_p, _P]),
     "pp_workspace_bytes": (c_longlong, [c_int, c_int, _P]),
-    "pp_conv3x3_splitk_slices": (c_int, [c_int]),
+    "pp_conv3x3_splitk_slices": (c_int, [c_int] * 7),
     "pp_clock_probe": (c_int, [_P, _P, ctypes.c_uint, _P]),
     "pp_probmap_decode": (
         c_int,

@@ -29,6 +29,7 @@ static Option g_options[] = {
     {"conv_pool_split", 1},    // 0: split-fp16 first tower stage as conv + pooling launches instead of pooling in the conv epilogue
     {"decode_wgs_per_cu", 3},  // most workgroups per CU the decode kernel sizes its band buffer for (5 .. 1): more than 3 measured slower at bs 64 (4.25 workgroups per CU are balanced by the dispatcher, not by residency; smaller buffers mean more bands)
     {"qkv_attn_pair", 0},      // 1: pp_qkv_attention_split with a head PAIR per workgroup (one workgroup per CU; measured slower)
+    {"ksplit_channels", 1},    // pp_conv3x3_splitk_slices: 0 = never the four channel-range slices of the split-fp16 wide-tile kernel (whole-tap slices only)
     {"ksplit9_below", 1024},   // pp_conv3x3_splitk_slices: tower stages with fewer output rows than this take nine K-slices (one tap each) instead of three
 };
 
@@ -123,7 +124,7 @@ long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* sh) {
             tower_hw(index, h, w, ph, pw);
             if (buffer == PP_WS_TOWER) return 4ll * sh->n_img * h * w * E * esz;
             if (buffer == PP_WS_TOWER_PARTIAL)   // K-slices as pp_conv3x3_splitk_slices says for this stage's rows, fp32
-                return (long long)pp_conv3x3_splitk_slices((int)(sh->n_img * h * w)) * 4 * sh->n_img * h * w * E * 4;
+                return (long long)pp_conv3x3_splitk_slices(sh->prec, sh->n_img, (int)h, (int)w, sh->embed, sh->embed, 4) * 4 * sh->n_img * h * w * E * 4;
             return 4ll * sh->n_img * (h / ph) * (w / pw) * E * esz;
         }
         default: break;
@@ -132,7 +133,15 @@ long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* sh) {
     return PP_ERR_INVALID_ARG;
 }
 
-int pp_conv3x3_splitk_slices(int rows) { return rows < pp::option("ksplit9_below") ? 9 : 3; }
+int pp_conv3x3_splitk_slices(int prec, int B, int H, int W, int Cin, int Cout, int groups) {
+    const long long rows = (long long)B * H * W;
+    // split-fp16, enough rows for whole 256 x 192 tiles: four channel quarters on the wide-tile kernel when that fills the chip
+    // (4 x 4 tower stage at bs 64 with flip test: 8 row tiles x 2 column tiles x 4 towers x 4 slices = 256 workgroups of 27 stages)
+    if (prec == PP_PREC_F16X3 && pp::option("panel") && pp::option("ksplit_channels") && pp::option("psplit_tap_inner") >= 1 && Cin % 128 == 0 &&
+        Cout % 192 == 0 && ((rows + 255) / 256) * (Cout / 192) * groups * 4 >= 192)
+        return 4;
+    return rows < pp::option("ksplit9_below") ? 9 : 3;
+}
 
 int pp_abi_version(void) { return PP_ABI_VERSION; }
 

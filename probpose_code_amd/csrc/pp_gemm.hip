@@ -561,7 +561,8 @@ extern "C" int pp_conv3x3_splitk(int prec, const void* act_nhwc, const void* wei
     using namespace pp;
     PP_REQUIRE(act_nhwc && weight && partials, PP_ERR_INVALID_ARG, "pp_conv3x3_splitk: NULL argument");
     PP_REQUIRE(groups >= 1 && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PP_ERR_INVALID_ARG, "pp_conv3x3_splitk: bad shape");
-    PP_REQUIRE(ksplit == 1 || ksplit == 3 || ksplit == 9, PP_ERR_UNSUPPORTED, "pp_conv3x3_splitk: ksplit must be 1, 3 or 9 (whole taps)");
+    PP_REQUIRE(ksplit >= 1 && ksplit <= 16 && (ksplit == 1 || ksplit == 3 || ksplit == 9 || Cin % (32 * ksplit) == 0), PP_ERR_UNSUPPORTED,
+               "pp_conv3x3_splitk: ksplit must be 1, 3 or 9 (whole taps), or a count of channel ranges (Cin % (32 ksplit) == 0, split-fp16 wide-tile kernel)");
     GemmParams p{};
     p.A = act_nhwc; p.W = weight; p.C = partials; p.bias = nullptr; p.residual = nullptr;
     p.M = B * H * W; p.N = Cout;
@@ -575,6 +576,13 @@ extern "C" int pp_conv3x3_splitk(int prec, const void* act_nhwc, const void* wei
     PP_REQUIRE(ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_conv3x3_splitk: operands must be smaller than 2 GiB");
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     p.strideA_z = stride_act_g; p.strideW_z = stride_w_g; p.strideC_z = (long long)p.M * Cout; p.strideBias_z = 0;
+    // Channel-range slices (pp_conv3x3_splitk_slices picks them for the split-fp16 4 x 4 tower stage: four quarters of the channels on
+    // 256 x 192 tiles = one workgroup per CU): the wide-tile split kernel only. Whole-tap slices (3, 9): the kernels below.
+    if (ksplit != 1 && ksplit != 3 && ksplit != 9) {
+        PP_REQUIRE(panel_enabled() && panel_split_supported(p, prec, groups * ksplit), PP_ERR_UNSUPPORTED,
+                   "pp_conv3x3_splitk: this slice count is a channel-range split, built for the split-fp16 wide-tile kernel only (use pp_conv3x3_splitk_slices)");
+        return panel_split_gemm(p, prec, groups * ksplit, reinterpret_cast<hipStream_t>(stream));
+    }
     if (panel_enabled() && panel_gemm_supported(p, prec, groups * ksplit))  // enough 256 x 192 tiles to fill the chip
         return panel_gemm(p, groups * ksplit, reinterpret_cast<hipStream_t>(stream));
     return gemm(p, prec, groups * ksplit, reinterpret_cast<hipStream_t>(stream));

@@ -107,8 +107,15 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
 
     const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
     const int ntiles = ntn * ntm * p.groups;
-    const int nsteps = p.K / KS;
-    const int cps = p.Cin / KS;  // stages per tap (Linear: Cin = K, one "tap")
+    const int nsteps = p.K / KS;  // K = the length of ONE K-slice under split-K
+    const int cps = p.Cin / KS;   // stages per tap (Linear: Cin = K, one "tap")
+    // Split-K (3x3 convolutions with few output rows - the 4 x 4 stage of the scalar towers: 64 tiles for 256 CUs): `groups` counts
+    // (K slice, problem) pairs, z = slice * nprob + problem. A slice is a CHANNEL range - channels [slice Cin / ksplit, ...) of all
+    // nine taps, walked taps-inner like the unsplit convolution - so that any slice count dividing Cin / 32 works (four quarters of
+    // 384 channels = 256 workgroups x 27 stages: one round of the chip); every slice writes its fp32 partial sums to its own plane
+    // C + z strideC_z, the pooling kernel adds them up (pp_sum_maxpool_relu_nhwc).
+    const int nprob = p.ksplit > 1 ? p.groups / p.ksplit : p.groups;
+    const int cslice = p.ksplit > 1 ? p.Cin / p.ksplit : p.Cin;  // channels per slice
 
     // XCD-aware tile order as in pp_panel_gemm.hip: row panel -> group -> column tile, contiguous runs per XCD
     auto decode_tile = [&](int t, int& z, int& m0, int& n0) {
@@ -136,12 +143,17 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
     int a_y[JA], a_x[JA];
     unsigned w_voff;
     __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
-    int i_tile = blockIdx.x, i_step = 0, i_tap = 0, i_c0 = 0, i_py = 0, i_px = 0;
+    int i_tile = blockIdx.x, i_step = 0, i_tap = 0, i_c0 = 0, i_py = 0, i_px = 0, i_cbeg = 0;
     bool i_live = true;
     auto setup_issue_tile = [&]() {
         int z = 0, m0 = 0, n0 = 0;
         i_live = i_tile < ntiles;
         if (i_live) decode_tile(i_tile, z, m0, n0);
+        i_cbeg = 0;
+        if (p.ksplit > 1) {  // (z of the output plane stays slice * nprob + problem: see the epilogue)
+            i_cbeg = (z / nprob) * cslice;
+            z = z % nprob;
+        }
         if (GATHER == G_DECONV) {
             i_py = p.py < 0 ? (z >> 1) : p.py;
             i_px = p.py < 0 ? (z & 1) : p.px;
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
         w_voff = (unsigned)(n0 + 8 * (wv + 8 * JA - NA) + d_l) * (unsigned)(p.ldw * ESZ) + d_kbytes;  // n < N: N % BN == 0
         i_step = 0;
         i_tap = 0;
-        i_c0 = 0;
+        i_c0 = i_cbeg;
     };
     auto issue_instr = [&](int buf, int j) {
         char* dst = smem + buf * STAGE + (wv + 8 * j) * 1024;
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, i_live ? w_voff + kb : OOB, 0, 0, 0);
         }
     };
-    const int ntaps = p.K / p.Cin;
+    const int ntaps = p.K / cslice;
     auto advance_cursor = [&]() {
         if (p.tap_inner) {
             // channel block -> taps: the nine (four) shifted reads of a 128-byte column block of the tile's pixels follow each
@@ -204,8 +216,8 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
             }
         } else {
             i_c0 += KS;
-            if (i_c0 == p.Cin) {
-                i_c0 = 0;
+            if (i_c0 == i_cbeg + cslice) {
+                i_c0 = i_cbeg;
                 ++i_tap;
             }
         }
@@ -612,7 +624,11 @@ static void shape_dims(int shape, int& BM, int& BN) {
 }
 
 bool panel_split_supported(const GemmParams& p, int prec, int groups) {
-    if (p.planar_P > 0 || p.ksplit > 1) return false;
+    if (p.planar_P > 0) return false;
+    if (p.ksplit > 1) {  // split-K: channel-range slices of a split-fp16 3x3 convolution walked taps-inner, fp32 partial sums out
+        if (prec != PP_PREC_F16X3 || p.gather != G_CONV3 || p.out_bf16 != 0 || p.bias || p.residual || p.head_w || p.pool_h > 0 || p.act != ACT_NONE) return false;
+        if (groups % p.ksplit != 0 || p.Cin % (32 * p.ksplit) != 0 || p.K != 9 * (p.Cin / p.ksplit) || option("psplit_tap_inner") < 1) return false;
+    }
     if (p.pool_h > 0) {  // fused MaxPool + ReLU: one 16 x 12 image per 192-row tile, a quarter of the tile = one row of windows
         if (prec != PP_PREC_F16X3 || p.gather != G_CONV3 || p.out_bf16 != 2 || p.residual || p.head_w) return false;
         if (p.H * p.Wd != 192 || p.pool_h * p.Wd != 48 || p.H != 4 * p.pool_h || p.Wd % p.pool_w != 0 || p.M % 192 != 0 || p.N % 192 != 0) return false;
@@ -621,7 +637,7 @@ bool panel_split_supported(const GemmParams& p, int prec, int groups) {
     if (prec == PP_PREC_F16X3) {
         if (p.head_w && !(p.gather == G_DECONV && p.N == 256 && p.head_n >= 1 && p.head_n <= 28)) return false;
         if (p.out_bf16 != 0 && p.out_bf16 != 2) return false;
-        if (p.K % 64 != 0 || p.Cin % 32 != 0 || p.ldc % 32 != 0 || p.lda % 32 != 0 || p.ldw % 32 != 0) return false;
+        if (p.K % 32 != 0 || p.Cin % 32 != 0 || p.ldc % 32 != 0 || p.lda % 32 != 0 || p.ldw % 32 != 0) return false;
         if (p.strideA_z % 32 != 0 || p.strideW_z % 32 != 0 || p.strideC_z % 32 != 0) return false;
     } else if (prec == PP_PREC_BF16) {  // convolutions have their own kernel (pp_panel_gemm.hip: fused head, split-K partials)
         if (p.gather == G_LINEAR ? (p.K < panel_linear_min_k(p.out_bf16 != 0)) : !panel_bf16_conv()) return false;
@@ -649,6 +665,7 @@ int panel_split_gemm(const GemmParams& p_in, int prec, int groups, hipStream_t s
     // re-reads of each miss L2), so it is only honoured together. Deconvolutions measured 1 - 3 % slower taps-inner: off.
     const int ti = option("psplit_tap_inner");
     p.tap_inner = (p.gather == G_CONV3 && ti >= 1) || (p.gather == G_DECONV && ti >= 2) ? 1 : 0;
+    PP_REQUIRE(p.ksplit <= 1 || p.tap_inner, PP_ERR_UNSUPPORTED, "pp panel split gemm: split-K slices are channel ranges walked taps-inner");
     p.tile_order = (p.gather == G_CONV3 && p.tap_inner && option("psplit_conv_weight_major") != 0) ? 1 : 0;
     if (p.gather == G_LINEAR) p.Cin = p.K;
     PP_REQUIRE(p.a_bytes > 0 && p.w_bytes > 0 && p.a_bytes < OOB && p.w_bytes < OOB, PP_ERR_UNSUPPORTED,

@@ -155,12 +155,12 @@ class ProbPoseEngine:
                 "reshapes them to (B, 1, K) (probmap_head.py:780-783), which needs 1x1"
             )
 
-    def ksplit(self, rows: int) -> int:
-        """K-slices of a small tower convolution with `rows` output pixels over the batch (3 = one kernel row of taps per slice,
-        9 = one tap): the library's own rule (pp_conv3x3_splitk_slices; PP_WS_TOWER_PARTIAL is sized by the same rule). Stages
-        with fewer than 1024 rows (the 2 x 2 maps at bs 64: 144 tiles for 256 CUs with three slices) take nine: split-K launch
-        48 -> 27 us, the nine-way sum costs 5 us more (dev switch: pp_set_option("ksplit9_below", rows))."""
-        return int(_lib.lib.pp_conv3x3_splitk_slices(int(rows)))
+    def ksplit(self, nb: int, th: int, tw: int) -> int:
+        """K-slices of a small tower convolution over nb images of th x tw pixels: the library's own rule
+        (pp_conv3x3_splitk_slices; PP_WS_TOWER_PARTIAL is sized by the same rule). 3 = one kernel row of taps per slice; 9 = one tap
+        (stages with fewer than 1024 rows - the 2 x 2 maps at bs 64: split-K launch 48 -> 27 us, the nine-way sum costs 5 us more);
+        4 = four channel ranges on the split-fp16 wide-tile kernel (the 4 x 4 maps at bs 64: one 256 x 192 tile per CU)."""
+        return int(_lib.lib.pp_conv3x3_splitk_slices(self.prec, int(nb), int(th), int(tw), self.E, self.E, 4))
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, B: int, passes: int, slot: int = 0) -> Dict[str, torch.Tensor]:
@@ -209,7 +209,7 @@ class ProbPoseEngine:
             ph, pw_ = self.pools[j]
             ws[f"t{j}"] = buf("tower", (4, nb, th, tw, E), index=j)
             if nb * th * tw * 4 < 128 * 128:
-                ks = self.ksplit(nb * th * tw)
+                ks = self.ksplit(nb, th, tw)
                 ws[f"tp{j}"] = buf("tower_partial", (ks, 4, nb, th, tw, E), f32, index=j)  # split-K partial sums of the small tower stages
             ws[f"p{j}"] = buf("tower_pooled", (4, nb, th // ph, tw // pw_, E), index=j)
         self._ws[key] = ws

@@ -182,6 +182,42 @@ def test_conv3x3_grouped_and_splitk_split():
 
 
 @gpu
+@pytest.mark.parametrize("B", [128, 272])
+def test_conv3x3_splitk_channel_slices_wide_tiles(B):
+    """The 4 x 4 stage of the scalar towers at the bench shape (128 images x 16 pixels, 384 channels, four towers): four
+    channel-range K-slices on the wide-tile kernel (one 256 x 192 tile per CU), partial sums reduced by the pooling kernel -
+    against torch fp64 on the unrounded operands; and the library's own slice rule picks exactly this form for the shape."""
+    L = _lib()
+    G, H, W, C = 4, 4, 4, 384  # (B = 272: 17 row tiles, two tiles per workgroup - the 27-stage tiles run on through the two-stage ring - and a ragged last row tile)
+    assert L.lib.pp_conv3x3_splitk_slices(F16X3, B, H, W, C, C, G) == 4
+    assert L.lib.pp_conv3x3_splitk_slices(F16X3, 8, H, W, C, C, G) in (3, 9), "too few rows for the wide tiles: whole-tap slices"
+    x = _rand(G, B, C, H, W, seed=61)
+    w = _rand(G, C, C, 3, 3, seed=62, scale=1 / math.sqrt(9 * C))
+    b = _rand(G, C, seed=63)
+    xd = _sp(x.permute(0, 1, 3, 4, 2).contiguous())
+    wd = _sp(w.permute(0, 1, 3, 4, 2).reshape(G, C, 9 * C).contiguous())
+    bd = b.cuda()
+    part = torch.full((4, G, B, H, W, C), float("nan"), device="cuda")
+    L.call("pp_conv3x3_splitk", F16X3, xd.data_ptr(), wd.data_ptr(), part.data_ptr(), B, H, W, C, C, G, B * H * W * C, C * 9 * C, 4, None)
+    pooled = torch.empty((G * B, H // 2, W // 2, C), device="cuda")
+    L.call("pp_sum_maxpool_relu_nhwc", part.data_ptr(), 4, G * B * H * W * C, bd.data_ptr(), B, pooled.data_ptr(), SPLIT,
+           G * B, H, W, C, 2, 2, None)
+    torch.cuda.synchronize()
+    ref = torch.stack([F.conv2d(x[g].double(), w[g].double(), None, padding=1) for g in range(G)])  # (G, B, C, H, W)
+    torch.testing.assert_close(part.sum(0).cpu().double().permute(0, 1, 4, 2, 3), ref, **TOL)
+    # every slice is the convolution over ITS channel range
+    for s_ in range(4):
+        cs = slice(96 * s_, 96 * (s_ + 1))
+        ref_s = F.conv2d(x[1][:, cs].double(), w[1][:, cs].double(), None, padding=1)
+        torch.testing.assert_close(part[s_, 1].cpu().double().permute(0, 3, 1, 2), ref_s, **TOL)
+    ref2 = F.relu(F.max_pool2d((ref + b.double()[:, None, :, None, None]).reshape(G * B, C, H, W), 2, 2)).permute(0, 2, 3, 1)
+    torch.testing.assert_close(_unsp(pooled), ref2, **TOL)
+    # a slice count the kernel does not take is refused, not mis-computed
+    with pytest.raises(L.ProbPoseLibraryError):
+        L.call("pp_conv3x3_splitk", F16X3, xd.data_ptr(), wd.data_ptr(), part.data_ptr(), B, H, W, C, C, G, B * H * W * C, C * 9 * C, 5, None)
+
+
+@gpu
 def test_deconv_all_phases_split():
     L = _lib()
     B, H, W, Cin, Cout = 2, 8, 6, 128, 64
