@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-/* 2: + pp_clock_probe, pp_conv3x3_splitk_slices, option "ksplit9_below"; PP_WS_TOWER_PARTIAL sized for the slice count the
+/* 2: + pp_clock_probe, pp_conv3x3_splitk_slices, pp_conv3x3_winograd_maxpool_relu, pp_winograd_scratch_bytes, option "ksplit9_below"; PP_WS_TOWER_PARTIAL sized for the slice count the
  *    library itself picks (round 3 added pp_workspace_bytes / pp_set_option / the split-fp16 layer kernels under version 1). */
 #define PP_ABI_VERSION 2
 
@@ -97,7 +97,8 @@ enum {
     PP_WS_TOWER = 10,        /* (4, n_img, h, w, embed) operand format: convolution output of tower stage `index`         */
     PP_WS_TOWER_PARTIAL = 11,/* (slices, 4, n_img, h, w, embed) fp32: split-K partial sums of tower stage `index`, slices =
                               * pp_conv3x3_splitk_slices(prec, n_img, h, w, embed, embed, 4)                                                    */
-    PP_WS_TOWER_POOLED = 12  /* (4, n_img, h / ph, w / pw, embed) operand format: pooled output of tower stage `index`     */
+    PP_WS_TOWER_POOLED = 12, /* (4, n_img, h / ph, w / pw, embed) operand format: pooled output of tower stage `index`     */
+    PP_WS_WINOGRAD = 13      /* pp_conv3x3_winograd_maxpool_relu's scratch for the first tower stage (pp_winograd_scratch_bytes)  */
 };
 long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* shape);
 
@@ -393,6 +394,20 @@ int pp_conv3x3_splitk(int prec, const void* act_nhwc, const void* weight, float*
 int pp_sum_maxpool_relu_nhwc(const float* partials, int nsplit, long long split_stride, const float* bias,
                              int images_per_group, void* out, int out_bf16, int N, int H, int W, int C, int ph, int pw,
                              void* stream);
+
+/* First stage of the scalar towers in its Winograd F(2x2, 3x3) form (PP_PREC_F16X3 only; split-fp16 operands):
+ *     Conv2d(Cin -> Cout, k3, p1) + folded BatchNorm -> MaxPool2d(pool_h, pool_w) -> ReLU      (probmap_head.py:261-294)
+ * for `groups` towers that SHARE the input act_nhwc (B, H, W, Cin), in two launches: the input transform (every 4 x 4 patch ->
+ * 16 planes [p][B * 48 tiles][Cin] in v_scratch, pp_winograd_scratch_bytes) and 16 position GEMMs with the output transform,
+ * pooling, bias and ReLU in the epilogue - 2.25x fewer MFMAs than the implicit GEMM (pp_conv3x3_maxpool_relu), only the pooled
+ * map is stored. u_packed: (groups, 16, Cout, Cin) split format, U_p = (G g G^T)_p of the BatchNorm-folded 3 x 3 weights
+ * g (Cout, Cin, 3, 3), G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], p = 4 a + b (probpose_code_amd/weights.py computes it in
+ * fp64). bias (groups, Cout) fp32; out_pooled (groups, B, H / pool_h, W / pool_w, Cout) split format. Built for H x W = 16 x 12,
+ * pooling (4, 3), Cin % 128 == 0, Cout % 96 == 0; anything else returns PP_ERR_UNSUPPORTED (use pp_conv3x3_maxpool_relu). */
+long long pp_winograd_scratch_bytes(int B, int H, int W, int Cin);
+int pp_conv3x3_winograd_maxpool_relu(const void* act_nhwc, const void* u_packed, const float* bias, void* v_scratch,
+                                     void* out_pooled, int B, int H, int W, int Cin, int Cout, int pool_h, int pool_w, int groups,
+                                     void* stream);
 
 /* Last layer of the four scalar towers (Conv1x1 -> Sigmoid; ReLU for the error tower,
  * probmap_head.py:280-290,405) on the 1x1 pooled feature, fused with the flip-test average of the

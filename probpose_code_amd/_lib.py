@@ -117,6 +117,8 @@ SIGNATURES = {
     "pp_layernorm": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_int, _P]),
     "pp_maxpool_relu_nhwc": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pp_conv3x3_maxpool_relu": (c_int, [c_int, _P, _P, _P, _P, _P] + [c_int] * 8 + [c_longlong] * 3 + [c_int, _P]),
+    "pp_winograd_scratch_bytes": (c_longlong, [c_int] * 4),
+    "pp_conv3x3_winograd_maxpool_relu": (c_int, [_P] * 5 + [c_int] * 8 + [_P]),
     "pp_tower_final": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
 }
 
@@ -133,7 +135,7 @@ class PlanShape(ctypes.Structure):
 
 
 # PP_WS_* of the header
-WS = dict(patches=0, x=1, h=2, qkv=3, att=4, ln2=5, ffn=6, feat=7, logits=8, deconv=9, tower=10, tower_partial=11, tower_pooled=12)
+WS = dict(patches=0, x=1, h=2, qkv=3, att=4, ln2=5, ffn=6, feat=7, logits=8, deconv=9, tower=10, tower_partial=11, tower_pooled=12, winograd=13)
 
 
 def workspace_bytes(buffer: str, shape: "PlanShape", index: int = 0) -> int:

@@ -127,6 +127,10 @@ long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* sh) {
                 return (long long)pp_conv3x3_splitk_slices(sh->prec, sh->n_img, (int)h, (int)w, sh->embed, sh->embed, 4) * 4 * sh->n_img * h * w * E * 4;
             return 4ll * sh->n_img * (h / ph) * (w / pw) * E * esz;
         }
+        case PP_WS_WINOGRAD: {
+            const long long n = pp_winograd_scratch_bytes(sh->n_img, sh->feat_h, sh->feat_w, sh->embed);
+            return n > 0 ? n : 0;  // 0: the Winograd form does not apply to this shape (no scratch needed)
+        }
         default: break;
     }
     set_error("pp_workspace_bytes: unknown buffer %d (index %d)", buffer, index);

@@ -36,7 +36,7 @@ CONV3X3, DECONV = 1, 2
 
 # launch-plan switches and their shipped values (fuse_resln: None = on for E = 384 only, True = also the E = 768 row-owner kernel)
 PLAN_DEFAULTS = dict(fuse_mlp=True, fuse_proj=True, fuse_qkv=True, split_k=True, fuse_attn=True, fuse_head=True, fuse_resln=None,
-                     fuse_pool=True, fuse_qkv_attn=True)
+                     fuse_pool=True, fuse_qkv_attn=True, winograd=True)
 
 
 def plan_from_env() -> Dict[str, object]:
@@ -139,6 +139,11 @@ class ProbPoseEngine:
         # f16x3, 192-token sequences of 32-dim heads: qkv Linear + attention of a layer in one launch, one workgroup per
         # (sequence, head); the qkv tensor never reaches HBM (pp_qkv_attn_split.hip). PP_FUSE_QKV_ATTN=0: pp_gemm + pp_attention
         self.fuse_qkv_attn = precision == "f16x3" and pl["fuse_qkv_attn"] and self.Np == 192 and self.hd == 32 and self.E == 384
+        # f16x3, 16 x 12 feature maps: the first tower stage in its Winograd F(2x2, 3x3) form (pp_winograd.hip: 2.25x fewer MFMAs)
+        self.winograd = (precision == "f16x3" and pl["winograd"] and self.w.has("tower0.wino")
+                         and _lib.lib.pp_winograd_scratch_bytes(1, self.Hp, self.Wp, self.E) > 0)
+        if self.w.has("tower0.wino") and not self.winograd:
+            self.w.t.pop("tower0.wino")  # (37.7 MB at ViT-S that no launch of this plan reads)
         self._logits_phased = False
         self.profile: Optional[Dict[str, list]] = None
         self.stage_hook = None  # callable(name) invoked between stages of the launch plan ("embed", "layer<i>", "backbone"); dev / scheduling experiments
@@ -205,6 +210,9 @@ class ProbPoseEngine:
                 ws[f"d{j}"] = buf("deconv", (nb, hh, ww, c), index=j)
             else:
                 ws[f"d{j}"] = e(nb, hh, ww, c)
+        if self.winograd:
+            nbytes = _lib.workspace_bytes("winograd", shape)
+            ws["wino"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         for j, (th, tw) in enumerate(self.tower_hw):
             ph, pw_ = self.pools[j]
             ws[f"t{j}"] = buf("tower", (4, nb, th, tw, E), index=j)
@@ -404,7 +412,11 @@ class ProbPoseEngine:
                 src = ws[f"p{j}"]
                 stride_src = nb * (th // ph) * (tw // pw_) * E
                 continue
-            if self.fuse_pool:
+            if j == 0 and self.winograd and stride_src == 0 and (ph, pw_) == (4, 3):
+                # first stage, Winograd F(2x2, 3x3): input transform + 16 position GEMMs with output transform, pooling, bias, ReLU
+                self._call("conv3x3", "pp_conv3x3_winograd_maxpool_relu", src.data_ptr(), w["tower0.wino"].data_ptr(), w["tower0.b"].data_ptr(),
+                           ws["wino"].data_ptr(), ws["p0"].data_ptr(), nb, th, tw, E, E, ph, pw_, 4, st)
+            elif self.fuse_pool:
                 # conv + BN -> MaxPool -> ReLU in one launch where the halo-staged kernel holds whole images per tile (bf16,
                 # 16 x 12 maps); the C side takes the two-launch route through `out` for every other shape
                 self._call("conv3x3", "pp_conv3x3_maxpool_relu", self.prec, src.data_ptr(), w[f"tower{j}.w"].data_ptr(),

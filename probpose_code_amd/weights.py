@@ -104,6 +104,14 @@ def pack_head_split(w32: torch.Tensor) -> torch.Tensor:
     return out.reshape(-1).view(torch.float32).contiguous()
 
 
+def winograd_weights(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, 3, 3) folded 3 x 3 weights -> (16, Cout, Cin) fp32: U_p = (G g G^T)[a][b], p = 4 a + b, of Winograd's
+    F(2x2, 3x3) (csrc/pp_winograd.hip), computed in fp64."""
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    u = torch.einsum("ai,ocij,bj->aboc", G, w.double(), G)
+    return u.reshape(16, w.shape[0], w.shape[1]).float()
+
+
 def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = False) -> PackedWeights:
     """``dtype``: operand dtype of the MFMA kernels (bf16 / fp32); ``split=True``: split-fp16 operands in a float32
     container (``to_split``)."""
@@ -170,7 +178,7 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
 
     # ---- scalar towers
     for c in range(3):
-        ws, bs = [], []
+        ws, bs, wino = [], [], []
         for tw in TOWERS:
             base = f"head.{tw}_layers."
             w = sd[base + f"{4 * c}.weight"].float()  # (Cout, Cin, 3, 3)
@@ -179,6 +187,10 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
             w = w * scale.view(-1, 1, 1, 1)
             ws.append(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))  # [n, (ky, kx, c)]
             bs.append(b * scale + shift)
+            if c == 0 and split:
+                wino.append(winograd_weights(w))
+        if c == 0 and split and w.shape[1] % 128 == 0 and w.shape[0] % 96 == 0:
+            t["tower0.wino"] = op(torch.stack(wino))  # (4, 16, Cout, Cin): the first stage's Winograd form (pp_conv3x3_winograd_maxpool_relu)
         t[f"tower{c}.w"] = op(torch.stack(ws))
         t[f"tower{c}.b"] = f32(torch.stack(bs))
     t["tower_out.w"] = f32(torch.stack([sd[f"head.{tw}_layers.12.weight"].float().reshape(K, -1) for tw in TOWERS]))

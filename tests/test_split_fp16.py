@@ -218,6 +218,50 @@ def test_conv3x3_splitk_channel_slices_wide_tiles(B):
 
 
 @gpu
+@pytest.mark.parametrize("B", [128, 6])
+def test_conv3x3_winograd_maxpool_relu_vs_fp64(B):
+    """First tower stage in its Winograd F(2x2, 3x3) form (pp_winograd.hip: input transform, 16 position GEMMs, output
+    transform + MaxPool(4, 3) + bias + ReLU in the epilogue), four towers sharing the input, against torch fp64 on the
+    unrounded operands: Conv2d(k3, p1) + bias -> MaxPool2d((4, 3)) -> ReLU (probmap_head.py:261-294). B = 128: the bench shape
+    (32 row blocks x 16 column tiles); B = 6: a ragged last row block (two of four images missing)."""
+    from probpose_code_amd.weights import winograd_weights
+
+    L = _lib()
+    G, H, W, C = 4, 16, 12, 384
+    x = _rand(B, C, H, W, seed=71)
+    w = _rand(G, C, C, 3, 3, seed=72, scale=1 / math.sqrt(9 * C))
+    b = _rand(G, C, seed=73, scale=0.3)
+    ref = torch.stack([F.relu(F.max_pool2d(F.conv2d(x.double(), w[g].double(), b[g].double(), padding=1), (4, 3))) for g in range(G)])
+    xd = _sp(x.permute(0, 2, 3, 1).contiguous())
+    ud = _sp(torch.stack([winograd_weights(w[g]) for g in range(G)]))
+    bd = b.cuda()
+    nbytes = L.lib.pp_winograd_scratch_bytes(B, H, W, C)
+    assert nbytes == 16 * B * 48 * C * 4
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    out = torch.full((G, B, 4, 4, C), float("nan"), device="cuda")
+    L.call("pp_conv3x3_winograd_maxpool_relu", xd.data_ptr(), ud.data_ptr(), bd.data_ptr(), scratch.data_ptr(), out.data_ptr(), B, H, W, C, C,
+           4, 3, G, None)
+    torch.cuda.synchronize()
+    got = _unsp(out).permute(0, 1, 4, 2, 3)
+    err = (got - ref).abs().max().item()
+    assert err <= 5e-5, f"max abs error {err:.2e} (ref scale {ref.abs().max().item():.2f})"
+    torch.testing.assert_close(got, ref, rtol=5e-5, atol=5e-5)
+    # the implicit-GEMM form of the same stage (POOL epilogue) gives the same map to rounding
+    wd = _sp(w.permute(0, 1, 3, 4, 2).reshape(G, C, 9 * C).contiguous())
+    if B * H * W >= 192 * 8:
+        out2 = torch.empty((G, B, 4, 4, C), device="cuda")
+        full = torch.empty((G, B, H, W, C), device="cuda")
+        L.call("pp_conv3x3_maxpool_relu", F16X3, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out2.data_ptr(), full.data_ptr(), B, H, W, C, C, 4, 3, G,
+               0, C * 9 * C, C, SPLIT, None)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(_unsp(out2).permute(0, 1, 4, 2, 3), got, rtol=5e-5, atol=5e-5)
+    # shapes the kernel is not built for are refused
+    with pytest.raises(L.ProbPoseLibraryError):
+        L.call("pp_conv3x3_winograd_maxpool_relu", xd.data_ptr(), ud.data_ptr(), bd.data_ptr(), scratch.data_ptr(), out.data_ptr(), B, 24, 18, C, C,
+               4, 3, G, None)
+
+
+@gpu
 def test_deconv_all_phases_split():
     L = _lib()
     B, H, W, Cin, Cout = 2, 8, 6, 128, 64
