@@ -84,6 +84,9 @@ def parse(argv=None):
     ap.add_argument("--no-second-mode", "--no-parity-mode", dest="no_second_mode", action="store_true",
                     help="skip the second bench in the other precision (bf16 `throughput_mode` beside an f16x3 headline and vice versa)")
     ap.add_argument("--no-config4", action="store_true", help="skip the bounded ViT-B 384x288 record")
+    ap.add_argument("--config4-batch", type=int, default=64, help="batch size of the `config4` record (SURVEY 8d: 64)")
+    ap.add_argument("--config4-only", action="store_true",
+                    help="run ONLY BASELINE config 4 (ViT-B 384x288) - for the profile passes of scripts/collect_profiles.sh; prints its record as the JSON line")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the `drop_in` record (model.test_step / test_step_stream timed)")
     ap.add_argument("--no-bs512-decode", action="store_true",
                     help="skip roofline_targets.head_decode_bs512 (counter passes: its launches would mix into the step's decode kernel)")
@@ -203,7 +206,7 @@ def kernel_work_per_step(eng, B, passes, tag):
     return res_fl, res_by, res_n, f"_ZN2pp11gemm_kernelI{t}Li0ELi0EEEvNS_10GemmParamsE"
 
 
-def pmc_traffic(kernel_mangled, precision, B):
+def pmc_traffic(kernel_mangled, precision, B, prefix=""):
     """HBM bytes per launch of `kernel_mangled` from the committed rocprofv3 --pmc passes (profiles/), or None."""
     if B != 64:
         return None, None
@@ -211,7 +214,10 @@ def pmc_traffic(kernel_mangled, precision, B):
              "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE": "pp::ffs::ffn_split_kernel(",
              "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE": "pp::ffs::proj_ffn_split_kernel(",
              "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE": "pp::qka::qkv_attention_split_kernel("}.get(kernel_mangled)
-    for name in (f"r03_{precision}_bs64_hbm_traffic.json", f"r02_{precision}_bs64_hbm_traffic.json", f"r01_{precision}_bs64_hbm_traffic.json"):
+    short = short or {"_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1ELi2ELb0ELb0EEEvNS_10GemmParamsE": "void pp::psplit::panel_split_kernel<0, 8, 3, true, 2, false, false>("}.get(kernel_mangled)
+    names = (f"r04_{prefix}{precision}_bs64_hbm_traffic.json",) if prefix else \
+        (f"r04_{precision}_bs64_hbm_traffic.json", f"r03_{precision}_bs64_hbm_traffic.json", f"r02_{precision}_bs64_hbm_traffic.json", f"r01_{precision}_bs64_hbm_traffic.json")
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         try:
             ks = json.load(open(path))["kernels"]
@@ -629,53 +635,62 @@ def instrumented_pass(eng, crops, flip, reps=5):
 
 
 def config4_record(dev, args):
-    """BASELINE config 4 - ProbPose-base (ViT-B 12 x 768, 12 heads x 64), 384x288 crops, 17-keypoint head, bs 32, flip test,
-    one GPU - as a bounded, driver-timed record: both precisions through the same two-deep pipeline as the headline (10 timed
-    steps), the dominant kernel's roofline from an instrumented pass, and parity against the oracle on 4 crops (the CPU model
-    takes ~1.5 s per 384x288 crop pair)."""
+    """BASELINE config 4 - ProbPose-base (ViT-B 12 x 768, 12 heads x 64), 384x288 crops, 17-keypoint head, bs 64, flip
+    test, one GPU - as a bounded, driver-timed record: both precisions through the same two-deep pipeline as the headline (10 timed
+    steps), the dominant kernel's roofline from an instrumented pass (+ its counter traffic from the committed profile), and parity
+    of the LAST TIMED REPLAY's output against the oracle on its first 16 crops (the CPU model takes ~1 s per 384x288 crop). A
+    second, shorter entry repeats the f16x3 run at bs 32 (the batch size of the round-3 record)."""
     from oracle import model_ref as M
     from probpose_code_amd import synthetic as S
     from probpose_code_amd.dist import ResultGather
     from probpose_code_amd.engine import ProbPoseEngine
 
-    B4, img, steps, warm = 32, (384, 288), 10, 3
+    B4, img, steps, warm, NPAR = args.config4_batch, (384, 288), 10, 3, 16
     sd4 = S.synthetic_state_dict("base", img_size=img, seed=0, logit_scale=2.0)
     crops_cpu = S.synthetic_crops(B4, img_size=img, seed=7)
     crops = crops_cpu.to(dev)
     flip = S.COCO_FLIP_INDICES
     rec = {"workload": f"ProbPose-base (ViT-B 12x768, 12 heads x 64) bs{B4} random 384x288 uint8 crops, flip_test=True, 96x72 heatmaps, "
                        "seeded random-init weights; same step definition and two-deep pipeline as the headline",
-           "gflop_per_crop": None, "steps": steps, "warmup": warm}
+           "batch": B4, "gflop_per_crop": None, "steps": steps, "warmup": warm}
     ref = None
+    npar = min(NPAR, B4)
     if not args.no_parity:
         torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-        ref = M.predict(sd4, crops_cpu[:4], 12, S.IMG_MEAN, S.IMG_STD, input_size=(288, 384))
+        ref = M.predict(sd4, crops_cpu[:npar], 12, S.IMG_MEAN, S.IMG_STD, input_size=(288, 384))
     depth = max(1, args.in_flight)
-    for prec in (PARITY_PRECISION, THROUGHPUT_PRECISION):
+
+    def run(prec, B, k, w):
         eng = ProbPoseEngine(sd4, 12, img_size=img, precision=prec, input_size=(288, 384), device=dev)
-        gather = ResultGather(B4, eng.K, dev, 1)
-        dt, _ = timed_run(eng, crops, gather, flip, steps, warm, not args.no_graph, None, dev, depth, 1)
-        prof, reps = instrumented_pass(eng, crops, flip, reps=2)
-        per_tag = {k: (float(np.sum(v)) / reps, len(v) // reps) for k, v in prof.items()}
-        dom = max(per_tag, key=lambda k: per_tag[k][0])
-        r = {"value": B4 * steps / dt, "unit": "crops/s", "ms_per_step": dt / steps * 1e3, "dtype_detail": DTYPE_DETAIL[prec],
-             "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_tag.items(), key=lambda kv: -kv[1][0])}}
-        work = kernel_work_per_step(eng, B4, 2, dom)
+        gather = ResultGather(B, eng.K, dev, 1)
+        dt, snap = timed_run(eng, crops[:B].contiguous(), gather, flip, k, w, not args.no_graph, None, dev, depth, 1)
+        prof, reps = instrumented_pass(eng, crops[:B].contiguous(), flip, reps=2)
+        per_tag = {kk: (float(np.sum(v)) / reps, len(v) // reps) for kk, v in prof.items()}
+        dom = max(per_tag, key=lambda kk: per_tag[kk][0])
+        r = {"value": B * k / dt, "unit": "crops/s", "ms_per_step": dt / k * 1e3, "batch": B, "dtype_detail": DTYPE_DETAIL[prec],
+             "kernel_ms_per_step": {kk: round(v[0], 4) for kk, v in sorted(per_tag.items(), key=lambda kv: -kv[1][0])}}
+        work = kernel_work_per_step(eng, B, 2, dom)
         if work is not None and work[2] == per_tag[dom][1]:
             fl, by, n, mangled = work
             secs = per_tag[dom][0] / n * 1e-3
+            traffic, src = pmc_traffic(mangled, prec, B, prefix="config4_")
             r["roofline"] = {"bound": "mfma", "kernel": dom, "kernel_mangled": mangled, "launches_per_step": n, "avg_launch_ms": secs * 1e3,
                              "achieved": fl / n / secs / 1e12, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
-                             "frac": fl / n / secs / 1e12 / PEAK_TFLOPS[prec], "traffic": None,
+                             "frac": fl / n / secs / 1e12 / PEAK_TFLOPS[prec], "traffic": traffic, "traffic_source": src,
+                             "algorithmic_mbytes_per_launch": by / n / 1e6,
                              "derived_ceiling_TFLOPs": PEAK_TFLOPS[prec] / MFMA_PER_PRODUCT[prec]}
-        if ref is not None:
-            out = eng.forward(crops[:4].contiguous(), True, flip)
-            torch.cuda.synchronize()
-            snap = {k: out[k].detach().cpu().numpy().copy() for k in ("keypoints", "scores", "scalars")}
-            r["parity_vs_oracle"] = parity_record(prec, 4, snap, ref, "eager forward of the first 4 crops")
-        rec[prec] = r
         del eng
         torch.cuda.empty_cache()
+        return r, snap
+
+    for prec in (PARITY_PRECISION, THROUGHPUT_PRECISION):
+        r, snap = run(prec, B4, steps, warm)
+        if ref is not None:
+            sub = {"keypoints": snap["keypoints"][:npar], "scalars": snap["scalars"][:, :npar]}
+            r["parity_vs_oracle"] = parity_record(prec, npar, sub, ref, f"last timed step (hipGraph replay of the bs {B4} pipeline), its first {npar} crops")
+        rec[prec] = r
+    if B4 != 32:
+        rec["f16x3_bs32"] = run(PARITY_PRECISION, 32, 6, 2)[0]
     # algorithmic FLOPs per crop with flip test (MAC = 2): backbone Linear layers + attention + patch embed + the head
     Np, E, Fd, L = 24 * 18, 768, 3072, 12
     fl = 2 * (L * (2.0 * Np * E * 3 * E + 2.0 * Np * E * E + 4.0 * Np * E * Fd + 4.0 * 12 * Np * Np * 64) + 2.0 * Np * E * 768)
@@ -685,7 +700,6 @@ def config4_record(dev, args):
     for prec in (PARITY_PRECISION, THROUGHPUT_PRECISION):
         rec[prec]["path_tflops"] = rec[prec]["value"] * fl / 1e12
     return rec
-
 
 
 def drop_in_record(dev, args, sd, B):
@@ -785,6 +799,12 @@ def main(argv=None):
     from probpose_code_amd import synthetic as S
     from probpose_code_amd.dist import ResultGather
 
+    if args.config4_only:
+        if world != 1 or args.stub:
+            print("bench.py: --config4-only is a single-GPU run", file=sys.stderr)
+            return 2
+        print(json.dumps({"metric": "person-crops/sec @ 384x288 (BASELINE config 4)", "n_gpus": 1, "config4": config4_record(dev, args)}))
+        return 0
     B = args.batch
     flip = S.COCO_FLIP_INDICES
     use_graph = not args.no_graph

@@ -402,8 +402,8 @@ int pp_sum_maxpool_relu_nhwc(const float* partials, int nsplit, long long split_
  * pooling, bias and ReLU in the epilogue - 2.25x fewer MFMAs than the implicit GEMM (pp_conv3x3_maxpool_relu), only the pooled
  * map is stored. u_packed: (groups, 16, Cout, Cin) split format, U_p = (G g G^T)_p of the BatchNorm-folded 3 x 3 weights
  * g (Cout, Cin, 3, 3), G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], p = 4 a + b (probpose_code_amd/weights.py computes it in
- * fp64). bias (groups, Cout) fp32; out_pooled (groups, B, H / pool_h, W / pool_w, Cout) split format. Built for H x W = 16 x 12,
- * pooling (4, 3), Cin % 128 == 0, Cout % 96 == 0; anything else returns PP_ERR_UNSUPPORTED (use pp_conv3x3_maxpool_relu). */
+ * fp64). bias (groups, Cout) fp32; out_pooled (groups, B, H / pool_h, W / pool_w, Cout) split format. Built for H % 4 == 0, W % 6 == 0
+ * (16 x 12, 24 x 18), pooling (4, 3), Cin % 128 == 0, Cout % 96 == 0; anything else returns PP_ERR_UNSUPPORTED (use pp_conv3x3_maxpool_relu). */
 long long pp_winograd_scratch_bytes(int B, int H, int W, int Cin);
 int pp_conv3x3_winograd_maxpool_relu(const void* act_nhwc, const void* u_packed, const float* bias, void* v_scratch,
                                      void* out_pooled, int B, int H, int W, int Cin, int Cout, int pool_h, int pool_w, int groups,

@@ -1,6 +1,6 @@
 // Winograd F(2x2, 3x3) form of the first stage of the four scalar towers in the parity precision (PP_PREC_F16X3):
 //     Conv2d(C -> C, k3, p1) + BatchNorm (folded) -> MaxPool2d(4, 3) -> ReLU        (probmap_head.py:261-294)
-// on 16 x 12 feature maps, four towers sharing the input. As an implicit GEMM (pp_panel_split.hip, POOL form) this stage is
+// on H x W feature maps with H % 4 == 0 and W % 6 == 0 (16 x 12 at ViT-S 256x192, 24 x 18 at ViT-B 384x288), four towers sharing the input. As an implicit GEMM (pp_panel_split.hip, POOL form) this stage is
 // 261 GFLOP at bs 64 with flip test = 15 % of the path's FLOPs and 0.65 - 0.73 ms of a 5.2 ms step; every algorithmic product
 // costs three fp16 MFMAs. Winograd's minimal filtering computes a 2 x 2 output tile from a 4 x 4 input tile with 16
 // multiplications per (input channel, output channel) instead of 36:
@@ -11,14 +11,17 @@
 //     (hi + lo is exact in fp32; B has entries 0, +-1 only), re-split and stored as 16 planes [p][tile][C] - the A operand of
 //     the GEMMs (151 MB at bs 64; L2 / MALL resident for the kernel that follows);
 //   * U_p = (G g G^T)_p of the BN-folded weights comes pre-computed in fp64 and split (weights.py: tower0.wino);
-//   * pp::wino::gemm_pool_kernel: a workgroup owns 192 tiles (four whole images: one image = one wave row group) x 96 output
+//   * tiles are numbered GROUP-major: a group = 2 x 3 tiles = 4 x 6 output pixels = two windows of the MaxPool2d(4, 3) that
+//     follows, so that any run of 6 n tiles pools on its own;
+//   * pp::wino::gemm_pool_kernel: a workgroup owns 192 tiles (32 groups; at 16 x 12 four whole images) x 96 output
 //     channels and walks the 16 positions x C / 32 K-steps as ONE stream of 36 KiB stages (192 V rows + 96 U rows, LDS-DMA)
 //     on a ring of four (three in flight); 8 waves x (48 tiles x 48 channels), the stage loop of pp_panel_split.hip (hi x hi
 //     while the lo fragments arrive, one barrier, lo x hi and hi x lo while the next stage's hi fragments replace the dying
 //     ones). The position's sums live in 36 accumulator registers; at the end of a position they are folded into the four
 //     output accumulators of the 2 x 2 tile with the coefficients of A^T (0, +-1): 180 accumulator registers per lane, one
-//     workgroup per CU. Epilogue, image by image: the 16 x 12 x 96 outputs go to LDS as fp32, are max-pooled (4, 3), get
-//     bias + ReLU and leave as the split format - only the pooled (4, 4) map is stored, as in the POOL form.
+//     workgroup per CU. Epilogue, one wave row group (48 tiles = 8 groups) at a time: the 8 x (4 x 6) x 96 outputs go to LDS as
+//     fp32, are max-pooled (4, 3), get bias + ReLU and leave as the split format - only the pooled map is stored, as in the
+//     POOL form.
 //
 // Numerics: the transforms add at most four values (input) / nine values (output) in fp32; measured against torch fp64 on the
 // unrounded operands the pooled outputs agree to the same 2e-5 the implicit-GEMM kernels meet (tests/test_split_fp16.py).
@@ -37,22 +40,23 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #endif
 constexpr int DBG = WINO_DBG;
 
-constexpr int IH = 16, IW = 12, TX = IW / 2, TPI = (IH / 2) * (IW / 2);  // 48 tiles of 2 x 2 outputs per image
-constexpr int PH = 4, PW = 3, OH = IH / PH, OW = IW / PW;                // MaxPool2d(4, 3) -> 4 x 4
-constexpr int BT = 4 * TPI, BN = 96, THREADS = 512;
+constexpr int PH = 4, PW = 3;            // MaxPool2d(4, 3)
+constexpr int GT = 6, GPX = 24;          // a group: 2 x 3 tiles of 2 x 2 outputs = 4 x 6 pixels = two pooling windows
+constexpr int BT = 192, BN = 96, THREADS = 512;  // 32 groups x 96 channels per workgroup; a wave row group = 48 tiles = 8 groups
 constexpr int STAGE = (BT + BN) * 128;  // 36 KiB: one 128-byte block of K per row
 constexpr int NST = 4;
 constexpr int LDS = NST * STAGE;        // 144 KiB
 constexpr int PITCH = 100;              // floats per pixel of the epilogue staging (16-byte aligned, 2-way conflicts at worst)
 constexpr unsigned OOB = 0x7ffffff0u;
-static_assert(IH * IW * PITCH * 4 <= LDS, "epilogue staging fits the ring");
+static_assert(8 * GPX * PITCH * 4 <= LDS, "epilogue staging fits the ring");
 
 struct Params {
     const void* V;      // [16][T][Cin] split: transformed input tiles
     const void* U;      // [groups][16][Cout][Cin] split: transformed weights
     const float* bias;  // [groups][Cout] (folded BatchNorm shift)
-    void* out;          // [groups][nb][4][4][Cout] split: pooled, ReLU'd
-    int nb, T, Cin, Cout, groups;
+    void* out;          // [groups][nb][H / 4][W / 3][Cout] split: pooled, ReLU'd
+    int nb, T, Cin, Cout, groups;  // T = nb * (H / 2) * (W / 2) tiles
+    int H, W;
     unsigned v_bytes, u_bytes;
 };
 
@@ -69,14 +73,19 @@ __device__ __forceinline__ void wait_vm_lgkm() {
 // ---------------------------------------------------------------------------------------------------------------------
 // V_p[tile][c] = (B^T d B)[a][b], p = 4 a + b, d = the 4 x 4 input patch at rows 2 ty - 1 .., columns 2 tx - 1 .. (zero outside
 // the image: the convolution's padding), B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]. One thread per (tile, four channels).
-__global__ __launch_bounds__(256) void input_transform_kernel(const char* __restrict__ feat, char* __restrict__ V, int nb, int C) {
+__global__ __launch_bounds__(256) void input_transform_kernel(const char* __restrict__ feat, char* __restrict__ V, int nb, int C, int H, int W) {
     const int G4 = C >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long T = (long long)nb * TPI;
+    const int GX = W / 6, GY = H / 4;
+    const long long T = (long long)nb * GY * GX * GT;
     if (idx >= T * G4) return;
     const int g4 = (int)(idx % G4);
     const long long tile = idx / G4;
-    const int img = (int)(tile / TPI), t = (int)(tile - (long long)img * TPI), ty = t / TX, tx = t - ty * TX;
+    // group-major tile index -> (image, tile row, tile column)
+    const int tl = (int)(tile % GT);
+    const long long grp = tile / GT;
+    const int gx = (int)(grp % GX), gy = (int)((grp / GX) % GY), img = (int)(grp / ((long long)GX * GY));
+    const int ty = 2 * gy + tl / 3, tx = 3 * gx + tl % 3;
     const int boff = (g4 >> 3) * 128 + (g4 & 7) * 8;  // hi halves of the four channels inside a pixel row; lo: + 64
     f32x4 d[4][4];
 #pragma unroll
@@ -85,8 +94,8 @@ __global__ __launch_bounds__(256) void input_transform_kernel(const char* __rest
         for (int c = 0; c < 4; ++c) {
             const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + c;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y >= 0 && y < IH && x >= 0 && x < IW) {
-                const char* src = feat + ((size_t)(img * IH + y) * IW + x) * (size_t)(C * 4) + boff;
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                const char* src = feat + ((size_t)(img * H + y) * W + x) * (size_t)(C * 4) + boff;
                 const f16x4 h = *reinterpret_cast<const f16x4*>(src), l = *reinterpret_cast<const f16x4*>(src + 64);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = (float)h[j] + (float)l[j];
@@ -266,9 +275,11 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pool_kernel(const Params p) {
     __syncthreads();
     if (DBG & 8) return;
     float* stage = reinterpret_cast<float*>(smem);
-    const int pp_ = tid / 12, cq = tid - pp_ * 12;  // pooling: thread -> (pooled pixel, eight channels); 192 of the 512 threads
+    const int GX = p.W / 6, GY = p.H / 4, OW = 2 * GX;
+    const long long ngroups = (long long)p.nb * GY * GX;
+    const int pp_ = tid / 12, cq = tid - pp_ * 12;  // pooling: thread -> (pooled pixel = (group, window) of the row group, eight channels); 192 of the 512 threads
     f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
-    if (tid < OH * OW * 12 && p.bias) {
+    if (tid < 16 * 12 && p.bias) {
         bv0 = *reinterpret_cast<const f32x4*>(p.bias + (size_t)g * p.Cout + n0 + 8 * cq);
         bv1 = *reinterpret_cast<const f32x4*>(p.bias + (size_t)g * p.Cout + n0 + 8 * cq + 4);
     }
@@ -277,10 +288,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pool_kernel(const Params p) {
         if (rg == i) {
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) {
-                const int t = 16 * rf + fr, ty = t / TX, tx = t - ty * TX;
+                const int t = 16 * rf + fr, grp = t / GT, tl = t - grp * GT, tyl = tl / 3, txl = tl - tyl * 3;
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
-                    const int pix = (2 * ty + (o >> 1)) * IW + 2 * tx + (o & 1);
+                    const int pix = grp * GPX + (2 * tyl + (o >> 1)) * 6 + 2 * txl + (o & 1);
 #pragma unroll
                     for (int cf = 0; cf < 3; ++cf)
                         *reinterpret_cast<f32x4*>(stage + pix * PITCH + 48 * cg + 16 * cf + 4 * fg) = Y[o][cf][rf];
@@ -288,16 +299,17 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pool_kernel(const Params p) {
             }
         }
         __syncthreads();
-        const int img = rb * 4 + i;
-        if (tid < OH * OW * 12 && img < p.nb) {
-            const int py = pp_ / OW, px = pp_ - py * OW;
+        const int grp = pp_ >> 1, wnd = pp_ & 1;
+        const long long gidx = (long long)rb * (BT / GT) + i * 8 + grp;  // global group: (image, group row, group column)
+        if (tid < 16 * 12 && gidx < ngroups) {
+            const int gx = (int)(gidx % GX), gy = (int)((gidx / GX) % GY), img = (int)(gidx / ((long long)GX * GY));
             const float ninf = -__builtin_inff();
             f32x4 m0 = {ninf, ninf, ninf, ninf}, m1 = m0;
 #pragma unroll
             for (int y = 0; y < PH; ++y)
 #pragma unroll
                 for (int x = 0; x < PW; ++x) {
-                    const float* s = stage + ((py * PH + y) * IW + px * PW + x) * PITCH + 8 * cq;
+                    const float* s = stage + (grp * GPX + y * 6 + wnd * PW + x) * PITCH + 8 * cq;
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(s), v1 = *reinterpret_cast<const f32x4*>(s + 4);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pool_kernel(const Params p) {
                 hv[4 + q] = split_hi(r1);
                 lv[4 + q] = split_lo(r1, hv[4 + q]);
             }
-            const size_t eoff = ((((size_t)g * p.nb + img) * OH + py) * OW + px) * (size_t)p.Cout + n0 + 8 * cq;
+            const size_t eoff = ((((size_t)g * p.nb + img) * GY + gy) * OW + 2 * gx + wnd) * (size_t)p.Cout + n0 + 8 * cq;
             char* o = split_addr(p.out, eoff);
             *reinterpret_cast<f16x8*>(o) = hv;
             *reinterpret_cast<f16x8*>(o + 64) = lv;
@@ -328,8 +340,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pool_kernel(const Params p) {
 
 extern "C" long long pp_winograd_scratch_bytes(int B, int H, int W, int Cin) {
     using namespace pp;
-    if (B <= 0 || H != wino::IH || W != wino::IW || Cin <= 0 || Cin % 128 != 0) return PP_ERR_UNSUPPORTED;
-    return 16ll * B * wino::TPI * Cin * 4;
+    if (B <= 0 || H <= 0 || W <= 0 || H % 4 != 0 || W % 6 != 0 || Cin <= 0 || Cin % 128 != 0) return PP_ERR_UNSUPPORTED;
+    return 16ll * B * (H / 2) * (W / 2) * Cin * 4;
 }
 
 extern "C" int pp_conv3x3_winograd_maxpool_relu(const void* act_nhwc, const void* u_packed, const float* bias, void* v_scratch,
@@ -338,17 +350,17 @@ extern "C" int pp_conv3x3_winograd_maxpool_relu(const void* act_nhwc, const void
     using namespace pp;
     PP_REQUIRE(act_nhwc && u_packed && v_scratch && out_pooled, PP_ERR_INVALID_ARG, "pp_conv3x3_winograd_maxpool_relu: NULL argument");
     PP_REQUIRE(B > 0 && groups >= 1, PP_ERR_INVALID_ARG, "pp_conv3x3_winograd_maxpool_relu: bad B / groups");
-    PP_REQUIRE(H == wino::IH && W == wino::IW && pool_h == wino::PH && pool_w == wino::PW, PP_ERR_UNSUPPORTED,
-               "pp_conv3x3_winograd_maxpool_relu: built for 16 x 12 feature maps pooled (4, 3) (ProbPose-S @ 256x192)");
+    PP_REQUIRE(H > 0 && W > 0 && H % 4 == 0 && W % 6 == 0 && pool_h == wino::PH && pool_w == wino::PW, PP_ERR_UNSUPPORTED,
+               "pp_conv3x3_winograd_maxpool_relu: built for feature maps with H % 4 == 0, W % 6 == 0 pooled (4, 3) (16 x 12, 24 x 18)");
     PP_REQUIRE(Cin % 128 == 0 && Cout % wino::BN == 0, PP_ERR_UNSUPPORTED,
                "pp_conv3x3_winograd_maxpool_relu: Cin must be a multiple of 128, Cout of 96");
-    const long long T = (long long)B * wino::TPI;
+    const long long T = (long long)B * (H / 2) * (W / 2);
     const long long vb = 16ll * T * Cin * 4, ub = 16ll * groups * Cout * (long long)Cin * 4;
     PP_REQUIRE(vb < wino::OOB && ub < wino::OOB, PP_ERR_UNSUPPORTED, "pp_conv3x3_winograd_maxpool_relu: operands must be smaller than 2 GiB");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long long items = T * (Cin / 4);
     hipLaunchKernelGGL(wino::input_transform_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
-                       reinterpret_cast<const char*>(act_nhwc), reinterpret_cast<char*>(v_scratch), B, Cin);
+                       reinterpret_cast<const char*>(act_nhwc), reinterpret_cast<char*>(v_scratch), B, Cin, H, W);
     PP_LAUNCH_CHECK();
     wino::Params p{};
     p.V = v_scratch;
@@ -360,11 +372,14 @@ extern "C" int pp_conv3x3_winograd_maxpool_relu(const void* act_nhwc, const void
     p.Cin = Cin;
     p.Cout = Cout;
     p.groups = groups;
+    p.H = H;
+    p.W = W;
     p.v_bytes = (unsigned)vb;
     p.u_bytes = (unsigned)ub;
-    const int grid = ((B + 3) / 4) * groups * (Cout / wino::BN);
+    const long long grid = ((T + wino::BT - 1) / wino::BT) * groups * (Cout / wino::BN);
+    PP_REQUIRE(grid < (1ll << 30), PP_ERR_UNSUPPORTED, "pp_conv3x3_winograd_maxpool_relu: too many tiles");
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino::gemm_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, wino::LDS));
-    hipLaunchKernelGGL(wino::gemm_pool_kernel, dim3(grid), dim3(wino::THREADS), wino::LDS, s, p);
+    hipLaunchKernelGGL(wino::gemm_pool_kernel, dim3((unsigned)grid), dim3(wino::THREADS), wino::LDS, s, p);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
