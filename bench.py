@@ -85,6 +85,7 @@ def parse(argv=None):
                     help="skip the second bench in the other precision (bf16 `throughput_mode` beside an f16x3 headline and vice versa)")
     ap.add_argument("--no-config4", action="store_true", help="skip the bounded ViT-B 384x288 record")
     ap.add_argument("--config4-batch", type=int, default=64, help="batch size of the `config4` record (SURVEY 8d: 64)")
+    ap.add_argument("--config4-quick", action="store_true", help="with --config4-only: f16x3 at --config4-batch only, 3 timed steps (counter passes)")
     ap.add_argument("--config4-only", action="store_true",
                     help="run ONLY BASELINE config 4 (ViT-B 384x288) - for the profile passes of scripts/collect_profiles.sh; prints its record as the JSON line")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the `drop_in` record (model.test_step / test_step_stream timed)")
@@ -646,6 +647,9 @@ def config4_record(dev, args):
     from probpose_code_amd.engine import ProbPoseEngine
 
     B4, img, steps, warm, NPAR = args.config4_batch, (384, 288), 10, 3, 16
+    quick = getattr(args, "config4_quick", False)
+    if quick:
+        steps, warm = 3, 1
     sd4 = S.synthetic_state_dict("base", img_size=img, seed=0, logit_scale=2.0)
     crops_cpu = S.synthetic_crops(B4, img_size=img, seed=7)
     crops = crops_cpu.to(dev)
@@ -683,13 +687,14 @@ def config4_record(dev, args):
         torch.cuda.empty_cache()
         return r, snap
 
-    for prec in (PARITY_PRECISION, THROUGHPUT_PRECISION):
+    precs = (PARITY_PRECISION,) if quick else (PARITY_PRECISION, THROUGHPUT_PRECISION)
+    for prec in precs:
         r, snap = run(prec, B4, steps, warm)
         if ref is not None:
             sub = {"keypoints": snap["keypoints"][:npar], "scalars": snap["scalars"][:, :npar]}
             r["parity_vs_oracle"] = parity_record(prec, npar, sub, ref, f"last timed step (hipGraph replay of the bs {B4} pipeline), its first {npar} crops")
         rec[prec] = r
-    if B4 != 32:
+    if B4 != 32 and not quick:
         rec["f16x3_bs32"] = run(PARITY_PRECISION, 32, 6, 2)[0]
     # algorithmic FLOPs per crop with flip test (MAC = 2): backbone Linear layers + attention + patch embed + the head
     Np, E, Fd, L = 24 * 18, 768, 3072, 12
@@ -697,7 +702,7 @@ def config4_record(dev, args):
     fl += 2 * (2.0 * (4 * Np) * 256 * 4 * E + 2.0 * (16 * Np) * 256 * 4 * 256 + 2.0 * (16 * Np) * 17 * 256)  # deconv x2 + final 1x1
     fl += 2 * 4 * (2.0 * Np * E * 9 * E + 2.0 * 36 * E * 9 * E + 2.0 * 9 * E * 9 * E)                      # four towers x three 3x3 stages
     rec["gflop_per_crop"] = fl / 1e9
-    for prec in (PARITY_PRECISION, THROUGHPUT_PRECISION):
+    for prec in precs:
         rec[prec]["path_tflops"] = rec[prec]["value"] * fl / 1e12
     return rec
 

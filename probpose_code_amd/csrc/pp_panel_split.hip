@@ -118,7 +118,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
     const int cslice = p.ksplit > 1 ? p.Cin / p.ksplit : p.Cin;  // channels per slice
 
     // XCD-aware tile order as in pp_panel_gemm.hip: row panel -> group -> column tile, contiguous runs per XCD
-    auto decode_tile = [&](int t, int& z, int& m0, int& n0) {
+    auto decode_tile = [&](int t, int& z, int& m0, int& n0) __attribute__((always_inline)) {
         if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);
         if (p.tile_order == 1) {
             // weight-major: a contiguous run of tiles (= what one XCD works on at a time) shares ONE (group, column tile) weight set
@@ -145,7 +145,10 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
     __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
     int i_tile = blockIdx.x, i_step = 0, i_tap = 0, i_c0 = 0, i_py = 0, i_px = 0, i_cbeg = 0;
     bool i_live = true;
-    auto setup_issue_tile = [&]() {
+    // (always_inline on every lambda that touches the per-instruction cursor arrays: called from several sites the compiler kept
+    // setup_issue_tile / issue_instr out of line, which forces a_y / a_x / a_voff - captured by reference - into SCRATCH memory:
+    // 7 - 9 scratch loads and stores per K-step inside the stage loop of every instantiation, rounds 2 - 3)
+    auto setup_issue_tile = [&]() __attribute__((always_inline)) {
         int z = 0, m0 = 0, n0 = 0;
         i_live = i_tile < ntiles;
         if (i_live) decode_tile(i_tile, z, m0, n0);
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
         i_tap = 0;
         i_c0 = i_cbeg;
     };
-    auto issue_instr = [&](int buf, int j) {
+    auto issue_instr = [&](int buf, int j) __attribute__((always_inline)) {
         char* dst = smem + buf * STAGE + (wv + 8 * j) * 1024;
         if (j < JA) {
             int dy = 0, dx = 0;
@@ -206,21 +209,18 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
         }
     };
     const int ntaps = p.K / cslice;
-    auto advance_cursor = [&]() {
-        if (p.tap_inner) {
-            // channel block -> taps: the nine (four) shifted reads of a 128-byte column block of the tile's pixels follow each
-            // other directly - the re-reads of the gather hit in L2 whatever else the XCD's workgroups stream meanwhile
-            if (++i_tap == ntaps) {
-                i_tap = 0;
-                i_c0 += KS;
-            }
-        } else {
-            i_c0 += KS;
-            if (i_c0 == i_cbeg + cslice) {
-                i_c0 = i_cbeg;
-                ++i_tap;
-            }
-        }
+    auto advance_cursor = [&]() __attribute__((always_inline)) {
+        // channel block -> taps (tap_inner: the nine (four) shifted reads of a 128-byte column block of the tile's pixels follow each
+        // other directly - the re-reads of the gather hit in L2 whatever else the XCD's workgroups stream meanwhile) or tap ->
+        // channel blocks. Written as straight-line selects ON PURPOSE: as two branches with `i_tap = ...` / `i_c0 = ...` in each, the
+        // compiler sank the stores into one store through a selected pointer, which pins the cursor in SCRATCH memory - every stage of
+        // every instantiation then began with two scratch loads and an s_waitcnt vmcnt(0) in front of its DMA issue (rounds 2 - 3;
+        // found in round 4 from -Rpass-analysis=kernel-resource-usage: ScratchSize 12 - 64 bytes per lane at 180 - 250 registers).
+        const bool ti = p.tap_inner != 0;
+        const int tap = i_tap + (ti ? 1 : 0), c0 = i_c0 + (ti ? 0 : KS);
+        const bool wrap = ti ? tap == ntaps : c0 == i_cbeg + cslice;
+        i_tap = ti ? (wrap ? 0 : tap) : tap + (wrap ? 1 : 0);
+        i_c0 = ti ? c0 + (wrap ? KS : 0) : (wrap ? i_cbeg : c0);
         if (++i_step == nsteps) {
             i_tile += gridDim.x;
             setup_issue_tile();
@@ -232,10 +232,10 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
     const int sw = f_row & 7;
     const int a_frag_off = (rg * (BM / 2) + f_row) * 128;
     const int w_frag_off = BM * 128 + (cg * (BN / 4) + f_row) * 128;
-    auto frag_a = [&](int buf, int lo, int rf) -> u32x4 {
+    auto frag_a = [&](int buf, int lo, int rf) __attribute__((always_inline)) -> u32x4 {
         return *reinterpret_cast<const u32x4*>(smem + buf * STAGE + (((lo * 4 + f_kg) ^ sw) << 4) + a_frag_off + rf * 2048);
     };
-    auto frag_w = [&](int buf, int lo, int cf) -> u32x4 {
+    auto frag_w = [&](int buf, int lo, int cf) __attribute__((always_inline)) -> u32x4 {
         return *reinterpret_cast<const u32x4*>(smem + buf * STAGE + (((lo * 4 + f_kg) ^ sw) << 4) + w_frag_off + cf * 2048);
     };
 

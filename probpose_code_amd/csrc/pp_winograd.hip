@@ -57,6 +57,7 @@ struct Params {
     void* out;          // [groups][nb][H / 4][W / 3][Cout] split: pooled, ReLU'd
     int nb, T, Cin, Cout, groups;  // T = nb * (H / 2) * (W / 2) tiles
     int H, W;
+    int order;          // tile order (see the kernel)
     unsigned v_bytes, u_bytes;
 };
 
@@ -141,11 +142,27 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pool_kernel(const Params p) {
     const int fr = lane & 15, fg = lane >> 4;
     const int sw = fr & 7;
 
-    const int CT = p.groups * (p.Cout / BN);  // column tiles; consecutive ids share the row block (and sit on one XCD)
+    // Tile order. The hardware deals workgroup ids round-robin to the eight XCDs; id -> (id & 7) * (n / 8) + (id >> 3) gives every XCD
+    // a contiguous run of logical ids, 32 of them resident at a time. A run is cut into SUPER TILES of 4 row blocks x 8 column tiles:
+    // per stage the 32 workgroups of an XCD then pull 4 x 24 KiB of V rows and 8 x 12 KiB of U rows through their L2 (192 KiB;
+    // 2 x 16 - column tiles fastest - is 240 KiB, and the HBM-side fetch of the launch was 1.19 GB against 0.6 GB of unique bytes
+    // per XCD round: WINO_ORDER 0).
+    const int CT = p.groups * (p.Cout / BN);  // column tiles
+    const int RB = (p.T + BT - 1) / BT;       // row blocks
     int id = blockIdx.x;
     const int nblk = gridDim.x;
     if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
-    const int ct = id % CT, rb = id / CT;
+    int ct, rb;
+    const int sc = p.order;  // column tiles per super tile (a power of two <= 32 dividing CT), 0: column tiles fastest over the whole run
+    if (sc > 0) {
+        const int sr = 32 / sc, st = id >> 5, w = id & 31, sct = st % (CT / sc), srb = st / (CT / sc);
+        rb = sr * srb + w / sc;
+        ct = sc * sct + w % sc;
+    } else {
+        ct = id % CT;
+        rb = id / CT;
+    }
+    if (rb >= RB) return;  // (the grid is padded to whole super tiles)
     const int g = (ct * BN) / p.Cout, n0 = ct * BN - g * p.Cout;
     const int KB = p.Cin >> 5;       // K-steps per position (a multiple of four)
     const int nstages = 16 * KB;
@@ -276,10 +293,18 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pool_kernel(const Params p) {
     if (DBG & 8) return;
     float* stage = reinterpret_cast<float*>(smem);
     const int GX = p.W / 6, GY = p.H / 4, OW = 2 * GX;
-    const long long ngroups = (long long)p.nb * GY * GX;
-    const int pp_ = tid / 12, cq = tid - pp_ * 12;  // pooling: thread -> (pooled pixel = (group, window) of the row group, eight channels); 192 of the 512 threads
+    const int ngroups = p.nb * GY * GX;  // (< 2^20: host check; the group index is decoded with float reciprocals, exact in that range -
+    // a 64-bit vector division here needs two dozen temporaries while the 144 output accumulators are still live, and the register
+    // allocator answered by keeping six of them in scratch for the WHOLE kernel: reloads inside the stage loop, 350 -> 447 us)
+    const float r_gx = 1.0f / (float)GX, r_gy = 1.0f / (float)GY;
+    // (lane / thread ids re-derived behind an opaque copy: everything computed from them below would otherwise be hoisted above the
+    // main loop, where all 256 registers are taken - 29 spilled, scratch reloads inside the stage loop, 350 -> 447 us)
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));
+    const int fr2 = tid2 & 15, fg2 = (tid2 >> 4) & 3;
+    const int pp_ = tid2 / 12, cq = tid2 - pp_ * 12;  // pooling: thread -> (pooled pixel = (group, window) of the row group, eight channels); 192 of the 512 threads
     f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
-    if (tid < 16 * 12 && p.bias) {
+    if (tid2 < 16 * 12 && p.bias) {
         bv0 = *reinterpret_cast<const f32x4*>(p.bias + (size_t)g * p.Cout + n0 + 8 * cq);
         bv1 = *reinterpret_cast<const f32x4*>(p.bias + (size_t)g * p.Cout + n0 + 8 * cq + 4);
     }
@@ -288,21 +313,22 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_pool_kernel(const Params p) {
         if (rg == i) {
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) {
-                const int t = 16 * rf + fr, grp = t / GT, tl = t - grp * GT, tyl = tl / 3, txl = tl - tyl * 3;
+                const int t = 16 * rf + fr2, grp = t / GT, tl = t - grp * GT, tyl = tl / 3, txl = tl - tyl * 3;
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     const int pix = grp * GPX + (2 * tyl + (o >> 1)) * 6 + 2 * txl + (o & 1);
 #pragma unroll
                     for (int cf = 0; cf < 3; ++cf)
-                        *reinterpret_cast<f32x4*>(stage + pix * PITCH + 48 * cg + 16 * cf + 4 * fg) = Y[o][cf][rf];
+                        *reinterpret_cast<f32x4*>(stage + pix * PITCH + 48 * cg + 16 * cf + 4 * fg2) = Y[o][cf][rf];
                 }
             }
         }
         __syncthreads();
         const int grp = pp_ >> 1, wnd = pp_ & 1;
-        const long long gidx = (long long)rb * (BT / GT) + i * 8 + grp;  // global group: (image, group row, group column)
-        if (tid < 16 * 12 && gidx < ngroups) {
-            const int gx = (int)(gidx % GX), gy = (int)((gidx / GX) % GY), img = (int)(gidx / ((long long)GX * GY));
+        const int gidx = rb * (BT / GT) + i * 8 + grp;  // global group: (image, group row, group column)
+        if (tid2 < 16 * 12 && gidx < ngroups) {
+            const int q1 = (int)(((float)gidx + 0.5f) * r_gx), gx = gidx - q1 * GX;  // gidx / GX, gidx % GX
+            const int img = (int)(((float)q1 + 0.5f) * r_gy), gy = q1 - img * GY;      // (gidx / GX) / GY, % GY
             const float ninf = -__builtin_inff();
             f32x4 m0 = {ninf, ninf, ninf, ninf}, m1 = m0;
 #pragma unroll
@@ -356,7 +382,8 @@ extern "C" int pp_conv3x3_winograd_maxpool_relu(const void* act_nhwc, const void
                "pp_conv3x3_winograd_maxpool_relu: Cin must be a multiple of 128, Cout of 96");
     const long long T = (long long)B * (H / 2) * (W / 2);
     const long long vb = 16ll * T * Cin * 4, ub = 16ll * groups * Cout * (long long)Cin * 4;
-    PP_REQUIRE(vb < wino::OOB && ub < wino::OOB, PP_ERR_UNSUPPORTED, "pp_conv3x3_winograd_maxpool_relu: operands must be smaller than 2 GiB");
+    PP_REQUIRE(vb < wino::OOB && ub < wino::OOB && T / wino::GT < (1 << 20), PP_ERR_UNSUPPORTED,
+               "pp_conv3x3_winograd_maxpool_relu: operands must be smaller than 2 GiB (and fewer than 2^20 tile groups)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long long items = T * (Cin / 4);
     hipLaunchKernelGGL(wino::input_transform_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
@@ -376,7 +403,12 @@ extern "C" int pp_conv3x3_winograd_maxpool_relu(const void* act_nhwc, const void
     p.W = W;
     p.v_bytes = (unsigned)vb;
     p.u_bytes = (unsigned)ub;
-    const long long grid = ((T + wino::BT - 1) / wino::BT) * groups * (Cout / wino::BN);
+    const long long ct_ = (long long)groups * (Cout / wino::BN), rb_ = (T + wino::BT - 1) / wino::BT;
+    int order = option("wino_order");
+    if (order < 0 || order > 32 || (order & (order - 1)) != 0 || (order > 0 && ct_ % order != 0)) order = 0;
+    p.order = order;
+    const long long sr_ = order > 0 ? 32 / order : 1;
+    const long long grid = ((rb_ + sr_ - 1) / sr_) * sr_ * ct_;  // whole super tiles (see the kernel)
     PP_REQUIRE(grid < (1ll << 30), PP_ERR_UNSUPPORTED, "pp_conv3x3_winograd_maxpool_relu: too many tiles");
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino::gemm_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, wino::LDS));
     hipLaunchKernelGGL(wino::gemm_pool_kernel, dim3((unsigned)grid), dim3(wino::THREADS), wino::LDS, s, p);

@@ -4,25 +4,27 @@
 # Kernel timing (--kernel-trace --stats) and the HBM counters (--pmc FETCH_SIZE, --pmc WRITE_SIZE) are separate runs;
 # PMC runs never carry another trace domain.
 set -u
-tag=${1:-r03_f16x3_bs64}
+tag=${1:-r04_f16x3_bs64}
 prec=${2:-f16x3}
+extra=${3:-}   # appended to every bench.py command, e.g. "--config4-only --config4-quick --no-parity" for BASELINE config 4 (tag r04_config4_f16x3_bs64)
+nodrop="--no-drop-in"
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/profiles
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_stats /tmp/prof_fetch /tmp/prof_write
-python $root/bench.py --steps 50 --warmup 10 --precision $prec > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec \
+python $root/bench.py --steps 50 --warmup 10 --precision $prec ${extra/--config4-quick/} > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 $nodrop --precision $prec $extra \
     > $out/${tag}_bench_under_rocprof.json 2> /tmp/prof_stats.log
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 # the same with strictly one step at a time on one stream (bench.py's default keeps two steps in flight: kernels of two steps
 # then share the chip and the per-kernel durations of the trace include that)
 rm -rf /tmp/prof_stats1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- python $root/bench.py --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec \
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- python $root/bench.py --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-parity-mode --no-config4 $nodrop --precision $prec $extra \
     > $out/${tag}_bench_under_rocprof_one_in_flight.json 2> /tmp/prof_stats1.log
 cp $(find /tmp/prof_stats1 -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_one_in_flight.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-bs512-decode --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-bs512-decode --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_write.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-bs512-decode --no-cpu-baseline --no-parity --no-parity-mode --no-config4 $nodrop --precision $prec $extra > /dev/null 2> /tmp/prof_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $root/bench.py --no-graph --steps 3 --warmup 1 --no-bs512-decode --no-cpu-baseline --no-parity --no-parity-mode --no-config4 $nodrop --precision $prec $extra > /dev/null 2> /tmp/prof_write.log
 python3 - "$out/${tag}_hbm_traffic.json" <<'PY'
 import csv, glob, json, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -32,7 +34,7 @@ for d, c in (("/tmp/prof_fetch", "FETCH_SIZE"), ("/tmp/prof_write", "WRITE_SIZE"
             if r["Counter_Name"] == c:
                 acc[r["Kernel_Name"]][c].append(float(r["Counter_Value"]))
 out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --no-graph --steps 3 "
-                "--warmup 1 --precision <mode of the file name>`, bs64, 1x MI355X. hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE "
+                "--warmup 1 --precision <mode of the file name>` (+ the extra arguments of the tag: --config4-only ... for the config4 files), bs64, 1x MI355X. hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE "
                 "reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section).",
        "kernels": {}}
 for k, d in acc.items():
@@ -51,7 +53,7 @@ i=0
 for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d /tmp/prof_sq$i -- python $root/bench.py --no-graph --in-flight 1 --steps 3 --warmup 1 --no-bs512-decode --no-cpu-baseline --no-parity --no-parity-mode --no-config4 --precision $prec > /dev/null 2> /tmp/prof_sq$i.log
+  rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d /tmp/prof_sq$i -- python $root/bench.py --no-graph --in-flight 1 --steps 3 --warmup 1 --no-bs512-decode --no-cpu-baseline --no-parity --no-parity-mode --no-config4 $nodrop --precision $prec $extra > /dev/null 2> /tmp/prof_sq$i.log
 done
 python3 - "$out/${tag}_sq_counters.txt" "$prec" <<'PY'
 import csv, glob, sys, collections
