@@ -199,6 +199,9 @@ def kernel_work_per_step(eng, B, passes, tag):
     if eng.precision == "f32":  # every output is fp32: one instantiation
         return act_fl + res_fl, act_by + res_by, act_n + res_n, "_ZN2pp11gemm_kernelIfLi0ELi0EEEvNS_10GemmParamsE"
     if tag == "gemm_bf16out":  # "operand-dtype output": bf16 or split-fp16
+        if eng.precision == "f16x3" and E >= 768 and (3 * E) % 192 == 0 and Fd % 192 == 0:
+            # K >= 768: the wide-tile split kernel (256 x 192 tiles; the fp32-output Linear layers run on the same instantiation)
+            return act_fl, act_by, act_n, "_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1ELi2ELb0ELb0EEEvNS_10GemmParamsE"
         if eng.precision == "f16x3" and (3 * E) % 192 == 0 and Fd % 192 == 0 and ((M + 191) // 192) * ((3 * E) // 192) >= 512:
             # the Linear layers with long output rows run on 192 x 192 tiles with the epilogue of one tile under the K-loop of
             # the next (pp_linear_ovl.hip; rocprofv3 lists it demangled: pp::lovl::linear_ovl_kernel(pp::GemmParams))

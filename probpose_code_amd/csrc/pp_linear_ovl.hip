@@ -327,6 +327,10 @@ bool linear_ovl_supported(const GemmParams& p, int prec, int groups) {
     if (p.out_bf16 != 0 && p.out_bf16 != 2) return false;
     if (p.N % lovl::BN != 0 || p.N > lovl::MAX_N || p.K % 32 != 0 || p.K / 32 < lovl::RF) return false;
     if (p.lda % 32 != 0 || p.ldw % 32 != 0 || p.ldc % 32 != 0) return false;
+    // K >= 768 (ViT-B): the wide-tile kernel wins since its stage cursor left scratch memory (round 4; ViT-B 384x288 bs 64, two steps in
+    // flight: 1 664 - 1 678 crops/s with this kernel for qkv / fc1, 1 706 - 1 708 without) - 24 K-steps amortise its epilogue, and this
+    // kernel still spills 15 registers (21 scratch accesses per tile, scripts/scratch_in_loops.py)
+    if (p.K >= 768) return false;
     const long long ntiles = (long long)(p.N / lovl::BN) * ((p.M + lovl::BM - 1) / lovl::BM);
     return ntiles >= 2 * 256;  // at least two tiles per CU: with one there is no next tile to hide the epilogue under
 }
