@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-/* 2: + pp_clock_probe, pp_conv3x3_splitk_slices, pp_conv3x3_winograd_maxpool_relu, pp_winograd_scratch_bytes, option "ksplit9_below"; PP_WS_TOWER_PARTIAL sized for the slice count the
+/* 2: + pp_clock_probe, pp_conv3x3_splitk_slices, pp_conv3x3_winograd_maxpool_relu, pp_winograd_scratch_bytes, pp_probmap_decode_flags, option "ksplit9_below"; PP_WS_TOWER_PARTIAL sized for the slice count the
  *    library itself picks (round 3 added pp_workspace_bytes / pp_set_option / the split-fp16 layer kernels under version 1). */
 #define PP_ABI_VERSION 2
 
@@ -68,6 +68,8 @@ int pp_device_cu_count(void);
  *   "decode_wgs_per_cu" (3)  pp_probmap_(head_)decode: workgroups per CU its LDS band buffer is sized for (5 .. 1)
  *   "qkv_attn_pair" (0)      1: pp_qkv_attention_split with a head pair per workgroup (measured slower; kept for A/B)
  *   "ksplit9_below" (1024)   pp_conv3x3_splitk_slices: output rows under which a small tower stage is cut into nine K-slices
+ *   "psplit_tail" (1)        0: split-fp16 Linear layers never send the rows of a ragged last round to a second launch on 128 x 192 tiles
+ *   "wino_order" (8)         pp_conv3x3_winograd_maxpool_relu: column tiles per 32-workgroup super tile (0: column tiles fastest)
  *   "ksplit_channels" (1)    pp_conv3x3_splitk_slices: 0 = whole-tap slices only (never the four channel ranges of the wide-tile kernel)
  * Unknown names return PP_ERR_INVALID_ARG. Not thread-safe against concurrent launches (set them before the first call).
  * (probpose_code_amd/_lib.py forwards PP_OPT_<NAME>=<int> environment variables here at import - host-side convenience.) */
@@ -381,6 +383,19 @@ int pp_probmap_head_decode_phased(const float* logits, const float* logits_flip,
                                   const double* taps, const int32_t* radius, int B, int K, int H, int W, double in_w,
                                   double in_h, float temperature, float normalize, float* avg_out, float* conv_out,
                                   float* locs, double* keypoints, float* scores, void* stream);
+
+/* The three decode entry points above as one, with flags: PP_DECODE_LOGITS (input = logits of the final 1x1 conv: temperature,
+ * Sparsemax, normalize, clamp first, as pp_probmap_head_decode; otherwise probability maps as pp_probmap_decode and temperature /
+ * normalize are ignored), PP_DECODE_PHASED (logits in the phase-separated layout of pp_deconv_head), PP_DECODE_SHIFT_HEATMAP
+ * (flip_heatmaps(..., shift_heatmap=True), mmpose/models/utils/tta.py:64-66: the flipped-back map is moved one pixel to the right
+ * before the average - column x takes the flipped pass's column W - x, column 0 its column W - 1; ignored without a flipped pass). */
+#define PP_DECODE_LOGITS 1
+#define PP_DECODE_PHASED 2
+#define PP_DECODE_SHIFT_HEATMAP 4
+int pp_probmap_decode_flags(const float* maps, const float* maps_flip, const int32_t* flip_indices, const double* taps,
+                            const int32_t* radius, int B, int K, int H, int W, double in_w, double in_h, float temperature,
+                            float normalize, float* avg_out, float* conv_out, float* locs, double* keypoints, float* scores,
+                            int flags, void* stream);
 
 /* Split-K form of the towers' 3x3 convolution for stages with few output pixels: the contraction is cut into ksplit slices -
  * 1, 3 or 9: whole taps (any precision); any other count with Cin % (32 ksplit) == 0: channel ranges [s Cin / ksplit, ...) of all nine

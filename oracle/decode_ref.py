@@ -153,14 +153,18 @@ def probmap_decode(
     return kpts, vals[None]
 
 
-def flip_back(heatmaps: np.ndarray, flip_indices: Sequence[int] = COCO_FLIP_INDICES) -> np.ndarray:
-    """tta.py:35-39: mirror the last axis, then permute the keypoint channels. (B, K, H, W)."""
-    return heatmaps[..., ::-1][:, list(flip_indices)]
+def flip_back(heatmaps: np.ndarray, flip_indices: Sequence[int] = COCO_FLIP_INDICES, shift_heatmap: bool = False) -> np.ndarray:
+    """tta.py:35-39: mirror the last axis, then permute the keypoint channels (B, K, H, W); ``shift_heatmap`` (:64-66):
+    ``heatmaps[..., 1:] = heatmaps[..., :-1].clone()`` - one pixel to the right, column 0 keeps its value."""
+    out = heatmaps[..., ::-1][:, list(flip_indices)]
+    if shift_heatmap:
+        out = np.concatenate([out[..., :1], out[..., :-1]], axis=-1)
+    return out
 
 
-def tta_average(hm: np.ndarray, hm_flipped_pass: np.ndarray, flip_indices=COCO_FLIP_INDICES) -> np.ndarray:
+def tta_average(hm: np.ndarray, hm_flipped_pass: np.ndarray, flip_indices=COCO_FLIP_INDICES, shift_heatmap: bool = False) -> np.ndarray:
     """probmap_head.py:757-763: ``(htm + flip_heatmaps(htm_flip)) * 0.5`` in float32."""
-    return ((hm + flip_back(hm_flipped_pass, flip_indices)) * np.float32(0.5)).astype(np.float32)
+    return ((hm + flip_back(hm_flipped_pass, flip_indices, shift_heatmap)) * np.float32(0.5)).astype(np.float32)
 
 
 def to_image_space(kpts, input_size, input_center, input_scale):

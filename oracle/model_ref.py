@@ -136,7 +136,7 @@ def head_forward(sd, feat, **kw):
 # --------------------------------------------------------------------------- estimator
 def predict(sd, imgs_u8_bgr: torch.Tensor, num_heads: int, mean, std, input_size=(192, 256), flip_test=True,
             flip_indices=D.COCO_FLIP_INDICES, input_center=None, input_scale=None, decode_backend="scipy",
-            normalize=1.0, freeze_oks=False) -> Dict[str, np.ndarray]:
+            normalize=1.0, freeze_oks=False, shift_heatmap=False) -> Dict[str, np.ndarray]:
     """TopdownPoseEstimator.predict (topdown.py:86-126) + ProbMapHead.predict (probmap_head.py:715-804)
     + add_pred_to_datasample (topdown.py:128-194), batched; returns the pred_instances fields stacked
     over the batch plus the intermediate tensors parity tests compare."""
@@ -148,7 +148,10 @@ def predict(sd, imgs_u8_bgr: torch.Tensor, num_heads: int, mean, std, input_size
             feat_f = vit_forward(sd, x.flip(-1), num_heads)
             htm_f, prob_f, vis_f, oks_f, err_f = head_forward(sd, feat_f, normalize=normalize)
             fi = list(flip_indices)
-            heat = (htm + htm_f.flip(-1)[:, fi]) * 0.5
+            back = htm_f.flip(-1)[:, fi]
+            if shift_heatmap:  # flip_heatmaps(..., shift_heatmap=True), tta.py:64-66
+                back = torch.cat([back[..., :1], back[..., :-1]], dim=-1)
+            heat = (htm + back) * 0.5
             prob = (prob + prob_f[:, fi]) * 0.5
             vis = (vis + vis_f[:, fi]) * 0.5
             oks = (oks + oks_f[:, fi]) * 0.5

@@ -69,6 +69,10 @@ SIGNATURES = {
         c_int,
         [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_float, c_float, _P, _P, _P, _P, _P, _P],
     ),
+    "pp_probmap_decode_flags": (
+        c_int,
+        [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_double, c_double, c_float, c_float, _P, _P, _P, _P, _P, c_int, _P],
+    ),
     "pp_deconv_head": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pp_deconv_head_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pp_gemm": (

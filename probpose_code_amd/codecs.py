@@ -136,12 +136,14 @@ class ProbMap(BaseKeypointCodec):
         flip_indices: Optional[Sequence[int]] = None,
         return_avg: bool = False,
         return_conv: bool = False,
+        shift_heatmap: bool = False,
     ) -> Dict[str, torch.Tensor]:
         """Batched decode on device tensors; nothing is copied to the host.
 
         heatmaps (B, K, H, W) float32 on a CUDA/HIP device; ``heatmaps_flip`` (same shape)
         is the output of the horizontally flipped pass -- it is flipped back, channel-permuted
-        by ``flip_indices`` and averaged inside the kernel (probmap_head.py:757-763).
+        by ``flip_indices`` and averaged inside the kernel (probmap_head.py:757-763); ``shift_heatmap``: the flipped-back
+        map is moved one pixel to the right first (``flip_heatmaps(..., shift_heatmap=True)``, models/utils/tta.py:64-66).
         Returns device tensors: ``keypoints`` (B, K, 2) f64 input-pixel space, ``scores``
         (B, K) f32, ``locs`` (B, K, 2) f32 heatmap space and optionally ``heatmaps`` (the
         averaged maps) / ``conv`` (the OKS-convolved maps).
@@ -172,11 +174,11 @@ class ProbMap(BaseKeypointCodec):
         conv = torch.empty_like(hm) if return_conv else None
         with torch.cuda.device(dev):
             _lib.call(
-                "pp_probmap_decode", _lib.ptr(hm), _lib.ptr(hmf), _lib.ptr(fi), _lib.ptr(taps), _lib.ptr(radius),
-                B, K, H, W, float(self.input_size[0]), float(self.input_size[1]),
+                "pp_probmap_decode_flags", _lib.ptr(hm), _lib.ptr(hmf), _lib.ptr(fi), _lib.ptr(taps), _lib.ptr(radius),
+                B, K, H, W, float(self.input_size[0]), float(self.input_size[1]), 1.0, 1.0,
                 _lib.ptr(avg), _lib.ptr(conv), _lib.ptr(out["locs"]), _lib.ptr(out["keypoints"]),
-                _lib.ptr(out["scores"]), _lib.stream_ptr(dev),
-            )  # fmt: skip
+                _lib.ptr(out["scores"]), 4 if shift_heatmap else 0, _lib.stream_ptr(dev),
+            )  # fmt: skip  (flags: PP_DECODE_SHIFT_HEATMAP = 4)
         if return_avg:
             out["heatmaps"] = avg
         if return_conv:

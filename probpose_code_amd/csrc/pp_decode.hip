@@ -248,7 +248,7 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
     const float* __restrict__ hm, const float* __restrict__ hm_flip, const int32_t* __restrict__ flip_indices,
     const double* __restrict__ taps, const int32_t* __restrict__ radius, int K, int H, int W, double in_w,
     double in_h, float temperature, float normalize, float* __restrict__ avg_out, float* __restrict__ conv_out,
-    float* __restrict__ locs, double* __restrict__ keypoints, float* __restrict__ scores, int phased, int cap) {
+    float* __restrict__ locs, double* __restrict__ keypoints, float* __restrict__ scores, int phased, int cap, int shift) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int bk = blockIdx.x;
@@ -289,9 +289,18 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
             int y, x;
             if (quad(e, y, x)) {
                 f32x4 v = src[y * W4 + (x >> 2)];
-                if (HAS_FLIP) {
+                if (HAS_FLIP && !shift) {
                     const f32x4 f = srcf[y * W4 + (W4 - 1 - (x >> 2))];
                     v = (v + f32x4{f[3], f[2], f[1], f[0]}) * 0.5f;
+                } else if (HAS_FLIP) {
+                    // shift_heatmap (tta.py:64-66): the flipped-back map moves one pixel to the right, column 0 keeps its value:
+                    // pixel x takes the flipped pass's pixel W - x (x >= 1), pixel 0 its pixel W - 1
+                    const float* fr_ = reinterpret_cast<const float*>(srcf) + y * W;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int xx = x + j;
+                        v[j] = (v[j] + fr_[xx >= 1 ? W - xx : W - 1]) * 0.5f;
+                    }
                 }
                 *reinterpret_cast<f32x4*>(mapf + y * Wp + PAD + x) = v;  // 16-byte aligned slot
                 if (avg_out) reinterpret_cast<f32x4*>(avg_out + (size_t)bk * HW)[y * W4 + (x >> 2)] = v;
@@ -406,11 +415,24 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
                 if (quad(e, y, xf)) {
                     // pixels xf .. xf + 3 of the flipped pass land at W-1-xf .. W-4-xf: the reversed quad at column W-4-xf; exactly
                     // one thread owns each cell
-                    f32x4* d = reinterpret_cast<f32x4*>(mapf + y * Wp + PAD + (W - 4 - xf));
-                    f32x4 v = *d;
+                    if (!shift) {
+                        f32x4* d = reinterpret_cast<f32x4*>(mapf + y * Wp + PAD + (W - 4 - xf));
+                        f32x4 v = *d;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[3 - j] = (v[3 - j] + clamp01(fmaxf(z1[e][j] - tau1, 0.0f) * normalize)) * 0.5f;
-                    *d = v;
+                        for (int j = 0; j < 4; ++j) v[3 - j] = (v[3 - j] + clamp01(fmaxf(z1[e][j] - tau1, 0.0f) * normalize)) * 0.5f;
+                        *d = v;
+                    } else {
+                        // shift_heatmap (tta.py:64-66): flipped pixel q lands at column W - q (q >= 1; q = 0 falls off), and the last
+                        // one, q = W - 1, also at column 0 - still exactly one thread per cell
+                        float* row = mapf + y * Wp + PAD;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int q = xf + j;
+                            const float pv = clamp01(fmaxf(z1[e][j] - tau1, 0.0f) * normalize);
+                            if (q >= 1) row[W - q] = (row[W - q] + pv) * 0.5f;
+                            if (q == W - 1) row[0] = (row[0] + pv) * 0.5f;
+                        }
+                    }
                 }
             }
         }
@@ -597,7 +619,7 @@ static long decode_rowd_doubles(int H, int W) {
 }
 
 typedef void (*DecodeKernel)(const float*, const float*, const int32_t*, const double*, const int32_t*, int, int, int,
-                             double, double, float, float, float*, float*, float*, double*, float*, int, int);
+                             double, double, float, float, float*, float*, float*, double*, float*, int, int, int);
 
 template <int NV>
 static DecodeKernel pick_kernel(bool from_logits, bool flip) {
@@ -610,7 +632,7 @@ static DecodeKernel pick_kernel(bool from_logits, bool flip) {
 static int decode_launch(bool from_logits, const float* hm, const float* hm_flip, const int32_t* flip_indices,
                          const double* taps, const int32_t* radius, int B, int K, int H, int W, double in_w,
                          double in_h, float temperature, float normalize, float* avg_out, float* conv_out, float* locs,
-                         double* keypoints, float* scores, void* stream, int phased = 0) {
+                         double* keypoints, float* scores, void* stream, int phased = 0, int shift = 0) {
     using namespace pp;
     PP_REQUIRE(B >= 0 && K > 0 && H > 0 && W > 0, PP_ERR_INVALID_ARG, "pp_probmap_(head_)decode: bad B/K/H/W");
     PP_REQUIRE(!phased || (from_logits && H % 2 == 0 && W % 8 == 0), PP_ERR_UNSUPPORTED,
@@ -638,7 +660,7 @@ static int decode_launch(bool from_logits, const float* hm, const float* hm_flip
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * K), dim3(DEC_THREADS), lds, s, hm, hm_flip, flip_indices, taps, radius, K, H,
-                       W, in_w, in_h, temperature, normalize, avg_out, conv_out, locs, keypoints, scores, phased, (int)cap);
+                       W, in_w, in_h, temperature, normalize, avg_out, conv_out, locs, keypoints, scores, phased, (int)cap, (hm_flip && shift) ? 1 : 0);
     PP_LAUNCH_CHECK();
     return PP_OK;
 }
@@ -666,4 +688,17 @@ extern "C" int pp_probmap_head_decode_phased(const float* logits, const float* l
                                              float* scores, void* stream) {
     return decode_launch(true, logits, logits_flip, flip_indices, taps, radius, B, K, H, W, in_w, in_h, temperature,
                          normalize, avg_out, conv_out, locs, keypoints, scores, stream, 1);
+}
+
+extern "C" int pp_probmap_decode_flags(const float* maps, const float* maps_flip, const int32_t* flip_indices, const double* taps,
+                                       const int32_t* radius, int B, int K, int H, int W, double in_w, double in_h, float temperature,
+                                       float normalize, float* avg_out, float* conv_out, float* locs, double* keypoints, float* scores,
+                                       int flags, void* stream) {
+    using namespace pp;
+    PP_REQUIRE((flags & ~(PP_DECODE_LOGITS | PP_DECODE_PHASED | PP_DECODE_SHIFT_HEATMAP)) == 0, PP_ERR_INVALID_ARG, "pp_probmap_decode_flags: unknown flag");
+    const bool logits = (flags & PP_DECODE_LOGITS) != 0;
+    PP_REQUIRE(logits || !(flags & PP_DECODE_PHASED), PP_ERR_INVALID_ARG, "pp_probmap_decode_flags: PP_DECODE_PHASED needs PP_DECODE_LOGITS");
+    return decode_launch(logits, maps, maps_flip, flip_indices, taps, radius, B, K, H, W, in_w, in_h, logits ? temperature : 1.f,
+                         logits ? normalize : 1.f, avg_out, conv_out, locs, keypoints, scores, stream, (flags & PP_DECODE_PHASED) ? 1 : 0,
+                         (flags & PP_DECODE_SHIFT_HEATMAP) ? 1 : 0);
 }

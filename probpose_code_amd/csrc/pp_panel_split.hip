@@ -697,11 +697,41 @@ int panel_split_gemm(const GemmParams& p_in, int prec, int groups, hipStream_t s
         default: kern = shape == 4 ? PP_PS(G_LINEAR, 6, 3, 3) : PP_PS(G_LINEAR, 8, 3, 2); break;
     }
 #undef PP_PS
+    int slots = device_cus();
+    slots -= slots % 8;
+    // Ragged last round of a Linear layer (one persistent workgroup per CU): the ViT-B projection / fc2 at bs 64 are 864 tiles of
+    // 256 x 192 = 3.375 rounds - the fourth round keeps 96 of 256 CUs busy for a whole tile time. The rows of the whole rounds go to this
+    // kernel, the tail rows to a second launch on 128 x 192 tiles (half the tile time, twice the tiles): 3 + ~0.5 rounds instead of 4
+    // (no 8-wave tile shape makes whole rounds at M = 2^11 x 27). Only where the tail fits ONE round of the small tiles.
+    if (p.gather == G_LINEAR && sp && shape == 2 && groups == 1 && p.res_mod == 0 && option("psplit_tail") != 0) {
+        const long long ntn = p.N / BN, ntm = (p.M + BM - 1) / BM, tiles = ntn * ntm;
+        const long long rounds = tiles / slots, rem = tiles % slots;
+        const long long m1 = (rounds * slots / ntn) * BM;  // rows of the whole rounds
+        const long long tail_tiles = m1 < p.M ? ntn * ((p.M - m1 + 127) / 128) : 0;
+        if (rounds >= 1 && rem > 0 && rem * 4 <= (long long)slots * 3 && tail_tiles > 0 && tail_tiles <= slots && m1 > 0) {
+            GemmParams p1 = p, p2 = p;
+            p1.M = (int)m1;
+            const size_t a_off = (size_t)m1 * p.lda * 4;
+            p2.M = p.M - (int)m1;
+            p2.A = reinterpret_cast<const char*>(p.A) + a_off;
+            p2.a_bytes = p.a_bytes - (unsigned)a_off;
+            p2.C = reinterpret_cast<char*>(p.C) + (size_t)m1 * p.ldc * 4;  // fp32 and split rows are both 4 bytes per element
+            if (p.residual) p2.residual = p.residual + (size_t)m1 * (p.ldres ? p.ldres : p.ldc);
+            void (*k1)(const GemmParams) = panel_split_kernel<G_LINEAR, 8, 3, true, 2>;
+            void (*k2)(const GemmParams) = panel_split_kernel<G_LINEAR, 4, 3, true, 2>;
+            const int lds1 = lds_bytes(256, 192, 2), lds2 = lds_bytes(128, 192, 2);
+            PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+            PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+            hipLaunchKernelGGL(k1, dim3(slots), dim3(THREADS), lds1, s, p1);
+            PP_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k2, dim3((unsigned)tail_tiles), dim3(THREADS), lds2, s, p2);
+            PP_LAUNCH_CHECK();
+            return PP_OK;
+        }
+    }
     const int lds = lds_bytes(BM, BN, shape >= 3 ? 3 : 2);
     const long long ntiles = (long long)(p.N / BN) * ((p.M + BM - 1) / BM) * groups;
     PP_REQUIRE(ntiles < (1ll << 30), PP_ERR_UNSUPPORTED, "pp panel split gemm: too many output tiles");
-    int slots = device_cus();
-    slots -= slots % 8;
     const int grid = (int)(ntiles < slots ? ntiles : slots);
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, s, p);

@@ -470,7 +470,7 @@ class ProbPoseEngine:
 
     @torch.no_grad()
     def run_head(self, feat_nhwc: torch.Tensor, flip_test: bool, flip_indices=None,
-                 return_heatmaps: bool = False, slot: int = 0) -> Dict[str, torch.Tensor]:
+                 return_heatmaps: bool = False, slot: int = 0, shift_heatmap: bool = False) -> Dict[str, torch.Tensor]:
         """NHWC features (passes*B, Hp, Wp, E) in the engine's operand dtype -> decoded results
         (ProbMapHead.forward + the flip-test merge + BaseHead.decode, probmap_head.py:746-779)."""
         passes = 2 if flip_test else 1
@@ -486,11 +486,12 @@ class ProbPoseEngine:
             logits = self.heatmap_logits(feat_nhwc, nb, ws, st)
             fi = self._flip_indices(flip_indices) if flip_test else None
             lf = logits[B:] if flip_test else None
-            self._call("head_decode", "pp_probmap_head_decode_phased" if self._logits_phased else "pp_probmap_head_decode", logits.data_ptr(), _lib.ptr(lf), _lib.ptr(fi), self.taps.data_ptr(),
+            flags = 1 | (2 if self._logits_phased else 0) | (4 if (shift_heatmap and flip_test) else 0)  # PP_DECODE_LOGITS | _PHASED | _SHIFT_HEATMAP
+            self._call("head_decode", "pp_probmap_decode_flags", logits.data_ptr(), _lib.ptr(lf), _lib.ptr(fi), self.taps.data_ptr(),
                       self.radius.data_ptr(), B, self.K, self.Hh, self.Wh, float(self.input_size[0]),
                       float(self.input_size[1]), self.temperature, -1.0 if self.normalize is None else float(self.normalize),  # (< 0: no Sparsemax)
                       ws["heatmaps"].data_ptr() if return_heatmaps else None, None, ws["locs"].data_ptr(),
-                      ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), st)
+                      ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), flags, st)
             scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, st)
         out = dict(keypoints=ws["keypoints"], scores=ws["scores"], locs=ws["locs"], scalars=scalars)
         if return_heatmaps:
@@ -499,23 +500,24 @@ class ProbPoseEngine:
 
     @torch.no_grad()
     def forward(self, imgs: torch.Tensor, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False,
-                return_features: bool = False, slot: int = 0) -> Dict[str, torch.Tensor]:
+                return_features: bool = False, slot: int = 0, shift_heatmap: bool = False) -> Dict[str, torch.Tensor]:
         """imgs: (B, 3, H, W) uint8 on the device (BGR CHW as PackPoseInputs emits). Returns device
         tensors (views into the cached workspace, valid until the next call with the same batch size):
         ``keypoints`` (B,K,2) f64 input-pixel space, ``scores`` (B,K) f32 (keypoints_conf), ``locs``,
         ``scalars`` (4,B,K) f32 [probability, visibility, oks, raw error], optionally ``heatmaps``."""
         feat = self.run_backbone(imgs, flip_test, slot)
-        out = self.run_head(feat, flip_test, flip_indices, return_heatmaps, slot)
+        out = self.run_head(feat, flip_test, flip_indices, return_heatmaps, slot, shift_heatmap)
         if return_features:
             out["features"] = feat
         return out
 
     # ------------------------------------------------------------------ hipGraph replay
-    def capture(self, B: int, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False, slot: int = 0):
+    def capture(self, B: int, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False, slot: int = 0,
+                shift_heatmap: bool = False):
         """Capture the whole launch sequence for batch size B into a HIP graph (the ~110 launches of one
         forward are launch-latency-bound from Python). Returns the static input buffer to fill. Every ``slot`` has its
         own workspace, input buffer and graph."""
-        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps, slot)
+        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps, bool(shift_heatmap), slot)
         if key in self._graphs:
             return self._graphs[key][1]
         static_in = torch.zeros((B, 3, self.H, self.W), dtype=torch.uint8, device=self.device)
@@ -523,21 +525,21 @@ class ProbPoseEngine:
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):  # warm-up: allocates the workspace, sets kernel attributes
             for _ in range(2):
-                self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot)
+                self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot, shift_heatmap=shift_heatmap)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            out = self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot)
+            out = self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot, shift_heatmap=shift_heatmap)
         self._graphs[key] = (graph, static_in, out)
         return static_in
 
     def forward_graph(self, imgs: torch.Tensor, flip_test: bool = True, flip_indices=None,
-                      return_heatmaps: bool = False, slot: int = 0) -> Dict[str, torch.Tensor]:
+                      return_heatmaps: bool = False, slot: int = 0, shift_heatmap: bool = False) -> Dict[str, torch.Tensor]:
         """Same contract as ``forward`` for uint8 crops, replaying the captured graph (on torch's current stream)."""
         B = imgs.shape[0]
-        static_in = self.capture(B, flip_test, flip_indices, return_heatmaps, slot)
-        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps, slot)
+        static_in = self.capture(B, flip_test, flip_indices, return_heatmaps, slot, shift_heatmap)
+        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps, bool(shift_heatmap), slot)
         graph, _, out = self._graphs[key]
         if imgs.data_ptr() != static_in.data_ptr():
             static_in.copy_(imgs, non_blocking=True)

@@ -27,11 +27,12 @@ from .dist import ResultGather
 
 class StepPipeline:
     def __init__(self, engine, batch: int, flip_indices, flip_test: bool = True, depth: int = 2, world: int = 1, group=None,
-                 use_graph: bool = True, force_collective: bool = False):
+                 use_graph: bool = True, force_collective: bool = False, shift_heatmap: bool = False):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.engine, self.batch, self.depth = engine, batch, depth
         self.flip_test, self.flip_indices = flip_test, flip_indices
+        self._kw = dict(shift_heatmap=True) if shift_heatmap else {}  # (stub engines of the CPU tests take no such keyword)
         # True: every batch has exactly ``batch`` rows and replays the slot's captured graph (captured here, up front);
         # "full": batches of exactly ``batch`` rows replay the slot's graph (captured when the first one arrives in the slot),
         # smaller ones are launched kernel by kernel; False: always kernel by kernel
@@ -57,7 +58,7 @@ class StepPipeline:
         self._copy_stream = torch.cuda.Stream(device=dev) if (self.cuda and depth > 1) else None
         if use_graph is True and self.cuda:
             for j in range(depth):
-                self._dev_in[j] = engine.capture(batch, flip_test, flip_indices, slot=j)
+                self._dev_in[j] = engine.capture(batch, flip_test, flip_indices, slot=j, **self._kw)
         if self.cuda:
             torch.cuda.synchronize(dev)
 
@@ -107,9 +108,9 @@ class StepPipeline:
                 crops_u8 = self._dev_in[j][:n]
             if self.use_graph is True or (self.use_graph == "full" and self.cuda and crops_u8.shape[0] == self.batch
                                           and crops_u8.dtype == torch.uint8):
-                out = eng.forward_graph(crops_u8, self.flip_test, self.flip_indices, slot=j)
+                out = eng.forward_graph(crops_u8, self.flip_test, self.flip_indices, slot=j, **self._kw)
             else:
-                out = eng.forward(crops_u8, self.flip_test, self.flip_indices, slot=j)
+                out = eng.forward(crops_u8, self.flip_test, self.flip_indices, slot=j, **self._kw)
             self.gathers[j](out)
         if s is not None and crops_u8.is_cuda:
             crops_u8.record_stream(s)

@@ -290,15 +290,16 @@ class ProbMapHead(nn.Module):
         flip = bool(test_cfg.get("flip_test", False))
         if flip:
             assert isinstance(feats, list) and len(feats) == 2
-            if test_cfg.get("flip_mode", "heatmap") != "heatmap" or test_cfg.get("shift_heatmap", False):
-                raise NotImplementedError("MI355X head implements flip_mode='heatmap', shift_heatmap=False (models/utils/tta.py:35-39; "
-                                          "the ProbPose config): the flip merge is fused into the decode kernel")
+            if test_cfg.get("flip_mode", "heatmap") != "heatmap":
+                raise NotImplementedError("MI355X head implements flip_mode='heatmap' (models/utils/tta.py:35-39; the ProbPose config): "
+                                          "'udp_combined' / 'offset' belong to other heads' outputs")
             flip_indices = batch_data_samples[0].metainfo["flip_indices"]
             x = torch.cat([self._to_nhwc(feats[0]), self._to_nhwc(feats[1])])
         else:
             flip_indices = None
             x = self._to_nhwc(feats)
-        out = self._engine.run_head(x, flip, flip_indices, return_heatmaps=bool(test_cfg.get("output_heatmaps", False)))
+        out = self._engine.run_head(x, flip, flip_indices, return_heatmaps=bool(test_cfg.get("output_heatmaps", False)),
+                                    shift_heatmap=flip and bool(test_cfg.get("shift_heatmap", False)))
         return self.pack_predictions(out, test_cfg)
 
     def pack_predictions(self, out: Dict[str, Tensor], test_cfg: dict = {}):
@@ -467,11 +468,13 @@ class TopdownPoseEstimator(nn.Module):
             raise NotImplementedError(
                 f"flip_mode={self.test_cfg.get('flip_mode')!r}: the MI355X path merges the flipped pass as flip_mode='heatmap' "
                 "(models/utils/tta.py:35-39; the ProbPose config); 'udp_combined' / 'offset' belong to other heads' outputs")
-        if flip and self.test_cfg.get("shift_heatmap", False):
-            raise NotImplementedError(
-                "shift_heatmap=True (tta.py:64-66: the flipped map moved one pixel to the right before averaging) is not built into "
-                "the fused flip-merge + decode kernel; the ProbPose config and every UDP config use shift_heatmap=False")
         return flip
+
+    @property
+    def _shift_heatmap(self) -> bool:
+        """``test_cfg.shift_heatmap`` (flip_heatmaps(..., shift_heatmap=True), tta.py:64-66): the flipped-back map moves one pixel to
+        the right before the average - done inside the fused flip-merge + decode kernel (PP_DECODE_SHIFT_HEATMAP)."""
+        return bool(self.test_cfg.get("flip_test", False)) and bool(self.test_cfg.get("shift_heatmap", False))
 
     def predict(self, inputs: Tensor, data_samples: list) -> list:
         """topdown.py:86-126, as ONE launch sequence: both flip-test passes are batched through the
@@ -489,10 +492,11 @@ class TopdownPoseEstimator(nn.Module):
         key = (B, flip, tuple(flip_indices) if flip_indices is not None else None, want_hm)
         seen = self._sizes_seen.get(key, 0)
         self._sizes_seen[key] = seen + 1
+        shift = self._shift_heatmap
         if self.graph_replay and seen >= 1 and inputs.dtype == torch.uint8:
-            out = eng.forward_graph(inputs, flip, flip_indices, return_heatmaps=want_hm)
+            out = eng.forward_graph(inputs, flip, flip_indices, return_heatmaps=want_hm, shift_heatmap=shift)
         else:
-            out = eng.forward(inputs, flip, flip_indices, return_heatmaps=want_hm)
+            out = eng.forward(inputs, flip, flip_indices, return_heatmaps=want_hm, shift_heatmap=shift)
         if self._gather is None or self._gather.batch < B:
             self._gather = ResultGather(max(B, 64), eng.K, eng.device, 1)
         self._gather(out)
@@ -537,7 +541,7 @@ class TopdownPoseEstimator(nn.Module):
             if pipe is None:
                 fi = samples[0].metainfo["flip_indices"] if flip else None
                 pipe = StepPipeline(self.engine, max_batch, fi, flip_test=flip, depth=depth,
-                                    use_graph="full" if self.graph_replay else False)
+                                    use_graph="full" if self.graph_replay else False, shift_heatmap=self._shift_heatmap)
             if inputs.shape[0] > max_batch:
                 raise ValueError(f"batch of {inputs.shape[0]} crops exceeds max_batch={max_batch}")
             while len(pending) >= depth:  # the slot about to be reused must have been read

@@ -97,6 +97,27 @@ def test_flip_average_decode_vs_oracle(hw, B):
         assert np.array_equal(sc[b][None], s_ref), f"sample {b}"
 
 
+@pytest.mark.parametrize("hw,B", [((64, 48), 16), ((96, 72), 4)])
+def test_flip_average_with_shift_heatmap_vs_oracle(hw, B):
+    """``shift_heatmap=True`` (flip_heatmaps, tta.py:64-66; oracle pinned to the reference's own function in
+    tests/golden/flip_heatmaps_shift.npz): the flipped-back map moves one pixel to the right inside the fused kernel."""
+    H, W = hw
+    rng = np.random.default_rng(12)
+    hm = _sparse_batch(rng, B, H, W)
+    hmf = _sparse_batch(rng, B, H, W)
+    hmf[:, :, :, 0] = rng.random((B, 17, H), dtype=np.float32)   # the flipped pass's first column falls off, its last one lands twice
+    hmf[:, :, :, -1] = rng.random((B, 17, H), dtype=np.float32)
+    codec = _codec(hw)
+    out = codec.decode_device(torch.from_numpy(hm).cuda(), torch.from_numpy(hmf).cuda(), FLIP, return_avg=True, shift_heatmap=True)
+    avg = D.tta_average(hm, hmf, FLIP, shift_heatmap=True)
+    assert np.array_equal(out["heatmaps"].cpu().numpy(), avg)
+    assert not np.array_equal(avg, D.tta_average(hm, hmf, FLIP))
+    kp, sc = out["keypoints"].cpu().numpy(), out["scores"].cpu().numpy()
+    for b in range(min(B, 4)):
+        k_ref, s_ref = D.probmap_decode(avg[b], tuple(codec.input_size), tuple(codec.heatmap_size))
+        assert np.array_equal(kp[b][None], k_ref, equal_nan=True) and np.array_equal(sc[b][None], s_ref), f"sample {b}"
+
+
 def test_convolved_map_stress_vs_scipy_direct_sum():
     """The kernel convolves separably (rows then columns, fp64) while ``scipy.ndimage.convolve`` - what the reference
     calls, post_processing.py:347-352 - accumulates the full 2-D kernel in fp64; both round once to fp32. The two are

@@ -157,6 +157,25 @@ def test_test_step_graph_replay_equals_eager_bit_for_bit(setup):
                 assert c[f].dtype == got[i][f].dtype and np.array_equal(c[f], got[i][f]), f"{f}: streamed batch {i} differs from test_step"
 
 
+def test_shift_heatmap_test_cfg_matches_the_oracle(setup):
+    """``test_cfg.shift_heatmap=True`` (flip_heatmaps(..., shift_heatmap=True), tta.py:64-66) through the drop-in call: keypoints
+    against the oracle with the shifted flip-back, on the eager and on the graph-replay path."""
+    from oracle import model_ref as M
+    from probpose_code_amd import apis
+    from probpose_code_amd import synthetic as S
+
+    sd, crops, center, scale, _ = setup
+    ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD, input_size=(192, 256), input_center=center, input_scale=scale, shift_heatmap=True)
+    model = apis.init_model(CFG, {"state_dict": sd}, device="cuda:0", cfg_options={"model.test_cfg.shift_heatmap": True})
+    with torch.no_grad():
+        runs = [model.test_step(apis.pack_crops(crops, center, scale, model.dataset_meta)) for _ in range(3)]  # eager, capture, replay
+    kps = [np.stack([ds.pred_instances.keypoints for ds in r]) for r in runs]
+    assert np.array_equal(kps[0], kps[2]), "graph replay differs from the eager launches"
+    d = np.abs(kps[2] - ref["keypoints"]).max(-1)
+    same = d < 2.0
+    assert same.mean() > 0.95 and d[same].max() <= 1e-3, f"{d[same].max():.2e} px, {int((~same).sum())} flips"
+
+
 @pytest.mark.parametrize("precision", ["bf16", "f16x3"])
 def test_graph_replay_equals_eager_bit_for_bit(precision):
     """bench.py times forward_graph (hipGraph replay): it must produce exactly what the eager launch sequence does,

@@ -93,10 +93,9 @@ def test_mixed_metainfo_dtypes_fall_back_to_the_per_sample_map(model):
 
 def test_flip_modes_outside_the_path_are_rejected_with_the_reason(model):
     model.test_cfg = dict(flip_test=True, flip_mode="heatmap", shift_heatmap=True)
-    with pytest.raises(NotImplementedError, match="shift_heatmap=True"):
-        model._check_flip_cfg()
+    assert model._check_flip_cfg() is True and model._shift_heatmap is True  # (tta.py:64-66: built into the fused flip merge)
     model.test_cfg = dict(flip_test=True, flip_mode="udp_combined")
     with pytest.raises(NotImplementedError, match="flip_mode='udp_combined'"):
         model._check_flip_cfg()
     model.test_cfg = dict(flip_test=False, shift_heatmap=True)
-    assert model._check_flip_cfg() is False
+    assert model._check_flip_cfg() is False and model._shift_heatmap is False

@@ -355,6 +355,43 @@ def test_fused_sparsemax_decode_vs_oracle(hw, B, flip):
     assert n_same >= 0.98 * B * K  # argmax flips only on near-ties
 
 
+def test_fused_sparsemax_decode_shift_heatmap_both_layouts():
+    """pp_probmap_decode_flags with PP_DECODE_SHIFT_HEATMAP on logits (tta.py:64-66 inside the fused Sparsemax + flip merge + decode):
+    the averaged map against the oracle's shifted flip-back, and the phase-separated layout bit-identical to the planar one."""
+    from oracle import decode_ref as D
+    from oracle import model_ref as M
+    from probpose_code_amd import _lib as L
+    from probpose_code_amd.codecs import oks_kernel_taps
+
+    B, K, H, W = 6, 17, 64, 48
+    g = torch.Generator().manual_seed(33)
+    smooth = F.interpolate(torch.randn(2 * B, K, H // 4, W // 4, generator=g), size=(H, W), mode="bicubic")
+    logits = (2.5 * smooth + 0.3 * torch.randn(2 * B, K, H, W, generator=g)).contiguous()
+    probs = torch.clamp(M.sparsemax(logits.reshape(2 * B, K, -1) / 0.5) * 1.0, 0, 1).reshape(2 * B, K, H, W).numpy()
+    avg = D.tta_average(probs[:B], probs[B:], shift_heatmap=True)
+    taps, radius = oks_kernel_taps(K, H, W)
+    td, rd = torch.from_numpy(taps).cuda(), torch.from_numpy(radius).cuda()
+    fi = torch.tensor(D.COCO_FLIP_INDICES, dtype=torch.int32).cuda()
+    planar = logits.cuda()
+    phased = planar.reshape(2 * B, K, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 2, 4).contiguous()  # (py, px) blocks of (H/2, W/2)
+    outs = []
+    for flags, src in ((1 | 4, planar), (1 | 2 | 4, phased)):
+        hm = torch.empty((B, K, H, W), device="cuda")
+        locs = torch.empty((B, K, 2), device="cuda")
+        kp = torch.empty((B, K, 2), dtype=torch.float64, device="cuda")
+        sc = torch.empty((B, K), device="cuda")
+        L.call("pp_probmap_decode_flags", src.data_ptr(), src[B:].data_ptr(), fi.data_ptr(), td.data_ptr(), rd.data_ptr(), B, K, H, W, 192.0, 256.0,
+               0.5, 1.0, hm.data_ptr(), None, locs.data_ptr(), kp.data_ptr(), sc.data_ptr(), flags, None)
+        outs.append((hm.cpu(), locs.cpu(), kp.cpu(), sc.cpu()))
+    assert np.abs(outs[0][0].numpy() - avg).max() < 2e-6
+    assert np.abs(outs[0][0].numpy() - D.tta_average(probs[:B], probs[B:])).max() > 1e-3, "the shift did nothing"
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    with pytest.raises(L.ProbPoseLibraryError):  # PP_DECODE_PHASED without PP_DECODE_LOGITS
+        L.call("pp_probmap_decode_flags", planar.data_ptr(), None, None, td.data_ptr(), rd.data_ptr(), B, K, H, W, 192.0, 256.0, 0.5, 1.0, None, None,
+               locs.data_ptr(), kp.data_ptr(), sc.data_ptr(), 2, None)
+
+
 @pytest.mark.parametrize("prec", [F32, BF16])
 @pytest.mark.parametrize("M,K,res_mod,E", [(192, 384, 0, 384), (480, 1536, 0, 384), (384, 768, 192, 384),
                                            (250, 768, 0, 768), (448, 3072, 0, 768), (864, 768, 432, 768)])

@@ -59,6 +59,13 @@ def test_flip_back_matches_reference(golden_dir):
     assert np.array_equal(D.flip_back(g["x"], g["flip_indices"]), g["y"])
 
 
+def test_flip_back_with_shift_matches_reference(golden_dir):
+    # flip_heatmaps(..., shift_heatmap=True) of the reference (tta.py:64-66; tests/golden/make_golden_flip_shift.py)
+    g = np.load(os.path.join(golden_dir, "flip_heatmaps_shift.npz"))
+    assert np.array_equal(D.flip_back(g["x"], g["flip_indices"], shift_heatmap=True), g["y_shift"])
+    assert np.array_equal(D.flip_back(g["x"], g["flip_indices"]), g["y_plain"])
+
+
 def test_reference_batched_call_is_broken(golden_dir):
     # the reference's own B>1 form raises; the oracle therefore only restates the 3-D form
     assert str(np.load(os.path.join(golden_dir, "quirks.npz"))["batched_call_raises"]) == "ValueError"

@@ -353,6 +353,33 @@ def test_panel_split_linear(act, split_out, K):
     torch.testing.assert_close(_unsp(out) if split_out else out.cpu().double(), ref, **TOL)
 
 
+@gpu
+@pytest.mark.parametrize("res,split_out", [(True, 0), (False, 1)])
+def test_panel_split_linear_ragged_round_tail(res, split_out):
+    """A Linear layer whose 256 x 192 tiles make whole rounds of the chip plus a short last one (79 row tiles x 4 = 316 tiles: one
+    round of 256 + 60): the rows of the whole rounds run on the wide tiles, the tail rows (3 616, the last tile 32 rows) in a
+    second launch on 128 x 192 tiles - fp32 output with residual (the ViT-B projection / fc2 form) and split output - against
+    torch fp64; and the same result with the tail launch switched off."""
+    L = _lib()
+    M, N, K = 20000, 768, 768
+    a, w, b = _rand(M, K, seed=81), _rand(N, K, seed=82, scale=1 / math.sqrt(K)), _rand(N, seed=83)
+    r = _rand(M, N, seed=84)
+    ref = a.double() @ w.double().t() + b.double() + (r.double() if res else 0)
+    ad, wd, bd, rd = _sp(a), _sp(w), b.cuda(), r.cuda()
+    outs = []
+    for tail in (1, 0):
+        L.set_option("psplit_tail", tail)
+        out = torch.full((M, N), float("nan"), device="cuda")
+        L.call("pp_gemm", F16X3, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if res else None, 0, out.data_ptr(), M, N, K, K, K, N, 0,
+               SPLIT if split_out else 0, 0, None)
+        got = _unsp(out) if split_out else out.cpu().double()
+        assert not torch.isnan(got).any(), "rows left unwritten"
+        torch.testing.assert_close(got, ref, **TOL)
+        outs.append(out.clone())
+    L.set_option("psplit_tail", 1)
+    assert torch.equal(outs[0], outs[1]), "the tail launch changes the bits (same K order per output: it must not)"
+
+
 # ---- the overlapped-epilogue kernel (pp_linear_ovl.hip) takes split Linear layers without residual once there are at least two
 # 192 x 192 tiles per CU (qkv / fc1 of the ViT at bs 64): tail rows, the three activations, both output formats, and a bias
 # that must come out of LDS for every column tile
