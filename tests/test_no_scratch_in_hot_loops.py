@@ -1,0 +1,63 @@
+"""CPU (build check, no GPU): the stage loops of the hot kernels must not touch scratch memory.
+
+Round 4 found the wide-tile split kernel loading its DMA cursor from scratch in every K-step (a local the compiler could not
+promote: two scratch loads + `s_waitcnt vmcnt(0)` in front of each stage's DMA issue, since round 2) and the first generalised
+Winograd kernel keeping six accumulators in scratch for the whole launch - neither shows up in any numerics test, both cost
+8 - 27 % of their kernels. This test compiles the sources to gfx950 ISA (hipcc cross-compiles without a GPU) and asserts that no
+loop that contains MFMAs contains a scratch instruction (scripts/scratch_in_loops.py is the dev-side tool with the same logic).
+"""
+import os
+import re
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "probpose_code_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+# kernels allowed to keep scratch accesses in an OUTER (per-tile) loop: the fused 1x1-head deconvolution reloads six registers per tile
+OUTER_OK = ("panel_split_kernelILi2ELi6ELi4ELb1ELi2ELb1",)
+
+
+def _loops_with_scratch(src):
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-I{CSRC}", f"-I{ROOT}/include", "-c", os.path.join(CSRC, src),
+                        "-o", "x.o", "--save-temps"], cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        asm = [f for f in os.listdir(td) if f.endswith("gfx950.s")][0]
+        lines = open(os.path.join(td, asm)).read().split("\n")
+    funcs, cur = {}, None
+    for l in lines:
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur = m.group(1)
+            funcs[cur] = []
+        elif l.startswith(".Lfunc_end"):
+            cur = None
+        elif cur:
+            funcs[cur].append(l)
+    bad = []
+    for name, body in funcs.items():
+        labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"(\.LBB\d+_\d+):", l)] if m}
+        loops = []
+        for i, l in enumerate(body):
+            m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                loops.append((labels[m.group(1)], i))
+        inner = [(a, b) for a, b in loops if not any(a2 >= a and b2 <= b and (a2, b2) != (a, b) for a2, b2 in loops)]
+        for a, b in loops:
+            n_scr = sum("scratch_" in x for x in body[a:b])
+            n_mfma = sum("v_mfma" in x for x in body[a:b])
+            if n_scr and n_mfma and ((a, b) in inner or not any(k in name for k in OUTER_OK)):
+                bad.append((name, a, b, n_scr, n_mfma))
+    return bad
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_hot_kernels_keep_scratch_out_of_their_mfma_loops():
+    srcs = ["pp_panel_split.hip", "pp_winograd.hip", "pp_qkv_attn_split.hip", "pp_ffn_split.hip"]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        results = list(ex.map(_loops_with_scratch, srcs))
+    bad = [(s,) + b for s, r in zip(srcs, results) for b in r]
+    assert not bad, "scratch memory inside an MFMA loop:\n" + "\n".join(f"  {s}: {n[:80]} lines {a}-{b}: {k} scratch ops / {m} MFMAs" for s, n, a, b, k, m in bad)
