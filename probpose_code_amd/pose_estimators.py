@@ -321,8 +321,17 @@ class ProbMapHead(nn.Module):
         sc = np.ascontiguousarray(np.moveaxis(rec[..., 2:7], -1, 0).astype(np.float32))  # (5, B, K): conf, prob, vis, oks, err
         conf, probabilities, visibilities, oks, errors = (sc[i].reshape(B, 1, C) for i in range(5))
         errors = errors / np.sqrt(eng.Hh**2 + eng.Wh**2)  # :786-787, the same expression (its result dtype is numpy's promotion rule's)
-        preds = []
+        preds = _BatchPreds()
+        preds.keypoints_batch = kpts  # (add_pred_to_datasample maps the whole batch to image space through this array)
+        fast = hasattr(InstanceData, "_set_data_fields")  # (the in-repo containers; mmengine's own InstanceData: field by field)
         for pi in range(B):
+            if fast:
+                p = InstanceData()
+                p._set_data_fields(dict(keypoints=kpts[pi:pi + 1], keypoint_scores=conf[pi] if self.freeze_oks else oks[pi],
+                                        keypoints_conf=conf[pi], keypoints_probs=probabilities[pi], keypoints_visible=visibilities[pi],
+                                        keypoints_oks=oks[pi], keypoints_error=errors[pi]))
+                preds.append(p)
+                continue
             p = InstanceData(keypoints=kpts[pi:pi + 1], keypoint_scores=conf[pi])
             p.set_field(conf[pi], "keypoints_conf")
             p.set_field(probabilities[pi], "keypoints_probs")
@@ -594,29 +603,32 @@ class TopdownPoseEstimator(nn.Module):
     @staticmethod
     def _map_batch_to_image_space(batch_pred_instances, batch_data_samples) -> bool:
         """One evaluation of topdown.py:165-167 for the batch; False = not applicable (the caller maps sample by sample)."""
+        base = getattr(batch_pred_instances, "keypoints_batch", None)
         n = len(batch_pred_instances)
-        if n < 2 or any(p is None for p in batch_pred_instances):
+        if base is None or n < 2 or base.ndim != 3 or base.shape[0] != n or base.dtype != np.float64:
             return False
-        base = batch_pred_instances[0].keypoints.base
-        if base is None or base.ndim != 3 or base.shape[0] != n or base.dtype != np.float64:
-            return False
-        for i, p in enumerate(batch_pred_instances):
-            k = p.keypoints
-            if k.base is not base or k.shape != (1,) + base.shape[1:] or k.ctypes.data != base[i].ctypes.data:
+        for p in batch_pred_instances:  # every sample still holds ITS row of the batch array (nobody swapped a field in between)
+            if p is None or p.keypoints.base is not base or p.keypoints.shape[0] != 1:
                 return False
         try:
-            metas = [ds.metainfo for ds in batch_data_samples]
-            cen = [np.asarray(m["input_center"]) for m in metas]
-            sca = [np.asarray(m["input_scale"]) for m in metas]
-            siz = [np.asarray(m["input_size"]) for m in metas]
-        except KeyError:
+            cen = [np.asarray(ds.input_center) for ds in batch_data_samples]
+            sca = [np.asarray(ds.input_scale) for ds in batch_data_samples]
+            siz = [np.asarray(ds.input_size) for ds in batch_data_samples]
+        except AttributeError:
             return False
         for arrs in (cen, sca, siz):
-            if any(a.shape != (2,) or a.dtype != arrs[0].dtype for a in arrs):
+            d0 = arrs[0].dtype
+            if any(a.shape != (2,) or a.dtype != d0 for a in arrs):
                 return False
         cen, sca, siz = (np.stack(a)[:, None, :] for a in (cen, sca, siz))  # (B, 1, 2): broadcast over the K keypoints
         base[..., :2] = base[..., :2] / siz * sca + cen - 0.5 * sca
         return True
+
+
+class _BatchPreds(list):
+    """``list[InstanceData]`` of one batch whose ``keypoints`` are rows of ONE (B, K, 2) array, kept in ``keypoints_batch``."""
+
+    keypoints_batch = None
 
 
 def build_pose_estimator(cfg: dict):

@@ -59,6 +59,14 @@ except Exception:  # noqa: BLE001
                 raise AttributeError(f"{name} has been used as a private attribute, which is immutable.")
             self.set_field(value, name)
 
+        def _set_data_fields(self, fields: Dict[str, Any]) -> None:
+            """Several data fields at once without the per-field checks of ``set_field`` (the caller guarantees that none of the
+            names is a metainfo field): the packaging loop of a batch sets ~10 fields on each of its samples."""
+            self._data_fields.update(fields)
+            d = self.__dict__
+            for k, v in fields.items():
+                d[k] = v
+
         def __delattr__(self, name: str) -> None:
             object.__delattr__(self, name)
             self._data_fields.discard(name)
