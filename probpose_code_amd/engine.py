@@ -212,7 +212,8 @@ class ProbPoseEngine:
                 ws[f"d{j}"] = e(nb, hh, ww, c)
         if self.winograd:
             nbytes = _lib.workspace_bytes("winograd", shape)
-            ws["wino"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            # (the kernel addresses its planes with 32-bit offsets: batches beyond ~900 crops with flip test at ViT-S take the direct kernel)
+            ws["wino"] = torch.empty(nbytes, dtype=torch.uint8, device=dev) if 0 < nbytes < 0x7FFFFFF0 else None
         for j, (th, tw) in enumerate(self.tower_hw):
             ph, pw_ = self.pools[j]
             ws[f"t{j}"] = buf("tower", (4, nb, th, tw, E), index=j)
@@ -412,7 +413,7 @@ class ProbPoseEngine:
                 src = ws[f"p{j}"]
                 stride_src = nb * (th // ph) * (tw // pw_) * E
                 continue
-            if j == 0 and self.winograd and stride_src == 0 and (ph, pw_) == (4, 3):
+            if j == 0 and self.winograd and ws.get("wino") is not None and stride_src == 0 and (ph, pw_) == (4, 3):
                 # first stage, Winograd F(2x2, 3x3): input transform + 16 position GEMMs with output transform, pooling, bias, ReLU
                 self._call("conv3x3", "pp_conv3x3_winograd_maxpool_relu", src.data_ptr(), w["tower0.wino"].data_ptr(), w["tower0.b"].data_ptr(),
                            ws["wino"].data_ptr(), ws["p0"].data_ptr(), nb, th, tw, E, E, ph, pw_, 4, st)
