@@ -624,3 +624,29 @@ def test_wide_tile_bf16_linear_long_k(out_bf16, act, res):
     L.call("pp_gemm", BF16, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr() if res else None, 0, out.data_ptr(), M, N, K, K, K, N,
            act, out_bf16, 0, None)
     torch.testing.assert_close(out.cpu().double(), ref, **(dict(rtol=2e-2, atol=2e-2) if out_bf16 else dict(rtol=2e-3, atol=2e-3)))
+
+
+def test_clock_probe_reports_a_plausible_shader_clock():
+    """pp_clock_probe (bench hygiene): one sleeping wavefront brackets wall time with s_memtime / s_memrealtime; it stops at the
+    host's flag (pinned memory, plain store) or at its time limit, and cycles / ticks * 100 is a shader clock in MHz."""
+    import time
+
+    L = _lib()
+    words = torch.zeros(3, dtype=torch.int64).pin_memory()
+    side = torch.cuda.Stream()
+    base = words.data_ptr()
+    L.call("pp_clock_probe", base, base + 16, 2_000_000, side.cuda_stream)
+    t0 = time.perf_counter()
+    time.sleep(0.02)
+    words[2] = 1
+    side.synchronize()
+    assert time.perf_counter() - t0 < 1.0, "the probe ignored the stop flag"
+    cyc, ticks = int(words[0]), int(words[1])
+    assert 1_500_000 <= ticks <= 60_000_000, ticks          # 15 ms .. 0.6 s of the 100 MHz counter
+    assert 50.0 <= cyc / ticks * 100.0 <= 3000.0, cyc / ticks * 100.0
+    words.zero_()
+    L.call("pp_clock_probe", base, None, 5_000, side.cuda_stream)  # no flag: runs to its limit (5 ms)
+    side.synchronize()
+    assert 400_000 <= int(words[1]) <= 5_000_000
+    with pytest.raises(L.ProbPoseLibraryError):
+        L.call("pp_clock_probe", None, None, 1000, None)
