@@ -28,6 +28,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef PF
 #define PF 2  // XDIRECT: A-steps of x fragments in flight ahead of the one being multiplied
 #endif
+#ifndef GELU
+#define GELU 0  // 1: after a chunk's twelve A-steps every computing wave runs the erfc-form GELU on its 24 accumulator values and writes the
+                // (hi, lo) pairs into the G tile (12 ds_write_b64) - exposed, all waves at the same time (no second accumulator set at 168 registers)
+#endif
 #ifndef ABL  // timing-only ablations: 1 no DMA traffic (empty descriptors), 4 no MFMA
 #define ABL 0
 #endif
@@ -228,6 +232,37 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
                 for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
                     for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wh[nf], xl[rf], pacc[rf][nf]);
+#if GELU
+                if (t == NA - 1) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) {
+                            h4 hv, lv;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float x = pacc[rf][nf][q];
+                                const float z = fabsf(x) * 0.70710678118654752440f;
+                                const float tt = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+                                float qq = __builtin_fmaf(tt, 1.061405429f, -1.453152027f);
+                                qq = __builtin_fmaf(tt, qq, 1.421413741f);
+                                qq = __builtin_fmaf(tt, qq, -0.284496736f);
+                                qq = __builtin_fmaf(tt, qq, 0.254829592f);
+                                const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.44269504088896340736f);
+                                const float ez = tt * qq * e;
+                                const float gv = 0.5f * x * (x < 0.f ? ez : 2.0f - ez);
+                                hv[q] = (_Float16)gv;
+                                lv[q] = (_Float16)(gv - (float)hv[q]);
+                                pacc[rf][nf][q] = 0.f;
+                            }
+                            char* gs = smem + cg * G_KB + (rows0 + rf * 16) * 128 + (f_kg & 1) * 8;
+                            const int c = 2 * nf + (f_kg >> 1);
+                            *reinterpret_cast<h4*>(gs + ((c ^ sw) << 4)) = hv;
+                            *reinterpret_cast<h4*>(gs + (((4 + c) ^ sw) << 4)) = lv;
+                        }
+                }
+#endif
             } else {
                 const int sb = t - NA, half = sb & 1;
                 u32x4 wh[3], wl[3];
@@ -297,7 +332,7 @@ int main() {
         if (ms / 20 < best) best = ms / 20;
     }
     hipError_t err = hipGetLastError();
-    printf("MODE=%d XDIRECT=%d PF=%d ABL=%d: %.1f us per launch (240 steps: %.0f ns per step), err=%s\n", MODE, XDIRECT, PF, ABL, best * 1e3, best * 1e6 / 240,
+    printf("MODE=%d GELU=%d XDIRECT=%d PF=%d ABL=%d: %.1f us per launch (240 steps: %.0f ns per step), err=%s\n", MODE, GELU, XDIRECT, PF, ABL, best * 1e3, best * 1e6 / 240,
            hipGetErrorString(err));
     return 0;
 }
