@@ -10,6 +10,6 @@ import json, sys
 d = json.load(open("/tmp/ab.json"))
 k = d["kernel_ms_per_step"]
 print(f"{sys.argv[1]:>10s}: {d['value']:8.0f} crops/s  {d['ms_per_step']:.3f} ms/step  clock {d['clock']['shader_clock_MHz']:.0f} MHz  per GHz {d['clock']['crops_per_s_per_GHz']:.0f}  "
-      f"one-in-flight {d['one_step_in_flight']['ms_per_step']:.3f}  " + "  ".join(f"{n} {k.get(n)}" for n in ("deconv_head", "deconv", "conv3x3", "conv3x3_splitk", "gemm_res_ln")))
+      f"one-in-flight {d['one_step_in_flight']['ms_per_step']:.3f}  " + "  ".join(f"{n} {k.get(n)}" for n in ("proj_ffn_split", "qkv_attention")))
 PY
 done; done
