@@ -162,10 +162,15 @@ def kernel_work_per_step(eng, B, passes, tag):
     if tag == "mlp_res_ln":  # fc1 + GELU + fc2 + residual + LN per layer
         return L * 4.0 * M * E * Fd, L * (M * E * 2 + 2 * M * E * 4 + M * E * 2), L, "_ZN2pp3mlp17mlp_res_ln_kernelILb0ELb0ELb0EEEvNS0_6ParamsE"
     if tag == "ffn_split":  # f16x3: fc1 + GELU + fc2 + residual + LN per layer; h in, residual in, x out, h out (4 bytes each)
-        return L * 4.0 * M * E * Fd, L * 4 * M * E * 4, L, "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE"
+        from probpose_code_amd import _lib
+        dma = _lib.get_option("ffn_dma_waves") != 0  # the twelve-wave form (pp_ffn_dma.hip) or the eight-wave one (pp_ffn_split.hip)
+        return L * 4.0 * M * E * Fd, L * 4 * M * E * 4, L, "_ZN2pp3ffd14ffn_dma_kernelENS_3ffs6ParamsE" if dma else "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE"
     if tag == "proj_ffn_split":  # f16x3: proj + residual + ln2 + fc1 + GELU + fc2 + residual + LN per layer; attention rows in,
         # residual in, x out, h out (4 bytes each); the ln2 rows a workgroup parks in L2 and streams back are not algorithmic bytes
-        return L * (4.0 * M * E * Fd + 2.0 * M * E * E), L * 4 * M * E * 4, L, "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE"
+        from probpose_code_amd import _lib
+        dma = _lib.get_option("ffn_dma_waves") != 0
+        return (L * (4.0 * M * E * Fd + 2.0 * M * E * E), L * 4 * M * E * 4, L,
+                "_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE" if dma else "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE")
     if tag == "qkv_attention":  # f16x3: qkv Linear + attention per (sequence, head); LayerNorm rows in, attention rows out
         att_fl = 4.0 * (B * passes) * eng.heads * eng.Np * eng.Np * eng.hd
         return L * (2.0 * M * 3 * E * E + att_fl), L * 2 * M * E * 4, L, "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE"
@@ -218,6 +223,7 @@ def pmc_traffic(kernel_mangled, precision, B, prefix=""):
     short = {"_ZN2pp4lovl17linear_ovl_kernelENS_10GemmParamsE": "pp::lovl::linear_ovl_kernel(",
              "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE": "pp::ffs::ffn_split_kernel(",
              "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE": "pp::ffs::proj_ffn_split_kernel(",
+             "_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE": "pp::ffd::proj_ffn_dma_kernel(",
              "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE": "pp::qka::qkv_attention_split_kernel("}.get(kernel_mangled)
     short = short or {"_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1ELi2ELb0ELb0EEEvNS_10GemmParamsE": "void pp::psplit::panel_split_kernel<0, 8, 3, true, 2, false, false>("}.get(kernel_mangled)
     names = (f"r04_{prefix}{precision}_bs64_hbm_traffic.json",) if prefix else \

@@ -68,6 +68,8 @@ int pp_device_cu_count(void);
  *   "decode_wgs_per_cu" (3)  pp_probmap_(head_)decode: workgroups per CU its LDS band buffer is sized for (5 .. 1)
  *   "qkv_attn_pair" (0)      1: pp_qkv_attention_split with a head pair per workgroup (measured slower; kept for A/B)
  *   "ksplit9_below" (1024)   pp_conv3x3_splitk_slices: output rows under which a small tower stage is cut into nine K-slices
+ *   "ffn_dma_waves" (1)      0: the fused f16x3 feed-forward launches run the eight-wave kernel (pp_ffn_split.hip) instead of the
+ *                            twelve-wave one (pp_ffn_dma.hip: eight computing waves + four waves that only issue the LDS-DMA)
  *   "psplit_tail" (1)        0: split-fp16 Linear layers never send the rows of a ragged last round to a second launch on 128 x 192 tiles
  *   "wino_order" (8)         pp_conv3x3_winograd_maxpool_relu: column tiles per 32-workgroup super tile (0: column tiles fastest)
  *   "ksplit_channels" (1)    pp_conv3x3_splitk_slices: 0 = whole-tap slices only (never the four channel ranges of the wide-tile kernel)

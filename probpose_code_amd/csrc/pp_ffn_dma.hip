@@ -1,0 +1,486 @@
+// The fused f16x3 feed-forward launch of pp_ffn_split.hip (same arithmetic, same packed weight streams, same results bit
+// for bit) with the LDS-DMA issue taken OUT of the computing waves:
+//     [x <- x + att Wp^T + bp ; h <- LN2(x)]   x <- x + GELU(h W1^T + b1) W2^T + b2 ;   h_next <- LayerNorm(x)
+// (mmpretrain TransformerEncoderLayer [3P]; call site mmpose/models/pose_estimators/base.py:206).
+//
+//   * 768 threads = 12 waves, three per SIMD, at <= 168 registers each:
+//       waves 0-7   compute: wave (rg, cg) = rows 48 rg .. +47, column quarter cg - the tiles of pp_ffn_split.hip - and issue NO
+//                   memory instruction inside the step loop: per step one barrier, the fragment reads, 18 / 27 MFMAs;
+//       waves 8-11  one per SIMD: issue ALL buffer_load ... lds pieces (7 per A-step, 6 per B-step each) three steps ahead and
+//                   do the counted s_waitcnt vmcnt(N) in front of every barrier.
+//     A buffer_load ... lds holds its wave for 60 - 180 cycles when the texture path is busy; in the eight-wave kernel that
+//     wave also owns MFMAs, and the role alternation there hides the stall behind the OTHER wave of the SIMD at the price of
+//     two barriers per step. Here the stalls belong to a wave that has nothing else to do.
+//   * the price is the register budget (512 / 3): no second accumulator set, so a chunk's GELU is not spread under the next
+//     chunk's steps - it runs between the chunk's A-steps and its B-steps, all eight waves at once (~12 x 0.35 us per launch);
+//   * steps, ring (four 28 KiB slots), G tile, LayerNorm epilogue, k-block sawtooth and chunk rotation as in pp_ffn_split.hip.
+//   * the plain-load / LDS-DMA retire-order hazard of the eight-wave kernel (a younger plain load may retire before an older
+//     piece's LDS write) cannot occur: the waves that count pieces issue nothing else.
+// Measured as a skeleton first (scripts/micro/ffn12d.hip MODE=1 GELU=1): 148 - 150 us against 161 us for the eight-wave loop.
+#include "pp_common.h"
+#include "pp_split.h"
+#include "pp_ffn_params.h"
+
+namespace pp {
+namespace ffd {
+
+using ffs::Params;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int BM = 96, E = 384, CHUNK = 128;
+constexpr int CW = 8, WAVES = 12, THREADS = WAVES * 64;
+constexpr int KB = E / 32;
+constexpr int G_KB = BM * 128;
+constexpr int OFF_G = 0;
+constexpr int OFF_RING = 4 * G_KB;
+constexpr int SLOTB = 28 * 1024, NSLOT = 4;
+constexpr int LDS = OFF_RING + NSLOT * SLOTB;
+constexpr int X_OFF = 16 * 1024;
+constexpr int NA = KB, NB = 8, STEPS = NA + NB;
+constexpr int A_BLOCK = CHUNK * 128;
+constexpr int B_BLOCK = (E / 2) * 128;
+constexpr int B_PART = NA * A_BLOCK;
+constexpr int CHUNK_BYTES = B_PART + NB * B_BLOCK;
+constexpr int NPROJ = 2 * KB;  // steps of the projection phase
+static_assert(LDS == 160 * 1024, "LDS map");
+static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must repeat");
+
+#ifndef FFD_DEPTH
+#define FFD_DEPTH 3  // steps a DMA wave may have in flight behind the one the computing waves are about to read: 2 or 3
+#endif
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+// (n is a compile-time constant after unrolling; the builtin wants a literal)
+__device__ __forceinline__ void wait_vm_n(int n) {
+    switch (n) {
+        case 0: wait_vm<0>(); break;
+        case 6: wait_vm<6>(); break;
+        case 7: wait_vm<7>(); break;
+        case 9: wait_vm<9>(); break;
+        case 12: wait_vm<12>(); break;
+        case 13: wait_vm<13>(); break;
+        case 14: wait_vm<14>(); break;
+        case 15: wait_vm<15>(); break;
+        default: wait_vm<0>(); break;
+    }
+}
+// pieces one DMA wave issues for a step of the main loop / of the projection phase
+__host__ __device__ constexpr int n_main(int t) { return (((t % STEPS) + STEPS) % STEPS) < NA ? 7 : 6; }
+__host__ __device__ constexpr int n_proj(int s) { return s < NPROJ ? 6 + ((s & 1) == 0 ? 3 : 0) : 0; }
+
+__device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------- DMA waves
+// Barrier protocol (every wave of the workgroup executes the same sequence of s_barrier):
+//   PROJ: 24 step barriers | P1 | LayerNorm 2 | P2 ;   main: 20 per chunk | E1 | LayerNorm 2
+template <bool PROJ>
+__device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int lane, int m0, int nchunks, int c_rot) {
+    char* const ring = smem + OFF_RING;
+    const int x_l = lane >> 3;
+    const unsigned v_w = (unsigned)lane * 16u;
+    // an x piece is 8 rows x 128 B: lane (row l = lane >> 3, physical chunk lane & 7) fetches logical chunk (lane & 7) ^ l
+    const unsigned v_x = (unsigned)(m0 + x_l) * (unsigned)(E * 4) + (unsigned)(((lane & 7) ^ x_l) << 4);
+
+    if constexpr (PROJ) {
+        auto issue_p = [&](int s) {
+            if (s >= NPROJ) return;
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wproj), 0, p.wproj_bytes, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int q = d + 4 * u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ring + (s & 3) * SLOTB + q * 1024), 16, v_w, s * B_BLOCK + q * 1024, 0, 0);
+            }
+            if ((s & 1) == 0) {
+                const int kb = s >> 1;
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.att), 0, p.att_bytes, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int q = d + 4 * u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(smem + OFF_G + (kb & 3) * G_KB + q * 1024), 16, v_x,
+                                                             kb * 128 + q * 8 * E * 4, 0, 0);
+                }
+            }
+        };
+        issue_p(0);
+        issue_p(1);
+        issue_p(2);
+#pragma unroll
+        for (int s = 0; s < NPROJ; ++s) {
+            // step s must have landed: the pieces of the steps behind it may be out
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm_n((FFD_DEPTH == 3 ? n_proj(s + 1) : 0) + n_proj(s + 2));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_p(s + 3);
+        }
+        __builtin_amdgcn_s_barrier();  // P1
+        __builtin_amdgcn_s_barrier();  // LayerNorm (ln2)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();  // P2: the ln2 rows are in L2
+    }
+
+    // piece set of step t (0 .. 19) of the chunk visited ci-th; past the last chunk the descriptors have no extent (the DMA writes
+    // zeros, the counts stay the same)
+    auto issue = [&](int ci, int t) {
+        const bool live = ci < nchunks;
+        int c = (live ? ci : 0) + c_rot;
+        c = c >= nchunks ? c - nchunks : c;
+        const int base = c * CHUNK_BYTES;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wpack), 0, live ? p.w_bytes : 0u, 0x00020000);
+        char* dst = ring + (t & 3) * SLOTB;
+        if (t < NA) {
+            const int kb = (ci & 1) ? NA - 1 - t : t;  // odd visits walk the k-blocks backwards (pp_ffn_split.hip: the L2 finds the rows)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = d + 4 * u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + q * 1024), 16, v_w, base + kb * A_BLOCK + q * 1024, 0, 0);
+            }
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.h), 0, live ? p.h_bytes : 0u, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int q = d + 4 * u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(dst + X_OFF + q * 1024), 16, v_x, kb * 128 + q * 8 * E * 4, 0, 0);
+            }
+        } else {
+            const int sb = t - NA;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int q = d + 4 * u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + q * 1024), 16, v_w, base + B_PART + sb * B_BLOCK + q * 1024, 0, 0);
+            }
+        }
+    };
+    issue(0, 0);
+    issue(0, 1);
+    issue(0, 2);
+    for (int ci = 0; ci < nchunks; ++ci) {
+#pragma unroll
+        for (int t = 0; t < STEPS; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm_n((FFD_DEPTH == 3 ? n_main(t + 1) : 0) + n_main(t + 2));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // (all computing waves are past their reads of step t - 1: its slot takes step t + 3)
+            if (t + 3 < STEPS) issue(ci, t + 3); else issue(ci + 1, t + 3 - STEPS);
+        }
+    }
+    wait_vm<0>();                  // the fillers
+    __builtin_amdgcn_s_barrier();  // E1
+    __builtin_amdgcn_s_barrier();  // LayerNorm
+    __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------- computing waves
+template <bool PROJ>
+__device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv, int lane, int m0, int nchunks, int c_rot) {
+    const int rg = wv >> 2, cg = wv & 3;
+    const int f_row = lane & 15, f_kg = lane >> 4;
+    auto chunk_of = [&](int i) { const int c = i + c_rot; return c >= nchunks ? c - nchunks : c; };
+
+    // fragment reads: hi halves in 16-byte chunk f_kg, lo halves in chunk 4 + f_kg of a line, swizzled by line & 7. The register
+    // budget has no room for an address register per line set: every read address is ONE of two per-lane offsets (hi / lo chunk of
+    // line f_row) plus a wave-uniform offset the compiler cannot fold or hoist (it lives in an SGPR, made opaque per step), plus
+    // the fragment stride as an instruction offset.
+    const int sw = f_row & 7;
+    const int lane_hi = f_row * 128 + ((f_kg ^ sw) << 4), lane_lo = f_row * 128 + (((4 + f_kg) ^ sw) << 4);
+    const int rows0 = rg * 48 + f_row;
+    auto opaque_s = [](int v) { asm volatile("" : "+s"(v)); return v; };
+    auto rd = [&](int lane_off, int uni, int imm) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + (lane_off + uni) + imm); };
+    const int u_a = OFF_RING + cg * 32 * 128;           // A-step W1 lines of this wave (units 32 cg ..) inside a slot
+    const int u_b = OFF_RING + cg * 48 * 128;           // B-step W2 lines (outputs 48 cg ..)
+    const int u_x = OFF_RING + X_OFF + rg * 48 * 128;   // x lines of an A slot (rows 48 rg ..)
+    const int u_g = OFF_G + rg * 48 * 128;              // row lines of a G buffer
+
+    f32x4 acc[3][6];   // [row fragment][half * 3 + nf]: columns 192 half + 48 cg + 16 nf + 4 f_kg + (0..3)
+    f32x4 pacc[3][2];  // P of the chunk in its A-steps
+    f32x4 b1v[2];
+    u32x4 bgh[3], bgl[3];
+
+    auto step_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        // lgkmcnt(0): this wave's LDS writes (the G tile) are in before anyone is let through; its reads were consumed by the MFMAs
+        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // 48 x 48 tile of one column half: acc[:, half] += G-like rows (bgh, bgl) x weight half block in ring slot `so`
+    auto b_step = [&](int slot, int half, int gbuf, bool load_g) {
+        u32x4 wh[3], wl[3];
+        const int ub = opaque_s(u_b + slot * SLOTB);
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) {
+            wh[nf] = rd(lane_hi, ub, nf * 2048);
+            wl[nf] = rd(lane_lo, ub, nf * 2048);
+        }
+        if (load_g) {
+            const int ug = opaque_s(u_g + gbuf * G_KB);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) {
+                bgh[rf] = rd(lane_hi, ug, rf * 2048);
+                bgl[rf] = rd(lane_lo, ug, rf * 2048);
+            }
+        }
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) acc[rf][half * 3 + nf] = mma(wh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+    };
+    // LayerNorm of the 96 x 384 block in the accumulators (pp_ffn_split.hip layernorm_rows: same operations in the same order)
+    // Stores as buffer stores: the row part of the address (and the lane's column part) in the VGPR offset - rows past M fall out
+    // of the descriptor's extent and are dropped by the hardware (the range check covers the VGPR offset, not the scalar one) -
+    // the wave-uniform column part in the scalar offset: two address registers for the whole epilogue.
+    const unsigned v_rowx = (unsigned)(m0 + rows0) * (unsigned)(E * 4) + (unsigned)f_kg * 16u;                            // fp32 rows
+    const unsigned v_rowh = (unsigned)(m0 + rows0) * (unsigned)(E * 4) + (unsigned)f_kg * 8u;  // split rows: the lane's four hi halves (lo: + 64)
+    auto layernorm_rows = [&](const float* gamma, const float* beta, float* x_dst, void* h_dst, bool store_x) {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(x_dst, 0, p.h_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(h_dst, 0, p.h_bytes, 0x00020000);
+        float* stat = reinterpret_cast<float*>(smem + OFF_G);
+        float mean[3], rstd[3];
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            float sm = 0.f;
+#pragma unroll
+            for (int cf = 0; cf < 6; ++cf) {
+                const f32x4 v = acc[rf][cf];
+                sm += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            if (f_kg == 0) stat[cg * BM + rows0 + rf * 16] = sm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            const int r = rows0 + rf * 16;
+            mean[rf] = ((stat[r] + stat[BM + r]) + (stat[2 * BM + r] + stat[3 * BM + r])) * (1.0f / E);
+            float q = 0.f;
+#pragma unroll
+            for (int cf = 0; cf < 6; ++cf)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dd = acc[rf][cf][k] - mean[rf];
+                    q = __builtin_fmaf(dd, dd, q);
+                }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            if (f_kg == 0) stat[(4 + cg) * BM + r] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            const int r = rows0 + rf * 16;
+            const float var = ((stat[4 * BM + r] + stat[5 * BM + r]) + (stat[6 * BM + r] + stat[7 * BM + r])) * (1.0f / E);
+            rstd[rf] = 1.0f / sqrtf(var + p.eps);
+        }
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) {
+            const int cb = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16;  // (wave-uniform)
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cb + f_kg * 4), b = *reinterpret_cast<const f32x4*>(beta + cb + f_kg * 4);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) {
+                const f32x4 v = acc[rf][cf];
+                float mu = mean[rf];
+                const float rs = rstd[rf];
+                asm("" : "+v"(mu));  // (a second, opaque copy: with the same value as in the variance pass the compiler keeps all 72 differences v - mean alive from there to here)
+                f32x4 hv = {(v[0] - mu) * rs * g[0] + b[0], (v[1] - mu) * rs * g[1] + b[1], (v[2] - mu) * rs * g[2] + b[2],
+                            (v[3] - mu) * rs * g[3] + b[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { float t = hv[j]; split_pin(t); hv[j] = t; }
+                if (store_x) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rx, v_rowx + rf * (16 * E * 4), cb * 4, 0);
+                // two 8-byte buffer stores per lane (hi halves, lo halves). Not the v_permlane16_swap pairing of split_store4_rowpair:
+                // with three waves per SIMD the swap's first destination register came back stale in lanes 12 - 15 of every row
+                // (a few words per launch, wait states on either side did not help; scripts/micro/ffn_forms_engine1.py)
+                f16x4 h, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = split_hi(hv[j]);
+                    l[j] = split_lo(hv[j], h[j]);
+                }
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const int so = (cb >> 5) * 128 + (cb & 16) * 2;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, h), rh, v_rowh + rf * (16 * E * 4), so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, l), rh, v_rowh + rf * (16 * E * 4), so + 64, 0);
+            }
+        }
+    };
+
+    // the residual rows, straight into the accumulators
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, p.h_bytes, 0x00020000);
+#pragma unroll
+    for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) {
+            const int cb = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16;
+            acc[rf][cf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, v_rowx + rf * (16 * E * 4), cb * 4, 0));  // (rows past M: zeros, never stored)
+        }
+
+    if constexpr (PROJ) {
+        // ---- attention output projection + residual, then ln2:  acc <- x + att Wp^T + bp ;  h <- LN2(acc). 24 steps shaped like
+        // the B-steps: step s = 2 kb + half takes the Wp half block from ring slot s & 3, the attention rows' k-block kb from G buffer kb & 3
+#pragma unroll 1
+        for (int kp = 0; kp < NPROJ / 4; ++kp) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                step_barrier();
+                b_step(q, q & 1, ((4 * kp + q) >> 1) & 3, (q & 1) == 0);
+            }
+        }
+        // + bp (after the sums, as residual + (sum + bias) rounds closest to the reference's x + proj(...))
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bp + (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
+        }
+        __syncthreads();  // P1: the G buffers are out of use
+        layernorm_rows(p.gamma2, p.beta2, nullptr, const_cast<void*>(p.h), false);
+        // the rows must be in L2 before the DMA waves ask for them (a store counts in vmcnt until the L2 has acknowledged it)
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));
+        __syncthreads();  // P2
+    }
+
+    // + b2 (pp_ffn_split.hip adds it before the first B-step accumulates: same sum order)
+#pragma unroll
+    for (int cf = 0; cf < 6; ++cf) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b2 + (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4);
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
+    }
+    auto load_b1 = [&](int ci) {
+        const int c = chunk_of(ci < nchunks ? ci : 0);
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) b1v[nf] = *reinterpret_cast<const f32x4*>(p.b1 + c * CHUNK + cg * 32 + nf * 16 + f_kg * 4);
+    };
+    load_b1(0);
+
+    for (int ci = 0; ci < nchunks; ++ci) {
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf];
+        load_b1(ci + 1);
+        // ---- A-steps: P += x[:, kb] W1[chunk, kb]^T, wave tile 48 rows x 32 units
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            step_barrier();
+            const int ua = opaque_s(u_a + (t & 3) * SLOTB), ux = opaque_s(u_x + (t & 3) * SLOTB);
+            u32x4 wh[2], wl[2], xh[3], xl[3];
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                wh[nf] = rd(lane_hi, ua, nf * 2048);
+                wl[nf] = rd(lane_lo, ua, nf * 2048);
+            }
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) {
+                xh[rf] = rd(lane_hi, ux, rf * 2048);
+                xl[rf] = rd(lane_lo, ux, rf * 2048);
+            }
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wh[nf], xh[rf], pacc[rf][nf]);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wl[nf], xh[rf], pacc[rf][nf]);
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                for (int rf = 0; rf < 3; ++rf) pacc[rf][nf] = mma(wh[nf], xl[rf], pacc[rf][nf]);
+        }
+        // ---- GELU(P) -> (hi, lo) -> G tile (gelu_erfc_as of pp_split.h, Abramowitz & Stegun 7.1.26: same operations in the same
+        // order per value as pp_ffn_split.hip). The G tile is free: the previous chunk's B-steps ended before this chunk's A-steps.
+        // Lane holds units 32 cg + 16 nf + 4 f_kg + (0..3) of its rows: k-block cg of the chunk, 16-byte chunk 2 nf + (f_kg >> 1)
+        // (+ 4 for lo), upper or lower 8 bytes.
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                f16x4 hv, lv;
+                float x[4], z[4], tt[4], qq[4], e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = pacc[rf][nf][u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) z[u] = fabsf(x[u]) * 0.70710678118654752440f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tt[u] = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z[u], 1.0f));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[u] = __builtin_amdgcn_exp2f(-(z[u] * z[u]) * 1.44269504088896340736f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], 1.061405429f, -1.453152027f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], 1.421413741f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], -0.284496736f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], 0.254829592f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float erfc_z = tt[u] * qq[u] * e[u];
+                    float g = 0.5f * x[u] * (x[u] < 0.f ? erfc_z : 2.0f - erfc_z);
+                    split_pin(g);
+                    hv[u] = split_hi(g);
+                    lv[u] = split_lo(g, hv[u]);
+                }
+                char* gs = smem + OFF_G + cg * G_KB + (rows0 + rf * 16) * 128 + (f_kg & 1) * 8;
+                const int c = 2 * nf + (f_kg >> 1);
+                *reinterpret_cast<f16x4*>(gs + ((c ^ sw) << 4)) = hv;
+                *reinterpret_cast<f16x4*>(gs + (((4 + c) ^ sw) << 4)) = lv;
+            }
+        // ---- B-steps (j, half): acc[:, half] += G[:, j] W2[half, chunk j]^T, wave tile 48 rows x 48 outputs (the barrier of the
+        // first one publishes the G tile)
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) {
+            step_barrier();
+            b_step((NA + sb) & 3, sb & 1, sb >> 1, (sb & 1) == 0);
+        }
+    }
+    // ---- LayerNorm epilogue: G is out of use once every wave is past its last B-step
+    __syncthreads();  // E1
+    layernorm_rows(p.gamma, p.beta, p.x_out, p.h_out, true);
+}
+
+template <bool PROJ>
+__device__ __forceinline__ void body(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM;
+    const int nchunks = p.F / CHUNK;
+    const int c_rot = (int)(blockIdx.x & 7) % nchunks;  // the workgroups of an XCD walk the chunks in the same order
+    if (wv >= CW) dma_role<PROJ>(p, smem, wv - CW, lane, m0, nchunks, c_rot);
+    else compute_role<PROJ>(p, smem, wv, lane, m0, nchunks, c_rot);
+}
+
+__global__ __launch_bounds__(THREADS) void ffn_dma_kernel(const Params p) { body<false>(p); }
+__global__ __launch_bounds__(THREADS) void proj_ffn_dma_kernel(const Params p) { body<true>(p); }
+
+}  // namespace ffd
+
+namespace ffs {
+// called from the entry points in pp_ffn_split.hip when the option "ffn_dma_waves" is on
+int launch_dma_form(const Params& p, bool proj, hipStream_t s) {
+    auto kern = proj ? ffd::proj_ffn_dma_kernel : ffd::ffn_dma_kernel;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ffd::LDS));
+    hipLaunchKernelGGL(kern, dim3((p.M + ffd::BM - 1) / ffd::BM), dim3(ffd::THREADS), ffd::LDS, s, p);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+}  // namespace ffs
+}  // namespace pp

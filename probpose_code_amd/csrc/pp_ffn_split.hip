@@ -49,6 +49,7 @@
 // DMA pieces and GELU placed between the MFMAs with sched_group_barrier) measured the same 180 us.
 #include "pp_common.h"
 #include "pp_split.h"
+#include "pp_ffn_params.h"
 
 namespace pp {
 namespace ffs {
@@ -79,29 +80,6 @@ constexpr unsigned OOB = 0x7ffffff0u;
 static_assert(LDS == 160 * 1024, "LDS map");
 static_assert(NA % NSLOT == 0 && STEPS % NSLOT == 0, "ring positions must repeat per chunk");
 
-struct Params {
-    const void* h;         // [M, 384] split: LayerNorm-ed block input
-    const void* wpack;     // pre-packed W1 / W2 stream (pp_ffn_split_pack_weights)
-    const float* b1;       // [F]
-    const float* b2;       // [384]
-    const float* residual; // fp32 [M, 384] (may alias x_out)
-    float* x_out;          // fp32 [M, 384]
-    const float* gamma;
-    const float* beta;
-    void* h_out;           // [M, 384] split: LayerNorm(x_out) (may alias h)
-    int M, F;
-    unsigned h_bytes, w_bytes;
-    float eps;
-    unsigned long long* trace;  // dev only (FFS_DBG & 512): s_memtime at every barrier of block 0, waves 0 and 4
-    // PROJ form (attention output projection + residual + ln2 in front of the FFN): h is then a scratch tensor this kernel
-    // writes (ln2 output) before it streams it back
-    const void* att;       // [M, 384] split: attention output (heads concatenated)
-    const void* wproj;     // pre-packed Wp stream (pp_proj_split_pack_weights)
-    const float* bp;       // [384]
-    const float* gamma2;   // ln2
-    const float* beta2;
-    unsigned att_bytes, wproj_bytes;
-};
 
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
     if (DBG & 4) return c;
@@ -323,6 +301,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             for (int u = 0; u < n; ++u) {
                 const float erfc_z = t[u] * q[u] * e[u];
                 g[u] = 0.5f * x[u] * (x[u] < 0.f ? erfc_z : 2.0f - erfc_z);
+                split_pin(g[u]);  // (pp_split.h)
             }
         }
 #pragma unroll
@@ -370,7 +349,7 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
             case 15: sq[0] = sx[0] < 0.f ? sq[0] : se[0]; break;
             case 16: sq[1] = sx[1] < 0.f ? sq[1] : se[1]; break;
             case 17: sg[0] = 0.5f * sx[0]; sg[1] = 0.5f * sx[1]; break;
-            case 18: sg[0] = sg[0] * sq[0]; sg[1] = sg[1] * sq[1]; break;
+            case 18: sg[0] = sg[0] * sq[0]; sg[1] = sg[1] * sq[1]; split_pin(sg[0]); split_pin(sg[1]); break;
             default: break;
         }
         switch (k) {
@@ -587,9 +566,13 @@ __device__ __forceinline__ void ffn_split_body(const Params p) {  // (by value: 
                 const bool live = m0 + rows0 + rf * 16 < p.M;
                 const size_t off = (size_t)(m0 + rows0 + rf * 16) * E + n;
                 const f32x4 v = acc[rf][cf];
-                const float mu = mean[rf], rs = rstd[rf];
-                const f32x4 hv = {(v[0] - mu) * rs * g[0] + b[0], (v[1] - mu) * rs * g[1] + b[1], (v[2] - mu) * rs * g[2] + b[2],
-                                  (v[3] - mu) * rs * g[3] + b[3]};
+                float mu = mean[rf];
+                const float rs = rstd[rf];
+                asm("" : "+v"(mu));  // (a second, opaque copy: with the same value as in the variance pass the compiler keeps all 72 differences v - mean alive from there to here)
+                f32x4 hv = {(v[0] - mu) * rs * g[0] + b[0], (v[1] - mu) * rs * g[1] + b[1], (v[2] - mu) * rs * g[2] + b[2],
+                            (v[3] - mu) * rs * g[3] + b[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { float t = hv[j]; split_pin(t); hv[j] = t; }  // (pp_split.h)
                 if (x_dst && live) *reinterpret_cast<f32x4*>(x_dst + off) = v;
 #ifndef FFS_PAIR_STORE
 #define FFS_PAIR_STORE 1  // dev A/B switch: 0 two 8-byte stores per lane and fragment
@@ -830,9 +813,11 @@ __global__ void pack_proj_kernel(const char* __restrict__ wp, char* __restrict__
 }
 
 unsigned long long* g_trace = nullptr;
+int launch_dma_form(const Params& p, bool proj, hipStream_t s);  // pp_ffn_dma.hip
 
 template <bool PROJ>
 static int launch(const Params& p, hipStream_t s) {
+    if (option("ffn_dma_waves") != 0) return launch_dma_form(p, PROJ, s);
     auto kern = PROJ ? proj_ffn_split_kernel : ffn_split_kernel;
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     hipLaunchKernelGGL(kern, dim3((p.M + BM - 1) / BM), dim3(THREADS), LDS, s, p);

@@ -26,6 +26,13 @@ typedef float split_f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ _Float16 split_hi(float x) { return (_Float16)x; }
 __device__ __forceinline__ _Float16 split_lo(float x, _Float16 hi) { return (_Float16)(x - (float)hi); }
+// Files built with -fno-slp-vectorize (pp_ffn_split.hip, pp_ffn_dma.hip) must pin a value in a register before they split it when it
+// is the result of a multiplication: the compiler then fuses product, conversion and difference into
+//     v_fma_mixlo_f16 hi, a, b, 0   ;   v_fma_mix_f32 d, a, b, -hi     (d = a * b - hi without the product's fp32 rounding)
+// and the (hi, lo) pairs that come out of that sequence were measurably worse on gfx950: 2e-4 instead of 1e-5 on the FFN output
+// (tests/test_split_fp16.py test_ffn_split_fused_vs_fp64; the instructions themselves keep fp16 subnormals,
+// scripts/micro/mix_denorm_probe.hip). With the vectoriser on the conversions pair up into v_cvt_pk_f16_f32 and the pattern never forms.
+__device__ __forceinline__ void split_pin(float& x) { asm("" : "+v"(x)); }
 
 // address of the hi half of element `idx` of a split tensor (the lo half lives 64 bytes further)
 __device__ __forceinline__ char* split_addr(void* base, size_t idx) {

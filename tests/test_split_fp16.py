@@ -465,9 +465,19 @@ def _ffn_pack(L, w1, w2, E, F_):
     return packed
 
 
+@pytest.fixture
+def ffn_form(request):
+    """both forms of the fused feed-forward launch: 1 = twelve waves (pp_ffn_dma.hip, shipped), 0 = eight waves (pp_ffn_split.hip)"""
+    L = _lib()
+    L.set_option("ffn_dma_waves", request.param)
+    yield request.param
+    L.set_option("ffn_dma_waves", 1)
+
+
 @gpu
+@pytest.mark.parametrize("ffn_form", [1, 0], indirect=True)
 @pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (24576, 1536)])
-def test_ffn_split_fused_vs_fp64(M, F_):
+def test_ffn_split_fused_vs_fp64(M, F_, ffn_form):
     """pp_ffn_split_residual_layernorm (fc1 - GELU - fc2 + residual + LayerNorm in one launch, hidden activation on the CU)
     against torch fp64 on the unrounded fp32 inputs; the bs 64 shape of the bench included; repeated launches bit-identical
     (a ring / barrier race shows up as run-to-run differences long before it shows up as a tolerance failure)."""
@@ -493,7 +503,8 @@ def test_ffn_split_fused_vs_fp64(M, F_):
 
 
 @gpu
-def test_ffn_split_fused_in_place_and_errors():
+@pytest.mark.parametrize("ffn_form", [1, 0], indirect=True)
+def test_ffn_split_fused_in_place_and_errors(ffn_form):
     """residual aliasing x_out and h_in aliasing h_out (how the engine calls it), and the argument checks."""
     L = _lib()
     M, E, F_ = 96 * 5 + 17, 384, 512
@@ -524,8 +535,9 @@ def _proj_inputs(M, E=384, seed=80):
 
 
 @gpu
+@pytest.mark.parametrize("ffn_form", [1, 0], indirect=True)
 @pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (24576, 1536)])
-def test_proj_ffn_split_fused_vs_fp64(M, F_):
+def test_proj_ffn_split_fused_vs_fp64(M, F_, ffn_form):
     """pp_proj_ffn_split_residual_layernorm (projection + residual + ln2 + FFN + residual + LayerNorm in one launch) against
     torch fp64 on the unrounded fp32 inputs, called the way the engine calls it (residual aliases x_out, the attention rows
     alias h_out); repeated launches bit-identical; a ragged last tile; the bs 64 shape."""
@@ -599,7 +611,8 @@ def test_qkv_attention_split_fused_vs_fp64(n_seq, bias, pair):
 
 
 @gpu
-def test_proj_ffn_split_two_streams_under_contention():
+@pytest.mark.parametrize("ffn_form", [1, 0], indirect=True)
+def test_proj_ffn_split_two_streams_under_contention(ffn_form):
     """Two independent problems through pp_proj_ffn_split_residual_layernorm on two streams at once must each give the result
     they give alone, bit for bit. This is the condition bench.py's two steps in flight create; it caught counted vmcnt waits
     that allowed plain loads issued between LDS-DMA pieces to be outstanding (the two kinds do not retire in order with
@@ -639,6 +652,75 @@ def test_proj_ffn_split_two_streams_under_contention():
         for k, (d, (xo, ho)) in enumerate(zip(probs, want)):
             assert torch.equal(d["xo"], xo), f"iteration {it}, stream {k}: x_out differs from the solo launch"
             assert torch.equal(d["ho"].view(torch.int32), ho.view(torch.int32)), f"iteration {it}, stream {k}: h_out differs"
+
+
+@gpu
+@pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (24576, 1536)])
+def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_):
+    """pp_set_option("ffn_dma_waves", 1) routes both fused feed-forward entry points to the twelve-wave kernel (pp_ffn_dma.hip:
+    eight computing waves + four DMA waves). Held to the same fp64 references and tolerances as the eight-wave kernel above, in
+    place as the engine calls them, a ragged last tile included; the two forms agree to rounding (same sums in the same order,
+    the compiler contracts the LayerNorm arithmetic differently); repeated launches bit-identical, also when two launches share
+    the chip (what two steps in flight create)."""
+    L = _lib()
+    E = 384
+    h, r, w1, b1, w2, b2, g, be = _ffn_inputs(M, F_, seed=300)
+    att, wp, bp, g2, be2 = _proj_inputs(M, seed=320)
+    x_ref = r.double() + F.gelu(h.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    h_ref = F.layer_norm(x_ref, (E,), g.double(), be.double(), 1e-6)
+    x_mid = r.double() + att.double() @ wp.double().t() + bp.double()
+    h_mid = F.layer_norm(x_mid, (E,), g2.double(), be2.double(), 1e-6)
+    xp_ref = x_mid + F.gelu(h_mid @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    hp_ref = F.layer_norm(xp_ref, (E,), g.double(), be.double(), 1e-6)
+    packed = _ffn_pack(L, w1, w2, E, F_)
+    wpp = torch.empty(E * E, dtype=torch.float32, device="cuda")
+    L.call("pp_proj_split_pack_weights", _sp(wp).data_ptr(), wpp.data_ptr(), E, None)
+    dev = [t.cuda() for t in (bp, g2, be2, b1, b2, g, be)]
+
+    def ffn(stream=None):
+        hd, xd = _sp(h), r.cuda()
+        L.call("pp_ffn_split_residual_layernorm", hd.data_ptr(), packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), xd.data_ptr(),
+               xd.data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(), 1e-6, hd.data_ptr(), M, E, F_, stream)
+        return xd, hd
+
+    def proj(stream=None):
+        ad, xd = _sp(att), r.cuda()
+        scratch = torch.full((M, E), float("nan"), device="cuda")
+        L.call("pp_proj_ffn_split_residual_layernorm", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(),
+               dev[2].data_ptr(), scratch.data_ptr(), packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), xd.data_ptr(),
+               xd.data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(), 1e-6, ad.data_ptr(), M, E, F_, stream)
+        return xd, ad, scratch
+
+    def same(a, b):
+        return all(torch.equal(u.view(torch.int32), v.view(torch.int32)) for u, v in zip(a, b))
+
+    try:
+        L.set_option("ffn_dma_waves", 0)
+        eight_f, eight_p = [t.cpu() for t in ffn()], [t.cpu() for t in proj()]
+        L.set_option("ffn_dma_waves", 1)
+        want_f, want_p = [t.cpu() for t in ffn()], [t.cpu() for t in proj()]
+        torch.testing.assert_close(want_f[0].double(), x_ref, **TOL)
+        torch.testing.assert_close(_unsp(want_f[1]), h_ref, **TOL)
+        torch.testing.assert_close(_unsp(want_p[2]), h_mid, **TOL)
+        torch.testing.assert_close(want_p[0].double(), xp_ref, rtol=3e-5, atol=3e-5)
+        torch.testing.assert_close(_unsp(want_p[1]), hp_ref, rtol=3e-5, atol=3e-5)
+        torch.testing.assert_close(want_f[0], eight_f[0], rtol=2e-6, atol=2e-6)
+        torch.testing.assert_close(want_p[0], eight_p[0], rtol=2e-6, atol=2e-6)
+        for _ in range(3):
+            assert same([t.cpu() for t in ffn()], want_f), "FFN form: run-to-run difference"
+            assert same([t.cpu() for t in proj()], want_p), "projection + FFN form: run-to-run difference"
+        if M >= 24576:
+            s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+            for it in range(10):
+                torch.cuda.synchronize()
+                with torch.cuda.stream(s0):
+                    a = proj(s0.cuda_stream)
+                with torch.cuda.stream(s1):
+                    b = ffn(s1.cuda_stream)
+                torch.cuda.synchronize()
+                assert same([t.cpu() for t in a], want_p) and same([t.cpu() for t in b], want_f), f"contended launch {it}"
+    finally:
+        L.set_option("ffn_dma_waves", 1)
 
 
 @gpu
