@@ -47,6 +47,9 @@ constexpr int NPROJ = 2 * KB;  // steps of the projection phase
 static_assert(LDS == 160 * 1024, "LDS map");
 static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must repeat");
 
+#ifndef FFD_DMA_PRIO
+#define FFD_DMA_PRIO 0  // dev A/B: priority of the DMA waves (s_setprio)
+#endif
 #ifndef FFD_DEPTH
 #define FFD_DEPTH 3  // steps a DMA wave may have in flight behind the one the computing waves are about to read: 2 or 3
 #endif
@@ -84,6 +87,7 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
 template <bool PROJ>
 __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int lane, int m0, int nchunks, int c_rot) {
     char* const ring = smem + OFF_RING;
+    if (FFD_DMA_PRIO) __builtin_amdgcn_s_setprio(FFD_DMA_PRIO);
     const int x_l = lane >> 3;
     const unsigned v_w = (unsigned)lane * 16u;
     // an x piece is 8 rows x 128 B: lane (row l = lane >> 3, physical chunk lane & 7) fetches logical chunk (lane & 7) ^ l
