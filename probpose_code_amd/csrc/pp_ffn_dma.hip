@@ -50,6 +50,9 @@ static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must rep
 #ifndef FFD_DMA_PRIO
 #define FFD_DMA_PRIO 0  // dev A/B: priority of the DMA waves (s_setprio)
 #endif
+#ifndef FFD_READS_FIRST
+#define FFD_READS_FIRST 1
+#endif
 #ifndef FFD_DEPTH
 #define FFD_DEPTH 3  // steps a DMA wave may have in flight behind the one the computing waves are about to read: 2 or 3
 #endif
@@ -219,27 +222,39 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     auto b_step = [&](int slot, int half, int gbuf, bool load_g) {
         u32x4 wh[3], wl[3];
         const int ub = opaque_s(u_b + slot * SLOTB);
-#pragma unroll
-        for (int nf = 0; nf < 3; ++nf) {
-            wh[nf] = rd(lane_hi, ub, nf * 2048);
-            wl[nf] = rd(lane_lo, ub, nf * 2048);
-        }
+        const int ug = opaque_s(u_g + gbuf * G_KB);
+        // reads in the order the MFMAs want them
+        wh[0] = rd(lane_hi, ub, 0);
+        if (load_g) bgh[0] = rd(lane_hi, ug, 0);
+        wh[1] = rd(lane_hi, ub, 2048);
+        wh[2] = rd(lane_hi, ub, 4096);
         if (load_g) {
-            const int ug = opaque_s(u_g + gbuf * G_KB);
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf) {
-                bgh[rf] = rd(lane_hi, ug, rf * 2048);
-                bgl[rf] = rd(lane_lo, ug, rf * 2048);
-            }
+            bgh[1] = rd(lane_hi, ug, 2048);
+            bgh[2] = rd(lane_hi, ug, 4096);
         }
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) wl[nf] = rd(lane_lo, ub, nf * 2048);
+        if (load_g) {
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) bgl[rf] = rd(lane_lo, ug, rf * 2048);
+        }
+#if FFD_READS_FIRST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+#if FFD_READS_FIRST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+#if FFD_READS_FIRST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int nf = 0; nf < 3; ++nf)
 #pragma unroll
@@ -385,24 +400,35 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             step_barrier();
             const int ua = opaque_s(u_a + (t & 3) * SLOTB), ux = opaque_s(u_x + (t & 3) * SLOTB);
             u32x4 wh[2], wl[2], xh[3], xl[3];
+            // reads in the order the MFMAs want them (LDS returns in order, the first product needs two fragments, not eight)
+            wh[0] = rd(lane_hi, ua, 0);
+            xh[0] = rd(lane_hi, ux, 0);
+            wh[1] = rd(lane_hi, ua, 2048);
+            xh[1] = rd(lane_hi, ux, 2048);
+            xh[2] = rd(lane_hi, ux, 4096);
+            wl[0] = rd(lane_lo, ua, 0);
+            wl[1] = rd(lane_lo, ua, 2048);
 #pragma unroll
-            for (int nf = 0; nf < 2; ++nf) {
-                wh[nf] = rd(lane_hi, ua, nf * 2048);
-                wl[nf] = rd(lane_lo, ua, nf * 2048);
-            }
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf) {
-                xh[rf] = rd(lane_hi, ux, rf * 2048);
-                xl[rf] = rd(lane_lo, ux, rf * 2048);
-            }
+            for (int rf = 0; rf < 3; ++rf) xl[rf] = rd(lane_lo, ux, rf * 2048);
+#if FFD_READS_FIRST
+            // every fragment read of the step is issued before its first MFMA (left alone the scheduler loads the lo row fragments
+            // into the registers of the hi ones, i.e. in the MIDDLE of the step, and waits for them there)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wh[nf], xh[rf], pacc[rf][nf]);
+#if FFD_READS_FIRST
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wl[nf], xh[rf], pacc[rf][nf]);
+#if FFD_READS_FIRST
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
