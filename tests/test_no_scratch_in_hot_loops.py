@@ -21,12 +21,20 @@ HIPCC = "/opt/rocm/bin/hipcc"
 OUTER_OK = ("panel_split_kernelILi2ELi6ELi4ELb1ELi2ELb1",)
 
 
-def _loops_with_scratch(src):
+# per-source flags of probpose_code_amd/csrc/Makefile
+EXTRA_FLAGS = {"pp_ffn_split.hip": ["-fno-slp-vectorize"], "pp_ffn_dma.hip": ["-fno-slp-vectorize"], "pp_mlp.hip": ["-fno-slp-vectorize"]}
+
+
+def _isa(src):
     with tempfile.TemporaryDirectory() as td:
-        subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-I{CSRC}", f"-I{ROOT}/include", "-c", os.path.join(CSRC, src),
-                        "-o", "x.o", "--save-temps"], cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-I{CSRC}", f"-I{ROOT}/include"] + EXTRA_FLAGS.get(src, []) +
+                       ["-c", os.path.join(CSRC, src), "-o", "x.o", "--save-temps"], cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         asm = [f for f in os.listdir(td) if f.endswith("gfx950.s")][0]
-        lines = open(os.path.join(td, asm)).read().split("\n")
+        return open(os.path.join(td, asm)).read().split("\n")
+
+
+def _loops_with_scratch(src):
+    lines = _isa(src)
     funcs, cur = {}, None
     for l in lines:
         m = re.match(r"^(_Z\w+):", l)
@@ -56,8 +64,25 @@ def _loops_with_scratch(src):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 def test_hot_kernels_keep_scratch_out_of_their_mfma_loops():
-    srcs = ["pp_panel_split.hip", "pp_winograd.hip", "pp_qkv_attn_split.hip", "pp_ffn_split.hip"]
+    srcs = ["pp_panel_split.hip", "pp_winograd.hip", "pp_qkv_attn_split.hip", "pp_ffn_split.hip", "pp_ffn_dma.hip"]
     with ThreadPoolExecutor(max_workers=4) as ex:
         results = list(ex.map(_loops_with_scratch, srcs))
     bad = [(s,) + b for s, r in zip(srcs, results) for b in r]
     assert not bad, "scratch memory inside an MFMA loop:\n" + "\n".join(f"  {s}: {n[:80]} lines {a}-{b}: {k} scratch ops / {m} MFMAs" for s, n, a, b, k, m in bad)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_twelve_wave_feed_forward_kernels_fit_three_waves_per_simd_without_scratch():
+    """pp_ffn_dma.hip runs twelve waves per workgroup = three per SIMD: every wave has 512 / 3 -> 168 registers, and the kernel was
+    built on the condition that nothing spills (a spill inside the LayerNorm phase was the first suspect when stale words showed up
+    in its output). The kernel descriptors of both entry kernels must say so."""
+    text = "\n".join(_isa("pp_ffn_dma.hip"))
+    kernels = re.findall(r"\.amdhsa_kernel (\w+)(.*?)\.end_amdhsa_kernel", text, flags=re.S)
+    seen = {}
+    for name, body in kernels:
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        seen[name] = (vgpr, scratch)
+    assert any("ffn_dma_kernel" in n for n in seen) and any("proj_ffn_dma_kernel" in n for n in seen), seen
+    for name, (vgpr, scratch) in seen.items():
+        assert vgpr <= 168 and scratch == 0, f"{name}: {vgpr} registers, {scratch} bytes of scratch per lane"
