@@ -52,6 +52,10 @@ int conv_halo(const GemmParams& p, int groups, hipStream_t s);
 bool panel_split_supported(const GemmParams& p, int prec, int groups);
 int panel_split_gemm(const GemmParams& p, int prec, int groups, hipStream_t s);
 
+// pp_linear_dma.hip: twelve-wave 192 x 192 tiles (eight computing waves + four DMA-only waves) for the large PP_PREC_F16X3 Linear layers
+bool linear_dma_supported(const GemmParams& p, int prec, int groups);
+int linear_dma_gemm(const GemmParams& p, hipStream_t s);
+
 
 // pp_linear_ovl.hip: split-fp16 Linear layers (qkv / fc1 of the f16x3 mode) on 192 x 192 tiles with two accumulator sets - the
 // epilogue of tile t (activation, split, stores) runs under the K-loop of tile t + 1

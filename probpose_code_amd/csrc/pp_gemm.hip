@@ -513,6 +513,7 @@ extern "C" int pp_gemm(int prec, const void* act, const void* weight, const floa
     PP_REQUIRE(ab < 0x7ffffff0u && wb < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_gemm: operands must be smaller than 2 GiB");
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     PP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, PP_ERR_UNSUPPORTED, "pp_gemm: lda/ldw must be multiples of 8 elements");
+    if (panel_enabled() && linear_dma_supported(p, prec, 1)) return linear_dma_gemm(p, reinterpret_cast<hipStream_t>(stream));
     if (panel_enabled() && linear_ovl_supported(p, prec, 1)) return linear_ovl_gemm(p, reinterpret_cast<hipStream_t>(stream));
     if (panel_enabled() && panel_split_supported(p, prec, 1)) return panel_split_gemm(p, prec, 1, reinterpret_cast<hipStream_t>(stream));
     return gemm(p, prec, 1, reinterpret_cast<hipStream_t>(stream));

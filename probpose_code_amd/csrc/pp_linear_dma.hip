@@ -1,0 +1,233 @@
+// Dense layer for gfx950 in the parity precision (PP_PREC_F16X3: split-fp16 operands, pp_split.h, three fp16 MFMAs per product),
+// twelve-wave form:     out[m, n] = act_fn(sum_k a[m, k] w[n, k] + bias[n]) + residual[r(m), n]
+// (every nn.Linear of the ViT-B backbone at 384x288 - qkv, proj, fc1 (+ GELU), fc2; mmpretrain VisionTransformer [3P], call site
+// mmpose/models/pose_estimators/base.py:206, ctor args configs/body_2d_keypoint/topdown_probmap/coco/td-pm_ProbPose-small_8xb64-210e_coco-256x192.py:56-67
+// with arch 'base'). pp_gemm routes here before the wide-tile kernel (pp_panel_split.hip) when the shape allows it.
+//
+// The structure is pp_ffn_dma.hip's, applied to a plain GEMM:
+//   * one workgroup = one 192 x 192 output tile, 768 threads = 12 waves, three per SIMD, <= 168 registers, no scratch;
+//   * waves 0-7 compute: wave (rg, cg) = rows 48 rg .., columns 96 cg .. = 3 x 6 fragments (72 accumulator registers); per K-step
+//     (32 elements = one 128-byte block per row) one barrier, 18 fragment reads issued before the first MFMA, 54 MFMAs; they
+//     issue no memory instruction in the loop;
+//   * waves 8-11, one per SIMD, issue every buffer_load ... lds piece (a stage = 192 activation rows + 192 weight rows = 48 KiB =
+//     48 pieces of 8 rows x 128 B, 12 per wave) two stages ahead on a ring of three, and do the counted vmcnt wait in front of each
+//     barrier;
+//   * tiles in bands of four row tiles, row tile fastest: the workgroups resident on one XCD share one row tile per band and half of the
+//     weight column tiles (see the kernel);
+//   * rows past M: the activation descriptor ends at row M (the DMA writes zeros), the output descriptor too (stores are dropped).
+// OPT-IN (pp_set_option("linear_dma", 1)): the step loop alone is 20 % shorter than the wide-tile kernel's (scripts/micro/gemm12.hip, M = 55 296:
+// 450 / 583 / 622 us for (N, K) = (2304, 768) / (3072, 768) / (768, 3072)), but a 192 x 192 tile leaves the CU through a store path of
+// ~8 B/clk (147 KB = 9 us per tile) and with 144 KiB of LDS no second workgroup is resident to run beside that epilogue: whole launches
+// measure 573 / 746 / 667 us against 557 / 763 / 686 for the wide-tile kernel, which overlaps its stores (scripts/micro/linear_forms_bench.py);
+// BASELINE config 4: 1 671 - 1 674 against 1 670 - 1 684 crops/s.
+#include "pp_common.h"
+#include "pp_gemm.h"
+#include "pp_split.h"
+
+namespace pp {
+namespace ldm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int BM = 192, BN = 192, CW = 8, WAVES = 12, THREADS = WAVES * 64, NSTAGE = 3;
+constexpr int STAGE = (BM + BN) * 128, B_OFF = BM * 128, LDS = NSTAGE * STAGE;
+static_assert(LDS <= 160 * 1024, "LDS map");
+
+struct Params {
+    const char* a;     // [M, K] split rows
+    const char* w;     // [N, K] split rows
+    const float* bias; // [N] or NULL
+    const float* residual;  // fp32 [*, ldres] or NULL
+    char* out;         // [M, N]: split rows (out_split) or fp32
+    int M, N, K, ldres, res_mod, act, out_split, ntn;
+};
+
+#define LDM_WAITVM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
+
+__device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // tile of this workgroup: bands of 4 row tiles, row tile fastest inside a band. Consecutive ids go round the eight XCDs, so XCD x
+    // gets row tile x % 4 of every band and the column tiles of parity x / 4: the workgroups resident on an XCD share their
+    // activation rows and half of the weights in its L2
+    const int ntm = (p.M + BM - 1) / BM;
+    const int t_lin = (int)blockIdx.x;
+    const int band = t_lin / (4 * p.ntn), r = t_lin % (4 * p.ntn);
+    const int rows_in_band = ntm - band * 4 < 4 ? ntm - band * 4 : 4;
+    const int tm = band * 4 + r % rows_in_band, tn = r / rows_in_band;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int ksteps = p.K / 32;
+    const int rows_left = p.M - m0 < BM ? p.M - m0 : BM;
+
+    if (wv >= CW) {
+        // ---------------- DMA waves: a piece is 8 rows x 128 B; lane (row l = lane >> 3, physical chunk lane & 7) fetches logical chunk (lane & 7) ^ l
+        const int d = wv - CW;
+        const int x_l = lane >> 3;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a) + (size_t)m0 * p.K * 4, 0, (unsigned)rows_left * (unsigned)(p.K * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w) + (size_t)n0 * p.K * 4, 0, (unsigned)BN * (unsigned)(p.K * 4), 0x00020000);
+        const unsigned v = (unsigned)x_l * (unsigned)(p.K * 4) + (unsigned)(((lane & 7) ^ x_l) << 4);
+        const int row8 = 8 * p.K * 4;
+        auto issue = [&](int k, int st) {
+            char* dst = smem + st * STAGE;
+            const bool live = k < ksteps;
+            const int kk = live ? k : 0;  // (past the end: a harmless re-read keeps the counts)
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int q = d + 4 * u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dst + q * 1024), 16, v + (unsigned)(q * row8), kk * 128, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int q = d + 4 * u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + B_OFF + q * 1024), 16, v + (unsigned)(q * row8), kk * 128, 0, 0);
+            }
+        };
+        issue(0, 0);
+        issue(1, 1);
+        int st_i = 2;
+        for (int k = 0; k < ksteps; ++k) {
+            __builtin_amdgcn_sched_barrier(0);
+            LDM_WAITVM(12);  // stage k has landed: this wave's twelve pieces of stage k + 1 may be out
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue(k + 2, st_i);  // (all computing waves are past their reads of stage k - 1)
+            st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
+        }
+        LDM_WAITVM(0);
+        return;
+    }
+
+    // ---------------- computing waves
+    const int rg = wv >> 1, cg = wv & 1;
+    const int f_row = lane & 15, f_kg = lane >> 4, sw = f_row & 7;
+    const int lane_hi = f_row * 128 + ((f_kg ^ sw) << 4), lane_lo = f_row * 128 + (((4 + f_kg) ^ sw) << 4);
+    auto opq = [](int v) { asm volatile("" : "+s"(v)); return v; };
+    auto rd = [&](int lane_off, int uni, int imm) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + (lane_off + uni) + imm); };
+    f32x4 acc[3][6];  // [row fragment i][column fragment j]: row 48 rg + 16 i + f_row, columns 96 cg + 16 j + 4 f_kg + (0..3)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int st = 0;
+    for (int k = 0; k < ksteps; ++k) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int ua = opq(st * STAGE + rg * 48 * 128), ub = opq(st * STAGE + B_OFF + cg * 96 * 128);
+        u32x4 ah[3], al[3], bh[6], bl[6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ah[i] = rd(lane_hi, ua, i * 2048);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bh[j] = rd(lane_hi, ub, j * 2048);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) al[i] = rd(lane_lo, ua, i * 2048);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bl[j] = rd(lane_lo, ub, j * 2048);
+        __builtin_amdgcn_sched_barrier(0);  // every fragment read of the step ahead of its first MFMA (pp_ffn_dma.hip)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], ah[i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = mma(bl[j], ah[i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], al[i], acc[i][j]);
+        st = st + 1 == NSTAGE ? 0 : st + 1;
+    }
+
+    // ---------------- epilogue: act_fn(sum + bias) + residual, rows out as split fp16 (two 8-byte halves per lane) or fp32 (16 bytes).
+    // Output addressing through a buffer descriptor that ends at row M: the row part of the offset in the VGPR (range-checked), the
+    // wave-uniform column part in the scalar offset.
+    const int row0 = rg * 48 + f_row;  // + 16 i
+    const size_t ldo = (size_t)p.N * 4;  // bytes per output row in either format
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)m0 * ldo, 0, (unsigned)rows_left * (unsigned)ldo, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int n = n0 + cg * 96 + j * 16;  // (wave-uniform) first column of the fragment; the lane's four: n + 4 f_kg ..
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n + f_kg * 4);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int m = m0 + row0 + i * 16;
+            f32x4 v = acc[i][j] + bv;
+            if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erfc_as(v[e]);
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p.residual && m < p.M) {
+                const int rr = p.res_mod > 0 ? m % p.res_mod : m;
+                v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)rr * p.ldres + n + f_kg * 4);
+            }
+            const unsigned vrow = (unsigned)(row0 + i * 16) * (unsigned)ldo;
+            if (p.out_split) {
+                f16x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[e];
+                    split_pin(t);
+                    h[e] = split_hi(t);
+                    l[e] = split_lo(t, h[e]);
+                }
+                const int so = (n >> 5) * 128 + (n & 16) * 2;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), ro, vrow + (unsigned)f_kg * 8u, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l), ro, vrow + (unsigned)f_kg * 8u, so + 64, 0);
+            } else {
+                // (two 8-byte stores, not one of 16: a buffer_store_dwordx4 with an SGPR offset read its data registers late here - lanes
+                //  12 - 15 of every row got the values the NEXT fragment's arithmetic had already written over them)
+                const u32x4 q = __builtin_bit_cast(u32x4, v);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{q[0], q[1]}, ro, vrow + (unsigned)f_kg * 16u, n * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{q[2], q[3]}, ro, vrow + (unsigned)f_kg * 16u, n * 4 + 8, 0);
+            }
+        }
+    }
+}
+
+}  // namespace ldm
+
+bool linear_dma_supported(const GemmParams& p, int prec, int groups) {
+    if (option("linear_dma") == 0) return false;
+    if (prec != PP_PREC_F16X3 || groups != 1 || p.gather != G_LINEAR || p.planar_P > 0 || p.ksplit > 1 || p.head_w || p.pool_h > 0) return false;
+    if (p.out_bf16 != 0 && p.out_bf16 != 2) return false;
+    if (p.K % 32 != 0 || p.K < 64 || p.N % ldm::BN != 0 || p.lda != p.K || p.ldw != p.K || p.ldc != p.N) return false;
+    if (p.residual && (p.out_bf16 == 2 || ((p.ldres ? p.ldres : p.ldc) % 4) != 0)) return false;
+    if ((size_t)ldm::BM * p.K * 4 >= 0x7ffffff0u || (size_t)ldm::BM * p.N * 4 >= 0x7ffffff0u) return false;
+    const long long ntiles = (long long)(p.N / ldm::BN) * ((p.M + ldm::BM - 1) / ldm::BM);
+    return ntiles >= 512;  // two rounds of the chip at least; smaller problems stay with the 128 x 128 / wide-tile kernels
+}
+
+int linear_dma_gemm(const GemmParams& g, hipStream_t s) {
+    ldm::Params p{};
+    p.a = reinterpret_cast<const char*>(g.A);
+    p.w = reinterpret_cast<const char*>(g.W);
+    p.bias = g.bias;
+    p.residual = g.residual;
+    p.out = reinterpret_cast<char*>(g.C);
+    p.M = g.M; p.N = g.N; p.K = g.K;
+    p.ldres = g.ldres ? g.ldres : g.ldc;
+    p.res_mod = g.res_mod;
+    p.act = g.act;
+    p.out_split = g.out_bf16 == 2;
+    p.ntn = g.N / ldm::BN;
+    const int grid = p.ntn * ((g.M + ldm::BM - 1) / ldm::BM);
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldm::linear_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
+    hipLaunchKernelGGL(ldm::linear_dma_kernel, dim3(grid), dim3(ldm::THREADS), ldm::LDS, s, p);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+}  // namespace pp

@@ -380,6 +380,42 @@ def test_panel_split_linear_ragged_round_tail(res, split_out):
     assert torch.equal(outs[0], outs[1]), "the tail launch changes the bits (same K order per output: it must not)"
 
 
+@gpu
+@pytest.mark.parametrize("act,split_out,res,res_mod,bias,K", [(1, 1, False, 0, True, 96), (0, 0, True, 0, True, 768), (2, 1, False, 0, False, 64),
+                                                           (0, 0, True, 100, False, 128)])
+def test_linear_dma_twelve_wave_tiles(act, split_out, res, res_mod, bias, K):
+    """pp_gemm on the opt-in twelve-wave 192 x 192 kernel (pp_linear_dma.hip: >= 512 tiles, N % 192 == 0 - the Linear layers of ViT-B at bs 64)
+    against torch fp64 on the unrounded inputs: the three activations, both output formats, residual rows and a broadcast residual
+    table (res_mod), no bias, a ragged last row tile (77 rows), K = 64 (two stages) .. 768; repeated launches bit-identical; and the
+    wide-tile kernel (option linear_dma = 0) gives the same numbers to rounding."""
+    L = _lib()
+    M, N = 192 * 128 + 77, 768  # 129 x 4 = 516 tiles
+    a, w = _rand(M, K, seed=91), _rand(N, K, seed=92, scale=1 / math.sqrt(K))
+    b = _rand(N, seed=93) if bias else None
+    r = _rand(res_mod if res_mod else M, N, seed=94) if res else None
+    ref = a.double() @ w.double().t() + (b.double() if bias else 0)
+    ref = F.gelu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+    if res:
+        ref = ref + (r.double()[torch.arange(M) % res_mod] if res_mod else r.double())
+    ad, wd = _sp(a), _sp(w)
+    bd, rd = (b.cuda() if bias else None), (r.cuda() if res else None)
+    outs = []
+    try:
+        for opt in (1, 1, 0):
+            L.set_option("linear_dma", opt)
+            out = torch.full((M, N), float("nan"), device="cuda")
+            L.call("pp_gemm", F16X3, ad.data_ptr(), wd.data_ptr(), L.ptr(bd), L.ptr(rd), res_mod, out.data_ptr(), M, N, K, K, K, N, act,
+                   SPLIT if split_out else 0, 0, None)
+            got = _unsp(out) if split_out else out.cpu().double()
+            assert not torch.isnan(got).any(), "rows left unwritten"
+            torch.testing.assert_close(got, ref, **TOL)
+            outs.append((out.clone(), got))
+    finally:
+        L.set_option("linear_dma", 0)
+    assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32)), "run-to-run difference"
+    torch.testing.assert_close(outs[0][1], outs[2][1], rtol=3e-6, atol=3e-6)
+
+
 # ---- the overlapped-epilogue kernel (pp_linear_ovl.hip) takes split Linear layers without residual once there are at least two
 # 192 x 192 tiles per CU (qkv / fc1 of the ViT at bs 64): tail rows, the three activations, both output formats, and a bias
 # that must come out of LDS for every column tile
