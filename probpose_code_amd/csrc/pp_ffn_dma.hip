@@ -50,6 +50,12 @@ static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must rep
 #ifndef FFD_DMA_PRIO
 #define FFD_DMA_PRIO 0  // dev A/B: priority of the DMA waves (s_setprio)
 #endif
+#ifndef FFD_X128
+#define FFD_X128 1
+#endif
+#ifndef FFD_STORE16
+#define FFD_STORE16 0
+#endif
 #ifndef FFD_READS_FIRST
 #define FFD_READS_FIRST 1
 #endif
@@ -322,10 +328,24 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                             (v[3] - mu) * rs * g[3] + b[3]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { float t = hv[j]; split_pin(t); hv[j] = t; }
-                if (store_x) {  // (8-byte stores: see below)
+#if FFD_STORE16
+                {   // dev A/B: 16-byte stores in the FLAT encoding, as the eight-wave kernel does (64-bit addresses, `live` predicate)
+                    const bool live = m0 + rows0 + rf * 16 < p.M;
+                    const size_t off = (size_t)(m0 + rows0 + rf * 16) * E + cb + f_kg * 4;
+                    if (store_x && live) *reinterpret_cast<f32x4*>(x_dst + off) = v;
+                    split_store4_rowpair(h_dst, off, hv, live);
+                    continue;
+                }
+#endif
+                if (store_x) {
                     const u32x4 vq = __builtin_bit_cast(u32x4, v);
+#if FFD_X128
+                    // one 16-byte store: its data registers are the accumulators themselves, which nothing writes again (see below)
+                    __builtin_amdgcn_raw_buffer_store_b128(vq, rx, v_rowx + rf * (16 * E * 4), cb * 4, 0);
+#else
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{vq[0], vq[1]}, rx, v_rowx + rf * (16 * E * 4), cb * 4, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{vq[2], vq[3]}, rx, v_rowx + rf * (16 * E * 4), cb * 4 + 8, 0);
+#endif
                 }
                 // Two 8-byte buffer stores per lane (hi halves, lo halves), never a 16-byte one: a buffer_store_dwordx4 with an SGPR
                 // offset reads its data registers LATE on this chip when the texture path is busy - the compiler assumes such a store
