@@ -50,6 +50,9 @@ static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must rep
 #ifndef FFD_DMA_PRIO
 #define FFD_DMA_PRIO 0  // dev A/B: priority of the DMA waves (s_setprio)
 #endif
+#ifndef FFD_H128
+#define FFD_H128 1
+#endif
 #ifndef FFD_X128
 #define FFD_X128 1
 #endif
@@ -272,6 +275,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     // the wave-uniform column part in the scalar offset: two address registers for the whole epilogue.
     const unsigned v_rowx = (unsigned)(m0 + rows0) * (unsigned)(E * 4) + (unsigned)f_kg * 16u;                            // fp32 rows
     const unsigned v_rowh = (unsigned)(m0 + rows0) * (unsigned)(E * 4) + (unsigned)f_kg * 8u;  // split rows: the lane's four hi halves (lo: + 64)
+    const unsigned v_rowh2 = (unsigned)(m0 + rows0) * (unsigned)(E * 4) + (unsigned)(f_kg >> 1) * 16u + (unsigned)(f_kg & 1) * 64u;  // row-pair form: 16-byte hi chunk (even f_kg) / lo chunk (odd)
     auto layernorm_rows = [&](const float* gamma, const float* beta, float* x_dst, void* h_dst, bool store_x) {
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(x_dst, 0, p.h_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(h_dst, 0, p.h_bytes, 0x00020000);
@@ -340,19 +344,20 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 if (store_x) {
                     const u32x4 vq = __builtin_bit_cast(u32x4, v);
 #if FFD_X128
-                    // one 16-byte store: its data registers are the accumulators themselves, which nothing writes again (see below)
                     __builtin_amdgcn_raw_buffer_store_b128(vq, rx, v_rowx + rf * (16 * E * 4), cb * 4, 0);
+                    asm volatile("s_nop 3" ::"v"(vq));  // (wait states behind a 16-byte buffer store: scripts/micro/mubuf_store_hazard.hip)
 #else
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{vq[0], vq[1]}, rx, v_rowx + rf * (16 * E * 4), cb * 4, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{vq[2], vq[3]}, rx, v_rowx + rf * (16 * E * 4), cb * 4 + 8, 0);
 #endif
                 }
-                // Two 8-byte buffer stores per lane (hi halves, lo halves), never a 16-byte one: a buffer_store_dwordx4 with an SGPR
-                // offset reads its data registers LATE on this chip when the texture path is busy - the compiler assumes such a store
-                // has no write-data hazard and lets the next fragment's conversions overwrite the registers right behind it, and
-                // lanes 12 - 15 of every row then stored those newer values (a handful of 4-byte words per launch on a full chip;
-                // first seen behind the v_permlane16_swap pairing of split_store4_rowpair and wrongly blamed on the swap; the same
-                // thing hit pp_linear_dma.hip's fp32 rows, where no swap is involved; scripts/micro/ffn_forms_engine1.py, ldm_dbg.py)
+                // WAIT STATES BEHIND 16-BYTE BUFFER STORES. A buffer_store_dwordx4 reads its data registers one cycle late for lanes
+                // 12 - 15 of every row; an instruction that writes one of them directly behind the store changes what those lanes store.
+                // The hardware wants one wait state (SGPR soffset) or two (immediate) there - scripts/micro/mubuf_store_hazard.hip
+                // shows it in isolation - and the compiler inserts none for the SGPR form, which is the form used here. Seen as a
+                // handful of stale 4-byte words per launch on a full chip (first behind the v_permlane16_swap below and wrongly blamed
+                // on the swap; then in pp_linear_dma.hip's fp32 rows, where no swap is involved). Every 16-byte buffer store of this
+                // file is followed by an explicit s_nop that depends on its data.
                 f16x4 h, l;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -360,8 +365,20 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                     l[j] = split_lo(hv[j], h[j]);
                 }
                 const int so = (cb >> 5) * 128 + (cb & 16) * 2;
+#if FFD_H128
+                {   // the row-pair form of split_store4_rowpair (lanes f_kg, f_kg ^ 1 exchange halves: the even one stores the 16-byte hi chunk,
+                    // the odd one the lo chunk), as ONE 16-byte buffer store followed by the wait states the compiler does not insert
+                    const u32x2_t hu = __builtin_bit_cast(u32x2_t, h), lu = __builtin_bit_cast(u32x2_t, l);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(hu[1], lu[1], false, false);
+                    u32x4 q = {s0[0], s1[0], s0[1], s1[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(q, rh, v_rowh2 + rf * (16 * E * 4), so, 0);
+                    asm volatile("s_nop 3" ::"v"(q));
+                }
+#else
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, h), rh, v_rowh + rf * (16 * E * 4), so, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, l), rh, v_rowh + rf * (16 * E * 4), so + 64, 0);
+#endif
             }
         }
     };

@@ -187,11 +187,11 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), ro, vrow + (unsigned)f_kg * 8u, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l), ro, vrow + (unsigned)f_kg * 8u, so + 64, 0);
             } else {
-                // (two 8-byte stores, not one of 16: a buffer_store_dwordx4 with an SGPR offset read its data registers late here - lanes
-                //  12 - 15 of every row got the values the NEXT fragment's arithmetic had already written over them)
+                // (one 16-byte store + the wait states the compiler does not insert behind a buffer_store_dwordx4 with an SGPR offset:
+                //  its data registers are read a cycle late for lanes 12 - 15 of every row, scripts/micro/mubuf_store_hazard.hip)
                 const u32x4 q = __builtin_bit_cast(u32x4, v);
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{q[0], q[1]}, ro, vrow + (unsigned)f_kg * 16u, n * 4, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{q[2], q[3]}, ro, vrow + (unsigned)f_kg * 16u, n * 4 + 8, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(q, ro, vrow + (unsigned)f_kg * 16u, n * 4, 0);
+                asm volatile("s_nop 3" ::"v"(q));
             }
         }
     }
