@@ -20,6 +20,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef NSLOT
 #define NSLOT 3
 #endif
+#ifndef ALT
+#define ALT 0  // 1 (with SYNC 0): role-alternating computing waves - the two waves of a SIMD (row groups 0 / 1) are never in the same kind of
+               // segment: two barriers per step, rg 0 reads its fragments while rg 1 multiplies the previous step's, then the other way round
+#endif
 #ifndef SYNC
 #define SYNC 1  // 1 flags, 0 one barrier per step (the form of ffn12d.hip, here with NSLOT slots)
 #endif
@@ -130,6 +134,9 @@ __global__ __launch_bounds__(THREADS) void ffn12f_kernel(const char* __restrict_
                 if (SYNC) signal(f_ready + slot_g, lane);
                 else __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+#if ALT
+                __builtin_amdgcn_s_barrier();  // the second barrier of the step (rg 0: reads | MFMAs, rg 1: MFMAs of the previous step | reads)
+#endif
                 // step g + DEPTH goes into the slot of step g - 1: every computing wave must be past its reads of that step
                 if (SYNC && g >= 1) {
                     const int sp = slot_g == 0 ? NSLOT - 1 : slot_g - 1;
@@ -147,6 +154,10 @@ __global__ __launch_bounds__(THREADS) void ffn12f_kernel(const char* __restrict_
             }
         }
         WAITVM_ONLY(0);
+#if ALT
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+#endif
         __syncthreads();
         return;
     }
@@ -165,6 +176,142 @@ __global__ __launch_bounds__(THREADS) void ffn12f_kernel(const char* __restrict_
         pacc[rf][0] = pacc[rf][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     u32x4 bgh[RF], bgl[RF];
+#if ALT
+    {
+        u32x4 wh[3], wl[3], xh[RF], xl[RF];
+        auto Lseg = [&](int t, int slot) {  // all fragment reads of step t
+            const int so = opq(slot * SLOTB);
+            if (t < NA) {
+                const int ua = opq(OFF_RING + cg * 32 * 128 + so), ux = opq(OFF_RING + X_OFF + rg * 48 * 128 + so);
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) wh[nf] = rd(lane_hi, ua, nf * 2048);
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) xh[rf] = rd(lane_hi, ux, rf * 2048);
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) wl[nf] = rd(lane_lo, ua, nf * 2048);
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) xl[rf] = rd(lane_lo, ux, rf * 2048);
+            } else {
+                const int sb = t - NA;
+                const int ub = opq(OFF_RING + cg * 48 * 128 + so);
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf) wh[nf] = rd(lane_hi, ub, nf * 2048);
+                if ((sb & 1) == 0) {
+                    const int ug = opq(rg * 48 * 128 + (sb >> 1) * G_KB);
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf) bgh[rf] = rd(lane_hi, ug, rf * 2048);
+                }
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf) wl[nf] = rd(lane_lo, ub, nf * 2048);
+                if ((sb & 1) == 0) {
+                    const int ug = opq(rg * 48 * 128 + (sb >> 1) * G_KB);
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf) bgl[rf] = rd(lane_lo, ug, rf * 2048);
+                }
+            }
+        };
+        auto Cseg = [&](int t) {  // the MFMAs of step t (+ the chunk's GELU behind its last A-step)
+            if (t < NA) {
+                if (t == 0) {
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf) pacc[rf][0] = pacc[rf][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                    for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wh[nf], xh[rf], pacc[rf][nf]);
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                    for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wl[nf], xh[rf], pacc[rf][nf]);
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                    for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wh[nf], xl[rf], pacc[rf][nf]);
+                if (t == NA - 1) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) {
+                            h4 hv, lv;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float x = pacc[rf][nf][q];
+                                const float z = fabsf(x) * 0.70710678118654752440f;
+                                const float tt = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+                                float qq = __builtin_fmaf(tt, 1.061405429f, -1.453152027f);
+                                qq = __builtin_fmaf(tt, qq, 1.421413741f);
+                                qq = __builtin_fmaf(tt, qq, -0.284496736f);
+                                qq = __builtin_fmaf(tt, qq, 0.254829592f);
+                                const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.44269504088896340736f);
+                                const float ez = tt * qq * e;
+                                float gv = 0.5f * x * (x < 0.f ? ez : 2.0f - ez);
+                                asm("" : "+v"(gv));
+                                hv[q] = (_Float16)gv;
+                                lv[q] = (_Float16)(gv - (float)hv[q]);
+                            }
+                            char* gs = smem + cg * G_KB + (rows0 + rf * 16) * 128 + (f_kg & 1) * 8;
+                            const int c = 2 * nf + (f_kg >> 1);
+                            *reinterpret_cast<h4*>(gs + ((c ^ sw) << 4)) = hv;
+                            *reinterpret_cast<h4*>(gs + (((4 + c) ^ sw) << 4)) = lv;
+                        }
+                }
+            } else {
+                const int half = (t - NA) & 1;
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                    for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                    for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                    for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+            }
+        };
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));  // lgkmcnt(0): fragments in / G writes out
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int slot = 0;
+        if (rg == 0) {
+            for (int ci = 0; ci < NCH; ++ci) {
+#pragma clang loop unroll(full)
+                for (int t = 0; t < STEPS; ++t) {
+                    bar();
+                    Lseg(t, slot);
+                    bar();
+                    Cseg(t);
+                    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+                }
+            }
+            bar();
+            bar();
+        } else {
+            bar();
+            bar();
+            Lseg(0, 0);
+            slot = 1;
+            for (int ci = 0; ci < NCH; ++ci) {
+#pragma clang loop unroll(full)
+                for (int t = 1; t <= STEPS; ++t) {  // step t of chunk ci (t = 20: step 0 of the next chunk)
+                    bar();
+                    Cseg(t - 1);
+                    bar();
+                    if (t < STEPS || ci + 1 < NCH) Lseg(t % STEPS, slot);
+                    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+                }
+            }
+            // (barrier count: 2 + 2 * 20 * NCH = rg 0's 2 * 20 * NCH + 1 ... + 1: one more below)
+        }
+    }
+#else
     int slot = 0;
     unsigned pre_flag = 0;
     for (int ci = 0; ci < NCH; ++ci) {
@@ -280,6 +427,7 @@ __global__ __launch_bounds__(THREADS) void ffn12f_kernel(const char* __restrict_
             slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
     }
+#endif
     __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | 0);
     __syncthreads();
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
@@ -320,6 +468,6 @@ int main() {
         if (ms / 20 < best) best = ms / 20;
     }
     hipError_t err = hipGetLastError();
-    printf("SYNC=%d NSLOT=%d: %.1f us per launch (240 steps: %.0f ns per step), err=%s\n", SYNC, NSLOT, best * 1e3, best * 1e6 / 240, hipGetErrorString(err));
+    printf("ALT=%d SYNC=%d NSLOT=%d: %.1f us per launch (240 steps: %.0f ns per step), err=%s\n", ALT, SYNC, NSLOT, best * 1e3, best * 1e6 / 240, hipGetErrorString(err));
     return 0;
 }
