@@ -68,8 +68,8 @@ int pp_device_cu_count(void);
  *   "decode_wgs_per_cu" (3)  pp_probmap_(head_)decode: workgroups per CU its LDS band buffer is sized for (5 .. 1)
  *   "qkv_attn_pair" (0)      1: pp_qkv_attention_split with a head pair per workgroup (measured slower; kept for A/B)
  *   "ksplit9_below" (1024)   pp_conv3x3_splitk_slices: output rows under which a small tower stage is cut into nine K-slices
- *   "linear_dma" (0)         1: large split-fp16 Linear layers (pp_gemm, N % 192 == 0, >= 512 tiles) run the twelve-wave 192 x 192 kernel
- *                            (pp_linear_dma.hip) instead of the wide-tile kernel (measured no faster; kept for A/B)
+ *   "linear_dma" (1)         0: large split-fp16 Linear layers (pp_gemm, N % 192 == 0, >= 512 tiles) stay on the wide-tile kernel instead of the
+ *                            twelve-wave 192 x 192 kernels (pp_linear_dma.hip: persistent, finished tiles leave through the DMA waves)
  *   "ffn_dma_waves" (1)      0: the fused f16x3 feed-forward launches run the eight-wave kernel (pp_ffn_split.hip) instead of the
  *                            twelve-wave one (pp_ffn_dma.hip: eight computing waves + four waves that only issue the LDS-DMA)
  *   "psplit_tail" (1)        0: split-fp16 Linear layers never send the rows of a ragged last round to a second launch on 128 x 192 tiles

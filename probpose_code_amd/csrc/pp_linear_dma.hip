@@ -15,11 +15,11 @@
 //   * tiles in bands of four row tiles, row tile fastest: the workgroups resident on one XCD share one row tile per band and half of the
 //     weight column tiles (see the kernel);
 //   * rows past M: the activation descriptor ends at row M (the DMA writes zeros), the output descriptor too (stores are dropped).
-// OPT-IN (pp_set_option("linear_dma", 1)): the step loop alone is 20 % shorter than the wide-tile kernel's (scripts/micro/gemm12.hip, M = 55 296:
-// 450 / 583 / 622 us for (N, K) = (2304, 768) / (3072, 768) / (768, 3072)), but a 192 x 192 tile leaves the CU through a store path of
-// ~8 B/clk (147 KB = 9 us per tile) and with 144 KiB of LDS no second workgroup is resident to run beside that epilogue: whole launches
-// measure 573 / 746 / 667 us against 557 / 763 / 686 for the wide-tile kernel, which overlaps its stores (scripts/micro/linear_forms_bench.py);
-// BASELINE config 4: 1 671 - 1 674 against 1 670 - 1 684 crops/s.
+// Two kernels: layers WITH a residual run the plain form above (every workgroup one tile; its epilogue - 147 KB through a store path of
+// ~8 B/clk = 9 us per tile - is exposed: whole launches 667 against 686 us for fc2 on the wide-tile kernel); layers without one run the
+// PERSISTENT form below, where finished tiles leave through the DMA waves. Step loop alone (scripts/micro/gemm12.hip, M = 55 296): 450 /
+// 583 / 622 us for (N, K) = (2304, 768) / (3072, 768) / (768, 3072); whole launches (scripts/micro/linear_forms_bench.py): qkv 519 - 529
+// against 549 - 557 us, fc1 + GELU 742 - 747 against 775 - 779; BASELINE config 4: 1 730 - 1 785 against 1 692 - 1 694 crops/s.
 #include "pp_common.h"
 #include "pp_gemm.h"
 #include "pp_split.h"
@@ -197,6 +197,210 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// PERSISTENT form (no residual): one workgroup per CU walks the tiles; a finished tile - bias added by the computing waves - is HANDED
+// to the four DMA waves through LDS (fp32, row pitch 784 B: the ring's 144 KiB + 6 KiB); each holds a quarter of it in 144 registers
+// per lane, applies the activation, splits and stores it while the computing waves are in the next tile's K loop: the ~9 us a
+// 192 x 192 tile takes to leave the CU (store path ~8 B/clk) and the activation's VALU work are no longer on the computing waves'
+// time line. The DMA waves' counted wait stays correct with stores in flight: loads retire in order among themselves, so "at most
+// the twelve pieces of the next stage outstanding" implies this stage has landed whatever else the count holds.
+constexpr int H_PITCH = 784;  // bytes per row of the hand-off tile: rows shift by four banks, eight lanes x 16 B never collide
+static_assert(BM * H_PITCH <= 160 * 1024, "hand-off tile");
+constexpr int LDS_P = BM * H_PITCH > LDS ? BM * H_PITCH : LDS;
+
+template <int ACT>
+__global__ __launch_bounds__(THREADS) void linear_dma_persistent_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntm = (p.M + BM - 1) / BM;
+    const int ntiles = ntm * p.ntn;
+    const int ksteps = p.K / 32;
+    // tiles in bands of four row tiles, row tile fastest (an XCD-grid order - XCD x owns a column quarter and a row parity, its
+    // share of the weights resident in its L2 - measured slower: 555 against 519 - 529 us for the qkv layer)
+    auto tile_m = [&](int t) { const int band = t / (4 * p.ntn), r = t % (4 * p.ntn); const int rib = ntm - band * 4 < 4 ? ntm - band * 4 : 4; return band * 4 + r % rib; };
+    auto tile_n = [&](int t) { const int band = t / (4 * p.ntn), r = t % (4 * p.ntn); const int rib = ntm - band * 4 < 4 ? ntm - band * 4 : 4; return r / rib; };
+    auto bar = []() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const size_t ldo = (size_t)p.N * 4;
+
+    if (wv >= CW) {
+        // ================= DMA waves
+        const int d = wv - CW;
+        const int x_l = lane >> 3;
+        const unsigned v = (unsigned)x_l * (unsigned)(p.K * 4) + (unsigned)(((lane & 7) ^ x_l) << 4);
+        const int row8 = 8 * p.K * 4;
+        f32x4 hold[36];  // rows 48 d .. +47 of the previous tile, element (i * 256 + 4 lane) of the 48 x 192 block in chunk i
+        int pm0 = 0, pn0 = 0, prows = 0;
+        bool have = false;
+        // chunk i of the held tile: activation, split / fp32, store
+        auto finish = [&](int i) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));  // (opaque: the per-chunk offsets are computed here, not hoisted out of the K loop into 100 registers)
+            const int t = ln * 4 + (i % 3) * 64;               // element offset inside three rows' worth (768 = 4 x 192)
+            const int row = (i * 4) / 3 + (t >= 192 ? 1 : 0), col = t >= 192 ? t - 192 : t;
+            f32x4 x = hold[i];  // (the bias was added by the computing waves)
+            asm volatile("" : "+v"(x));  // (opaque: otherwise the activation is hoisted to the hand-off and the tile is held twice)
+            if (ACT == ACT_GELU) {  // one value at a time: this wave has 24 registers beside its quarter tile
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = gelu_erfc_as(x[e]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (ACT == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+            }
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)pm0 * ldo, 0, (unsigned)prows * (unsigned)ldo, 0x00020000);
+            const unsigned vrow = (unsigned)(48 * d + row) * (unsigned)ldo;
+            const int n = pn0 + col;
+            if (p.out_split) {
+                f16x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y = x[e];
+                    split_pin(y);
+                    h[e] = split_hi(y);
+                    l[e] = split_lo(y, h[e]);
+                }
+                const unsigned cb = (unsigned)((n >> 5) * 128 + (n & 31) * 2);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), ro, vrow + cb, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l), ro, vrow + cb + 64u, 0, 0);
+            } else {
+                const u32x4 q = __builtin_bit_cast(u32x4, x);
+                __builtin_amdgcn_raw_buffer_store_b128(q, ro, vrow + (unsigned)n * 4u, 0, 0);
+                asm volatile("s_nop 3" ::"v"(q));
+            }
+        };
+        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            const int m0 = tile_m(t) * BM, n0 = tile_n(t) * BN;
+            const int rows_left = p.M - m0 < BM ? p.M - m0 : BM;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a) + (size_t)m0 * p.K * 4, 0, (unsigned)rows_left * (unsigned)(p.K * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w) + (size_t)n0 * p.K * 4, 0, (unsigned)BN * (unsigned)(p.K * 4), 0x00020000);
+            auto issue = [&](int k, int st) {
+                char* dst = smem + st * STAGE;
+                int r8 = row8;
+                asm volatile("" : "+s"(r8));  // (opaque: six hoisted offset registers are six registers of tile this wave cannot hold)
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int q = d + 4 * u;
+                    const unsigned vq = v + (unsigned)(q * r8);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dst + q * 1024), 16, vq, k * 128, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + B_OFF + q * 1024), 16, vq, k * 128, 0, 0);
+                }
+            };
+            issue(0, 0);
+            issue(1, 1);
+            int st_i = 2;
+            for (int k = 0; k < ksteps; ++k) {
+                // the held tile leaves two chunks per step (statically indexed registers: a switch over the step)
+                if (have && k < 18) {
+                    switch (k) {
+#define LDM_CASE(K) case K: finish(2 * K); finish(2 * K + 1); break;
+                        LDM_CASE(0) LDM_CASE(1) LDM_CASE(2) LDM_CASE(3) LDM_CASE(4) LDM_CASE(5) LDM_CASE(6) LDM_CASE(7) LDM_CASE(8)
+                        LDM_CASE(9) LDM_CASE(10) LDM_CASE(11) LDM_CASE(12) LDM_CASE(13) LDM_CASE(14) LDM_CASE(15) LDM_CASE(16) LDM_CASE(17)
+#undef LDM_CASE
+                        default: break;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < ksteps) LDM_WAITVM(12); else LDM_WAITVM(0);  // stage k has landed (loads retire in order; stores only make the wait longer)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 2 < ksteps) issue(k + 2, st_i);
+                st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
+            }
+            if (have && ksteps < 18) {  // (short K: the rest of the held tile leaves here)
+#pragma unroll
+                for (int i = 0; i < 36; ++i)
+                    if (i >= 2 * ksteps) finish(i);
+            }
+            bar();  // X1: every computing wave is past its last fragment read
+            bar();  // X2: the tile is in LDS
+            {
+                const char* src = smem + (48 * d) * H_PITCH;
+#pragma unroll
+                for (int i = 0; i < 36; ++i) {
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));  // (opaque: see finish)
+                    const int tt = ln * 4 + (i % 3) * 64;
+                    const int row = (i * 4) / 3 + (tt >= 192 ? 1 : 0), col = tt >= 192 ? tt - 192 : tt;
+                    hold[i] = *reinterpret_cast<const f32x4*>(src + row * H_PITCH + col * 4);
+                }
+                __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));  // lgkmcnt(0)
+            }
+            bar();  // X3: the ring is free again
+            pm0 = m0; pn0 = n0; prows = rows_left; have = true;
+        }
+        if (have) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) finish(i);
+        }
+        return;
+    }
+
+    // ================= computing waves
+    const int rg = wv >> 1, cg = wv & 1;
+    const int f_row = lane & 15, f_kg = lane >> 4, sw = f_row & 7;
+    const int lane_hi = f_row * 128 + ((f_kg ^ sw) << 4), lane_lo = f_row * 128 + (((4 + f_kg) ^ sw) << 4);
+    auto opq = [](int v) { asm volatile("" : "+s"(v)); return v; };
+    auto rd = [&](int lane_off, int uni, int imm) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + (lane_off + uni) + imm); };
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        f32x4 acc[3][6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int st = 0;
+        for (int k = 0; k < ksteps; ++k) {
+            bar();
+            const int ua = opq(st * STAGE + rg * 48 * 128), ub = opq(st * STAGE + B_OFF + cg * 96 * 128);
+            u32x4 ah[3], al[3], bh[6], bl[6];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ah[i] = rd(lane_hi, ua, i * 2048);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) bh[j] = rd(lane_hi, ub, j * 2048);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) al[i] = rd(lane_lo, ua, i * 2048);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) bl[j] = rd(lane_lo, ub, j * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], ah[i], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = mma(bl[j], ah[i], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], al[i], acc[i][j]);
+            st = st + 1 == NSTAGE ? 0 : st + 1;
+        }
+        bar();  // X1
+        {
+            char* dst = smem + (rg * 48 + f_row) * H_PITCH + (cg * 96 + f_kg * 4) * 4;
+            const int n0 = tile_n(t) * BN;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + cg * 96 + j * 16 + f_kg * 4);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(dst + i * 16 * H_PITCH + j * 64) = acc[i][j] + bv;
+            }
+            __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));  // lgkmcnt(0)
+        }
+        bar();  // X2
+        bar();  // X3
+    }
+}
+
 }  // namespace ldm
 
 bool linear_dma_supported(const GemmParams& p, int prec, int groups) {
@@ -224,6 +428,15 @@ int linear_dma_gemm(const GemmParams& g, hipStream_t s) {
     p.out_split = g.out_bf16 == 2;
     p.ntn = g.N / ldm::BN;
     const int grid = p.ntn * ((g.M + ldm::BM - 1) / ldm::BM);
+    if (!g.residual) {  // persistent form: finished tiles leave through the DMA waves
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        auto kern = g.act == ACT_GELU ? ldm::linear_dma_persistent_kernel<ACT_GELU> : g.act == ACT_RELU ? ldm::linear_dma_persistent_kernel<ACT_RELU> : ldm::linear_dma_persistent_kernel<ACT_NONE>;
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS_P));
+        hipLaunchKernelGGL(kern, dim3(grid < cus ? grid : cus), dim3(ldm::THREADS), ldm::LDS_P, s, p);
+        PP_LAUNCH_CHECK();
+        return PP_OK;
+    }
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldm::linear_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
     hipLaunchKernelGGL(ldm::linear_dma_kernel, dim3(grid), dim3(ldm::THREADS), ldm::LDS, s, p);
     PP_LAUNCH_CHECK();

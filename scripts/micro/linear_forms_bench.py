@@ -28,4 +28,4 @@ run(3072, 768, 1, True, False)
 run(3072, 768, 0, True, False)
 run(768, 768, 0, False, True)
 run(768, 3072, 0, False, True)
-L.set_option("linear_dma", 0)
+L.set_option("linear_dma", 1)

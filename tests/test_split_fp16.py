@@ -384,7 +384,7 @@ def test_panel_split_linear_ragged_round_tail(res, split_out):
 @pytest.mark.parametrize("act,split_out,res,res_mod,bias,K", [(1, 1, False, 0, True, 96), (0, 0, True, 0, True, 768), (2, 1, False, 0, False, 64),
                                                            (0, 0, True, 100, False, 128)])
 def test_linear_dma_twelve_wave_tiles(act, split_out, res, res_mod, bias, K):
-    """pp_gemm on the opt-in twelve-wave 192 x 192 kernel (pp_linear_dma.hip: >= 512 tiles, N % 192 == 0 - the Linear layers of ViT-B at bs 64)
+    """pp_gemm on the twelve-wave 192 x 192 kernels (pp_linear_dma.hip: >= 512 tiles, N % 192 == 0 - the Linear layers of ViT-B at bs 64)
     against torch fp64 on the unrounded inputs: the three activations, both output formats, residual rows and a broadcast residual
     table (res_mod), no bias, a ragged last row tile (77 rows), K = 64 (two stages) .. 768; repeated launches bit-identical; and the
     wide-tile kernel (option linear_dma = 0) gives the same numbers to rounding."""
@@ -411,7 +411,7 @@ def test_linear_dma_twelve_wave_tiles(act, split_out, res, res_mod, bias, K):
             torch.testing.assert_close(got, ref, **TOL)
             outs.append((out.clone(), got))
     finally:
-        L.set_option("linear_dma", 0)
+        L.set_option("linear_dma", 1)
     assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32)), "run-to-run difference"
     torch.testing.assert_close(outs[0][1], outs[2][1], rtol=3e-6, atol=3e-6)
 
