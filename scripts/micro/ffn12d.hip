@@ -32,6 +32,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define GELU 0  // 1: after a chunk's twelve A-steps every computing wave runs the erfc-form GELU on its 24 accumulator values and writes the
                 // (hi, lo) pairs into the G tile (12 ds_write_b64) - exposed, all waves at the same time (no second accumulator set at 168 registers)
 #endif
+#ifndef STAMP
+#define STAMP 0  // 1: wave 0 of workgroup 5 stamps s_memtime at the top of every step of chunk 6 (+ launch start / end with the 100 MHz counter)
+#endif
 #ifndef ABL  // timing-only ablations: 1 no DMA traffic (empty descriptors), 4 no MFMA
 #define ABL 0
 #endif
@@ -62,8 +65,9 @@ __device__ __forceinline__ void waitvm() {
 }
 
 __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* __restrict__ wpack, unsigned w_bytes, const char* __restrict__ h,
-                                                                    unsigned h_bytes, float* __restrict__ out) {
+                                                                    unsigned h_bytes, float* __restrict__ out, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool dma_wave = MODE == 1 && wv >= CW;
@@ -179,6 +183,8 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
     for (int ci = 0; ci < NCH; ++ci) {
 #pragma unroll
         for (int t = 0; t < STEPS; ++t) {
+            if (STAMP && ci == 6 && blockIdx.x == 5 && threadIdx.x == 0) stamps[t] = __builtin_amdgcn_s_memtime();
+            if (STAMP && ci == 7 && t == 0 && blockIdx.x == 5 && threadIdx.x == 0) stamps[STEPS] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
             if (MODE == 0) {
                 const int t1 = (t + 1) % STEPS, t2 = (t + 2) % STEPS;
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
                     for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wh[nf], xl[rf], pacc[rf][nf]);
 #if GELU
                 if (t == NA - 1) {
+                    if (STAMP && ci == 6 && blockIdx.x == 5 && threadIdx.x == 0) stamps[40] = __builtin_amdgcn_s_memtime();
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                     for (int rf = 0; rf < RF; ++rf)
@@ -293,6 +300,9 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
             }
         }
     }
+    if (STAMP && blockIdx.x == 5 && threadIdx.x == 0) {
+        stamps[30] = t_start; stamps[31] = __builtin_amdgcn_s_memtime(); stamps[32] = r_start; stamps[33] = __builtin_amdgcn_s_memrealtime();
+    }
     __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | 0);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -311,6 +321,9 @@ int main() {
     hipMalloc(&w, wbytes);
     hipMalloc(&h, hbytes);
     hipMalloc(&out, 256 * THREADS * 16);
+    unsigned long long* stamps;
+    hipMalloc(&stamps, 64 * 8);
+    hipMemset(stamps, 0, 64 * 8);
     std::vector<unsigned short> hw(wbytes / 2), hh(hbytes / 2);
     for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0x2c00 + (rand() & 0x3ff) + ((rand() & 1) << 15);
     for (size_t i = 0; i < hh.size(); ++i) hh[i] = 0x3800 + (rand() & 0x7ff) + ((rand() & 1) << 15);
@@ -322,9 +335,9 @@ int main() {
     hipEventCreate(&e1);
     float best = 1e9f;
     for (int rep = 0; rep < 6; ++rep) {
-        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(ffn12d_kernel, dim3(256), dim3(THREADS), LDS, 0, w, (unsigned)wbytes, h, (unsigned)hbytes, out);
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(ffn12d_kernel, dim3(256), dim3(THREADS), LDS, 0, w, (unsigned)wbytes, h, (unsigned)hbytes, out, stamps);
         hipEventRecord(e0);
-        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(ffn12d_kernel, dim3(256), dim3(THREADS), LDS, 0, w, (unsigned)wbytes, h, (unsigned)hbytes, out);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(ffn12d_kernel, dim3(256), dim3(THREADS), LDS, 0, w, (unsigned)wbytes, h, (unsigned)hbytes, out, stamps);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -334,5 +347,15 @@ int main() {
     hipError_t err = hipGetLastError();
     printf("MODE=%d GELU=%d XDIRECT=%d PF=%d ABL=%d: %.1f us per launch (240 steps: %.0f ns per step), err=%s\n", MODE, GELU, XDIRECT, PF, ABL, best * 1e3, best * 1e6 / 240,
            hipGetErrorString(err));
+    if (STAMP) {
+        unsigned long long st[64];
+        hipMemcpy(st, stamps, sizeof(st), hipMemcpyDeviceToHost);
+        const double cyc = (double)(st[31] - st[30]), us = (double)(st[33] - st[32]) / 100.0;
+        printf("  workgroup 5: %.0f cycles in %.1f us = %.0f MHz; chunk 6 steps (cycles): A", cyc, us, cyc / us);
+        for (int i = 0; i < NA; ++i) printf(" %llu", st[i + 1] - st[i]);
+        printf(" (GELU inside the last: %llu) | B", GELU ? st[NA] - st[40] : 0ull);
+        for (int i = NA; i < STEPS; ++i) printf(" %llu", st[i + 1] - st[i]);
+        printf("\n");
+    }
     return 0;
 }

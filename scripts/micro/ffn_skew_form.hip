@@ -1,0 +1,818 @@
+// dev record (round 5, stamped NEGATIVE): pp_ffn_dma.hip with its chunk phases skewed by one (option "ffn_skew") - A(0) GELU(0) | A(1) B(0) | ... | B(n-1),
+// GELU of chunk c + 1 in place between the MFMAs of B(c) (FFD_GELU_MODE 0: pinned 4 VALU per MFMA; 1: one block in front; 2: blocks staggered between the two
+// computing waves of a SIMD). Bit-identical outputs to the unskewed form; launch time 166.2 - 169.1 us against 164.8 (FFN), 189.0 - 191.8 against 187.0 (proj + FFN);
+// GRBM_GUI_ACTIVE 349.8 k against 345.6 k cycles per launch: VALU and MFMA issue of the waves of ONE SIMD do not overlap, the GELU costs its ~3.4 k cycles per
+// chunk wherever it is placed. Not built by the Makefile. Build / run: scripts/micro/ffd_variants.sh with this file copied over pp_ffn_dma.hip (+ the option row in pp_api.hip).
+// The fused f16x3 feed-forward launch of pp_ffn_split.hip (same packed weight streams, same sums in the same order; the two agree
+// to rounding - the GELU here is written max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2), two instructions shorter) with the LDS-DMA issue
+// taken OUT of the computing waves:
+//     [x <- x + att Wp^T + bp ; h <- LN2(x)]   x <- x + GELU(h W1^T + b1) W2^T + b2 ;   h_next <- LayerNorm(x)
+// (mmpretrain TransformerEncoderLayer [3P]; call site mmpose/models/pose_estimators/base.py:206).
+//
+//   * 768 threads = 12 waves, three per SIMD, at <= 168 registers each:
+//       waves 0-7   compute: wave (rg, cg) = rows 48 rg .. +47, column quarter cg - the tiles of pp_ffn_split.hip - and issue NO
+//                   memory instruction inside the step loop: per step one barrier, the fragment reads, 18 / 27 MFMAs;
+//       waves 8-11  one per SIMD: issue ALL buffer_load ... lds pieces (7 per A-step, 6 per B-step each) three steps ahead and
+//                   do the counted s_waitcnt vmcnt(N) in front of every barrier.
+//     A buffer_load ... lds holds its wave for 60 - 180 cycles when the texture path is busy; in the eight-wave kernel that
+//     wave also owns MFMAs, and the role alternation there hides the stall behind the OTHER wave of the SIMD at the price of
+//     two barriers per step. Here the stalls belong to a wave that has nothing else to do.
+//   * the price is the register budget (512 / 3): no second accumulator set, so a chunk's GELU is not spread under the next
+//     chunk's steps - it runs between the chunk's A-steps and its B-steps, all eight waves at once (~12 x 0.35 us per launch);
+//   * steps, ring (four 28 KiB slots), G tile, LayerNorm epilogue, k-block sawtooth and chunk rotation as in pp_ffn_split.hip.
+//   * the plain-load / LDS-DMA retire-order hazard of the eight-wave kernel (a younger plain load may retire before an older
+//     piece's LDS write) cannot occur: the waves that count pieces issue nothing else.
+// Measured as a skeleton first (scripts/micro/ffn12d.hip MODE=1 GELU=1): 148 - 150 us against 161 us for the eight-wave loop.
+//
+// SKEW form (round 5, option "ffn_skew", default): the exposed GELU is ~4.5 k cycles of a chunk's ~22 k (stamps of scripts/micro/ffn44.hip:
+// 48 values per SIMD at ~60 VALU cycles each, all waves at once, no MFMA issued meanwhile). The chunk's phases are therefore SKEWED by one:
+//     A(0) GELU(0) | A(1) B(0) | A(2) B(1) | ... | A(n-1) B(n-2) | B(n-1)
+// P(c) = the accumulators of chunk c's A-steps stays in its 24 registers THROUGH the B-steps of chunk c - 1 and is turned into GELU'd
+// (hi, lo) pairs IN PLACE there, one accumulator fragment per B-step, its ~100 VALU instructions pinned between that step's 27 MFMAs
+// (the other computing wave of the SIMD owns the matrix pipe meanwhile); the pairs go into the G tile in the LAST B-step of chunk c - 1,
+// when no wave reads the tile any more (its k-block 3 fragments were read in the step before), so no barrier is added. Only GELU(0) stays
+// exposed. Same sums in the same order as the unskewed form (bit-identical outputs); the DMA waves stream the same pieces in the new order.
+#include "pp_common.h"
+#include "pp_split.h"
+#include "pp_ffn_params.h"
+
+namespace pp {
+namespace ffd {
+
+using ffs::Params;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int BM = 96, E = 384, CHUNK = 128;
+constexpr int CW = 8, WAVES = 12, THREADS = WAVES * 64;
+constexpr int KB = E / 32;
+constexpr int G_KB = BM * 128;
+constexpr int OFF_G = 0;
+constexpr int OFF_RING = 4 * G_KB;
+constexpr int SLOTB = 28 * 1024, NSLOT = 4;
+constexpr int LDS = OFF_RING + NSLOT * SLOTB;
+constexpr int X_OFF = 16 * 1024;
+constexpr int NA = KB, NB = 8, STEPS = NA + NB;
+constexpr int A_BLOCK = CHUNK * 128;
+constexpr int B_BLOCK = (E / 2) * 128;
+constexpr int B_PART = NA * A_BLOCK;
+constexpr int CHUNK_BYTES = B_PART + NB * B_BLOCK;
+constexpr int NPROJ = 2 * KB;  // steps of the projection phase
+static_assert(LDS == 160 * 1024, "LDS map");
+static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must repeat");
+
+#ifndef FFD_DMA_PRIO
+#define FFD_DMA_PRIO 0  // dev A/B: priority of the DMA waves (s_setprio)
+#endif
+#ifndef FFD_GELU_RELU_FORM
+#define FFD_GELU_RELU_FORM 1
+#endif
+#ifndef FFD_H128
+#define FFD_H128 1
+#endif
+#ifndef FFD_X128
+#define FFD_X128 1
+#endif
+#ifndef FFD_STORE16
+#define FFD_STORE16 0
+#endif
+#ifndef FFD_READS_FIRST
+#define FFD_READS_FIRST 1
+#endif
+#ifndef FFD_GELU_MODE
+#define FFD_GELU_MODE 0  // SKEW form, how a B-step carries its GELU fragment: 0 = VALU instructions pinned between the MFMAs (both waves of a SIMD
+                         // alike); 1 = one block in front of the MFMAs; 2 = one block, in front of the MFMAs for row group 0 and behind them for row
+                         // group 1 (the two computing waves of a SIMD are (0, cg) and (1, cg): one multiplies while the other evaluates)
+#endif
+#ifndef FFD_GELU_VALU_PER_MFMA
+#define FFD_GELU_VALU_PER_MFMA 4  // SKEW form: VALU instructions pinned behind each MFMA of a B-step that carries a GELU fragment
+#endif
+#ifndef FFD_DEPTH
+#define FFD_DEPTH 3  // steps a DMA wave may have in flight behind the one the computing waves are about to read: 2 or 3
+#endif
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+// (n is a compile-time constant after unrolling; the builtin wants a literal)
+__device__ __forceinline__ void wait_vm_n(int n) {
+    switch (n) {
+        case 0: wait_vm<0>(); break;
+        case 6: wait_vm<6>(); break;
+        case 7: wait_vm<7>(); break;
+        case 9: wait_vm<9>(); break;
+        case 12: wait_vm<12>(); break;
+        case 13: wait_vm<13>(); break;
+        case 14: wait_vm<14>(); break;
+        case 15: wait_vm<15>(); break;
+        default: wait_vm<0>(); break;
+    }
+}
+// pieces one DMA wave issues for a step of the main loop / of the projection phase
+__host__ __device__ constexpr int n_main(int t) { return (((t % STEPS) + STEPS) % STEPS) < NA ? 7 : 6; }
+__host__ __device__ constexpr int n_proj(int s) { return s < NPROJ ? 6 + ((s & 1) == 0 ? 3 : 0) : 0; }
+
+__device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------- DMA waves
+// Barrier protocol (every wave of the workgroup executes the same sequence of s_barrier):
+//   PROJ: 24 step barriers | P1 | LayerNorm 2 | P2 ;   main: 20 per chunk | E1 | LayerNorm 2
+template <bool PROJ, bool SKEW>
+__device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int lane, int m0, int nchunks, int c_rot) {
+    char* const ring = smem + OFF_RING;
+    if (FFD_DMA_PRIO) __builtin_amdgcn_s_setprio(FFD_DMA_PRIO);
+    const int x_l = lane >> 3;
+    const unsigned v_w = (unsigned)lane * 16u;
+    // an x piece is 8 rows x 128 B: lane (row l = lane >> 3, physical chunk lane & 7) fetches logical chunk (lane & 7) ^ l
+    const unsigned v_x = (unsigned)(m0 + x_l) * (unsigned)(E * 4) + (unsigned)(((lane & 7) ^ x_l) << 4);
+
+    if constexpr (PROJ) {
+        auto issue_p = [&](int s) {
+            if (s >= NPROJ) return;
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wproj), 0, p.wproj_bytes, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int q = d + 4 * u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ring + (s & 3) * SLOTB + q * 1024), 16, v_w, s * B_BLOCK + q * 1024, 0, 0);
+            }
+            if ((s & 1) == 0) {
+                const int kb = s >> 1;
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.att), 0, p.att_bytes, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int q = d + 4 * u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(smem + OFF_G + (kb & 3) * G_KB + q * 1024), 16, v_x,
+                                                             kb * 128 + q * 8 * E * 4, 0, 0);
+                }
+            }
+        };
+        issue_p(0);
+        issue_p(1);
+        issue_p(2);
+#pragma unroll
+        for (int s = 0; s < NPROJ; ++s) {
+            // step s must have landed: the pieces of the steps behind it may be out
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm_n((FFD_DEPTH == 3 ? n_proj(s + 1) : 0) + n_proj(s + 2));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_p(s + 3);
+        }
+        __builtin_amdgcn_s_barrier();  // P1
+        __builtin_amdgcn_s_barrier();  // LayerNorm (ln2)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();  // P2: the ln2 rows are in L2
+    }
+
+    // piece set of step t (0 .. 19) of the chunk visited ci-th; past the last chunk the descriptors have no extent (the DMA writes
+    // zeros, the counts stay the same)
+    auto issue = [&](int ci, int t) {
+        const bool live = ci < nchunks;
+        int c = (live ? ci : 0) + c_rot;
+        c = c >= nchunks ? c - nchunks : c;
+        const int base = c * CHUNK_BYTES;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wpack), 0, live ? p.w_bytes : 0u, 0x00020000);
+        char* dst = ring + (t & 3) * SLOTB;
+        if (t < NA) {
+            const int kb = (ci & 1) ? NA - 1 - t : t;  // odd visits walk the k-blocks backwards (pp_ffn_split.hip: the L2 finds the rows)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = d + 4 * u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + q * 1024), 16, v_w, base + kb * A_BLOCK + q * 1024, 0, 0);
+            }
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.h), 0, live ? p.h_bytes : 0u, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int q = d + 4 * u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(dst + X_OFF + q * 1024), 16, v_x, kb * 128 + q * 8 * E * 4, 0, 0);
+            }
+        } else {
+            const int sb = t - NA;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int q = d + 4 * u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + q * 1024), 16, v_w, base + B_PART + sb * B_BLOCK + q * 1024, 0, 0);
+            }
+        }
+    };
+    issue(0, 0);
+    issue(0, 1);
+    issue(0, 2);
+    if constexpr (!SKEW) {
+        for (int ci = 0; ci < nchunks; ++ci) {
+#pragma unroll
+            for (int t = 0; t < STEPS; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                wait_vm_n((FFD_DEPTH == 3 ? n_main(t + 1) : 0) + n_main(t + 2));
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // (all computing waves are past their reads of step t - 1: its slot takes step t + 3)
+                if (t + 3 < STEPS) issue(ci, t + 3); else issue(ci + 1, t + 3 - STEPS);
+            }
+        }
+    } else {
+        // the skewed step sequence  A(0) | A(1) B(0) | ... | A(n-1) B(n-2) | B(n-1):  iteration `it` = [A(it) if it < n] [B(it - 1) if it >= 1].
+        // Same protocol per step; what differs is which steps follow a phase's last ones (piece counts 7 / 6 for the counted wait,
+        // and the step that goes out three ahead). Steps of a phase sit in slots t & 3 (12 and 8 steps: every phase starts in slot 0).
+        constexpr int PA = 7, PB = 6;
+        for (int it = 0; it <= nchunks; ++it) {
+            if (it < nchunks) {
+                // A(it) is followed by B(it - 1); A(0) by A(1) (by B(0) when there is one chunk only)
+                const bool then_b = it >= 1 || nchunks == 1;
+#pragma unroll
+                for (int t = 0; t < NA; ++t) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 2 < NA) wait_vm_n(2 * PA);
+                    else if (t + 1 < NA) { if (then_b) wait_vm_n(PA + PB); else wait_vm_n(2 * PA); }
+                    else { if (then_b) wait_vm_n(2 * PB); else wait_vm_n(2 * PA); }
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 3 < NA) issue(it, t + 3);
+                    else if (it >= 1) issue(it - 1, NA + t + 3 - NA);
+                    else if (nchunks == 1) issue(0, NA + t + 3 - NA);
+                    else issue(1, t + 3 - NA);
+                }
+            }
+            if (it >= 1) {
+                // B(it - 1) is followed by A(it + 1); B(n - 2) by B(n - 1); B(n - 1) by the fillers (B-shaped, no extent)
+                const bool then_a = it + 1 < nchunks;
+#pragma unroll
+                for (int sb = 0; sb < NB; ++sb) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (sb + 2 < NB) wait_vm_n(2 * PB);
+                    else if (sb + 1 < NB) { if (then_a) wait_vm_n(PB + PA); else wait_vm_n(2 * PB); }
+                    else { if (then_a) wait_vm_n(2 * PA); else wait_vm_n(2 * PB); }
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (sb + 3 < NB) issue(it - 1, NA + sb + 3);
+                    else if (then_a) issue(it + 1, sb + 3 - NB);
+                    else if (it + 1 == nchunks) issue(it, NA + sb + 3 - NB);
+                    else issue(nchunks, NA + sb + 3 - NB);
+                }
+            }
+        }
+    }
+    wait_vm<0>();                  // the fillers
+    __builtin_amdgcn_s_barrier();  // E1
+    __builtin_amdgcn_s_barrier();  // LayerNorm
+    __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------- computing waves
+template <bool PROJ, bool SKEW>
+__device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv, int lane, int m0, int nchunks, int c_rot) {
+    const int rg = wv >> 2, cg = wv & 3;
+    const int f_row = lane & 15, f_kg = lane >> 4;
+    auto chunk_of = [&](int i) { const int c = i + c_rot; return c >= nchunks ? c - nchunks : c; };
+
+    // fragment reads: hi halves in 16-byte chunk f_kg, lo halves in chunk 4 + f_kg of a line, swizzled by line & 7. The register
+    // budget has no room for an address register per line set: every read address is ONE of two per-lane offsets (hi / lo chunk of
+    // line f_row) plus a wave-uniform offset the compiler cannot fold or hoist (it lives in an SGPR, made opaque per step), plus
+    // the fragment stride as an instruction offset.
+    const int sw = f_row & 7;
+    const int lane_hi = f_row * 128 + ((f_kg ^ sw) << 4), lane_lo = f_row * 128 + (((4 + f_kg) ^ sw) << 4);
+    const int rows0 = rg * 48 + f_row;
+    auto opaque_s = [](int v) { asm volatile("" : "+s"(v)); return v; };
+    auto rd = [&](int lane_off, int uni, int imm) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + (lane_off + uni) + imm); };
+    const int u_a = OFF_RING + cg * 32 * 128;           // A-step W1 lines of this wave (units 32 cg ..) inside a slot
+    const int u_b = OFF_RING + cg * 48 * 128;           // B-step W2 lines (outputs 48 cg ..)
+    const int u_x = OFF_RING + X_OFF + rg * 48 * 128;   // x lines of an A slot (rows 48 rg ..)
+    const int u_g = OFF_G + rg * 48 * 128;              // row lines of a G buffer
+
+    f32x4 acc[3][6];   // [row fragment][half * 3 + nf]: columns 192 half + 48 cg + 16 nf + 4 f_kg + (0..3)
+    f32x4 pacc[3][2];  // P of the chunk in its A-steps
+    f32x4 b1v[2];
+    u32x4 bgh[3], bgl[3];
+
+    auto step_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        // lgkmcnt(0): this wave's LDS writes (the G tile) are in before anyone is let through; its reads were consumed by the MFMAs
+        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // 48 x 48 tile of one column half: acc[:, half] += G-like rows (bgh, bgl) x weight half block in ring slot `so`
+    auto b_step = [&](int slot, int half, int gbuf, bool load_g) {
+        u32x4 wh[3], wl[3];
+        const int ub = opaque_s(u_b + slot * SLOTB);
+        const int ug = opaque_s(u_g + gbuf * G_KB);
+        // reads in the order the MFMAs want them
+        wh[0] = rd(lane_hi, ub, 0);
+        if (load_g) bgh[0] = rd(lane_hi, ug, 0);
+        wh[1] = rd(lane_hi, ub, 2048);
+        wh[2] = rd(lane_hi, ub, 4096);
+        if (load_g) {
+            bgh[1] = rd(lane_hi, ug, 2048);
+            bgh[2] = rd(lane_hi, ug, 4096);
+        }
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) wl[nf] = rd(lane_lo, ub, nf * 2048);
+        if (load_g) {
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) bgl[rf] = rd(lane_lo, ug, rf * 2048);
+        }
+#if FFD_READS_FIRST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+#if FFD_READS_FIRST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+#if FFD_READS_FIRST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) acc[rf][half * 3 + nf] = mma(wh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+    };
+    // LayerNorm of the 96 x 384 block in the accumulators (pp_ffn_split.hip layernorm_rows: same operations in the same order)
+    // Stores as buffer stores: the row part of the address (and the lane's column part) in the VGPR offset - rows past M fall out
+    // of the descriptor's extent and are dropped by the hardware (the range check covers the VGPR offset, not the scalar one) -
+    // the wave-uniform column part in the scalar offset: two address registers for the whole epilogue.
+    const unsigned v_rowx = (unsigned)(m0 + rows0) * (unsigned)(E * 4) + (unsigned)f_kg * 16u;                            // fp32 rows
+    const unsigned v_rowh = (unsigned)(m0 + rows0) * (unsigned)(E * 4) + (unsigned)f_kg * 8u;  // split rows: the lane's four hi halves (lo: + 64)
+    const unsigned v_rowh2 = (unsigned)(m0 + rows0) * (unsigned)(E * 4) + (unsigned)(f_kg >> 1) * 16u + (unsigned)(f_kg & 1) * 64u;  // row-pair form: 16-byte hi chunk (even f_kg) / lo chunk (odd)
+    auto layernorm_rows = [&](const float* gamma, const float* beta, float* x_dst, void* h_dst, bool store_x) {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(x_dst, 0, p.h_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(h_dst, 0, p.h_bytes, 0x00020000);
+        float* stat = reinterpret_cast<float*>(smem + OFF_G);
+        float mean[3], rstd[3];
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            float sm = 0.f;
+#pragma unroll
+            for (int cf = 0; cf < 6; ++cf) {
+                const f32x4 v = acc[rf][cf];
+                sm += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            if (f_kg == 0) stat[cg * BM + rows0 + rf * 16] = sm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            const int r = rows0 + rf * 16;
+            mean[rf] = ((stat[r] + stat[BM + r]) + (stat[2 * BM + r] + stat[3 * BM + r])) * (1.0f / E);
+            float q = 0.f;
+#pragma unroll
+            for (int cf = 0; cf < 6; ++cf)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dd = acc[rf][cf][k] - mean[rf];
+                    q = __builtin_fmaf(dd, dd, q);
+                }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            if (f_kg == 0) stat[(4 + cg) * BM + r] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            const int r = rows0 + rf * 16;
+            const float var = ((stat[4 * BM + r] + stat[5 * BM + r]) + (stat[6 * BM + r] + stat[7 * BM + r])) * (1.0f / E);
+            rstd[rf] = 1.0f / sqrtf(var + p.eps);
+        }
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) {
+            const int cb = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16;  // (wave-uniform)
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cb + f_kg * 4), b = *reinterpret_cast<const f32x4*>(beta + cb + f_kg * 4);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) {
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const f32x4 v = acc[rf][cf];
+                float mu = mean[rf];
+                const float rs = rstd[rf];
+                asm("" : "+v"(mu));  // (a second, opaque copy: with the same value as in the variance pass the compiler keeps all 72 differences v - mean alive from there to here)
+                f32x4 hv = {(v[0] - mu) * rs * g[0] + b[0], (v[1] - mu) * rs * g[1] + b[1], (v[2] - mu) * rs * g[2] + b[2],
+                            (v[3] - mu) * rs * g[3] + b[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { float t = hv[j]; split_pin(t); hv[j] = t; }
+#if FFD_STORE16
+                {   // dev A/B: 16-byte stores in the FLAT encoding, as the eight-wave kernel does (64-bit addresses, `live` predicate)
+                    const bool live = m0 + rows0 + rf * 16 < p.M;
+                    const size_t off = (size_t)(m0 + rows0 + rf * 16) * E + cb + f_kg * 4;
+                    if (store_x && live) *reinterpret_cast<f32x4*>(x_dst + off) = v;
+                    split_store4_rowpair(h_dst, off, hv, live);
+                    continue;
+                }
+#endif
+                if (store_x) {
+                    const u32x4 vq = __builtin_bit_cast(u32x4, v);
+#if FFD_X128
+                    __builtin_amdgcn_raw_buffer_store_b128(vq, rx, v_rowx + rf * (16 * E * 4), cb * 4, 0);
+                    asm volatile("s_nop 3" ::"v"(vq));  // (wait states behind a 16-byte buffer store: scripts/micro/mubuf_store_hazard.hip)
+#else
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{vq[0], vq[1]}, rx, v_rowx + rf * (16 * E * 4), cb * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{vq[2], vq[3]}, rx, v_rowx + rf * (16 * E * 4), cb * 4 + 8, 0);
+#endif
+                }
+                // WAIT STATES BEHIND 16-BYTE BUFFER STORES. A buffer_store_dwordx4 reads its data registers one cycle late for lanes
+                // 12 - 15 of every row; an instruction that writes one of them directly behind the store changes what those lanes store.
+                // The hardware wants one wait state (SGPR soffset) or two (immediate) there - scripts/micro/mubuf_store_hazard.hip
+                // shows it in isolation - and the compiler inserts none for the SGPR form, which is the form used here. Seen as a
+                // handful of stale 4-byte words per launch on a full chip (first behind the v_permlane16_swap below and wrongly blamed
+                // on the swap; then in pp_linear_dma.hip's fp32 rows, where no swap is involved). Every 16-byte buffer store of this
+                // file is followed by an explicit s_nop that depends on its data.
+                f16x4 h, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = split_hi(hv[j]);
+                    l[j] = split_lo(hv[j], h[j]);
+                }
+                const int so = (cb >> 5) * 128 + (cb & 16) * 2;
+#if FFD_H128
+                {   // the row-pair form of split_store4_rowpair (lanes f_kg, f_kg ^ 1 exchange halves: the even one stores the 16-byte hi chunk,
+                    // the odd one the lo chunk), as ONE 16-byte buffer store followed by the wait states the compiler does not insert
+                    const u32x2_t hu = __builtin_bit_cast(u32x2_t, h), lu = __builtin_bit_cast(u32x2_t, l);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(hu[1], lu[1], false, false);
+                    u32x4 q = {s0[0], s1[0], s0[1], s1[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(q, rh, v_rowh2 + rf * (16 * E * 4), so, 0);
+                    asm volatile("s_nop 3" ::"v"(q));
+                }
+#else
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, h), rh, v_rowh + rf * (16 * E * 4), so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, l), rh, v_rowh + rf * (16 * E * 4), so + 64, 0);
+#endif
+            }
+        }
+    };
+
+    // the residual rows, straight into the accumulators
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, p.h_bytes, 0x00020000);
+#pragma unroll
+    for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) {
+            const int cb = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16;
+            acc[rf][cf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, v_rowx + rf * (16 * E * 4), cb * 4, 0));  // (rows past M: zeros, never stored)
+        }
+
+    if constexpr (PROJ) {
+        // ---- attention output projection + residual, then ln2:  acc <- x + att Wp^T + bp ;  h <- LN2(acc). 24 steps shaped like
+        // the B-steps: step s = 2 kb + half takes the Wp half block from ring slot s & 3, the attention rows' k-block kb from G buffer kb & 3
+#pragma unroll 1
+        for (int kp = 0; kp < NPROJ / 4; ++kp) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                step_barrier();
+                b_step(q, q & 1, ((4 * kp + q) >> 1) & 3, (q & 1) == 0);
+            }
+        }
+        // + bp (after the sums, as residual + (sum + bias) rounds closest to the reference's x + proj(...))
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bp + (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
+        }
+        __syncthreads();  // P1: the G buffers are out of use
+        layernorm_rows(p.gamma2, p.beta2, nullptr, const_cast<void*>(p.h), false);
+        // the rows must be in L2 before the DMA waves ask for them (a store counts in vmcnt until the L2 has acknowledged it)
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));
+        __syncthreads();  // P2
+    }
+
+    // + b2 (pp_ffn_split.hip adds it before the first B-step accumulates: same sum order)
+#pragma unroll
+    for (int cf = 0; cf < 6; ++cf) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b2 + (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4);
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
+    }
+    auto load_b1 = [&](int ci) {
+        const int c = chunk_of(ci < nchunks ? ci : 0);
+        if constexpr (SKEW) {
+            // (asked for between the MFMAs of a B-step: no 64-bit address to keep alive or to reload there - descriptor + lane & 0x30)
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b1), 0, (unsigned)p.F * 4u, 0x00020000);
+            int vo = lane;
+            asm volatile("" : "+v"(vo));
+            vo &= 0x30;
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+                b1v[nf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, vo, (c * CHUNK + cg * 32 + nf * 16) * 4, 0));
+        } else {
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) b1v[nf] = *reinterpret_cast<const f32x4*>(p.b1 + c * CHUNK + cg * 32 + nf * 16 + f_kg * 4);
+        }
+    };
+    load_b1(0);
+
+    // GELU of one accumulator fragment (gelu_erfc_as of pp_split.h, Abramowitz & Stegun 7.1.26: same operations in the same order per
+    // value as pp_ffn_split.hip), split: returns the four hi halves in dwords 0, 1 and the four lo halves in dwords 2, 3
+    auto gelu_split4 = [&](const f32x4& pv) -> f32x4 {
+        f16x4 hv, lv;
+        // (two values at a time: the fragment's arithmetic sits between MFMAs of a step that has ~16 registers to spare)
+#pragma unroll
+        for (int u0 = 0; u0 < 4; u0 += 2) {
+            float x[2], z[2], tt[2], qq[2], e[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) x[u] = pv[u0 + u];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) z[u] = fabsf(x[u]) * 0.70710678118654752440f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) tt[u] = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z[u], 1.0f));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) e[u] = __builtin_amdgcn_exp2f(-(z[u] * z[u]) * 1.44269504088896340736f);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) qq[u] = __builtin_fmaf(tt[u], 1.061405429f, -1.453152027f);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], 1.421413741f);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], -0.284496736f);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], 0.254829592f);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float erfc_z = tt[u] * qq[u] * e[u];
+#if FFD_GELU_RELU_FORM
+                // 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2): no compare / select, two instructions less per value
+                float g = __builtin_fmaf(-0.5f * fabsf(x[u]), erfc_z, fmaxf(x[u], 0.f));
+#else
+                float g = 0.5f * x[u] * (x[u] < 0.f ? erfc_z : 2.0f - erfc_z);
+#endif
+                split_pin(g);
+                hv[u0 + u] = split_hi(g);
+                lv[u0 + u] = split_lo(g, hv[u0 + u]);
+            }
+        }
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t hu = __builtin_bit_cast(u32x2_t, hv), lu = __builtin_bit_cast(u32x2_t, lv);
+        return __builtin_bit_cast(f32x4, u32x4{hu[0], hu[1], lu[0], lu[1]});
+    };
+    // the pairs of fragment (rf, nf) into the G tile. Lane holds units 32 cg + 16 nf + 4 f_kg + (0..3) of its rows: k-block cg of the
+    // chunk, 16-byte chunk 2 nf + (f_kg >> 1) (+ 4 for lo), upper or lower 8 bytes.
+    // (ONE address register for the twelve stores: the swizzled chunk (c ^ sw) << 4 with c = (f_kg >> 1) + 2 nf + 4 lo is the lane's
+    // base chunk XOR a constant, recomputed at the store behind an opaque copy - the compiler otherwise keeps four addresses alive
+    // through the B-steps and spills them)
+    const int g_base = OFF_G + cg * G_KB + rows0 * 128 + (f_kg & 1) * 8 + (((f_kg >> 1) ^ sw) << 4);
+    auto store_g = [&](int rf, int nf, const f32x4& pr) {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x4 q = __builtin_bit_cast(u32x4, pr);
+        int gb = g_base;
+        asm volatile("" : "+v"(gb));
+        *reinterpret_cast<u32x2_t*>(smem + (gb ^ (nf * 32)) + rf * 2048) = u32x2_t{q[0], q[1]};
+        *reinterpret_cast<u32x2_t*>(smem + (gb ^ (nf * 32 + 64)) + rf * 2048) = u32x2_t{q[2], q[3]};
+    };
+
+    if constexpr (SKEW) {
+        // ---- A(0) GELU(0) | A(1) B(0) | ... | A(n-1) B(n-2) | B(n-1)
+        for (int it = 0; it <= nchunks; ++it) {
+            if (it < nchunks) {
+#pragma unroll
+                for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                    for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf];
+                // A-steps of chunk it (the unskewed loop below, same reads and MFMAs in the same order)
+#pragma unroll
+                for (int t = 0; t < NA; ++t) {
+                    step_barrier();
+                    const int ua = opaque_s(u_a + (t & 3) * SLOTB), ux = opaque_s(u_x + (t & 3) * SLOTB);
+                    u32x4 wh[2], wl[2], xh[3], xl[3];
+                    wh[0] = rd(lane_hi, ua, 0);
+                    xh[0] = rd(lane_hi, ux, 0);
+                    wh[1] = rd(lane_hi, ua, 2048);
+                    xh[1] = rd(lane_hi, ux, 2048);
+                    xh[2] = rd(lane_hi, ux, 4096);
+                    wl[0] = rd(lane_lo, ua, 0);
+                    wl[1] = rd(lane_lo, ua, 2048);
+#pragma unroll
+                    for (int rf = 0; rf < 3; ++rf) xl[rf] = rd(lane_lo, ux, rf * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wh[nf], xh[rf], pacc[rf][nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wl[nf], xh[rf], pacc[rf][nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                        for (int rf = 0; rf < 3; ++rf) pacc[rf][nf] = mma(wh[nf], xl[rf], pacc[rf][nf]);
+                }
+                if (it == 0) {
+                    // GELU(0): nothing to hide behind. The G tile is free (the projection phase is over).
+#pragma unroll
+                    for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                        for (int nf = 0; nf < 2; ++nf) store_g(rf, nf, gelu_split4(pacc[rf][nf]));
+                    load_b1(1);
+                }
+            }
+            if (it >= 1) {
+                // B-steps of chunk it - 1; pacc holds P(it) (it < n): one fragment per step through GELU, in place, steps 0 .. 5; the
+                // pairs leave in step 7. For it == n the arithmetic runs on stale registers and nothing is stored.
+#pragma unroll
+                for (int sb = 0; sb < NB; ++sb) {
+                    step_barrier();
+                    if (sb == NB - 1 && it < nchunks) {
+#pragma unroll
+                        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                            for (int nf = 0; nf < 2; ++nf) store_g(rf, nf, pacc[rf][nf]);
+                    }
+                    const int slot = (NA + sb) & 3, half = sb & 1, gbuf = sb >> 1;
+                    const bool load_g = (sb & 1) == 0;
+                    u32x4 wh[3], wl[3];
+                    const int ub = opaque_s(u_b + slot * SLOTB);
+                    const int ug = opaque_s(u_g + gbuf * G_KB);
+                    wh[0] = rd(lane_hi, ub, 0);
+                    if (load_g) bgh[0] = rd(lane_hi, ug, 0);
+                    wh[1] = rd(lane_hi, ub, 2048);
+                    wh[2] = rd(lane_hi, ub, 4096);
+                    if (load_g) {
+                        bgh[1] = rd(lane_hi, ug, 2048);
+                        bgh[2] = rd(lane_hi, ug, 4096);
+                    }
+#pragma unroll
+                    for (int nf = 0; nf < 3; ++nf) wl[nf] = rd(lane_lo, ub, nf * 2048);
+                    if (load_g) {
+#pragma unroll
+                        for (int rf = 0; rf < 3; ++rf) bgl[rf] = rd(lane_lo, ug, rf * 2048);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (sb < 6 && (FFD_GELU_MODE == 0 || FFD_GELU_MODE == 1)) pacc[sb >> 1][sb & 1] = gelu_split4(pacc[sb >> 1][sb & 1]);
+                    if (sb < 6 && FFD_GELU_MODE == 2 && rg == 0) pacc[sb >> 1][sb & 1] = gelu_split4(pacc[sb >> 1][sb & 1]);
+                    if (FFD_GELU_MODE != 0) __builtin_amdgcn_sched_barrier(0);
+                    if (sb == 6) load_b1(it + 1);  // (the next chunk's bias: asked for late, its eight registers are free only behind the last GELU fragment)
+#pragma unroll
+                    for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                        for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+#pragma unroll
+                    for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                        for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+#pragma unroll
+                    for (int nf = 0; nf < 3; ++nf)
+#pragma unroll
+                        for (int rf = 0; rf < 3; ++rf) acc[rf][half * 3 + nf] = mma(wh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+                    if (sb < 6 && FFD_GELU_MODE == 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (rg == 1) pacc[sb >> 1][sb & 1] = gelu_split4(pacc[sb >> 1][sb & 1]);
+                    }
+                    if (sb < 6 && FFD_GELU_MODE == 0) {
+                        // pin the fragment's VALU instructions between the MFMAs (left alone they are issued as one block in front)
+#pragma unroll
+                        for (int i = 0; i < 27; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, FFD_GELU_VALU_PER_MFMA, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    } else
+    for (int ci = 0; ci < nchunks; ++ci) {
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf];
+        load_b1(ci + 1);
+        // ---- A-steps: P += x[:, kb] W1[chunk, kb]^T, wave tile 48 rows x 32 units
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            step_barrier();
+            const int ua = opaque_s(u_a + (t & 3) * SLOTB), ux = opaque_s(u_x + (t & 3) * SLOTB);
+            u32x4 wh[2], wl[2], xh[3], xl[3];
+            // reads in the order the MFMAs want them (LDS returns in order, the first product needs two fragments, not eight)
+            wh[0] = rd(lane_hi, ua, 0);
+            xh[0] = rd(lane_hi, ux, 0);
+            wh[1] = rd(lane_hi, ua, 2048);
+            xh[1] = rd(lane_hi, ux, 2048);
+            xh[2] = rd(lane_hi, ux, 4096);
+            wl[0] = rd(lane_lo, ua, 0);
+            wl[1] = rd(lane_lo, ua, 2048);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) xl[rf] = rd(lane_lo, ux, rf * 2048);
+#if FFD_READS_FIRST
+            // every fragment read of the step is issued before its first MFMA (left alone the scheduler loads the lo row fragments
+            // into the registers of the hi ones, i.e. in the MIDDLE of the step, and waits for them there)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wh[nf], xh[rf], pacc[rf][nf]);
+#if FFD_READS_FIRST
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wl[nf], xh[rf], pacc[rf][nf]);
+#if FFD_READS_FIRST
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                for (int rf = 0; rf < 3; ++rf) pacc[rf][nf] = mma(wh[nf], xl[rf], pacc[rf][nf]);
+        }
+        // ---- GELU(P) -> (hi, lo) -> G tile (gelu_erfc_as of pp_split.h, Abramowitz & Stegun 7.1.26: same operations in the same
+        // order per value as pp_ffn_split.hip). The G tile is free: the previous chunk's B-steps ended before this chunk's A-steps.
+        // Lane holds units 32 cg + 16 nf + 4 f_kg + (0..3) of its rows: k-block cg of the chunk, 16-byte chunk 2 nf + (f_kg >> 1)
+        // (+ 4 for lo), upper or lower 8 bytes.
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                f16x4 hv, lv;
+                float x[4], z[4], tt[4], qq[4], e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = pacc[rf][nf][u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) z[u] = fabsf(x[u]) * 0.70710678118654752440f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tt[u] = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z[u], 1.0f));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[u] = __builtin_amdgcn_exp2f(-(z[u] * z[u]) * 1.44269504088896340736f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], 1.061405429f, -1.453152027f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], 1.421413741f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], -0.284496736f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], 0.254829592f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float erfc_z = tt[u] * qq[u] * e[u];
+#if FFD_GELU_RELU_FORM
+                    // 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2): no compare / select, two instructions less per value
+                    float g = __builtin_fmaf(-0.5f * fabsf(x[u]), erfc_z, fmaxf(x[u], 0.f));
+#else
+                    float g = 0.5f * x[u] * (x[u] < 0.f ? erfc_z : 2.0f - erfc_z);
+#endif
+                    split_pin(g);
+                    hv[u] = split_hi(g);
+                    lv[u] = split_lo(g, hv[u]);
+                }
+                char* gs = smem + OFF_G + cg * G_KB + (rows0 + rf * 16) * 128 + (f_kg & 1) * 8;
+                const int c = 2 * nf + (f_kg >> 1);
+                *reinterpret_cast<f16x4*>(gs + ((c ^ sw) << 4)) = hv;
+                *reinterpret_cast<f16x4*>(gs + (((4 + c) ^ sw) << 4)) = lv;
+            }
+        // ---- B-steps (j, half): acc[:, half] += G[:, j] W2[half, chunk j]^T, wave tile 48 rows x 48 outputs (the barrier of the
+        // first one publishes the G tile)
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) {
+            step_barrier();
+            b_step((NA + sb) & 3, sb & 1, sb >> 1, (sb & 1) == 0);
+        }
+    }
+    // ---- LayerNorm epilogue: G is out of use once every wave is past its last B-step
+    __syncthreads();  // E1
+    layernorm_rows(p.gamma, p.beta, p.x_out, p.h_out, true);
+}
+
+template <bool PROJ, bool SKEW>
+__device__ __forceinline__ void body(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM;
+    const int nchunks = p.F / CHUNK;
+    const int c_rot = (int)(blockIdx.x & 7) % nchunks;  // the workgroups of an XCD walk the chunks in the same order
+    if (wv >= CW) dma_role<PROJ, SKEW>(p, smem, wv - CW, lane, m0, nchunks, c_rot);
+    else compute_role<PROJ, SKEW>(p, smem, wv, lane, m0, nchunks, c_rot);
+}
+
+__global__ __launch_bounds__(THREADS) void ffn_dma_kernel(const Params p) { body<false, false>(p); }
+__global__ __launch_bounds__(THREADS) void proj_ffn_dma_kernel(const Params p) { body<true, false>(p); }
+__global__ __launch_bounds__(THREADS) void ffn_dma_skew_kernel(const Params p) { body<false, true>(p); }
+__global__ __launch_bounds__(THREADS) void proj_ffn_dma_skew_kernel(const Params p) { body<true, true>(p); }
+
+}  // namespace ffd
+
+namespace ffs {
+// called from the entry points in pp_ffn_split.hip when the option "ffn_dma_waves" is on
+int launch_dma_form(const Params& p, bool proj, hipStream_t s) {
+    const bool skew = option("ffn_skew") != 0;
+    auto kern = skew ? (proj ? ffd::proj_ffn_dma_skew_kernel : ffd::ffn_dma_skew_kernel) : (proj ? ffd::proj_ffn_dma_kernel : ffd::ffn_dma_kernel);
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ffd::LDS));
+    hipLaunchKernelGGL(kern, dim3((p.M + ffd::BM - 1) / ffd::BM), dim3(ffd::THREADS), ffd::LDS, s, p);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+}  // namespace ffs
+}  // namespace pp
