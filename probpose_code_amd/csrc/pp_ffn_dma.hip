@@ -54,6 +54,9 @@ static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must rep
 #ifndef FFD_GELU_RELU_FORM
 #define FFD_GELU_RELU_FORM 1
 #endif
+#ifndef FFD_GELU_PACKED
+#define FFD_GELU_PACKED 1  // the chunk's GELU on value pairs with packed fp32 instructions and a v_fma_mix_f32 split (round 5); 0: one value per instruction (round 4)
+#endif
 #ifndef FFD_H128
 #define FFD_H128 1
 #endif
@@ -490,6 +493,50 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
+                char* gs = smem + OFF_G + cg * G_KB + (rows0 + rf * 16) * 128 + (f_kg & 1) * 8;
+                const int c = 2 * nf + (f_kg >> 1);
+#if FFD_GELU_PACKED
+                // Round 5: the chunk's GELU is ~3.4 k of its ~22 k cycles (stamps of scripts/micro/ffn12d.hip -DSTAMP=1), VALU-bound with both
+                // computing waves of a SIMD issuing at once, and it cannot be hidden behind MFMAs of the same SIMD (scripts/micro/ffn_skew_form.hip).
+                // What is left is fewer issue cycles per value (scripts/micro/valu_rate.hip, cycles per wave64 instruction and SIMD: plain fp32
+                // 3.0, v_pk_*_f32 4.9 for TWO values, v_rcp / v_exp 8.5, v_cvt 4.5, v_cvt_pk_f16_f32 and v_fma_mix_f32 4.7): the same A & S 7.1.26
+                // form on value PAIRS with packed fp32 instructions (constants folded: 1 + p z = 1 + (p / sqrt 2) |x|, exp(-z^2) =
+                // exp2(-(x sqrt(log2(e) / 2))^2), max(x, 0) = 0.5 x + 0.5 |x| exactly) and the lo half as g - hi by ONE v_fma_mix_f32 that
+                // reads hi straight from the packed fp16 pair (exact: the same difference as convert-back-and-subtract): ~56 instead of ~76
+                // issue cycles per value. |difference to the unpacked form| ~1e-7 relative (rounding of the folded constants).
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                unsigned hq[2], lq[2];
+#pragma unroll
+                for (int u0 = 0; u0 < 2; ++u0) {
+                    const f32x2 x = {pacc[rf][nf][2 * u0], pacc[rf][nf][2 * u0 + 1]};
+                    const f32x2 ax = __builtin_elementwise_abs(x);
+                    const f32x2 d = ax * 0.23164189265f + 1.0f;  // 0.3275911 / sqrt 2
+                    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                    const f32x2 uu = x * 0.84932180028801904272f;  // sqrt(log2(e) / 2)
+                    const f32x2 u2 = uu * uu;
+                    const f32x2 e = {__builtin_amdgcn_exp2f(-u2[0]), __builtin_amdgcn_exp2f(-u2[1])};
+                    f32x2 q = t * 1.061405429f + -1.453152027f;
+                    q = t * q + 1.421413741f;
+                    q = t * q + -0.284496736f;
+                    q = t * q + 0.254829592f;
+                    const f32x2 erfc_z = (t * q) * e;
+                    const f32x2 ma = ax * -0.5f;
+                    const f32x2 mx = x * 0.5f - ma;  // = max(x, 0), exactly
+                    f32x2 g = ma * erfc_z + mx;
+                    asm("" : "+v"(g));  // (split_pin: no fusion of the arithmetic into the conversions)
+                    const f16x2 hp = __builtin_convertvector(g, f16x2);  // v_cvt_pk_f16_f32, round to nearest even
+                    const unsigned hu = __builtin_bit_cast(unsigned, hp);
+                    f32x2 l;
+                    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l[0]) : "v"(g[0]), "v"(hu));
+                    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l[1]) : "v"(g[1]), "v"(hu));
+                    hq[u0] = hu;
+                    lq[u0] = __builtin_bit_cast(unsigned, __builtin_convertvector(l, f16x2));
+                }
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2_t*>(gs + ((c ^ sw) << 4)) = u32x2_t{hq[0], hq[1]};
+                *reinterpret_cast<u32x2_t*>(gs + (((4 + c) ^ sw) << 4)) = u32x2_t{lq[0], lq[1]};
+#else
                 f16x4 hv, lv;
                 float x[4], z[4], tt[4], qq[4], e[4];
 #pragma unroll
@@ -521,10 +568,9 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                     hv[u] = split_hi(g);
                     lv[u] = split_lo(g, hv[u]);
                 }
-                char* gs = smem + OFF_G + cg * G_KB + (rows0 + rf * 16) * 128 + (f_kg & 1) * 8;
-                const int c = 2 * nf + (f_kg >> 1);
                 *reinterpret_cast<f16x4*>(gs + ((c ^ sw) << 4)) = hv;
                 *reinterpret_cast<f16x4*>(gs + (((4 + c) ^ sw) << 4)) = lv;
+#endif
             }
         // ---- B-steps (j, half): acc[:, half] += G[:, j] W2[half, chunk j]^T, wave tile 48 rows x 48 outputs (the barrier of the
         // first one publishes the G tile)

@@ -10,7 +10,7 @@ objs=$(ls build/*.o | grep -v pp_ffn_dma.o)
 while [ $# -ge 2 ]; do
   tag=$1; flags=$2; shift 2
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -I../../include $flags -c pp_ffn_dma.hip -o "$here/build/ffd_$tag.o" \
-      -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A9 "proj_ffn_dma_skew" | grep -E "VGPRs:|VGPRs Spill|ScratchSize" | tr '\n' ' '; echo " <- $tag ($flags)"
+      -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A9 "proj_ffn_dma_kernel" | grep -E "VGPRs:|VGPRs Spill|ScratchSize" | tr '\n' ' '; echo " <- $tag ($flags)"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$here/build/lib_$tag.so" $objs "$here/build/ffd_$tag.o" ) &
 done
 wait

@@ -32,10 +32,21 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define GELU 0  // 1: after a chunk's twelve A-steps every computing wave runs the erfc-form GELU on its 24 accumulator values and writes the
                 // (hi, lo) pairs into the G tile (12 ds_write_b64) - exposed, all waves at the same time (no second accumulator set at 168 registers)
 #endif
+#ifndef ROLL
+#define ROLL 0  // MODE 1 only. 1: "rolling" fragment reads - a fragment register is re-read for the NEXT step right behind the last MFMA of THIS step that
+                // needs it (sweeps reordered hi x lo, hi x hi, lo x hi so that the first sweep's operands are free earliest); no second register set;
+                // the barrier of a step sits two MFMAs into it
+#endif
+#ifndef XREG
+#define XREG 0  // MODE 1 only. 1: the 96 x 384 block of x rows (144 KiB) lives in the DMA waves' REGISTERS (4 waves x 64 lanes x 144 registers - a wave that only
+                // issues loads has them to spare) and each A-step's k-block is written into its ring slot with three ds_write_b128 per lane instead of
+                // being re-streamed from L2 / MALL twelve times per launch: the ring's DMA carries weights only (16 KiB per A-step instead of 28)
+#endif
 #ifndef STAMP
 #define STAMP 0  // 1: wave 0 of workgroup 5 stamps s_memtime at the top of every step of chunk 6 (+ launch start / end with the 100 MHz counter)
 #endif
-#ifndef ABL  // timing-only ablations: 1 no DMA traffic (empty descriptors), 4 no MFMA
+#ifndef ABL  // timing-only ablations: 1 no DMA traffic (empty descriptors), 4 no MFMA, 16 no DMA instructions at all (the whole LDS holds a random pattern: same MFMA
+             // operand toggling and fragment reads, no L2 -> LDS fill), 32 every workgroup streams the SAME x rows (x pieces L2-hot), 64 all pieces from the first 28 KiB of the weight stream
 #define ABL 0
 #endif
 constexpr int BM = 96, E = 384, CHUNK = 128, NCH = 12;
@@ -47,10 +58,11 @@ constexpr int G_KB = BM * 128, OFF_RING = 4 * G_KB, SLOTB = 28 * 1024, LDS = OFF
 constexpr int NA = 12, NB = 8, STEPS = NA + NB;
 constexpr int A_BLOCK = CHUNK * 128, B_BLOCK = 192 * 128, B_PART = NA * A_BLOCK, CHUNK_BYTES = B_PART + NB * B_BLOCK;
 constexpr int X_OFF = 16 * 1024;
-constexpr int NXP = XDIRECT ? 0 : 12;       // x pieces of an A-step that go through the ring
+constexpr int NXP = (XDIRECT || XREG) ? 0 : 12;       // x pieces of an A-step that go through the ring
 constexpr int NPA = 16 + NXP, NPB = 24;     // pieces per step
 
 #define WAITVM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (0 << 8) | (((N) >> 4) << 14))       // vmcnt(N) lgkmcnt(0)
+#define WAITVM_LGKM0() __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14))  // lgkmcnt(0)
 #define WAITVM_ONLY(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))  // vmcnt(N)
 
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
     const int f_row = lane & 15, f_kg = lane >> 4;
     const int m0 = blockIdx.x * BM;
     char* const ring = smem + OFF_RING;
-    for (int i = tid; i < 4 * G_KB / 4; i += THREADS) reinterpret_cast<unsigned*>(smem)[i] = 0x2c003c00u + ((i * 2654435761u) >> 20 & 0x007f007fu);
+    for (int i = tid; i < ((ABL & 16) ? LDS : 4 * G_KB) / 4; i += THREADS) reinterpret_cast<unsigned*>(smem)[i] = 0x2c003c00u + ((i * 2654435761u) >> 13 & 0x83ff03ffu);
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wpack), 0, (ABL & 1) ? 0u : w_bytes, 0x00020000);
@@ -87,6 +99,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
     auto chunk_of = [&](int i) { return (i + c_rot) % NCH; };
     // piece q of step t of chunk ci -> slot t & 3.  A-step: q < 16 W1 pieces, 16 .. 27 x pieces; B-step: 24 W2 pieces
     auto piece = [&](int ci, int t, int q) {
+        if (ABL & 16) return;
         char* dst = ring + (t & 3) * SLOTB;
         const int base = chunk_of(ci % NCH) * CHUNK_BYTES;
         if (t < NA) {
@@ -100,6 +113,9 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
     constexpr int NISS = MODE == 1 ? 4 : 8;
     const int iw = MODE == 1 ? wv - CW : wv;
     auto n_own = [&](int t, int w) { const int n = t < NA ? NPA : NPB; return (n - w + NISS - 1) / NISS; };  // pieces wave w issues in step t
+#if XREG
+    u32x4 xr[NA][3];  // DMA wave d: rows 8 (d + 4 u) + (lane >> 3) of the block, the lane's (swizzled) 16-byte chunk of every k-block
+#endif
     auto issue = [&](int ci, int t) {
         const int n = t < NA ? NPA : NPB;
 #pragma unroll
@@ -107,6 +123,16 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
             const int q = iw + u * NISS;
             if (q < n) piece(ci, t, q);
         }
+#if XREG
+        if (t < NA) {
+            // (inline assembly: behind an LDS-DMA instruction the compiler waits vmcnt(0) in front of ordinary LDS accesses)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int a = OFF_RING + (t & 3) * SLOTB + X_OFF + (iw + 4 * u) * 1024 + lane * 16;
+                asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(xr[t][u]) : "memory");
+            }
+        }
+#endif
     };
     const int sw = f_row & 7;
     const int ch_hi = (f_kg ^ sw) << 4, ch_lo = ((4 + f_kg) ^ sw) << 4;
@@ -144,6 +170,15 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
     };
 #endif
 
+#if XREG
+    if (dma_wave) {
+#pragma unroll
+        for (int kb = 0; kb < NA; ++kb)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) xr[kb][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rh, v_x(iw + 4 * u), kb * 128, 0));
+        waitvm<0>();
+    }
+#endif
     if (MODE == 0 || dma_wave) {
         issue(0, 0);
         issue(0, 1);
@@ -157,6 +192,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
 #endif
     if (dma_wave) {
         // ---------------- DMA waves: at the top of step t the pieces of step t + 1 must have landed: own pieces of step t + 2 may be out
+        if (ROLL) { waitvm<0>(); if (XREG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }  // (prologue: the computing waves read step 0's fragments behind it)
         for (int ci = 0; ci < NCH; ++ci) {
 #pragma unroll
             for (int t = 0; t < STEPS; ++t) {
@@ -170,16 +206,154 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
                     case 7: waitvm<7>(); break;
                     default: waitvm<0>(); break;
                 }
+                if (XREG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's x writes are in
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 const int t3 = t + 3;
                 if (t3 < STEPS) issue(ci, t3); else issue(ci + 1, t3 - STEPS);
+                if (ROLL && GELU && t == NA - 1) __builtin_amdgcn_s_barrier();  // the computing waves' G-tile barrier (between barrier NA - 1 and barrier NA)
             }
         }
         WAITVM(0);
         return;
     }
     // ---------------- computing waves
+#if ROLL
+    {
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            WAITVM_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto opq = [](int v) { asm volatile("" : "+s"(v)); return v; };
+        u32x4 wh[2], wl[2], xh[RF], xl[RF];   // A-step fragments
+        u32x4 bwh[3], bwl[3];                 // B-step weight fragments (bgh / bgl: the G fragments)
+        bar();  // prologue
+        {
+            const int so = opq(0);
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) { wh[nf] = rd(la[0] + so + nf * 2048); wl[nf] = rd(la[1] + so + nf * 2048); }
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf) { xh[rf] = rd(lxa[0] + so + rf * 2048); xl[rf] = rd(lxa[1] + so + rf * 2048); }
+        }
+        for (int ci = 0; ci < NCH; ++ci) {
+#pragma unroll
+            for (int t = 0; t < NA; ++t) {
+                if (STAMP && ci == 6 && blockIdx.x == 5 && threadIdx.x == 0) stamps[t] = __builtin_amdgcn_s_memtime();
+                const int sn = opq(((t + 1) & 3) * SLOTB);
+                const bool na = t + 1 < NA;  // the next step is an A-step (else B-step 0: weights only, its G fragments come behind the GELU)
+                // S1: hi x lo
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int rf = i >> 1, nf = i & 1;
+                    pacc[rf][nf] = mma(wh[nf], xl[rf], pacc[rf][nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i == 1) bar();  // the barrier of step t: slot t + 1 has landed (the DMA waves run one step ahead of the protocol's minimum)
+                    if (na && nf == 1) xl[rf] = rd(lxa[1] + sn + rf * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // S2: hi x hi
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int rf = i >> 1, nf = i & 1;
+                    pacc[rf][nf] = mma(wh[nf], xh[rf], pacc[rf][nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (rf == 2) { if (na) wh[nf] = rd(la[0] + sn + nf * 2048); else bwh[nf] = rd(lb[0] + sn + nf * 2048); }
+                    if (!na && i == 5) bwh[2] = rd(lb[0] + sn + 2 * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // S3: lo x hi
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int rf = i >> 1, nf = i & 1;
+                    pacc[rf][nf] = mma(wl[nf], xh[rf], pacc[rf][nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (na && nf == 1) xh[rf] = rd(lxa[0] + sn + rf * 2048);
+                    if (rf == 2) { if (na) wl[nf] = rd(la[1] + sn + nf * 2048); else bwl[nf] = rd(lb[1] + sn + nf * 2048); }
+                    if (!na && i == 5) bwl[2] = rd(lb[1] + sn + 2 * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#if GELU
+            if (STAMP && ci == 6 && blockIdx.x == 5 && threadIdx.x == 0) stamps[40] = __builtin_amdgcn_s_memtime();
+            {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                    for (int nf = 0; nf < 2; ++nf) {
+                        h4 hv, lv;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float x = pacc[rf][nf][q];
+                            const float z = fabsf(x) * 0.70710678118654752440f;
+                            const float tt = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+                            float qq = __builtin_fmaf(tt, 1.061405429f, -1.453152027f);
+                            qq = __builtin_fmaf(tt, qq, 1.421413741f);
+                            qq = __builtin_fmaf(tt, qq, -0.284496736f);
+                            qq = __builtin_fmaf(tt, qq, 0.254829592f);
+                            const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.44269504088896340736f);
+                            const float ez = tt * qq * e;
+                            const float gv = 0.5f * x * (x < 0.f ? ez : 2.0f - ez);
+                            hv[q] = (_Float16)gv;
+                            lv[q] = (_Float16)(gv - (float)hv[q]);
+                            pacc[rf][nf][q] = 0.f;
+                        }
+                        char* gs = smem + cg * G_KB + (rows0 + rf * 16) * 128 + (f_kg & 1) * 8;
+                        const int c = 2 * nf + (f_kg >> 1);
+                        *reinterpret_cast<h4*>(gs + ((c ^ sw) << 4)) = hv;
+                        *reinterpret_cast<h4*>(gs + (((4 + c) ^ sw) << 4)) = lv;
+                    }
+                bar();  // the G tile is complete
+            }
+#endif
+            if (STAMP && ci == 6 && blockIdx.x == 5 && threadIdx.x == 0) stamps[41] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf) { bgh[rf] = rd(lx[0] + rf * 2048); bgl[rf] = rd(lx[1] + rf * 2048); }
+#pragma unroll
+            for (int sb = 0; sb < NB; ++sb) {
+                const int t = NA + sb, half = sb & 1;
+                if (STAMP && ci == 6 && blockIdx.x == 5 && threadIdx.x == 0) stamps[t] = __builtin_amdgcn_s_memtime();
+                if (STAMP && ci == 7 && blockIdx.x == 5 && threadIdx.x == 0 && sb == 0) {}
+                const int sn = opq(((t + 1) & 3) * SLOTB);
+                const int gn = opq((((sb >> 1) + 1) & 3) * G_KB);
+                const bool nb = sb + 1 < NB;      // the next step is a B-step
+                const bool newg = nb && half == 1;  // ... of the next k-block: new G fragments
+                // S1: hi x lo
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const int rf = i / 3, nf = i % 3;
+                    acc[rf][half * 3 + nf] = mma(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i == 1) bar();
+                    if (nf == 2) { if (newg) bgl[rf] = rd(lx[1] + gn + rf * 2048); else if (!nb) xl[rf] = rd(lxa[1] + sn + rf * 2048); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // S2: hi x hi
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const int rf = i / 3, nf = i % 3;
+                    acc[rf][half * 3 + nf] = mma(bwh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (rf == 2) { if (nb) bwh[nf] = rd(lb[0] + sn + nf * 2048); else if (nf < 2) wh[nf] = rd(la[0] + sn + nf * 2048); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // S3: lo x hi
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const int rf = i / 3, nf = i % 3;
+                    acc[rf][half * 3 + nf] = mma(bwl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nf == 2) { if (newg) bgh[rf] = rd(lx[0] + gn + rf * 2048); else if (!nb) xh[rf] = rd(lxa[0] + sn + rf * 2048); }
+                    if (rf == 2) { if (nb) bwl[nf] = rd(lb[1] + sn + nf * 2048); else if (nf < 2) wl[nf] = rd(la[1] + sn + nf * 2048); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (STAMP && ci == 6 && blockIdx.x == 5 && threadIdx.x == 0) stamps[STEPS] = __builtin_amdgcn_s_memtime();
+        }
+    }
+#else
     for (int ci = 0; ci < NCH; ++ci) {
 #pragma unroll
         for (int t = 0; t < STEPS; ++t) {
@@ -300,6 +474,7 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
             }
         }
     }
+#endif
     if (STAMP && blockIdx.x == 5 && threadIdx.x == 0) {
         stamps[30] = t_start; stamps[31] = __builtin_amdgcn_s_memtime(); stamps[32] = r_start; stamps[33] = __builtin_amdgcn_s_memrealtime();
     }
@@ -345,7 +520,7 @@ int main() {
         if (ms / 20 < best) best = ms / 20;
     }
     hipError_t err = hipGetLastError();
-    printf("MODE=%d GELU=%d XDIRECT=%d PF=%d ABL=%d: %.1f us per launch (240 steps: %.0f ns per step), err=%s\n", MODE, GELU, XDIRECT, PF, ABL, best * 1e3, best * 1e6 / 240,
+    printf("XREG=%d ROLL=%d MODE=%d GELU=%d XDIRECT=%d PF=%d ABL=%d: %.1f us per launch (240 steps: %.0f ns per step), err=%s\n", XREG, ROLL, MODE, GELU, XDIRECT, PF, ABL, best * 1e3, best * 1e6 / 240,
            hipGetErrorString(err));
     if (STAMP) {
         unsigned long long st[64];
@@ -353,7 +528,7 @@ int main() {
         const double cyc = (double)(st[31] - st[30]), us = (double)(st[33] - st[32]) / 100.0;
         printf("  workgroup 5: %.0f cycles in %.1f us = %.0f MHz; chunk 6 steps (cycles): A", cyc, us, cyc / us);
         for (int i = 0; i < NA; ++i) printf(" %llu", st[i + 1] - st[i]);
-        printf(" (GELU inside the last: %llu) | B", GELU ? st[NA] - st[40] : 0ull);
+        printf(" (GELU%s: %llu) | B", ROLL ? " + G barrier behind the last" : " inside the last", GELU ? (ROLL ? st[41] - st[40] : st[NA] - st[40]) : 0ull);
         for (int i = NA; i < STEPS; ++i) printf(" %llu", st[i + 1] - st[i]);
         printf("\n");
     }
