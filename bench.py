@@ -205,11 +205,13 @@ def kernel_work_per_step(eng, B, passes, tag):
     if eng.precision == "f32":  # every output is fp32: one instantiation
         return act_fl + res_fl, act_by + res_by, act_n + res_n, "_ZN2pp11gemm_kernelIfLi0ELi0EEEvNS_10GemmParamsE"
     if tag == "gemm_bf16out":  # "operand-dtype output": bf16 or split-fp16
-        if eng.precision == "f16x3" and E >= 768 and (3 * E) % 192 == 0 and Fd % 192 == 0:
+        if eng.precision == "f16x3" and (3 * E) % 192 == 0 and Fd % 192 == 0:
             from probpose_code_amd import _lib
             if _lib.get_option("linear_dma") != 0 and ((M + 191) // 192) * ((3 * E) // 192) >= 512:
-                # the twelve-wave persistent kernel (pp_linear_dma.hip): qkv = <ACT_NONE>, fc1 = <ACT_GELU>; both in this tag
+                # the twelve-wave persistent kernel (pp_linear_dma.hip: pp_gemm tries it FIRST, at every K >= 64 - at K = 384 it is level with
+                # pp_linear_ovl.hip, scripts/micro/linear_k384_bench.py): qkv = <ACT_NONE>, fc1 = <ACT_GELU>; both in this tag
                 return act_fl, act_by, act_n, "_ZN2pp3ldm28linear_dma_persistent_kernelILi0EEEvNS0_6ParamsE|_ZN2pp3ldm28linear_dma_persistent_kernelILi1EEEvNS0_6ParamsE"
+        if eng.precision == "f16x3" and E >= 768 and (3 * E) % 192 == 0 and Fd % 192 == 0:
             # K >= 768: the wide-tile split kernel (256 x 192 tiles; the fp32-output Linear layers run on the same instantiation)
             return act_fl, act_by, act_n, "_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1ELi2ELb0ELb0EEEvNS_10GemmParamsE"
         if eng.precision == "f16x3" and (3 * E) % 192 == 0 and Fd % 192 == 0 and ((M + 191) // 192) * ((3 * E) // 192) >= 512:

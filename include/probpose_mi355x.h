@@ -28,9 +28,10 @@
 extern "C" {
 #endif
 
-/* 2: + pp_clock_probe, pp_conv3x3_splitk_slices, pp_conv3x3_winograd_maxpool_relu, pp_winograd_scratch_bytes, pp_probmap_decode_flags, option "ksplit9_below"; PP_WS_TOWER_PARTIAL sized for the slice count the
+/* 3: + pp_launch_count / pp_reset_launch_counts (diagnostics: which kernels a launch plan really ran).
+ * 2: + pp_clock_probe, pp_conv3x3_splitk_slices, pp_conv3x3_winograd_maxpool_relu, pp_winograd_scratch_bytes, pp_probmap_decode_flags, option "ksplit9_below"; PP_WS_TOWER_PARTIAL sized for the slice count the
  *    library itself picks (round 3 added pp_workspace_bytes / pp_set_option / the split-fp16 layer kernels under version 1). */
-#define PP_ABI_VERSION 2
+#define PP_ABI_VERSION 3
 
 enum {
     PP_OK = 0,
@@ -79,6 +80,15 @@ int pp_device_cu_count(void);
  * (probpose_code_amd/_lib.py forwards PP_OPT_<NAME>=<int> environment variables here at import - host-side convenience.) */
 int pp_set_option(const char* name, int value);
 int pp_get_option(const char* name, int* value);
+
+/* Diagnostics: kernel launches since the last reset, tallied on the host at launch time (a captured hipGraph counts once, at capture) under
+ * the launching source file's name - "pp_winograd.hip", "pp_ffn_dma.hip", "pp_qkv_attn_split.hip", "pp_linear_dma.hip", "pp_gemm.hip" ... - and
+ * for kernels that share a file under their own tag: "linear_dma_persistent" (twelve-wave Linear kernel, finished tiles through the DMA
+ * waves), "linear_dma_tile" (its one-tile-per-workgroup form), "winograd_input_transform", "winograd_gemm_pool", "layernorm". Lets a test
+ * assert WHICH kernels a launch plan ran (the reference has no counterpart: kernel selection there is cuDNN's, mmpose/models/heads/
+ * hybrid_heads/probmap_head.py:261-294 and mmpretrain's VisionTransformer only name the layers). Unknown names count 0. Not thread-safe. */
+long long pp_launch_count(const char* kernel);
+int pp_reset_launch_counts(void);
 
 /* Bytes of the caller-allocated buffers of one step of the launch plan (the library never allocates). `shape`
  * describes the step: prec = PP_PREC_*; n_img = crops x flip passes; n_tokens per image; embed / ffn widths; patch_k = 3 * patch

@@ -54,6 +54,8 @@ SIGNATURES = {
     "pp_device_cu_count": (c_int, []),
     "pp_set_option": (c_int, [c_char_p, c_int]),
     "pp_get_option": (c_int, [c_char_p, _P]),
+    "pp_launch_count": (c_longlong, [c_char_p]),
+    "pp_reset_launch_counts": (c_int, []),
     "pp_workspace_bytes": (c_longlong, [c_int, c_int, _P]),
     "pp_conv3x3_splitk_slices": (c_int, [c_int] * 7),
     "pp_clock_probe": (c_int, [_P, _P, ctypes.c_uint, _P]),
@@ -149,8 +151,41 @@ def workspace_bytes(buffer: str, shape: "PlanShape", index: int = 0) -> int:
     return int(n)
 
 
+_option_epoch = 0  # bumped by every set_option: engines drop workspaces / captured graphs sized or recorded under other options
+
+
+_option_first_values = {}  # name -> the value an option had before this process first changed it (restore_options)
+
+
 def set_option(name: str, value: int) -> None:
+    global _option_epoch
+    if name not in _option_first_values:
+        v = ctypes.c_int(0)
+        if lib.pp_get_option(name.encode(), ctypes.byref(v)) == PP_OK:
+            _option_first_values[name] = int(v.value)
     check("pp_set_option", lib.pp_set_option(name.encode(), int(value)))
+    _option_epoch += 1
+
+
+def restore_options() -> None:
+    """Every option this process has changed through ``set_option`` back to the value it had before the first change (the test
+    suite calls it after every test: a failing assertion must not leave a kernel switch off for the tests behind it)."""
+    for name, v in list(_option_first_values.items()):
+        if get_option(name) != v:
+            set_option(name, v)
+
+
+def option_epoch() -> int:
+    return _option_epoch
+
+
+def launch_count(kernel: str) -> int:
+    """Launches of a kernel family since ``reset_launch_counts()`` (pp_launch_count: source-file name or tag)."""
+    return int(lib.pp_launch_count(kernel.encode()))
+
+
+def reset_launch_counts() -> None:
+    lib.pp_reset_launch_counts()
 
 
 def get_option(name: str) -> int:

@@ -37,6 +37,29 @@ static Option g_options[] = {
     {"ksplit9_below", 1024},   // pp_conv3x3_splitk_slices: tower stages with fewer output rows than this take nine K-slices (one tap each) instead of three
 };
 
+// launch tallies (pp_launch_count / pp_reset_launch_counts): name -> launches since the last reset
+struct LaunchCount {
+    char name[48];
+    long long n;
+};
+static LaunchCount g_launches[96];
+static int g_n_launches = 0;
+
+void count_launch(const char* file_or_tag) {
+    const char* base = file_or_tag;
+    for (const char* c = file_or_tag; *c; ++c)
+        if (*c == '/') base = c + 1;
+    for (int i = 0; i < g_n_launches; ++i)
+        if (std::strcmp(g_launches[i].name, base) == 0) {
+            ++g_launches[i].n;
+            return;
+        }
+    if (g_n_launches < (int)(sizeof(g_launches) / sizeof(g_launches[0]))) {
+        std::snprintf(g_launches[g_n_launches].name, sizeof(g_launches[0].name), "%s", base);
+        g_launches[g_n_launches++].n = 1;
+    }
+}
+
 int option(const char* name) {
     for (const Option& o : g_options)
         if (std::strcmp(o.name, name) == 0) return o.value;
@@ -88,6 +111,22 @@ int pp_get_option(const char* name, int* value) {
         }
     set_error("pp_get_option: unknown option '%s'", name);
     return PP_ERR_INVALID_ARG;
+}
+
+long long pp_launch_count(const char* kernel) {
+    using namespace pp;
+    if (!kernel) {
+        set_error("pp_launch_count: NULL name");
+        return PP_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i < g_n_launches; ++i)
+        if (std::strcmp(g_launches[i].name, kernel) == 0) return g_launches[i].n;
+    return 0;
+}
+
+int pp_reset_launch_counts(void) {
+    pp::g_n_launches = 0;
+    return PP_OK;
 }
 
 long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* sh) {

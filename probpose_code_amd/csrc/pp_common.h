@@ -13,6 +13,9 @@ namespace pp {
 
 void set_error(const char* fmt, ...);
 int option(const char* name);  // explicit dev switches (pp_set_option); the library never reads the environment
+// Diagnostics (pp_launch_count): every kernel launch is tallied under its source file's name ("pp_winograd.hip") and, where a file holds
+// several kernel families, under an explicit tag as well ("linear_dma_persistent"). Host side, a few string compares per launch.
+void count_launch(const char* file_or_tag);
 
 inline int fail(int code, const char* what) {
     set_error("%s", what);
@@ -42,7 +45,16 @@ inline int fail(int code, const char* what) {
     } while (0)
 
 // Called after every kernel launch: surfaces launch-configuration errors without syncing.
-#define PP_LAUNCH_CHECK() PP_HIP_CHECK(hipGetLastError())
+#define PP_LAUNCH_CHECK()                  \
+    do {                                   \
+        ::pp::count_launch(__FILE__);      \
+        PP_HIP_CHECK(hipGetLastError());   \
+    } while (0)
+#define PP_LAUNCH_CHECK_AS(tag)            \
+    do {                                   \
+        ::pp::count_launch(tag);           \
+        PP_LAUNCH_CHECK();                 \
+    } while (0)
 
 constexpr int WAVE = 64;
 

@@ -411,7 +411,11 @@ bool linear_dma_supported(const GemmParams& p, int prec, int groups) {
     if (p.residual && (p.out_bf16 == 2 || ((p.ldres ? p.ldres : p.ldc) % 4) != 0)) return false;
     if ((size_t)ldm::BM * p.K * 4 >= 0x7ffffff0u || (size_t)ldm::BM * p.N * 4 >= 0x7ffffff0u) return false;
     const long long ntiles = (long long)(p.N / ldm::BN) * ((p.M + ldm::BM - 1) / ldm::BM);
-    return ntiles >= 512;  // two rounds of the chip at least; smaller problems stay with the 128 x 128 / wide-tile kernels
+    // two rounds of the chip at least; smaller problems stay with the 128 x 128 / wide-tile kernels. No lower bound on K beyond two stages: at
+    // the ViT-S shapes (K = 384; reached when the fused layer kernels are off or the token count is not 192) it is level with the
+    // overlapped-epilogue kernel it shadows - 71.5 / 111.2 / 160.8 / 255.7 us against 71.1 / 104.7 / 174.7 / 256.7 us for qkv / fc1 at
+    // M = 24 576 / 55 296 (scripts/micro/linear_k384_bench.py); option "linear_dma" = 0 hands those shapes back to pp_linear_ovl.hip
+    return ntiles >= 512;
 }
 
 int linear_dma_gemm(const GemmParams& g, hipStream_t s) {
@@ -434,12 +438,12 @@ int linear_dma_gemm(const GemmParams& g, hipStream_t s) {
         auto kern = g.act == ACT_GELU ? ldm::linear_dma_persistent_kernel<ACT_GELU> : g.act == ACT_RELU ? ldm::linear_dma_persistent_kernel<ACT_RELU> : ldm::linear_dma_persistent_kernel<ACT_NONE>;
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS_P));
         hipLaunchKernelGGL(kern, dim3(grid < cus ? grid : cus), dim3(ldm::THREADS), ldm::LDS_P, s, p);
-        PP_LAUNCH_CHECK();
+        PP_LAUNCH_CHECK_AS("linear_dma_persistent");
         return PP_OK;
     }
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldm::linear_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
     hipLaunchKernelGGL(ldm::linear_dma_kernel, dim3(grid), dim3(ldm::THREADS), ldm::LDS, s, p);
-    PP_LAUNCH_CHECK();
+    PP_LAUNCH_CHECK_AS("linear_dma_tile");
     return PP_OK;
 }
 

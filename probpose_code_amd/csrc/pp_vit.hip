@@ -167,7 +167,7 @@ static int launch_ln(const float* x, const float* g, const float* b, void* y, in
         case 1024: hipLaunchKernelGGL((layernorm_kernel<TO, 8>), grid, block, 0, s, x, g, b, yo, M, eps); break;
         default: return fail(PP_ERR_UNSUPPORTED, "pp_layernorm: embed dim must be 384, 768 or 1024");
     }
-    PP_LAUNCH_CHECK();
+    PP_LAUNCH_CHECK_AS("layernorm");
     return PP_OK;
 }
 

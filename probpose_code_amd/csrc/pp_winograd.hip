@@ -388,7 +388,7 @@ extern "C" int pp_conv3x3_winograd_maxpool_relu(const void* act_nhwc, const void
     const long long items = T * (Cin / 4);
     hipLaunchKernelGGL(wino::input_transform_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const char*>(act_nhwc), reinterpret_cast<char*>(v_scratch), B, Cin, H, W);
-    PP_LAUNCH_CHECK();
+    PP_LAUNCH_CHECK_AS("winograd_input_transform");
     wino::Params p{};
     p.V = v_scratch;
     p.U = u_packed;
@@ -412,6 +412,6 @@ extern "C" int pp_conv3x3_winograd_maxpool_relu(const void* act_nhwc, const void
     PP_REQUIRE(grid < (1ll << 30), PP_ERR_UNSUPPORTED, "pp_conv3x3_winograd_maxpool_relu: too many tiles");
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino::gemm_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, wino::LDS));
     hipLaunchKernelGGL(wino::gemm_pool_kernel, dim3((unsigned)grid), dim3(wino::THREADS), wino::LDS, s, p);
-    PP_LAUNCH_CHECK();
+    PP_LAUNCH_CHECK_AS("winograd_gemm_pool");
     return PP_OK;
 }

@@ -17,6 +17,7 @@ throughout, so the ViT output *is* the NHWC feature map the head convolutions ga
 """
 import math
 import os
+import warnings
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -90,7 +91,9 @@ class ProbPoseEngine:
         self.radius = torch.from_numpy(radius).to(self.device)
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._flip: Dict[tuple, torch.Tensor] = {}
-        self._graphs: Dict[tuple, tuple] = {}
+        self._graphs: Dict[tuple, tuple] = {}  # insertion order = least recently used first (see capture / forward_graph)
+        self.max_graphs = 8  # captured graphs kept (each pins a static input and, per batch size and slot, a workspace)
+        self._opt_epoch = _lib.option_epoch()
         # Launch-plan switches: every fusion below is on in the shipped plan; `plan` (constructor argument) turns single ones off
         # for A/B timing and for the tests of the unfused kernels, PP_FUSE_* environment variables do the same from outside a
         # script (read HERE, in the host-side mirror - the C library reads no environment, include/probpose_mi355x.h).
@@ -139,6 +142,23 @@ class ProbPoseEngine:
         # f16x3, 192-token sequences of 32-dim heads: qkv Linear + attention of a layer in one launch, one workgroup per
         # (sequence, head); the qkv tensor never reaches HBM (pp_qkv_attn_split.hip). PP_FUSE_QKV_ATTN=0: pp_gemm + pp_attention
         self.fuse_qkv_attn = precision == "f16x3" and pl["fuse_qkv_attn"] and self.Np == 192 and self.hd == 32 and self.E == 384
+        # Which layer plan this geometry gets - said once, loudly, when a ViT-S-like model misses the two-launch layer only because of
+        # its token count (pp_qkv_attn_split.hip is written for 192-token sequences of 32-dim heads; the projection + FFN launch takes
+        # any row count): it then runs qkv Linear + attention (pp_attention) + the fused projection / FFN launch, three launches per layer
+        # with the qkv tensor through HBM. ViT-B (E = 768) has no fused layer kernel at all.
+        if precision == "f16x3":
+            if self.fuse_qkv_attn and self._proj_packed:
+                self.layer_plan = "two launches per layer (pp_qkv_attention_split + pp_proj_ffn_split_residual_layernorm)"
+            elif self._proj_packed:
+                self.layer_plan = "three launches per layer (pp_gemm qkv + pp_attention + pp_proj_ffn_split_residual_layernorm)"
+            else:
+                self.layer_plan = "generic (pp_gemm / pp_attention / pp_layernorm per layer)"
+            if pl["fuse_qkv_attn"] and not self.fuse_qkv_attn and self.E == 384 and self.hd == 32:
+                warnings.warn(
+                    f"ProbPoseEngine: {self.Np}-token sequences ({img_size[0]}x{img_size[1]} input) miss the fused qkv + attention kernel, "
+                    f"which is built for 192 tokens (256x192); this model runs {self.layer_plan}", RuntimeWarning, stacklevel=2)
+        else:
+            self.layer_plan = "bf16 / f32 plan"
         # f16x3, 16 x 12 feature maps: the first tower stage in its Winograd F(2x2, 3x3) form (pp_winograd.hip: 2.25x fewer MFMAs)
         self.winograd = (precision == "f16x3" and pl["winograd"] and self.w.has("tower0.wino")
                          and _lib.lib.pp_winograd_scratch_bytes(1, self.Hp, self.Wp, self.E) > 0)
@@ -171,6 +191,7 @@ class ProbPoseEngine:
     def _workspace(self, B: int, passes: int, slot: int = 0) -> Dict[str, torch.Tensor]:
         """Buffers of one step at batch size B. ``slot`` > 0: a second (third ...) independent set, so that consecutive
         steps can be in flight at once on different streams (pipeline.py)."""
+        self._check_options()
         key = (B, passes, slot)
         if key in self._ws:
             return self._ws[key]
@@ -223,6 +244,17 @@ class ProbPoseEngine:
             ws[f"p{j}"] = buf("tower_pooled", (4, nb, th // ph, tw // pw_, E), index=j)
         self._ws[key] = ws
         return ws
+
+    def _check_options(self) -> None:
+        """Library options (pp_set_option) decide kernel selection AND buffer sizes - the split-K slice count of the small tower
+        convolutions, hence PP_WS_TOWER_PARTIAL, follows "panel" / "ksplit_channels" / "psplit_tap_inner" / "ksplit9_below": a workspace
+        cached, or a graph captured, before an option changed would run another plan than a fresh engine (or fail with
+        PP_ERR_UNSUPPORTED for a slice count its buffer was not sized for). Options are a development hook; when one changes, the
+        caches go."""
+        if _lib.option_epoch() != self._opt_epoch:
+            self._opt_epoch = _lib.option_epoch()
+            self._ws.clear()
+            self._graphs.clear()
 
     def _flip_indices(self, flip_indices) -> torch.Tensor:
         key = tuple(int(i) for i in flip_indices)
@@ -518,9 +550,17 @@ class ProbPoseEngine:
         """Capture the whole launch sequence for batch size B into a HIP graph (the ~110 launches of one
         forward are launch-latency-bound from Python). Returns the static input buffer to fill. Every ``slot`` has its
         own workspace, input buffer and graph."""
+        self._check_options()
         key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps, bool(shift_heatmap), slot)
         if key in self._graphs:
+            self._graphs[key] = self._graphs.pop(key)  # most recently used last
             return self._graphs[key][1]
+        while len(self._graphs) >= max(1, int(self.max_graphs)):  # least recently used out, with the workspace nothing else replays from
+            old_key = next(iter(self._graphs))
+            del self._graphs[old_key]
+            passes_old = 2 if old_key[1] else 1
+            if not any(k[0] == old_key[0] and k[-1] == old_key[-1] and (2 if k[1] else 1) == passes_old for k in self._graphs):
+                self._ws.pop((old_key[0], passes_old, old_key[-1]), None)
         static_in = torch.zeros((B, 3, self.H, self.W), dtype=torch.uint8, device=self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -528,7 +568,7 @@ class ProbPoseEngine:
             for _ in range(2):
                 self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot, shift_heatmap=shift_heatmap)
         torch.cuda.current_stream(self.device).wait_stream(side)
-        torch.cuda.synchronize(self.device)
+        side.synchronize()  # (this stream's warm-ups only; torch.cuda.graph below still synchronises the device when the capture begins)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot, shift_heatmap=shift_heatmap)

@@ -363,7 +363,7 @@ class TopdownPoseEstimator(nn.Module):
     def __init__(self, backbone: dict, neck: Optional[dict] = None, head: Optional[dict] = None,
                  train_cfg: Optional[dict] = None, test_cfg: Optional[dict] = None,
                  data_preprocessor: Optional[dict] = None, init_cfg=None, metainfo: Optional[dict] = None,
-                 precision: str = "f16x3", graph_replay: bool = True):
+                 precision: str = "f16x3", graph_replay: bool = True, graph_capture_after: int = 3, max_graphs: int = 8):
         super().__init__()
         if neck is not None:
             raise NotImplementedError("the ProbPose config has no neck")
@@ -374,6 +374,13 @@ class TopdownPoseEstimator(nn.Module):
         # ``predict`` replays the engine's captured hipGraph for a batch size it has met before (the first batch of a size runs
         # the same launches one by one - a one-off size never pays for a capture); False: always kernel by kernel
         self.graph_replay = bool(graph_replay)
+        # A capture costs two warm-up forwards, the capture itself and a device-wide synchronisation (torch.cuda.graph does one of its
+        # own), i.e. a stall of a few steps that also drains any StepPipeline slot in flight: it is paid at the
+        # ``graph_capture_after``-th batch of a size (3: the size has repeated twice - the fixed batches of a test dataloader get there in
+        # their third step, the changing person counts of a video mostly never), and the engine keeps at most ``max_graphs`` captured
+        # graphs (least recently used out, with their static inputs and workspaces).
+        self.graph_capture_after = max(2, int(graph_capture_after))
+        self.max_graphs = max(1, int(max_graphs))
         self._sizes_seen: Dict[tuple, int] = {}
         self._gather = None  # ResultGather of ``predict``: pinned host record buffer, grown to the largest batch met
         self.backbone = MODELS.build(backbone)
@@ -487,7 +494,7 @@ class TopdownPoseEstimator(nn.Module):
 
     def predict(self, inputs: Tensor, data_samples: list) -> list:
         """topdown.py:86-126, as ONE launch sequence: both flip-test passes are batched through the
-        backbone and the head consumes the features in place. A batch size met before replays the engine's captured
+        backbone and the head consumes the features in place. A batch size met ``graph_capture_after`` times replays the engine's captured
         hipGraph (bit-identical to the launches one by one, tests/test_estimator_gpu.py); the results come back as ONE
         fixed-layout record (``pp_pack_records``) through ONE copy into pinned host memory."""
         from .dist import ResultGather
@@ -502,7 +509,8 @@ class TopdownPoseEstimator(nn.Module):
         seen = self._sizes_seen.get(key, 0)
         self._sizes_seen[key] = seen + 1
         shift = self._shift_heatmap
-        if self.graph_replay and seen >= 1 and inputs.dtype == torch.uint8:
+        eng.max_graphs = self.max_graphs
+        if self.graph_replay and seen + 1 >= self.graph_capture_after and inputs.dtype == torch.uint8:
             out = eng.forward_graph(inputs, flip, flip_indices, return_heatmaps=want_hm, shift_heatmap=shift)
         else:
             out = eng.forward(inputs, flip, flip_indices, return_heatmaps=want_hm, shift_heatmap=shift)
@@ -622,6 +630,9 @@ class TopdownPoseEstimator(nn.Module):
                 return False
         cen, sca, siz = (np.stack(a)[:, None, :] for a in (cen, sca, siz))  # (B, 1, 2): broadcast over the K keypoints
         base[..., :2] = base[..., :2] / siz * sca + cen - 0.5 * sca
+        # the batch array is now in image space: a second add_pred_to_datasample on the same preds takes the per-sample path (which, like the
+        # reference's in-place `pred_instances.keypoints[..., :2] = ...`, maps whatever it is given once more - per sample, visibly)
+        batch_pred_instances.keypoints_batch = None
         return True
 
 

@@ -34,3 +34,13 @@ def lib_built():
 
         g.build()
     return so
+
+
+@pytest.fixture(autouse=True)
+def _library_options_restored():
+    """Library options (pp_set_option) are process-global: whatever a test switched - also one that failed half way - is back at its
+    first value before the next test runs, so no later test silently runs another kernel."""
+    yield
+    mod = sys.modules.get("probpose_code_amd._lib")
+    if mod is not None:
+        mod.restore_options()

@@ -125,8 +125,8 @@ def _fields_of(results):
 
 
 def test_test_step_graph_replay_equals_eager_bit_for_bit(setup):
-    """The drop-in call itself (`model.test_step`, mmpose/apis/inference.py:195-196) on the fast path: the first batch of a size
-    is launched kernel by kernel, the second captures the hipGraph, later ones replay it; the results come back through one
+    """The drop-in call itself (`model.test_step`, mmpose/apis/inference.py:195-196) on the fast path: the first two batches of a size
+    are launched kernel by kernel, the third captures the hipGraph (`graph_capture_after` = 3), later ones replay it; the results come back through one
     record copy. Every `pred_instances` field must equal the kernel-by-kernel estimator's (graph_replay=False) bit for bit, on
     DIFFERENT batches in a row, and `test_step_stream` (graph for full batches, two in flight) must deliver the same."""
     from probpose_code_amd import apis
@@ -136,7 +136,7 @@ def test_test_step_graph_replay_equals_eager_bit_for_bit(setup):
     fast = apis.init_model(CFG, {"state_dict": sd}, device="cuda:0")
     slow = apis.init_model(CFG, {"state_dict": sd}, device="cuda:0", cfg_options={"model.graph_replay": False})
     assert fast.graph_replay and not slow.graph_replay
-    batches = [S.synthetic_crops(B, seed=40 + i) for i in range(4)]
+    batches = [S.synthetic_crops(B, seed=40 + i) for i in range(5)]
     got = []
     with torch.no_grad():
         for i, crops in enumerate(batches):
@@ -146,9 +146,9 @@ def test_test_step_graph_replay_equals_eager_bit_for_bit(setup):
                 assert a[f].dtype == b[f].dtype and np.array_equal(a[f], b[f]), f"{f}: batch {i} differs between replay and eager test_step"
             got.append(a)
         key = (B, True, tuple(S.COCO_FLIP_INDICES), False)
-        assert fast._sizes_seen[key] == 4 and any(k[0] == B for k in fast.engine._graphs), "test_step did not reach the graph path"
+        assert fast._sizes_seen[key] == 5 and any(k[0] == B for k in fast.engine._graphs), "test_step did not reach the graph path"
         assert not slow.engine._graphs
-        assert not np.array_equal(got[2]["keypoints"], got[3]["keypoints"]), "a replay repeated the previous batch"
+        assert not np.array_equal(got[3]["keypoints"], got[4]["keypoints"]), "a replay repeated the previous batch"
         stream = list(fast.test_step_stream((apis.pack_crops(c, center, scale, fast.dataset_meta) for c in batches), depth=2, max_batch=B))
         assert any(k[0] == B and k[-1] == 1 for k in fast.engine._graphs), "test_step_stream did not capture its second slot's graph"
         for i, res in enumerate(stream):
@@ -168,10 +168,11 @@ def test_shift_heatmap_test_cfg_matches_the_oracle(setup):
     ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD, input_size=(192, 256), input_center=center, input_scale=scale, shift_heatmap=True)
     model = apis.init_model(CFG, {"state_dict": sd}, device="cuda:0", cfg_options={"model.test_cfg.shift_heatmap": True})
     with torch.no_grad():
-        runs = [model.test_step(apis.pack_crops(crops, center, scale, model.dataset_meta)) for _ in range(3)]  # eager, capture, replay
+        runs = [model.test_step(apis.pack_crops(crops, center, scale, model.dataset_meta)) for _ in range(4)]  # eager, eager, capture, replay
+    assert model.engine._graphs, "the fourth batch of a size must have replayed a captured graph"
     kps = [np.stack([ds.pred_instances.keypoints for ds in r]) for r in runs]
-    assert np.array_equal(kps[0], kps[2]), "graph replay differs from the eager launches"
-    d = np.abs(kps[2] - ref["keypoints"]).max(-1)
+    assert np.array_equal(kps[0], kps[3]), "graph replay differs from the eager launches"
+    d = np.abs(kps[3] - ref["keypoints"]).max(-1)
     same = d < 2.0
     assert same.mean() > 0.95 and d[same].max() <= 1e-3, f"{d[same].max():.2e} px, {int((~same).sum())} flips"
 
@@ -273,6 +274,85 @@ def test_config4_vit_base_384x288_bf16():
     assert (d < 2.0).all() and d.max() <= 1e-3, f"config 4 f16x3: {int((d >= 2).sum())} flips, L_inf {d[d < 2].max():.2e} px"
     for i, name in enumerate(("keypoints_probs", "keypoints_visible", "keypoints_oks")):
         assert np.abs(out["scalars"][i].cpu().numpy()[:, None] - ref[name]).max() <= 1e-3, name
+
+
+def test_config4_bs32_graph_replay_default_plan():
+    """BASELINE config 4 ON THE LAUNCH PLAN IT IS BENCHMARKED ON: ViT-B 384x288, f16x3, B = 32 crops with the flip
+    pass (27 648 token rows: 576 tiles of 192 x 192 for proj / fc2, more for qkv / fc1 - every Linear layer clears the 512-tile threshold of
+    pp_linear_dma.hip, as at bs 64), the 24 x 18 first tower stage in its Winograd form, captured as a hipGraph and REPLAYED. The library's
+    launch tally (pp_launch_count) proves which kernels the plan ran; keypoints / scalars of the replay against oracle.model_ref.predict on
+    the first 8 crops (crops are independent: eval-mode BatchNorm, per-crop decode) within 1e-3, no argmax flips
+    (reference workload: mmpose/models/heads/hybrid_heads/probmap_head.py:715-804 at heatmap 96 x 72)."""
+    from oracle import model_ref as M
+    from probpose_code_amd import ProbPoseEngine, _lib
+    from probpose_code_amd import synthetic as S
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    img, B, NREF = (384, 288), 32, 8
+    sd = S.synthetic_state_dict("base", img_size=img, seed=0, logit_scale=2.0)
+    x = S.synthetic_crops(B, img_size=img, seed=3)
+    ref = M.predict(sd, x[:NREF], 12, S.IMG_MEAN, S.IMG_STD, input_size=(288, 384))
+    eng = ProbPoseEngine(sd, 12, img_size=img, precision="f16x3", input_size=(288, 384))
+    assert eng.winograd, "the 24 x 18 tower stage must take the Winograd kernel"
+    xd = x.cuda()
+    _lib.reset_launch_counts()
+    eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)  # warm-up launches + the capture
+    torch.cuda.synchronize()
+    n_fwd = 3  # two eager warm-ups and the captured one (engine.capture)
+    assert _lib.launch_count("linear_dma_persistent") == 24 * n_fwd, "qkv / fc1 of every layer on the persistent twelve-wave kernel"
+    tally = {k: _lib.launch_count(k) for k in ("linear_dma_persistent", "linear_dma_tile", "winograd_gemm_pool", "pp_attention_dma.hip", "layernorm", "pp_gemm.hip", "pp_panel_split.hip")}
+    print("config 4 launch tally of three forwards:", tally)
+    assert _lib.launch_count("linear_dma_tile") == 25 * n_fwd, "patch embed + proj / fc2 of every layer on the twelve-wave kernel (one tile per workgroup)"
+    assert tally["pp_gemm.hip"] == 0, "no Linear layer of the plan on the 128 x 128 kernel"
+    assert tally["layernorm"] == 25 * n_fwd  # (E = 768 has no fused residual + LayerNorm in the default plan: DESIGN.md 4)
+    assert _lib.launch_count("winograd_gemm_pool") == n_fwd and _lib.launch_count("winograd_input_transform") == n_fwd
+    assert _lib.launch_count("pp_attention_dma.hip") == 12 * n_fwd, "432-token attention on the LDS-DMA kernel"
+    _lib.reset_launch_counts()
+    out = eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)  # a REPLAY: no host-side launch is tallied
+    torch.cuda.synchronize()
+    assert _lib.launch_count("linear_dma_persistent") == 0 and _lib.launch_count("pp_attention_dma.hip") == 0
+    kp = out["keypoints"].cpu().numpy()
+    assert np.isfinite(kp).all()
+    d = np.abs(kp[:NREF, None] - ref["keypoints_input_space"]).max(-1)
+    assert (d < 2.0).all() and d.max() <= 1e-3, f"config 4 bs {B} replay: {int((d >= 2).sum())} flips, L_inf {d[d < 2].max():.2e} px"
+    for i, name in enumerate(("keypoints_probs", "keypoints_visible", "keypoints_oks")):
+        assert np.abs(out["scalars"][i].cpu().numpy()[:NREF, None] - ref[name]).max() <= 1e-3, name
+    # the replay is deterministic and equals the eager plan bit for bit
+    eager = eng.forward(xd, True, S.COCO_FLIP_INDICES)
+    torch.cuda.synchronize()
+    assert torch.equal(eager["keypoints"], out["keypoints"])
+
+
+def test_vit_small_384x288_layer_plan_is_named_and_within_1e3():
+    """A ViT-S at another input size (432 tokens) misses the fused qkv + attention kernel, which is written for 192-token sequences:
+    the engine says so ONCE, by name (RuntimeWarning + `layer_plan`), and runs three launches per layer - the projection + FFN launch
+    takes any row count. Parity at that size against the oracle (f16x3: <= 1e-3 px, no flips)."""
+    from oracle import model_ref as M
+    from probpose_code_amd import ProbPoseEngine, _lib
+    from probpose_code_amd import synthetic as S
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    img = (384, 288)
+    sd = S.synthetic_state_dict("small", img_size=img, seed=0, logit_scale=2.0)
+    x = S.synthetic_crops(3, img_size=img, seed=5)
+    ref = M.predict(sd, x, 12, S.IMG_MEAN, S.IMG_STD, input_size=(288, 384))
+    with pytest.warns(RuntimeWarning, match="432-token sequences .* miss the fused qkv \\+ attention kernel"):
+        eng = ProbPoseEngine(sd, 12, img_size=img, precision="f16x3", input_size=(288, 384))
+    assert eng.layer_plan.startswith("three launches per layer") and not eng.fuse_qkv_attn
+    _lib.reset_launch_counts()
+    out = eng.forward(x.cuda(), True, S.COCO_FLIP_INDICES)
+    torch.cuda.synchronize()
+    assert _lib.launch_count("pp_ffn_dma.hip") == 12 and _lib.launch_count("pp_qkv_attn_split.hip") == 0
+    d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
+    assert (d < 2.0).all() and d.max() <= 1e-3, f"{int((d >= 2).sum())} flips, L_inf {d[d < 2].max():.2e} px"
+    for i, name in enumerate(("keypoints_probs", "keypoints_visible", "keypoints_oks")):
+        assert np.abs(out["scalars"][i].cpu().numpy()[:, None] - ref[name]).max() <= 1e-3, name
+    # the default geometry reports the two-launch layer and does not warn
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("error")
+        eng2 = ProbPoseEngine(S.synthetic_state_dict("small", seed=0), 12, precision="f16x3")
+    assert eng2.layer_plan.startswith("two launches per layer")
 
 
 def test_config4_row_owner_residual_layernorm_plan(monkeypatch):

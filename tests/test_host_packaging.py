@@ -91,6 +91,35 @@ def test_mixed_metainfo_dtypes_fall_back_to_the_per_sample_map(model):
         assert np.array_equal(ds.pred_instances.keypoints, want)
 
 
+def test_batched_and_per_sample_paths_agree_bit_for_bit_and_the_batch_is_mapped_once(model):
+    """The two code paths of `add_pred_to_datasample` (one map per batch / the reference's per-sample expression) on the same inputs -
+    float32 metainfo, float64 metainfo - give identical bits; and the batch array is marked as mapped: a second call on the
+    same preds behaves like the reference's in-place assignment (it maps the given keypoints again, per sample), never a silent second
+    batch map through the shared buffer."""
+    rng = np.random.default_rng(3)
+    B, K = 6, 17
+    rec = np.concatenate([rng.uniform(0, 255, (B, K, 2)), rng.random((B, K, 5)).astype(np.float32).astype(np.float64)], -1)
+    for variant in ("f32", "f64"):  # (input_size is a tuple in both, as PackPoseInputs hands it; center / scale are arrays as in the reference)
+        batch, _, _ = _batch(B, np.random.default_rng(4), np.float64 if variant == "f64" else np.float32)
+        fast = model.head.pack_records(rec.copy(), model.test_cfg)
+        assert fast.keypoints_batch is not None
+        out_fast = model.add_pred_to_datasample(fast, None, batch["data_samples"])
+        assert fast.keypoints_batch is None, "the batch map must mark the shared array as mapped"
+        kp_fast = np.stack([ds.pred_instances.keypoints for ds in out_fast]).copy()
+        batch2, _, _ = _batch(B, np.random.default_rng(4), np.float64 if variant == "f64" else np.float32)
+        slow = model.head.pack_records(rec.copy(), model.test_cfg)
+        slow.keypoints_batch = None  # force the per-sample path
+        out_slow = model.add_pred_to_datasample(slow, None, batch2["data_samples"])
+        kp_slow = np.stack([ds.pred_instances.keypoints for ds in out_slow])
+        assert kp_fast.dtype == kp_slow.dtype and np.array_equal(kp_fast, kp_slow), variant
+        # second call on the already mapped preds: per sample, like the reference (topdown.py:165-167 assigns in place)
+        again = model.add_pred_to_datasample(fast, None, batch["data_samples"])
+        for b, ds in enumerate(again):
+            m = ds.metainfo
+            want = kp_fast[b] / np.asarray(m["input_size"]) * np.asarray(m["input_scale"]) + np.asarray(m["input_center"]) - 0.5 * np.asarray(m["input_scale"])
+            assert np.array_equal(ds.pred_instances.keypoints, want)
+
+
 def test_flip_modes_outside_the_path_are_rejected_with_the_reason(model):
     model.test_cfg = dict(flip_test=True, flip_mode="heatmap", shift_heatmap=True)
     assert model._check_flip_cfg() is True and model._shift_heatmap is True  # (tta.py:64-66: built into the fused flip merge)
