@@ -69,6 +69,9 @@ static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must rep
 #ifndef FFD_READS_FIRST
 #define FFD_READS_FIRST 1
 #endif
+#ifndef FFD_ROLL
+#define FFD_ROLL 1  // rolling fragment reads, the barrier of a step inside its predecessor (round 5; 0: round 4's barrier | reads | MFMAs steps)
+#endif
 #ifndef FFD_DEPTH
 #define FFD_DEPTH 3  // steps a DMA wave may have in flight behind the one the computing waves are about to read: 2 or 3
 #endif
@@ -193,6 +196,7 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
             __builtin_amdgcn_sched_barrier(0);
             // (all computing waves are past their reads of step t - 1: its slot takes step t + 3)
             if (t + 3 < STEPS) issue(ci, t + 3); else issue(ci + 1, t + 3 - STEPS);
+            if (FFD_ROLL && t == NA) __builtin_amdgcn_s_barrier();  // the computing waves' G-tile barrier (between their barriers of steps NA and NA + 1)
         }
     }
     wait_vm<0>();                  // the fillers
@@ -439,6 +443,204 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     };
     load_b1(0);
 
+#if FFD_ROLL
+    {
+        // ROLLING FRAGMENT READS (round 5). In the loop below a step is [barrier | ten reads | wait | 18 / 27 MFMAs]: the reads' latency and the
+        // barrier skew sit in front of every step's MFMAs - stamps of scripts/micro/ffn12d.hip: 850 - 880 cycles per A-step against 576 of MFMA
+        // issue per SIMD, 1030 - 1100 per B-step against 864. There is no register set to read a step ahead into (168 registers), but none is
+        // needed: a fragment register is re-read for the NEXT step right behind the last MFMA of THIS step that uses it. The three sweeps run
+        // hi x lo, hi x hi, lo x hi, so the operands of the next step's first sweep (weights hi, rows lo) are free - and re-read - earliest,
+        // twelve or more MFMAs ahead of their use. The barrier of step t + 1 moves INTO step t (behind its second MFMA: everything this wave read
+        // from slot t is in registers since step t - 1; what it reads behind the barrier comes from slot t + 1, landed). The DMA waves' protocol
+        // is unchanged: their barrier s still means "step s has landed, its predecessor's slot is read out". Skeleton: 640 - 660 / 900 - 960
+        // cycles per A- / B-step, 234 k instead of 270 k cycles per launch (scripts/micro/ffn12d.hip -DROLL=1). The hi x lo product is now
+        // added first (it was last): same terms, another rounding order.
+        u32x4 wh[2], wl[2], xh[3], xl[3];  // A-step fragments
+        u32x4 bwh[3], bwl[3];              // B-step weight fragments (bgh / bgl: the G fragments)
+        step_barrier();  // the barrier of step 0
+        {
+            const int ua = opaque_s(u_a), ux = opaque_s(u_x);
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) { wh[nf] = rd(lane_hi, ua, nf * 2048); wl[nf] = rd(lane_lo, ua, nf * 2048); }
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) { xl[rf] = rd(lane_lo, ux, rf * 2048); xh[rf] = rd(lane_hi, ux, rf * 2048); }
+        }
+        for (int ci = 0; ci < nchunks; ++ci) {
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf];
+            load_b1(ci + 1);
+            // ---- A-steps: P += x[:, kb] W1[chunk, kb]^T, wave tile 48 rows x 32 units
+#pragma unroll
+            for (int t = 0; t < NA; ++t) {
+                const int sn = ((t + 1) & 3) * SLOTB;  // slot of the next step (t + 1 == NA: the first B-step's, weights only - its G fragments follow the GELU)
+                const int ua_n = opaque_s(u_a + sn), ux_n = opaque_s(u_x + sn), ub_n = opaque_s(u_b + sn);
+                const bool na = t + 1 < NA;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {  // hi x lo
+                    const int rf = i >> 1, nf = i & 1;
+                    pacc[rf][nf] = mma(wh[nf], xl[rf], pacc[rf][nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i == 1) step_barrier();  // the barrier of step t + 1
+                    if (na && nf == 1) xl[rf] = rd(lane_lo, ux_n, rf * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {  // hi x hi
+                    const int rf = i >> 1, nf = i & 1;
+                    pacc[rf][nf] = mma(wh[nf], xh[rf], pacc[rf][nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (rf == 2) { if (na) wh[nf] = rd(lane_hi, ua_n, nf * 2048); else bwh[nf] = rd(lane_hi, ub_n, nf * 2048); }
+                    if (!na && i == 5) bwh[2] = rd(lane_hi, ub_n, 2 * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {  // lo x hi
+                    const int rf = i >> 1, nf = i & 1;
+                    pacc[rf][nf] = mma(wl[nf], xh[rf], pacc[rf][nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (na && nf == 1) xh[rf] = rd(lane_hi, ux_n, rf * 2048);
+                    if (rf == 2) { if (na) wl[nf] = rd(lane_lo, ua_n, nf * 2048); else bwl[nf] = rd(lane_lo, ub_n, nf * 2048); }
+                    if (!na && i == 5) bwl[2] = rd(lane_lo, ub_n, 2 * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- GELU(P) -> (hi, lo) -> G tile (gelu_erfc_as of pp_split.h, Abramowitz & Stegun 7.1.26: same operations in the same
+            // order per value as pp_ffn_split.hip). The G tile is free: the previous chunk's B-steps ended before this chunk's A-steps.
+            // Lane holds units 32 cg + 16 nf + 4 f_kg + (0..3) of its rows: k-block cg of the chunk, 16-byte chunk 2 nf + (f_kg >> 1)
+            // (+ 4 for lo), upper or lower 8 bytes.
+    #pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+    #pragma unroll
+                for (int nf = 0; nf < 2; ++nf) {
+                    char* gs = smem + OFF_G + cg * G_KB + (rows0 + rf * 16) * 128 + (f_kg & 1) * 8;
+                    const int c = 2 * nf + (f_kg >> 1);
+    #if FFD_GELU_PACKED
+                    // Round 5: the chunk's GELU is ~3.4 k of its ~22 k cycles (stamps of scripts/micro/ffn12d.hip -DSTAMP=1), VALU-bound with both
+                    // computing waves of a SIMD issuing at once, and it cannot be hidden behind MFMAs of the same SIMD (scripts/micro/ffn_skew_form.hip).
+                    // What is left is fewer issue cycles per value (scripts/micro/valu_rate.hip, cycles per wave64 instruction and SIMD: plain fp32
+                    // 3.0, v_pk_*_f32 4.9 for TWO values, v_rcp / v_exp 8.5, v_cvt 4.5, v_cvt_pk_f16_f32 and v_fma_mix_f32 4.7): the same A & S 7.1.26
+                    // form on value PAIRS with packed fp32 instructions (constants folded: 1 + p z = 1 + (p / sqrt 2) |x|, exp(-z^2) =
+                    // exp2(-(x sqrt(log2(e) / 2))^2), max(x, 0) = 0.5 x + 0.5 |x| exactly) and the lo half as g - hi by ONE v_fma_mix_f32 that
+                    // reads hi straight from the packed fp16 pair (exact: the same difference as convert-back-and-subtract): ~56 instead of ~76
+                    // issue cycles per value. |difference to the unpacked form| ~1e-7 relative (rounding of the folded constants).
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                    unsigned hq[2], lq[2];
+    #pragma unroll
+                    for (int u0 = 0; u0 < 2; ++u0) {
+                        const f32x2 x = {pacc[rf][nf][2 * u0], pacc[rf][nf][2 * u0 + 1]};
+                        const f32x2 ax = __builtin_elementwise_abs(x);
+                        const f32x2 d = ax * 0.23164189265f + 1.0f;  // 0.3275911 / sqrt 2
+                        const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                        const f32x2 uu = x * 0.84932180028801904272f;  // sqrt(log2(e) / 2)
+                        const f32x2 u2 = uu * uu;
+                        const f32x2 e = {__builtin_amdgcn_exp2f(-u2[0]), __builtin_amdgcn_exp2f(-u2[1])};
+                        f32x2 q = t * 1.061405429f + -1.453152027f;
+                        q = t * q + 1.421413741f;
+                        q = t * q + -0.284496736f;
+                        q = t * q + 0.254829592f;
+                        const f32x2 erfc_z = (t * q) * e;
+                        const f32x2 ma = ax * -0.5f;
+                        const f32x2 mx = x * 0.5f - ma;  // = max(x, 0), exactly
+                        f32x2 g = ma * erfc_z + mx;
+                        asm("" : "+v"(g));  // (split_pin: no fusion of the arithmetic into the conversions)
+                        const f16x2 hp = __builtin_convertvector(g, f16x2);  // v_cvt_pk_f16_f32, round to nearest even
+                        const unsigned hu = __builtin_bit_cast(unsigned, hp);
+                        f32x2 l;
+                        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l[0]) : "v"(g[0]), "v"(hu));
+                        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l[1]) : "v"(g[1]), "v"(hu));
+                        hq[u0] = hu;
+                        lq[u0] = __builtin_bit_cast(unsigned, __builtin_convertvector(l, f16x2));
+                    }
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u32x2_t*>(gs + ((c ^ sw) << 4)) = u32x2_t{hq[0], hq[1]};
+                    *reinterpret_cast<u32x2_t*>(gs + (((4 + c) ^ sw) << 4)) = u32x2_t{lq[0], lq[1]};
+    #else
+                    f16x4 hv, lv;
+                    float x[4], z[4], tt[4], qq[4], e[4];
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = pacc[rf][nf][u];
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) z[u] = fabsf(x[u]) * 0.70710678118654752440f;
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) tt[u] = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z[u], 1.0f));
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) e[u] = __builtin_amdgcn_exp2f(-(z[u] * z[u]) * 1.44269504088896340736f);
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], 1.061405429f, -1.453152027f);
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], 1.421413741f);
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], -0.284496736f);
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], 0.254829592f);
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float erfc_z = tt[u] * qq[u] * e[u];
+    #if FFD_GELU_RELU_FORM
+                        // 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2): no compare / select, two instructions less per value
+                        float g = __builtin_fmaf(-0.5f * fabsf(x[u]), erfc_z, fmaxf(x[u], 0.f));
+    #else
+                        float g = 0.5f * x[u] * (x[u] < 0.f ? erfc_z : 2.0f - erfc_z);
+    #endif
+                        split_pin(g);
+                        hv[u] = split_hi(g);
+                        lv[u] = split_lo(g, hv[u]);
+                    }
+                    *reinterpret_cast<f16x4*>(gs + ((c ^ sw) << 4)) = hv;
+                    *reinterpret_cast<f16x4*>(gs + (((4 + c) ^ sw) << 4)) = lv;
+    #endif
+                }
+            step_barrier();  // the G tile is complete (an extra barrier: the DMA waves pass it behind their barrier of step NA)
+            {
+                const int ug = opaque_s(u_g);
+#pragma unroll
+                for (int rf = 0; rf < 3; ++rf) { bgl[rf] = rd(lane_lo, ug, rf * 2048); bgh[rf] = rd(lane_hi, ug, rf * 2048); }
+            }
+            // ---- B-steps (j, half): acc[:, half] += G[:, j] W2[half, chunk j]^T, wave tile 48 rows x 48 outputs
+#pragma unroll
+            for (int sb = 0; sb < NB; ++sb) {
+                const int half = sb & 1;
+                const int sn = ((NA + sb + 1) & 3) * SLOTB;
+                const int ub_n = opaque_s(u_b + sn), ua_n = opaque_s(u_a + sn), ux_n = opaque_s(u_x + sn);
+                const int ug_n = opaque_s(u_g + (((sb >> 1) + 1) & 3) * G_KB);
+                const bool nb = sb + 1 < NB;         // the next step is a B-step ...
+                const bool newg = nb && half == 1;   // ... of the next k-block: new G fragments
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {  // hi x lo
+                    const int rf = i / 3, nf = i % 3;
+                    acc[rf][half * 3 + nf] = mma(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i == 1 && (nb || ci + 1 < nchunks)) step_barrier();  // (the launch's last step has no successor: the epilogue's E1 is the DMA waves' next barrier)
+                    if (nf == 2) { if (newg) bgl[rf] = rd(lane_lo, ug_n, rf * 2048); else if (!nb) xl[rf] = rd(lane_lo, ux_n, rf * 2048); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {  // hi x hi
+                    const int rf = i / 3, nf = i % 3;
+                    acc[rf][half * 3 + nf] = mma(bwh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (rf == 2) { if (nb) bwh[nf] = rd(lane_hi, ub_n, nf * 2048); else if (nf < 2) wh[nf] = rd(lane_hi, ua_n, nf * 2048); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {  // lo x hi
+                    const int rf = i / 3, nf = i % 3;
+                    acc[rf][half * 3 + nf] = mma(bwl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nf == 2) { if (newg) bgh[rf] = rd(lane_hi, ug_n, rf * 2048); else if (!nb) xh[rf] = rd(lane_hi, ux_n, rf * 2048); }
+                    if (rf == 2) { if (nb) bwl[nf] = rd(lane_lo, ub_n, nf * 2048); else if (nf < 2) wl[nf] = rd(lane_lo, ua_n, nf * 2048); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+#else
+
     for (int ci = 0; ci < nchunks; ++ci) {
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
@@ -580,6 +782,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             b_step((NA + sb) & 3, sb & 1, sb >> 1, (sb & 1) == 0);
         }
     }
+#endif
     // ---- LayerNorm epilogue: G is out of use once every wave is past its last B-step
     __syncthreads();  // E1
     layernorm_rows(p.gamma, p.beta, p.x_out, p.h_out, true);

@@ -45,7 +45,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef STAMP
 #define STAMP 0  // 1: wave 0 of workgroup 5 stamps s_memtime at the top of every step of chunk 6 (+ launch start / end with the 100 MHz counter)
 #endif
-#ifndef ABL  // timing-only ablations: 1 no DMA traffic (empty descriptors), 4 no MFMA, 16 no DMA instructions at all (the whole LDS holds a random pattern: same MFMA
+#ifndef ABL  // timing-only ablations: 1 no DMA traffic (empty descriptors), 4 no MFMA, 128 no x pieces, 256 no weight pieces (as 16, for one kind), 16 no DMA instructions at all (the whole LDS holds a random pattern: same MFMA
              // operand toggling and fragment reads, no L2 -> LDS fill), 32 every workgroup streams the SAME x rows (x pieces L2-hot), 64 all pieces from the first 28 KiB of the weight stream
 #define ABL 0
 #endif
@@ -85,9 +85,9 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
     const bool dma_wave = MODE == 1 && wv >= CW;
     const int rg = (wv >> 2) & 1, cg = wv & 3;
     const int f_row = lane & 15, f_kg = lane >> 4;
-    const int m0 = blockIdx.x * BM;
+    const int m0 = (ABL & 32) ? 0 : blockIdx.x * BM;
     char* const ring = smem + OFF_RING;
-    for (int i = tid; i < ((ABL & 16) ? LDS : 4 * G_KB) / 4; i += THREADS) reinterpret_cast<unsigned*>(smem)[i] = 0x2c003c00u + ((i * 2654435761u) >> 13 & 0x83ff03ffu);
+    for (int i = tid; i < ((ABL & (16 | 128 | 256)) ? LDS : 4 * G_KB) / 4; i += THREADS) reinterpret_cast<unsigned*>(smem)[i] = 0x2c003c00u + ((i * 2654435761u) >> 13 & 0x83ff03ffu);
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wpack), 0, (ABL & 1) ? 0u : w_bytes, 0x00020000);
@@ -100,6 +100,8 @@ __global__ __launch_bounds__(THREADS, WAVES / 4) void ffn12d_kernel(const char* 
     // piece q of step t of chunk ci -> slot t & 3.  A-step: q < 16 W1 pieces, 16 .. 27 x pieces; B-step: 24 W2 pieces
     auto piece = [&](int ci, int t, int q) {
         if (ABL & 16) return;
+        if ((ABL & 128) && t < NA && q >= 16) return;             // no x pieces (their slot bytes keep the random pattern)
+        if ((ABL & 256) && !(t < NA && q >= 16)) return;          // no weight pieces
         char* dst = ring + (t & 3) * SLOTB;
         const int base = chunk_of(ci % NCH) * CHUNK_BYTES;
         if (t < NA) {
