@@ -407,6 +407,58 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     if constexpr (PROJ) {
         // ---- attention output projection + residual, then ln2:  acc <- x + att Wp^T + bp ;  h <- LN2(acc). 24 steps shaped like
         // the B-steps: step s = 2 kb + half takes the Wp half block from ring slot s & 3, the attention rows' k-block kb from G buffer kb & 3
+#if FFD_ROLL
+        // (rolling fragment reads as in the FFN loop below: the same three sweeps, the barrier of step s + 1 behind the second MFMA of step s)
+        {
+            u32x4 pwh[3], pwl[3];
+            step_barrier();  // the barrier of step 0
+            {
+                const int ub = opaque_s(u_b), ug = opaque_s(u_g);
+#pragma unroll
+                for (int nf = 0; nf < 3; ++nf) { pwh[nf] = rd(lane_hi, ub, nf * 2048); pwl[nf] = rd(lane_lo, ub, nf * 2048); }
+#pragma unroll
+                for (int rf = 0; rf < 3; ++rf) { bgl[rf] = rd(lane_lo, ug, rf * 2048); bgh[rf] = rd(lane_hi, ug, rf * 2048); }
+            }
+#pragma unroll 1
+            for (int kp = 0; kp < NPROJ / 4; ++kp) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int half = q & 1;
+                    const int ub_n = opaque_s(u_b + ((q + 1) & 3) * SLOTB);
+                    const int ug_n = opaque_s(u_g + ((((4 * kp + q) >> 1) + 1) & 3) * G_KB);
+                    const bool nb = q < 3 || kp + 1 < NPROJ / 4;  // a step follows
+                    const bool newg = nb && half == 1;             // ... of the next k-block: new attention-row fragments
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {  // hi x lo
+                        const int rf = i / 3, nf = i % 3;
+                        acc[rf][half * 3 + nf] = mma(pwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (i == 1 && nb) step_barrier();
+                        if (nf == 2 && newg) bgl[rf] = rd(lane_lo, ug_n, rf * 2048);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {  // hi x hi
+                        const int rf = i / 3, nf = i % 3;
+                        acc[rf][half * 3 + nf] = mma(pwh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (rf == 2 && nb) pwh[nf] = rd(lane_hi, ub_n, nf * 2048);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {  // lo x hi
+                        const int rf = i / 3, nf = i % 3;
+                        acc[rf][half * 3 + nf] = mma(pwl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (nf == 2 && newg) bgh[rf] = rd(lane_hi, ug_n, rf * 2048);
+                        if (rf == 2 && nb) pwl[nf] = rd(lane_lo, ub_n, nf * 2048);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+#else
 #pragma unroll 1
         for (int kp = 0; kp < NPROJ / 4; ++kp) {
 #pragma unroll
@@ -415,6 +467,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 b_step(q, q & 1, ((4 * kp + q) >> 1) & 3, (q & 1) == 0);
             }
         }
+#endif
         // + bp (after the sums, as residual + (sum + bias) rounds closest to the reference's x + proj(...))
 #pragma unroll
         for (int cf = 0; cf < 6; ++cf) {

@@ -695,8 +695,8 @@ def test_proj_ffn_split_two_streams_under_contention(ffn_form):
 def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_):
     """pp_set_option("ffn_dma_waves", 1) routes both fused feed-forward entry points to the twelve-wave kernel (pp_ffn_dma.hip:
     eight computing waves + four DMA waves). Held to the same fp64 references and tolerances as the eight-wave kernel above, in
-    place as the engine calls them, a ragged last tile included; the two forms agree to rounding (same sums in the same order,
-    the compiler contracts the LayerNorm arithmetic differently); repeated launches bit-identical, also when two launches share
+    place as the engine calls them, a ragged last tile included; the two forms agree to rounding (the same terms, summed in another
+    order since round 5); repeated launches bit-identical, also when two launches share
     the chip (what two steps in flight create)."""
     L = _lib()
     E = 384
@@ -740,8 +740,10 @@ def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_):
         torch.testing.assert_close(_unsp(want_p[2]), h_mid, **TOL)
         torch.testing.assert_close(want_p[0].double(), xp_ref, rtol=3e-5, atol=3e-5)
         torch.testing.assert_close(_unsp(want_p[1]), hp_ref, rtol=3e-5, atol=3e-5)
-        torch.testing.assert_close(want_f[0], eight_f[0], rtol=2e-6, atol=2e-6)
-        torch.testing.assert_close(want_p[0], eight_p[0], rtol=2e-6, atol=2e-6)
+        # (round 5: the twelve-wave kernel adds a block's hi x lo product FIRST - rolling fragment reads - the eight-wave one last: the same
+        # terms in another order; 2 of 9.4 M outputs of the bs 64 shape differ by 2.9e-6, the rest by < 2e-6)
+        torch.testing.assert_close(want_f[0], eight_f[0], rtol=5e-6, atol=5e-6)
+        torch.testing.assert_close(want_p[0], eight_p[0], rtol=5e-6, atol=5e-6)
         for _ in range(3):
             assert same([t.cpu() for t in ffn()], want_f), "FFN form: run-to-run difference"
             assert same([t.cpu() for t in proj()], want_p), "projection + FFN form: run-to-run difference"
