@@ -74,13 +74,9 @@ __device__ __forceinline__ void wait_vm_lgkm() {
 // (hi, lo) of four values of an accumulator fragment, regrouped by the row swap of split_store4_rowpair: the even-row lane
 // (bit 4 of the lane id clear) gets the 16-byte hi chunk of the pair's eight elements, the odd-row lane the lo chunk
 __device__ __forceinline__ u32x4 split_pair16(f32x4 v) {
-    f16x4 h, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = split_hi(v[j]);
-        l[j] = split_lo(v[j], h[j]);
-    }
-    const u32x2 hu = __builtin_bit_cast(u32x2, h), lu = __builtin_bit_cast(u32x2, l);
+    u32x2 hu, lu;
+    { unsigned h__, l__; split_pair(v[0], v[1], h__, l__); hu[0] = h__; lu[0] = l__; }
+    { unsigned h__, l__; split_pair(v[2], v[3], h__, l__); hu[1] = h__; lu[1] = l__; }
     const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
     const auto s1 = __builtin_amdgcn_permlane16_swap(hu[1], lu[1], false, false);
     return u32x4{s0[0], s1[0], s0[1], s1[1]};
@@ -218,14 +214,11 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
                 for (int rf = 0; rf < 3; ++rf) {
                     const int t0 = 48 * rg + 16 * rf + 4 * fg;
                     const f32x4 v = acc[cf][rf] + bs;
-                    f16x4 hv, lv;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        hv[j] = split_hi(v[j]);
-                        lv[j] = split_lo(v[j], hv[j]);
-                    }
-                    *reinterpret_cast<f16x4*>(Vh + d * SPV + t0) = hv;
-                    *reinterpret_cast<f16x4*>(Vl + d * SPV + t0) = lv;
+                    u32x2 hv, lv;
+                    { unsigned h__, l__; split_pair(v[0], v[1], h__, l__); hv[0] = h__; lv[0] = l__; }
+                    { unsigned h__, l__; split_pair(v[2], v[3], h__, l__); hv[1] = h__; lv[1] = l__; }
+                    *reinterpret_cast<u32x2*>(Vh + d * SPV + t0) = hv;
+                    *reinterpret_cast<u32x2*>(Vl + d * SPV + t0) = lv;
                 }
             }
         }
@@ -280,14 +273,12 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
         for (int blk = 0; blk < NT / 2; ++blk) {
             if (blk % 2 == 0) __builtin_amdgcn_sched_barrier(0);
             const f32x4 p0 = s[2 * blk], p1 = s[2 * blk + 1];
-            f16x8 ph, pl;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ph[j] = split_hi(p0[j]);
-                pl[j] = split_lo(p0[j], ph[j]);
-                ph[4 + j] = split_hi(p1[j]);
-                pl[4 + j] = split_lo(p1[j], ph[4 + j]);
-            }
+            u32x4 phu, plu;
+            { unsigned h__, l__; split_pair(p0[0], p0[1], h__, l__); phu[0] = h__; plu[0] = l__; }
+            { unsigned h__, l__; split_pair(p0[2], p0[3], h__, l__); phu[1] = h__; plu[1] = l__; }
+            { unsigned h__, l__; split_pair(p1[0], p1[1], h__, l__); phu[2] = h__; plu[2] = l__; }
+            { unsigned h__, l__; split_pair(p1[2], p1[3], h__, l__); phu[3] = h__; plu[3] = l__; }
+            const f16x8 ph = __builtin_bit_cast(f16x8, phu), pl = __builtin_bit_cast(f16x8, plu);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int off = (dt * 16 + fr) * SPV + blk * 32 + 4 * fg;

@@ -34,6 +34,24 @@ __device__ __forceinline__ _Float16 split_lo(float x, _Float16 hi) { return (_Fl
 // scripts/micro/mix_denorm_probe.hip). With the vectoriser on the conversions pair up into v_cvt_pk_f16_f32 and the pattern never forms.
 __device__ __forceinline__ void split_pin(float& x) { asm("" : "+v"(x)); }
 
+// (hi, lo) of a PAIR of values in 4 VALU instructions instead of 8 (round 5; issue cycles per wave64 instruction and SIMD, scripts/micro/
+// valu_rate.hip: v_cvt_f16_f32 / v_cvt_f32_f16 4.5, v_cvt_pk_f16_f32 and v_fma_mix_f32 4.7, v_sub_f32 3.0): the two hi halves by one
+// v_cvt_pk_f16_f32 (round to nearest even, like the single conversion), each lo half as fp16(g - hi) where g - hi is ONE v_fma_mix_f32
+// that reads hi straight out of the packed pair (fma(g, 1.0, -hi): exact, the same fp32 difference as convert-back-and-subtract - NOT the
+// fused product form of the trap described above: g is a finished fp32 value here), packed by a second v_cvt_pk_f16_f32.
+// hi = {fp16(a) | fp16(b) << 16}, lo likewise.
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    asm("" : "+v"(a));
+    asm("" : "+v"(b));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, f16x2_t));
+    float la, lb;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(la) : "v"(a), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(b), "v"(hi));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{la, lb}, f16x2_t));
+}
+
 // address of the hi half of element `idx` of a split tensor (the lo half lives 64 bytes further)
 __device__ __forceinline__ char* split_addr(void* base, size_t idx) {
     return reinterpret_cast<char*>(base) + (idx >> 5) * 128 + (idx & 31) * 2;
@@ -59,15 +77,11 @@ __device__ __forceinline__ void split_store4(void* base, size_t idx, split_f32x4
 // (v_permlane16_swap) gives the even-row lane the whole hi chunk and the odd-row lane the whole lo chunk - ONE 16-byte store
 // per lane instead of two 8-byte ones. Every lane of the wave must call it; `store` masks the store itself.
 __device__ __forceinline__ void split_store4_rowpair(void* base, size_t idx, split_f32x4 v, bool store) {
-    f16x4 h, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = split_hi(v[j]);
-        l[j] = split_lo(v[j], h[j]);
-    }
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    const u32x2_t hu = __builtin_bit_cast(u32x2_t, h), lu = __builtin_bit_cast(u32x2_t, l);
+    u32x2_t hu, lu;
+    { unsigned h__, l__; split_pair(v[0], v[1], h__, l__); hu[0] = h__; lu[0] = l__; }
+    { unsigned h__, l__; split_pair(v[2], v[3], h__, l__); hu[1] = h__; lu[1] = l__; }
     // swap(a, b): odd rows of a <-> even rows of b. Even-row lane: (own hi, partner's hi); odd-row lane: (partner's lo, own lo)
     const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
     const auto s1 = __builtin_amdgcn_permlane16_swap(hu[1], lu[1], false, false);
