@@ -51,6 +51,87 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+
+#ifndef LDM_ROLL_PERSISTENT
+#define LDM_ROLL_PERSISTENT 0  // the persistent kernel keeps round 4's loop: with the rolling one its qkv / fc1 launches measured 1.3 % SLOWER (15.45 -> 15.65 ms
+                               // per config 4 step; the DMA waves hold 144 registers of tile there and spill 16 instead of 8), the one-tile kernel 3.7 % faster
+#endif
+#ifndef LDM_ROLL
+#define LDM_ROLL 1  // rolling fragment reads in the K loop (round 5, as pp_ffn_dma.hip): 0 = round 4's barrier | 18 reads | 54 MFMAs steps
+#endif
+
+// K loop of a computing wave with ROLLING fragment reads (pp_ffn_dma.hip, round 5): the 18 fragment registers of a step are re-read for
+// the next stage right behind the last MFMA of this step that uses them - sweeps hi x lo, hi x hi, lo x hi, so the first sweep's operands
+// (weights hi, rows lo) are free earliest - and the barrier of stage k + 1 sits inside step k, behind the first row fragment's six MFMAs:
+// by then this wave's reads of stage k (issued during step k - 1) have long returned, so the lgkmcnt(0) in front of the barrier costs
+// nothing, and what is read behind it comes from stage k + 1, landed. The DMA waves' protocol is unchanged (their barrier k = "stage k has
+// landed, stage k - 1 is read out"). `ks` >= 1 steps; stage s sits in ring slot s % NSTAGE.
+__device__ __forceinline__ void k_loop_roll(f32x4 (&acc)[3][6], const char* smem, int lane_hi, int lane_lo, int rg, int cg, int ks) {
+    auto opq = [](int v) { asm volatile("" : "+s"(v)); return v; };
+    auto rd = [&](int lane_off, int uni, int imm) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + (lane_off + uni) + imm); };
+    auto bar = []() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));  // lgkmcnt(0): this wave's reads of the stage the barrier frees
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    u32x4 ah[3], al[3], bh[6], bl[6];
+    bar();  // stage 0 has landed
+    {
+        const int ua = opq(rg * 48 * 128), ub = opq(B_OFF + cg * 96 * 128);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bh[j] = rd(lane_hi, ub, j * 2048);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) al[i] = rd(lane_lo, ua, i * 2048);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ah[i] = rd(lane_hi, ua, i * 2048);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bl[j] = rd(lane_lo, ub, j * 2048);
+    }
+    int st = 0;
+    auto step = [&](bool more) {
+        const int sn = st + 1 == NSTAGE ? 0 : st + 1;
+        const int ua = opq(sn * STAGE + rg * 48 * 128), ub = opq(sn * STAGE + B_OFF + cg * 96 * 128);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {  // hi x lo
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                acc[i][j] = mma(bh[j], al[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) {
+                if (i == 0) bar();  // the barrier of stage k + 1
+                if (i >= 1) al[i - 1] = rd(lane_lo, ua, (i - 1) * 2048);
+                if (i == 2) al[2] = rd(lane_lo, ua, 2 * 2048);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)  // hi x hi
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                acc[i][j] = mma(bh[j], ah[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && i == 2) bh[j] = rd(lane_hi, ub, j * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)  // lo x hi
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                acc[i][j] = mma(bl[j], ah[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && j == 5) ah[i] = rd(lane_hi, ua, i * 2048);
+                if (more && i == 2) bl[j] = rd(lane_lo, ub, j * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        st = sn;
+    };
+    for (int k = 0; k + 1 < ks; ++k) step(true);
+    step(false);
+}
+
 __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -116,6 +197,9 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if LDM_ROLL
+    k_loop_roll(acc, smem, lane_hi, lane_lo, rg, cg, ksteps);
+#else
     int st = 0;
     for (int k = 0; k < ksteps; ++k) {
         __builtin_amdgcn_sched_barrier(0);
@@ -146,6 +230,8 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
             for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], al[i], acc[i][j]);
         st = st + 1 == NSTAGE ? 0 : st + 1;
     }
+
+#endif
 
     // ---------------- epilogue: act_fn(sum + bias) + residual, rows out as split fp16 (two 8-byte halves per lane) or fp32 (16 bytes).
     // Output addressing through a buffer descriptor that ends at row M: the row part of the offset in the VGPR (range-checked), the
@@ -355,6 +441,9 @@ __global__ __launch_bounds__(THREADS) void linear_dma_persistent_kernel(const Pa
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if LDM_ROLL_PERSISTENT
+        k_loop_roll(acc, smem, lane_hi, lane_lo, rg, cg, ksteps);
+#else
         int st = 0;
         for (int k = 0; k < ksteps; ++k) {
             bar();
@@ -383,6 +472,7 @@ __global__ __launch_bounds__(THREADS) void linear_dma_persistent_kernel(const Pa
                 for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], al[i], acc[i][j]);
             st = st + 1 == NSTAGE ? 0 : st + 1;
         }
+#endif
         bar();  // X1
         {
             char* dst = smem + (rg * 48 + f_row) * H_PITCH + (cg * 96 + f_kg * 4) * 4;
