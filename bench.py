@@ -232,8 +232,9 @@ def pmc_traffic(kernel_mangled, precision, B, prefix=""):
              "_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE": "pp::ffd::proj_ffn_dma_kernel(",
              "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE": "pp::qka::qkv_attention_split_kernel("}.get(kernel_mangled)
     short = short or {"_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1ELi2ELb0ELb0EEEvNS_10GemmParamsE": "void pp::psplit::panel_split_kernel<0, 8, 3, true, 2, false, false>("}.get(kernel_mangled)
-    names = (f"r04_{prefix}{precision}_bs64_hbm_traffic.json",) if prefix else \
-        (f"r04_{precision}_bs64_hbm_traffic.json", f"r03_{precision}_bs64_hbm_traffic.json", f"r02_{precision}_bs64_hbm_traffic.json", f"r01_{precision}_bs64_hbm_traffic.json")
+    names = (f"r05_{prefix}{precision}_bs64_hbm_traffic.json", f"r04_{prefix}{precision}_bs64_hbm_traffic.json") if prefix else \
+        (f"r05_{precision}_bs64_hbm_traffic.json", f"r04_{precision}_bs64_hbm_traffic.json", f"r03_{precision}_bs64_hbm_traffic.json",
+         f"r02_{precision}_bs64_hbm_traffic.json", f"r01_{precision}_bs64_hbm_traffic.json")
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         try:

@@ -1,3 +1,9 @@
+// dev record (round 5, stamped NEGATIVE as built): pp_ffn_dma.hip with hidden chunks in PAIRS that share every streamed x k-block (template parameter PAIR, option
+// "ffn_pair"): A-steps [W1(c0, kb) + x(kb)] [W1(c1, kb)], the x fragments stay in registers for the second step, x is streamed 6 instead of 12 times per launch.
+// On paper 160 - 166 live registers everywhere; the register allocator does not find it at the 168 a twelve-wave workgroup allows: 244 - 268 spilled registers with the
+// 40 steps of a pair unrolled, 146 with the k-blocks as run-time loops (the first sweep of a step then writes RENAMED accumulators: +24 registers in the A loop). With
+// the spills: 248 us against 158 (FFN), 272 against 182 (proj + FFN). The idea stands (fill ablations: the x pieces cost 9 % of the loop time), the build does not.
+// Not built by the Makefile.
 // The fused f16x3 feed-forward launch of pp_ffn_split.hip (same packed weight streams, same sums in the same order; the two agree
 // to rounding - the GELU here is written max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2), two instructions shorter) with the LDS-DMA issue
 // taken OUT of the computing waves:
@@ -88,6 +94,8 @@ __device__ __forceinline__ void wait_vm_n(int n) {
         case 6: wait_vm<6>(); break;
         case 7: wait_vm<7>(); break;
         case 9: wait_vm<9>(); break;
+        case 10: wait_vm<10>(); break;
+        case 11: wait_vm<11>(); break;
         case 12: wait_vm<12>(); break;
         case 13: wait_vm<13>(); break;
         case 14: wait_vm<14>(); break;
@@ -106,7 +114,7 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
 // ---------------------------------------------------------------- DMA waves
 // Barrier protocol (every wave of the workgroup executes the same sequence of s_barrier):
 //   PROJ: 24 step barriers | P1 | LayerNorm 2 | P2 ;   main: 20 per chunk | E1 | LayerNorm 2
-template <bool PROJ>
+template <bool PROJ, bool PAIR>
 __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int lane, int m0, int nchunks, int c_rot) {
     char* const ring = smem + OFF_RING;
     if (FFD_DMA_PRIO) __builtin_amdgcn_s_setprio(FFD_DMA_PRIO);
@@ -184,6 +192,60 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
             }
         }
     };
+    if constexpr (PAIR) {
+        // PAIRED chunks (see compute_role): a pair's 40 steps are  [W1(c0, kb) + x(kb)] [W1(c1, kb)]  x 12  |  B(c0) x 8  |  B(c1) x 8 ;
+        // 7 / 4 / 6 pieces per DMA wave and step. Same protocol per step.
+        const int npairs = nchunks >> 1;
+        auto issue2 = [&](int cp, int t) {
+            const bool live = cp < npairs;
+            const int cpl = live ? cp : 0;
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wpack), 0, live ? p.w_bytes : 0u, 0x00020000);
+            char* dst = ring + (t & 3) * SLOTB;
+            if (t < 2 * NA) {
+                int c = 2 * cpl + (t & 1) + c_rot;
+                c = c >= nchunks ? c - nchunks : c;
+                const int kb = (cp & 1) ? NA - 1 - (t >> 1) : (t >> 1);  // odd pair visits walk the k-blocks backwards
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = d + 4 * u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + q * 1024), 16, v_w, c * CHUNK_BYTES + kb * A_BLOCK + q * 1024, 0, 0);
+                }
+                if ((t & 1) == 0) {
+                    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.h), 0, live ? p.h_bytes : 0u, 0x00020000);
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int q = d + 4 * u;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(dst + X_OFF + q * 1024), 16, v_x, kb * 128 + q * 8 * E * 4, 0, 0);
+                    }
+                }
+            } else {
+                const int which = (t - 2 * NA) >> 3, sb = (t - 2 * NA) & 7;
+                int c = 2 * cpl + which + c_rot;
+                c = c >= nchunks ? c - nchunks : c;
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int q = d + 4 * u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + q * 1024), 16, v_w, c * CHUNK_BYTES + B_PART + sb * B_BLOCK + q * 1024, 0, 0);
+                }
+            }
+        };
+        constexpr int PS = 2 * STEPS;
+        auto n2 = [](int t) { t %= PS; return t < 2 * NA ? ((t & 1) == 0 ? 7 : 4) : 6; };
+        issue2(0, 0);
+        issue2(0, 1);
+        issue2(0, 2);
+        for (int cp = 0; cp < npairs; ++cp) {
+#pragma unroll
+            for (int t = 0; t < PS; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                wait_vm_n(n2(t + 1) + n2(t + 2));
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 3 < PS) issue2(cp, t + 3); else issue2(cp + 1, t + 3 - PS);
+                if (t == 2 * NA || t == 2 * NA + NB) __builtin_amdgcn_s_barrier();  // the computing waves' two G-tile barriers
+            }
+        }
+    } else {
     issue(0, 0);
     issue(0, 1);
     issue(0, 2);
@@ -199,6 +261,7 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
             if (FFD_ROLL && t == NA) __builtin_amdgcn_s_barrier();  // the computing waves' G-tile barrier (between their barriers of steps NA and NA + 1)
         }
     }
+    }
     wait_vm<0>();                  // the fillers
     __builtin_amdgcn_s_barrier();  // E1
     __builtin_amdgcn_s_barrier();  // LayerNorm
@@ -206,7 +269,7 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
 }
 
 // ---------------------------------------------------------------- computing waves
-template <bool PROJ>
+template <bool PROJ, bool PAIR>
 __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv, int lane, int m0, int nchunks, int c_rot) {
     const int rg = wv >> 2, cg = wv & 3;
     const int f_row = lane & 15, f_kg = lane >> 4;
@@ -285,8 +348,8 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     // of the descriptor's extent and are dropped by the hardware (the range check covers the VGPR offset, not the scalar one) -
     // the wave-uniform column part in the scalar offset: two address registers for the whole epilogue.
     auto layernorm_rows = [&](const float* gamma, const float* beta, float* x_dst, void* h_dst, bool store_x) {
-        // (row offsets recomputed here from an opaque copy of the lane id: kept as kernel-long constants they cost three registers through every step loop - with them the
-        // kernels spilled 3 - 8 registers around the loops, without them none)
+        // (row offsets recomputed here from an opaque copy of the lane id: kept as kernel-long constants they cost three registers the paired
+        // A-steps do not have)
         int ln_ = lane;
         asm volatile("" : "+v"(ln_));
         const int fk_ = ln_ >> 4;
@@ -599,6 +662,152 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             }
     };
 
+    if constexpr (PAIR) {
+        // PAIRED CHUNKS (round 5; needs an even number of chunks). The 96 x 384 block of x rows is re-streamed once per hidden chunk: 12 x 144 KiB per
+        // workgroup, 4.6 MB of rows per XCD and pass through a 4 MB L2 - about half of those re-reads come from beyond the L2 (counter traffic
+        // 395 MB per launch against 151 MB algorithmic), and the fill ablations of scripts/micro/ffn12d.hip price the x pieces at 9 % of the loop's
+        // TIME (the chip is power-limited: same cycles, 1.68 -> 1.82 GHz without them; 7.5 % of it is their coming from beyond the L2). Two chunks
+        // now share every x k-block: the A-steps of a pair run  [W1(c0, kb) + x(kb)] [W1(c1, kb)]  for kb = 0 .. 11, and with the rolling reads the
+        // x fragments simply STAY in their registers for the second step - no second read of the slot, no slot lifetime problem - so x is
+        // streamed six times per launch instead of twelve and the A-steps read a quarter less from LDS. Price: the second chunk's accumulators
+        // (24 registers) live through the first chunk's GELU and B-steps; the B-steps' fragments leave room for them (72 + 24 + 48 = 144).
+        f32x4 pacc1[3][2];  // P of the pair's second chunk (pacc: the first)
+        u32x4 wh[2], wl[2], xh[3], xl[3], bwh[3], bwl[3];
+        const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b1), 0, (unsigned)p.F * 4u, 0x00020000);
+        auto load_b1x = [&](int ci, f32x4 (&dst)[2]) __attribute__((always_inline)) {  // (descriptor + lane & 0x30: no 64-bit address kept alive through the B-steps)
+            const int c = chunk_of(ci < nchunks ? ci : 0);
+            int vo = lane;
+            asm volatile("" : "+v"(vo));
+            vo &= 0x30;
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) dst[nf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb1, vo, (c * CHUNK + cg * 32 + nf * 16) * 4, 0));
+        };
+        f32x4 b1w[2];  // the first chunk's bias is b1v (loaded above), the second's b1w
+        load_b1x(1, b1w);
+        step_barrier();  // the barrier of step 0
+        {
+            const int ua = opaque_s(u_a), ux = opaque_s(u_x);
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) { wh[nf] = rd(lane_hi, ua, nf * 2048); wl[nf] = rd(lane_lo, ua, nf * 2048); }
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) { xl[rf] = rd(lane_lo, ux, rf * 2048); xh[rf] = rd(lane_hi, ux, rf * 2048); }
+        }
+        // one A-step: the three sweeps into `pa`; `reload_x`: the row fragments are re-read for the next step (second step of a k-block);
+        // `to_b`: the next step is a B-step (its weight fragments instead of W1's)
+        auto a_step = [&](f32x4 (&pa)[3][2], int slot_next, bool reload_x, bool to_b) __attribute__((always_inline)) {
+            const int sn = (slot_next & 3) * SLOTB;
+            const int ua_n = opaque_s(u_a + sn), ux_n = opaque_s(u_x + sn), ub_n = opaque_s(u_b + sn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {  // hi x lo
+                const int rf = i >> 1, nf = i & 1;
+                pa[rf][nf] = mma(wh[nf], xl[rf], pa[rf][nf]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 1) step_barrier();  // the barrier of the next step
+                if (reload_x && !to_b && nf == 1) xl[rf] = rd(lane_lo, ux_n, rf * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {  // hi x hi
+                const int rf = i >> 1, nf = i & 1;
+                pa[rf][nf] = mma(wh[nf], xh[rf], pa[rf][nf]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rf == 2) { if (!to_b) wh[nf] = rd(lane_hi, ua_n, nf * 2048); else bwh[nf] = rd(lane_hi, ub_n, nf * 2048); }
+                if (to_b && i == 5) bwh[2] = rd(lane_hi, ub_n, 2 * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {  // lo x hi
+                const int rf = i >> 1, nf = i & 1;
+                pa[rf][nf] = mma(wl[nf], xh[rf], pa[rf][nf]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (reload_x && !to_b && nf == 1) xh[rf] = rd(lane_hi, ux_n, rf * 2048);
+                if (rf == 2) { if (!to_b) wl[nf] = rd(lane_lo, ua_n, nf * 2048); else bwl[nf] = rd(lane_lo, ub_n, nf * 2048); }
+                if (to_b && i == 5) bwl[2] = rd(lane_lo, ub_n, 2 * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // the eight B-steps of one chunk (its G tile complete, bwh / bwl of its first step in registers). `next`: what follows the last step -
+        // 0 the other chunk's B-steps (weights only: its G fragments come behind its GELU), 1 the next pair's first A-step. `more` (run time):
+        // there IS a next pair - the launch's very last step has no barrier inside (the epilogue's E1 is the DMA waves' next one); its
+        // prefetches still run (they read a slot of fillers): every path through the loop body redefines the fragment registers, so that
+        // none of them is carried, spilled, through the GELU and the B-steps
+        auto b_phase = [&](int t0, int next, bool more) __attribute__((always_inline)) {
+            {
+                const int ug = opaque_s(u_g);
+#pragma unroll
+                for (int rf = 0; rf < 3; ++rf) { bgl[rf] = rd(lane_lo, ug, rf * 2048); bgh[rf] = rd(lane_hi, ug, rf * 2048); }
+            }
+            // (the k-blocks as a run-time loop over one two-step body - the last one apart, for what follows it: forty fully unrolled steps
+            // per pair sent the register allocator into spilling half the accumulators)
+            auto two_steps = [&](int jb, bool last_kb) __attribute__((always_inline)) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int sb = 2 * jb + half;
+                    const int sn = ((t0 + sb + 1) & 3) * SLOTB;
+                    const int ub_n = opaque_s(u_b + sn), ua_n = opaque_s(u_a + sn), ux_n = opaque_s(u_x + sn);
+                    const int ug_n = opaque_s(u_g + ((jb + 1) & 3) * G_KB);
+                    const bool nb = !(last_kb && half == 1);
+                    const bool newg = nb && half == 1;
+                    const bool wnext = nb || next == 0;   // B-step weights follow
+                    const bool anext = !nb && next == 1;  // an A-step follows
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {  // hi x lo
+                        const int rf = i / 3, nf = i % 3;
+                        acc[rf][half * 3 + nf] = mma(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (i == 1 && (nb || next == 0 || more)) step_barrier();
+                        if (nf == 2) { if (newg) bgl[rf] = rd(lane_lo, ug_n, rf * 2048); else if (anext) xl[rf] = rd(lane_lo, ux_n, rf * 2048); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {  // hi x hi
+                        const int rf = i / 3, nf = i % 3;
+                        acc[rf][half * 3 + nf] = mma(bwh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (rf == 2) { if (wnext) bwh[nf] = rd(lane_hi, ub_n, nf * 2048); else if (anext && nf < 2) wh[nf] = rd(lane_hi, ua_n, nf * 2048); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {  // lo x hi
+                        const int rf = i / 3, nf = i % 3;
+                        acc[rf][half * 3 + nf] = mma(bwl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (nf == 2) { if (newg) bgh[rf] = rd(lane_hi, ug_n, rf * 2048); else if (anext) xh[rf] = rd(lane_hi, ux_n, rf * 2048); }
+                        if (rf == 2) { if (wnext) bwl[nf] = rd(lane_lo, ub_n, nf * 2048); else if (anext && nf < 2) wl[nf] = rd(lane_lo, ua_n, nf * 2048); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int jb = 0; jb < NB / 2 - 1; ++jb) two_steps(jb, false);
+            two_steps(NB / 2 - 1, true);
+        };
+        const int npairs = nchunks >> 1;
+        for (int cp = 0; cp < npairs; ++cp) {
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) { pacc[rf][nf] = b1v[nf]; pacc1[rf][nf] = b1w[nf]; }
+            // ---- A-steps of both chunks, k-block by k-block
+#pragma unroll 1
+            for (int kbi = 0; kbi < NA - 1; ++kbi) {  // (a run-time loop over one k-block's two steps; the last k-block apart: B-steps follow it)
+                a_step(pacc, 2 * kbi + 1, false, false);
+                a_step(pacc1, 2 * kbi + 2, true, false);
+            }
+            a_step(pacc, 2 * NA - 1, false, false);
+            a_step(pacc1, 2 * NA, true, true);
+            gelu_chunk(pacc);
+            step_barrier();  // the G tile is complete (the DMA waves pass it behind their barrier of step 2 NA)
+            load_b1x(2 * cp + 2, b1v);  // the next pair's biases, asked for while their sixteen registers are free
+            b_phase(2 * NA, 0, true);
+            gelu_chunk(pacc1);
+            step_barrier();  // (behind the DMA waves' barrier of step 2 NA + NB)
+            load_b1x(2 * cp + 3, b1w);
+            b_phase(2 * NA + NB, 1, cp + 1 < npairs);
+        }
+    } else {
 #if FFD_ROLL
     {
         // ROLLING FRAGMENT READS (round 5). In the loop below a step is [barrier | ten reads | wait | 18 / 27 MFMAs]: the reads' latency and the
@@ -767,12 +976,13 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
         }
     }
 #endif
+    }
     // ---- LayerNorm epilogue: G is out of use once every wave is past its last B-step
     __syncthreads();  // E1
     layernorm_rows(p.gamma, p.beta, p.x_out, p.h_out, true);
 }
 
-template <bool PROJ>
+template <bool PROJ, bool PAIR>
 __device__ __forceinline__ void body(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -780,19 +990,23 @@ __device__ __forceinline__ void body(const Params p) {
     const int m0 = blockIdx.x * BM;
     const int nchunks = p.F / CHUNK;
     const int c_rot = (int)(blockIdx.x & 7) % nchunks;  // the workgroups of an XCD walk the chunks in the same order
-    if (wv >= CW) dma_role<PROJ>(p, smem, wv - CW, lane, m0, nchunks, c_rot);
-    else compute_role<PROJ>(p, smem, wv, lane, m0, nchunks, c_rot);
+    if (wv >= CW) dma_role<PROJ, PAIR>(p, smem, wv - CW, lane, m0, nchunks, c_rot);
+    else compute_role<PROJ, PAIR>(p, smem, wv, lane, m0, nchunks, c_rot);
 }
 
-__global__ __launch_bounds__(THREADS) void ffn_dma_kernel(const Params p) { body<false>(p); }
-__global__ __launch_bounds__(THREADS) void proj_ffn_dma_kernel(const Params p) { body<true>(p); }
+__global__ __launch_bounds__(THREADS) void ffn_dma_kernel(const Params p) { body<false, false>(p); }
+__global__ __launch_bounds__(THREADS) void proj_ffn_dma_kernel(const Params p) { body<true, false>(p); }
+__global__ __launch_bounds__(THREADS) void ffn_dma_pair_kernel(const Params p) { body<false, true>(p); }
+__global__ __launch_bounds__(THREADS) void proj_ffn_dma_pair_kernel(const Params p) { body<true, true>(p); }
 
 }  // namespace ffd
 
 namespace ffs {
 // called from the entry points in pp_ffn_split.hip when the option "ffn_dma_waves" is on
 int launch_dma_form(const Params& p, bool proj, hipStream_t s) {
-    auto kern = proj ? ffd::proj_ffn_dma_kernel : ffd::ffn_dma_kernel;
+    // an even number of hidden chunks: the paired form (two chunks share every streamed x k-block); option "ffn_pair" = 0 or an odd count: one at a time
+    const bool pair = FFD_ROLL && option("ffn_pair") != 0 && (p.F / ffd::CHUNK) % 2 == 0;
+    auto kern = pair ? (proj ? ffd::proj_ffn_dma_pair_kernel : ffd::ffn_dma_pair_kernel) : (proj ? ffd::proj_ffn_dma_kernel : ffd::ffn_dma_kernel);
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ffd::LDS));
     hipLaunchKernelGGL(kern, dim3((p.M + ffd::BM - 1) / ffd::BM), dim3(ffd::THREADS), ffd::LDS, s, p);
     PP_LAUNCH_CHECK();
