@@ -1,9 +1,12 @@
-// dev record (round 5, stamped NEGATIVE as built): pp_ffn_dma.hip with hidden chunks in PAIRS that share every streamed x k-block (template parameter PAIR, option
-// "ffn_pair"): A-steps [W1(c0, kb) + x(kb)] [W1(c1, kb)], the x fragments stay in registers for the second step, x is streamed 6 instead of 12 times per launch.
-// On paper 160 - 166 live registers everywhere; the register allocator does not find it at the 168 a twelve-wave workgroup allows: 244 - 268 spilled registers with the
-// 40 steps of a pair unrolled, 146 with the k-blocks as run-time loops (the first sweep of a step then writes RENAMED accumulators: +24 registers in the A loop). With
-// the spills: 248 us against 158 (FFN), 272 against 182 (proj + FFN). The idea stands (fill ablations: the x pieces cost 9 % of the loop time), the build does not.
-// Not built by the Makefile.
+// dev record (round 5, stamped NEGATIVE): pp_ffn_dma.hip with hidden chunks in PAIRS that share every streamed x k-block (template parameter PAIR, option "ffn_pair"):
+// A-steps [W1(c0, kb) + x(kb)] [W1(c1, kb)], the x fragments stay in registers for the second step, x is streamed 6 instead of 12 times per launch.
+// With the MFMA builtin the register allocator fails at 168 (244 - 268 spilled registers with the 40 steps of a pair unrolled, 146 with run-time k-block loops: the first
+// sweep of a step writes RENAMED accumulators there, +24 live registers). With the MFMAs as in-place inline assembly (mma_ip, this file) it holds: 12 - 17 spilled registers,
+// none inside the step loops. Measured, run-time loops (results equal the unpaired kernel to 4.8e-6, run to run identical): 160.1 us against 157.0 (FFN), 184.7 against
+// 180.4 (proj + FFN); GRBM_GUI_ACTIVE 348 k against 316 k cycles per launch at 2.09 against 1.95 GHz under the profiler: the ENERGY falls as the fill ablations say
+// (clock +7 %), the CYCLES rise by 10 % for a reason the round did not find (not the lgkmcnt(0) of the loop headers: the unrolled form has the same +10 %).
+// The unrolled form (FFD_PAIR_UNROLL 1) gives WRONG, run-to-run different results: an MFMA hazard the compiler does not pad inside asm statements - do not ship this
+// file without the wait states worked out. Not built by the Makefile.
 // The fused f16x3 feed-forward launch of pp_ffn_split.hip (same packed weight streams, same sums in the same order; the two agree
 // to rounding - the GELU here is written max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2), two instructions shorter) with the LDS-DMA issue
 // taken OUT of the computing waves:
@@ -75,6 +78,9 @@ static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must rep
 #ifndef FFD_READS_FIRST
 #define FFD_READS_FIRST 1
 #endif
+#ifndef FFD_PAIR_UNROLL
+#define FFD_PAIR_UNROLL 1  // PAIR form: the k-block loops unrolled (counted lgkmcnt waits) or as run-time loops (the compiler waits lgkmcnt(0) at every loop header)
+#endif
 #ifndef FFD_ROLL
 #define FFD_ROLL 1  // rolling fragment reads, the barrier of a step inside its predecessor (round 5; 0: round 4's barrier | reads | MFMAs steps)
 #endif
@@ -110,6 +116,16 @@ __host__ __device__ constexpr int n_proj(int s) { return s < NPROJ ? 6 + ((s & 1
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+
+// In-place MFMA as inline assembly (PAIR form only): acc += a b with the accumulator tied to one register tuple. The builtin form lets the
+// register allocator RENAME the destination of a step's first sweep inside the run-time k-block loop (+24 live registers: 146 spilled);
+// tied, the loop holds at 160. The compiler's hazard recogniser does not see an MFMA in an asm statement: the VALU reads of the
+// accumulators (GELU, LayerNorm) are preceded by explicit wait states (mfma_settle), the loads that overwrite fragment registers are
+// ordered by s_waitcnt like any other use, and an accumulator is touched again six MFMAs (96 cycles) later at the earliest.
+__device__ __forceinline__ void mma_ip(const u32x4& a, const u32x4& b, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // ---------------------------------------------------------------- DMA waves
 // Barrier protocol (every wave of the workgroup executes the same sequence of s_barrier):
@@ -701,7 +717,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
             for (int i = 0; i < 6; ++i) {  // hi x lo
                 const int rf = i >> 1, nf = i & 1;
-                pa[rf][nf] = mma(wh[nf], xl[rf], pa[rf][nf]);
+                mma_ip(wh[nf], xl[rf], pa[rf][nf]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (i == 1) step_barrier();  // the barrier of the next step
                 if (reload_x && !to_b && nf == 1) xl[rf] = rd(lane_lo, ux_n, rf * 2048);
@@ -710,7 +726,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
             for (int i = 0; i < 6; ++i) {  // hi x hi
                 const int rf = i >> 1, nf = i & 1;
-                pa[rf][nf] = mma(wh[nf], xh[rf], pa[rf][nf]);
+                mma_ip(wh[nf], xh[rf], pa[rf][nf]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (rf == 2) { if (!to_b) wh[nf] = rd(lane_hi, ua_n, nf * 2048); else bwh[nf] = rd(lane_hi, ub_n, nf * 2048); }
                 if (to_b && i == 5) bwh[2] = rd(lane_hi, ub_n, 2 * 2048);
@@ -719,7 +735,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
             for (int i = 0; i < 6; ++i) {  // lo x hi
                 const int rf = i >> 1, nf = i & 1;
-                pa[rf][nf] = mma(wl[nf], xh[rf], pa[rf][nf]);
+                mma_ip(wl[nf], xh[rf], pa[rf][nf]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (reload_x && !to_b && nf == 1) xh[rf] = rd(lane_hi, ux_n, rf * 2048);
                 if (rf == 2) { if (!to_b) wl[nf] = rd(lane_lo, ua_n, nf * 2048); else bwl[nf] = rd(lane_lo, ub_n, nf * 2048); }
@@ -755,7 +771,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
                     for (int i = 0; i < 9; ++i) {  // hi x lo
                         const int rf = i / 3, nf = i % 3;
-                        acc[rf][half * 3 + nf] = mma(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+                        mma_ip(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
                         __builtin_amdgcn_sched_barrier(0);
                         if (i == 1 && (nb || next == 0 || more)) step_barrier();
                         if (nf == 2) { if (newg) bgl[rf] = rd(lane_lo, ug_n, rf * 2048); else if (anext) xl[rf] = rd(lane_lo, ux_n, rf * 2048); }
@@ -764,7 +780,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
                     for (int i = 0; i < 9; ++i) {  // hi x hi
                         const int rf = i / 3, nf = i % 3;
-                        acc[rf][half * 3 + nf] = mma(bwh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                        mma_ip(bwh[nf], bgh[rf], acc[rf][half * 3 + nf]);
                         __builtin_amdgcn_sched_barrier(0);
                         if (rf == 2) { if (wnext) bwh[nf] = rd(lane_hi, ub_n, nf * 2048); else if (anext && nf < 2) wh[nf] = rd(lane_hi, ua_n, nf * 2048); }
                         __builtin_amdgcn_sched_barrier(0);
@@ -772,7 +788,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
                     for (int i = 0; i < 9; ++i) {  // lo x hi
                         const int rf = i / 3, nf = i % 3;
-                        acc[rf][half * 3 + nf] = mma(bwl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                        mma_ip(bwl[nf], bgh[rf], acc[rf][half * 3 + nf]);
                         __builtin_amdgcn_sched_barrier(0);
                         if (nf == 2) { if (newg) bgh[rf] = rd(lane_hi, ug_n, rf * 2048); else if (anext) xh[rf] = rd(lane_hi, ux_n, rf * 2048); }
                         if (rf == 2) { if (wnext) bwl[nf] = rd(lane_lo, ub_n, nf * 2048); else if (anext && nf < 2) wl[nf] = rd(lane_lo, ua_n, nf * 2048); }
@@ -780,7 +796,11 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                     }
                 }
             };
+#if FFD_PAIR_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
             for (int jb = 0; jb < NB / 2 - 1; ++jb) two_steps(jb, false);
             two_steps(NB / 2 - 1, true);
         };
@@ -791,22 +811,29 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) { pacc[rf][nf] = b1v[nf]; pacc1[rf][nf] = b1w[nf]; }
             // ---- A-steps of both chunks, k-block by k-block
+#if FFD_PAIR_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
-            for (int kbi = 0; kbi < NA - 1; ++kbi) {  // (a run-time loop over one k-block's two steps; the last k-block apart: B-steps follow it)
+#endif
+            for (int kbi = 0; kbi < NA - 1; ++kbi) {  // (one k-block's two steps; the last k-block apart: B-steps follow it)
                 a_step(pacc, 2 * kbi + 1, false, false);
                 a_step(pacc1, 2 * kbi + 2, true, false);
             }
             a_step(pacc, 2 * NA - 1, false, false);
             a_step(pacc1, 2 * NA, true, true);
+            mfma_settle();
             gelu_chunk(pacc);
             step_barrier();  // the G tile is complete (the DMA waves pass it behind their barrier of step 2 NA)
             load_b1x(2 * cp + 2, b1v);  // the next pair's biases, asked for while their sixteen registers are free
             b_phase(2 * NA, 0, true);
+            mfma_settle();
             gelu_chunk(pacc1);
             step_barrier();  // (behind the DMA waves' barrier of step 2 NA + NB)
             load_b1x(2 * cp + 3, b1w);
             b_phase(2 * NA + NB, 1, cp + 1 < npairs);
         }
+        mfma_settle();
     } else {
 #if FFD_ROLL
     {
