@@ -164,13 +164,18 @@ def kernel_work_per_step(eng, B, passes, tag):
     if tag == "ffn_split":  # f16x3: fc1 + GELU + fc2 + residual + LN per layer; h in, residual in, x out, h out (4 bytes each)
         from probpose_code_amd import _lib
         dma = _lib.get_option("ffn_dma_waves") != 0  # the twelve-wave form (pp_ffn_dma.hip) or the eight-wave one (pp_ffn_split.hip)
-        return L * 4.0 * M * E * Fd, L * 4 * M * E * 4, L, "_ZN2pp3ffd14ffn_dma_kernelENS_3ffs6ParamsE" if dma else "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE"
+        pair = _lib.get_option("ffn_pair") != 0 and (Fd // 128) % 2 == 0  # (launch_dma_form's choice: hidden chunks in pairs)
+        name = ("_ZN2pp3ffd19ffn_dma_pair_kernelENS_3ffs6ParamsE" if pair else "_ZN2pp3ffd14ffn_dma_kernelENS_3ffs6ParamsE") if dma else \
+            "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE"
+        return L * 4.0 * M * E * Fd, L * 4 * M * E * 4, L, name
     if tag == "proj_ffn_split":  # f16x3: proj + residual + ln2 + fc1 + GELU + fc2 + residual + LN per layer; attention rows in,
         # residual in, x out, h out (4 bytes each); the ln2 rows a workgroup parks in L2 and streams back are not algorithmic bytes
         from probpose_code_amd import _lib
         dma = _lib.get_option("ffn_dma_waves") != 0
-        return (L * (4.0 * M * E * Fd + 2.0 * M * E * E), L * 4 * M * E * 4, L,
-                "_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE" if dma else "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE")
+        pair = _lib.get_option("ffn_pair") != 0 and (Fd // 128) % 2 == 0
+        name = ("_ZN2pp3ffd24proj_ffn_dma_pair_kernelENS_3ffs6ParamsE" if pair else "_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE") if dma else \
+            "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE"
+        return L * (4.0 * M * E * Fd + 2.0 * M * E * E), L * 4 * M * E * 4, L, name
     if tag == "qkv_attention":  # f16x3: qkv Linear + attention per (sequence, head); LayerNorm rows in, attention rows out
         att_fl = 4.0 * (B * passes) * eng.heads * eng.Np * eng.Np * eng.hd
         return L * (2.0 * M * 3 * E * E + att_fl), L * 2 * M * E * 4, L, "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE"
@@ -230,6 +235,7 @@ def pmc_traffic(kernel_mangled, precision, B, prefix=""):
              "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE": "pp::ffs::ffn_split_kernel(",
              "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE": "pp::ffs::proj_ffn_split_kernel(",
              "_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE": "pp::ffd::proj_ffn_dma_kernel(",
+             "_ZN2pp3ffd24proj_ffn_dma_pair_kernelENS_3ffs6ParamsE": "pp::ffd::proj_ffn_dma_pair_kernel(",
              "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE": "pp::qka::qkv_attention_split_kernel("}.get(kernel_mangled)
     short = short or {"_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1ELi2ELb0ELb0EEEvNS_10GemmParamsE": "void pp::psplit::panel_split_kernel<0, 8, 3, true, 2, false, false>("}.get(kernel_mangled)
     names = (f"r05_{prefix}{precision}_bs64_hbm_traffic.json", f"r04_{prefix}{precision}_bs64_hbm_traffic.json") if prefix else \

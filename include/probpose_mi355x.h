@@ -73,6 +73,8 @@ int pp_device_cu_count(void);
  *                            twelve-wave 192 x 192 kernels (pp_linear_dma.hip: persistent, finished tiles leave through the DMA waves)
  *   "ffn_dma_waves" (1)      0: the fused f16x3 feed-forward launches run the eight-wave kernel (pp_ffn_split.hip) instead of the
  *                            twelve-wave one (pp_ffn_dma.hip: eight computing waves + four waves that only issue the LDS-DMA)
+ *   "ffn_pair" (1)           twelve-wave feed-forward launch: hidden chunks in pairs that share every streamed x k-block (x rows streamed 6 instead of 12
+ *                            times per launch; taken when F / 128 is even); 0: one chunk at a time
  *   "psplit_tail" (1)        0: split-fp16 Linear layers never send the rows of a ragged last round to a second launch on 128 x 192 tiles
  *   "wino_order" (8)         pp_conv3x3_winograd_maxpool_relu: column tiles per 32-workgroup super tile (0: column tiles fastest)
  *   "ksplit_channels" (1)    pp_conv3x3_splitk_slices: 0 = whole-tap slices only (never the four channel ranges of the wide-tile kernel)
@@ -84,7 +86,8 @@ int pp_get_option(const char* name, int* value);
 /* Diagnostics: kernel launches since the last reset, tallied on the host at launch time (a captured hipGraph counts once, at capture) under
  * the launching source file's name - "pp_winograd.hip", "pp_ffn_dma.hip", "pp_qkv_attn_split.hip", "pp_linear_dma.hip", "pp_gemm.hip" ... - and
  * for kernels that share a file under their own tag: "linear_dma_persistent" (twelve-wave Linear kernel, finished tiles through the DMA
- * waves), "linear_dma_tile" (its one-tile-per-workgroup form), "winograd_input_transform", "winograd_gemm_pool", "layernorm". Lets a test
+ * waves), "linear_dma_tile" (its one-tile-per-workgroup form), "ffn_dma_pair" / "ffn_dma_single" (the twelve-wave feed-forward launch in its
+ * paired-chunk / one-chunk form), "winograd_input_transform", "winograd_gemm_pool", "layernorm". Lets a test
  * assert WHICH kernels a launch plan ran (the reference has no counterpart: kernel selection there is cuDNN's, mmpose/models/heads/
  * hybrid_heads/probmap_head.py:261-294 and mmpretrain's VisionTransformer only name the layers). Unknown names count 0. Not thread-safe. */
 long long pp_launch_count(const char* kernel);

@@ -31,6 +31,7 @@ static Option g_options[] = {
     {"qkv_attn_pair", 0},      // 1: pp_qkv_attention_split with a head PAIR per workgroup (one workgroup per CU; measured slower)
     {"linear_dma", 1},         // large split-fp16 Linear layers (pp_gemm): 1 = the twelve-wave 192 x 192 kernels (pp_linear_dma.hip), 0 = the wide-tile kernel
     {"ffn_dma_waves", 1},      // fused f16x3 feed-forward launch: 1 = the twelve-wave form (pp_ffn_dma.hip: eight computing waves + four DMA waves), 0 = the eight-wave form (pp_ffn_split.hip)
+    {"ffn_pair", 1},           // twelve-wave feed-forward launch: 1 = hidden chunks in PAIRS that share every streamed x k-block (x streamed 6 instead of 12 times per launch; even chunk counts only), 0 = one chunk at a time
     {"psplit_tail", 1},        // split-fp16 Linear layers on the wide-tile kernel: 0 = no second launch on 128 x 192 tiles for the rows of a ragged last round
     {"wino_order", 8},         // pp_conv3x3_winograd_maxpool_relu: column tiles per 32-workgroup super tile (0: column tiles fastest over an XCD's run: 1.19 GB fetched per launch at bs 64; 8 = 4 row blocks x 8 column tiles: 0.72 GB, same launch time)
     {"ksplit_channels", 1},    // pp_conv3x3_splitk_slices: 0 = never the four channel-range slices of the split-fp16 wide-tile kernel (whole-tap slices only)

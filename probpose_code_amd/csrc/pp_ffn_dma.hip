@@ -69,6 +69,9 @@ static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must rep
 #ifndef FFD_READS_FIRST
 #define FFD_READS_FIRST 1
 #endif
+#ifndef FFD_PAIR_UNROLL
+#define FFD_PAIR_UNROLL 0  // PAIR form: the k-block loops unrolled (counted lgkmcnt waits) or as run-time loops (the compiler waits lgkmcnt(0) at every loop header)
+#endif
 #ifndef FFD_ROLL
 #define FFD_ROLL 1  // rolling fragment reads, the barrier of a step inside its predecessor (round 5; 0: round 4's barrier | reads | MFMAs steps)
 #endif
@@ -88,6 +91,8 @@ __device__ __forceinline__ void wait_vm_n(int n) {
         case 6: wait_vm<6>(); break;
         case 7: wait_vm<7>(); break;
         case 9: wait_vm<9>(); break;
+        case 10: wait_vm<10>(); break;
+        case 11: wait_vm<11>(); break;
         case 12: wait_vm<12>(); break;
         case 13: wait_vm<13>(); break;
         case 14: wait_vm<14>(); break;
@@ -103,10 +108,31 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// In-place MFMA as inline assembly (PAIR form only): acc += a b with the accumulator tied to one register tuple. The builtin form lets the
+// register allocator RENAME the destination of a step's first sweep inside the run-time k-block loop (+24 live registers: 146 spilled);
+// tied, the loop holds at 160. The compiler's hazard recogniser does not see an MFMA in an asm statement: the VALU reads of the
+// accumulators (GELU, LayerNorm) are preceded by explicit wait states (mfma_settle), the loads that overwrite fragment registers are
+// ordered by s_waitcnt like any other use, and an accumulator is touched again six MFMAs (96 cycles) later at the earliest.
+__device__ __forceinline__ void mma_ip(const u32x4& a, const u32x4& b, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// (the accumulator fragments are in / out operands of the wait-state block: a read of them cannot be scheduled in front of it)
+__device__ __forceinline__ void mfma_settle(f32x4 (&a)[3][2]) {
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]));
+}
+__device__ __forceinline__ void valu_settle(f32x4 (&a)[3][2]) {
+    asm volatile("s_nop 4" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]));
+}
+__device__ __forceinline__ void mfma_settle(f32x4 (&a)[3][6]) {
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[0][4]), "+v"(a[0][5]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]),
+                   "+v"(a[1][3]), "+v"(a[1][4]), "+v"(a[1][5]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[2][2]), "+v"(a[2][3]), "+v"(a[2][4]), "+v"(a[2][5]));
+}
+
 // ---------------------------------------------------------------- DMA waves
 // Barrier protocol (every wave of the workgroup executes the same sequence of s_barrier):
 //   PROJ: 24 step barriers | P1 | LayerNorm 2 | P2 ;   main: 20 per chunk | E1 | LayerNorm 2
-template <bool PROJ>
+template <bool PROJ, bool PAIR>
 __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int lane, int m0, int nchunks, int c_rot) {
     char* const ring = smem + OFF_RING;
     if (FFD_DMA_PRIO) __builtin_amdgcn_s_setprio(FFD_DMA_PRIO);
@@ -184,6 +210,64 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
             }
         }
     };
+    if constexpr (PAIR) {
+        // PAIRED chunks (see compute_role): a pair's 40 steps are  [W1(c0, kb) + x(kb)] [W1(c1, kb)]  x 12  |  B(c0) x 8  |  B(c1) x 8 ;
+        // 7 / 4 / 6 pieces per DMA wave and step. Same protocol per step.
+        const int npairs = nchunks >> 1;
+        auto issue2 = [&](int cp_, int t) {
+            // (the pair index through an opaque copy per step: otherwise the compiler computes the offsets of all forty steps at the loop head and
+            // spills 180 SGPRs - every piece then waits for a v_readlane and its hazard states)
+            int cp = cp_;
+            asm volatile("" : "+s"(cp));
+            const bool live = cp < npairs;
+            const int cpl = live ? cp : 0;
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wpack), 0, live ? p.w_bytes : 0u, 0x00020000);
+            char* dst = ring + (t & 3) * SLOTB;
+            if (t < 2 * NA) {
+                int c = 2 * cpl + (t & 1) + c_rot;
+                c = c >= nchunks ? c - nchunks : c;
+                const int kb = (cp & 1) ? NA - 1 - (t >> 1) : (t >> 1);  // odd pair visits walk the k-blocks backwards
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = d + 4 * u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + q * 1024), 16, v_w, c * CHUNK_BYTES + kb * A_BLOCK + q * 1024, 0, 0);
+                }
+                if ((t & 1) == 0) {
+                    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.h), 0, live ? p.h_bytes : 0u, 0x00020000);
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int q = d + 4 * u;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(dst + X_OFF + q * 1024), 16, v_x, kb * 128 + q * 8 * E * 4, 0, 0);
+                    }
+                }
+            } else {
+                const int which = (t - 2 * NA) >> 3, sb = (t - 2 * NA) & 7;
+                int c = 2 * cpl + which + c_rot;
+                c = c >= nchunks ? c - nchunks : c;
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int q = d + 4 * u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + q * 1024), 16, v_w, c * CHUNK_BYTES + B_PART + sb * B_BLOCK + q * 1024, 0, 0);
+                }
+            }
+        };
+        constexpr int PS = 2 * STEPS;
+        auto n2 = [](int t) { t %= PS; return t < 2 * NA ? ((t & 1) == 0 ? 7 : 4) : 6; };
+        issue2(0, 0);
+        issue2(0, 1);
+        issue2(0, 2);
+        for (int cp = 0; cp < npairs; ++cp) {
+#pragma unroll
+            for (int t = 0; t < PS; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                wait_vm_n(n2(t + 1) + n2(t + 2));
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 3 < PS) issue2(cp, t + 3); else issue2(cp + 1, t + 3 - PS);
+                if (t == 2 * NA || t == 2 * NA + NB) __builtin_amdgcn_s_barrier();  // the computing waves' two G-tile barriers
+            }
+        }
+    } else {
     issue(0, 0);
     issue(0, 1);
     issue(0, 2);
@@ -199,6 +283,7 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
             if (FFD_ROLL && t == NA) __builtin_amdgcn_s_barrier();  // the computing waves' G-tile barrier (between their barriers of steps NA and NA + 1)
         }
     }
+    }
     wait_vm<0>();                  // the fillers
     __builtin_amdgcn_s_barrier();  // E1
     __builtin_amdgcn_s_barrier();  // LayerNorm
@@ -206,7 +291,7 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
 }
 
 // ---------------------------------------------------------------- computing waves
-template <bool PROJ>
+template <bool PROJ, bool PAIR>
 __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv, int lane, int m0, int nchunks, int c_rot) {
     const int rg = wv >> 2, cg = wv & 3;
     const int f_row = lane & 15, f_kg = lane >> 4;
@@ -285,12 +370,17 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     // of the descriptor's extent and are dropped by the hardware (the range check covers the VGPR offset, not the scalar one) -
     // the wave-uniform column part in the scalar offset: two address registers for the whole epilogue.
     auto layernorm_rows = [&](const float* gamma, const float* beta, float* x_dst, void* h_dst, bool store_x) {
-        // (row offsets recomputed here from an opaque copy of the lane id: kept as kernel-long constants they cost three registers through every step loop - with them the
-        // kernels spilled 3 - 8 registers around the loops, without them none)
-        int ln_ = lane;
-        asm volatile("" : "+v"(ln_));
+        // (row offsets recomputed here from an opaque copy of the lane id: kept as kernel-long constants they cost three registers the paired
+        // A-steps do not have)
+        unsigned ones_ = ~0u;
+        asm volatile("" : "+s"(ones_));  // (opaque: the lane id is recomputed HERE by v_mbcnt, not kept - or spilled - through the step loops)
+        const int ln_ = (int)__builtin_amdgcn_mbcnt_hi(ones_, __builtin_amdgcn_mbcnt_lo(ones_, 0u));
         const int fk_ = ln_ >> 4;
-        const unsigned row_ = (unsigned)(m0 + rg * 48 + (ln_ & 15)) * (unsigned)(E * 4);
+        const int rows0_ = rg * 48 + (ln_ & 15);
+        // (the row sums' exchanges address their partner from ln_ too: __shfl_xor's own lane id is one value for both LayerNorms of the fused
+        // kernel, which the paired form then carries - in scratch - through the whole chunk loop)
+        auto shx = [&](float v, int m) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((ln_ ^ m) << 2, __builtin_bit_cast(int, v))); };
+        const unsigned row_ = (unsigned)(m0 + rows0_) * (unsigned)(E * 4);
         const unsigned v_rowx = row_ + (unsigned)fk_ * 16u;                                            // fp32 rows
         const unsigned v_rowh = row_ + (unsigned)fk_ * 8u;                                             // split rows: the lane's four hi halves (lo: + 64)
         const unsigned v_rowh2 = row_ + (unsigned)(fk_ >> 1) * 16u + (unsigned)(fk_ & 1) * 64u;       // row-pair form: 16-byte hi chunk (even f_kg) / lo chunk (odd)
@@ -307,14 +397,14 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 const f32x4 v = acc[rf][cf];
                 sm += (v[0] + v[1]) + (v[2] + v[3]);
             }
-            sm += __shfl_xor(sm, 16);
-            sm += __shfl_xor(sm, 32);
-            if (f_kg == 0) stat[cg * BM + rows0 + rf * 16] = sm;
+            sm += shx(sm, 16);
+            sm += shx(sm, 32);
+            if (fk_ == 0) stat[cg * BM + rows0_ + rf * 16] = sm;
         }
         __syncthreads();
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
-            const int r = rows0 + rf * 16;
+            const int r = rows0_ + rf * 16;
             mean[rf] = ((stat[r] + stat[BM + r]) + (stat[2 * BM + r] + stat[3 * BM + r])) * (1.0f / E);
             float q = 0.f;
 #pragma unroll
@@ -324,21 +414,21 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                     const float dd = acc[rf][cf][k] - mean[rf];
                     q = __builtin_fmaf(dd, dd, q);
                 }
-            q += __shfl_xor(q, 16);
-            q += __shfl_xor(q, 32);
-            if (f_kg == 0) stat[(4 + cg) * BM + r] = q;
+            q += shx(q, 16);
+            q += shx(q, 32);
+            if (fk_ == 0) stat[(4 + cg) * BM + r] = q;
         }
         __syncthreads();
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
-            const int r = rows0 + rf * 16;
+            const int r = rows0_ + rf * 16;
             const float var = ((stat[4 * BM + r] + stat[5 * BM + r]) + (stat[6 * BM + r] + stat[7 * BM + r])) * (1.0f / E);
             rstd[rf] = 1.0f / sqrtf(var + p.eps);
         }
 #pragma unroll
         for (int cf = 0; cf < 6; ++cf) {
             const int cb = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16;  // (wave-uniform)
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cb + f_kg * 4), b = *reinterpret_cast<const f32x4*>(beta + cb + f_kg * 4);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cb + fk_ * 4), b = *reinterpret_cast<const f32x4*>(beta + cb + fk_ * 4);
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) {
                 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -352,8 +442,8 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 for (int j = 0; j < 4; ++j) { float t = hv[j]; split_pin(t); hv[j] = t; }
 #if FFD_STORE16
                 {   // dev A/B: 16-byte stores in the FLAT encoding, as the eight-wave kernel does (64-bit addresses, `live` predicate)
-                    const bool live = m0 + rows0 + rf * 16 < p.M;
-                    const size_t off = (size_t)(m0 + rows0 + rf * 16) * E + cb + f_kg * 4;
+                    const bool live = m0 + rows0_ + rf * 16 < p.M;
+                    const size_t off = (size_t)(m0 + rows0_ + rf * 16) * E + cb + fk_ * 4;
                     if (store_x && live) *reinterpret_cast<f32x4*>(x_dst + off) = v;
                     split_store4_rowpair(h_dst, off, hv, live);
                     continue;
@@ -384,7 +474,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 }
                 const int so = (cb >> 5) * 128 + (cb & 16) * 2;
 #if FFD_H128
-                {   // the row-pair form of split_store4_rowpair (lanes f_kg, f_kg ^ 1 exchange halves: the even one stores the 16-byte hi chunk,
+                {   // the row-pair form of split_store4_rowpair (lanes fk_, fk_ ^ 1 exchange halves: the even one stores the 16-byte hi chunk,
                     // the odd one the lo chunk), as ONE 16-byte buffer store followed by the wait states the compiler does not insert
                     const u32x2_t hu = __builtin_bit_cast(u32x2_t, h), lu = __builtin_bit_cast(u32x2_t, l);
                     const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
@@ -599,6 +689,165 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             }
     };
 
+    if constexpr (PAIR) {
+        // PAIRED CHUNKS (round 5; needs an even number of chunks). The 96 x 384 block of x rows is re-streamed once per hidden chunk: 12 x 144 KiB per
+        // workgroup, 4.6 MB of rows per XCD and pass through a 4 MB L2 - about half of those re-reads come from beyond the L2 (counter traffic
+        // 395 MB per launch against 151 MB algorithmic), and the fill ablations of scripts/micro/ffn12d.hip price the x pieces at 9 % of the loop's
+        // TIME (the chip is power-limited: same cycles, 1.68 -> 1.82 GHz without them; 7.5 % of it is their coming from beyond the L2). Two chunks
+        // now share every x k-block: the A-steps of a pair run  [W1(c0, kb) + x(kb)] [W1(c1, kb)]  for kb = 0 .. 11, and with the rolling reads the
+        // x fragments simply STAY in their registers for the second step - no second read of the slot, no slot lifetime problem - so x is
+        // streamed six times per launch instead of twelve and the A-steps read a quarter less from LDS. Price: the second chunk's accumulators
+        // (24 registers) live through the first chunk's GELU and B-steps; the B-steps' fragments leave room for them (72 + 24 + 48 = 144).
+        f32x4 pacc1[3][2];  // P of the pair's second chunk (pacc: the first)
+        u32x4 wh[2], wl[2], xh[3], xl[3], bwh[3], bwl[3];
+        const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b1), 0, (unsigned)p.F * 4u, 0x00020000);
+        auto load_b1x = [&](int ci, f32x4 (&dst)[2]) __attribute__((always_inline)) {  // (descriptor + lane & 0x30: no 64-bit address kept alive through the B-steps)
+            const int c = chunk_of(ci < nchunks ? ci : 0);
+            int vo = lane;
+            asm volatile("" : "+v"(vo));
+            vo &= 0x30;
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) dst[nf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb1, vo, (c * CHUNK + cg * 32 + nf * 16) * 4, 0));
+        };
+        f32x4 b1w[2];  // the first chunk's bias is b1v (loaded above), the second's b1w
+        load_b1x(1, b1w);
+        step_barrier();  // the barrier of step 0
+        {
+            const int ua = opaque_s(u_a), ux = opaque_s(u_x);
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) { wh[nf] = rd(lane_hi, ua, nf * 2048); wl[nf] = rd(lane_lo, ua, nf * 2048); }
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) { xl[rf] = rd(lane_lo, ux, rf * 2048); xh[rf] = rd(lane_hi, ux, rf * 2048); }
+        }
+        // one A-step: the three sweeps into `pa`; `reload_x`: the row fragments are re-read for the next step (second step of a k-block);
+        // `to_b`: the next step is a B-step (its weight fragments instead of W1's)
+        auto a_step = [&](f32x4 (&pa)[3][2], int slot_next, bool reload_x, bool to_b) __attribute__((always_inline)) {
+            const int sn = (slot_next & 3) * SLOTB;
+            const int ua_n = opaque_s(u_a + sn), ux_n = opaque_s(u_x + sn), ub_n = opaque_s(u_b + sn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {  // hi x lo
+                const int rf = i >> 1, nf = i & 1;
+                mma_ip(wh[nf], xl[rf], pa[rf][nf]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 1) step_barrier();  // the barrier of the next step
+                if (reload_x && !to_b && nf == 1) xl[rf] = rd(lane_lo, ux_n, rf * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {  // hi x hi
+                const int rf = i >> 1, nf = i & 1;
+                mma_ip(wh[nf], xh[rf], pa[rf][nf]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rf == 2) { if (!to_b) wh[nf] = rd(lane_hi, ua_n, nf * 2048); else bwh[nf] = rd(lane_hi, ub_n, nf * 2048); }
+                if (to_b && i == 5) bwh[2] = rd(lane_hi, ub_n, 2 * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {  // lo x hi
+                const int rf = i >> 1, nf = i & 1;
+                mma_ip(wl[nf], xh[rf], pa[rf][nf]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (reload_x && !to_b && nf == 1) xh[rf] = rd(lane_hi, ux_n, rf * 2048);
+                if (rf == 2) { if (!to_b) wl[nf] = rd(lane_lo, ua_n, nf * 2048); else bwl[nf] = rd(lane_lo, ub_n, nf * 2048); }
+                if (to_b && i == 5) bwl[2] = rd(lane_lo, ub_n, 2 * 2048);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // the eight B-steps of one chunk (its G tile complete, bwh / bwl of its first step in registers). `next`: what follows the last step -
+        // 0 the other chunk's B-steps (weights only: its G fragments come behind its GELU), 1 the next pair's first A-step. `more` (run time):
+        // there IS a next pair - the launch's very last step has no barrier inside (the epilogue's E1 is the DMA waves' next one); its
+        // prefetches still run (they read a slot of fillers): every path through the loop body redefines the fragment registers, so that
+        // none of them is carried, spilled, through the GELU and the B-steps
+        auto b_phase = [&](int t0, int next, bool more) __attribute__((always_inline)) {
+            {
+                const int ug = opaque_s(u_g);
+#pragma unroll
+                for (int rf = 0; rf < 3; ++rf) { bgl[rf] = rd(lane_lo, ug, rf * 2048); bgh[rf] = rd(lane_hi, ug, rf * 2048); }
+            }
+            // (the k-blocks as a run-time loop over one two-step body - the last one apart, for what follows it: forty fully unrolled steps
+            // per pair sent the register allocator into spilling half the accumulators)
+            auto two_steps = [&](int jb, bool last_kb) __attribute__((always_inline)) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int sb = 2 * jb + half;
+                    const int sn = ((t0 + sb + 1) & 3) * SLOTB;
+                    const int ub_n = opaque_s(u_b + sn), ua_n = opaque_s(u_a + sn), ux_n = opaque_s(u_x + sn);
+                    const int ug_n = opaque_s(u_g + ((jb + 1) & 3) * G_KB);
+                    const bool nb = !(last_kb && half == 1);
+                    const bool newg = nb && half == 1;
+                    const bool wnext = nb || next == 0;   // B-step weights follow
+                    const bool anext = !nb && next == 1;  // an A-step follows
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {  // hi x lo
+                        const int rf = i / 3, nf = i % 3;
+                        mma_ip(bwh[nf], bgl[rf], acc[rf][half * 3 + nf]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (i == 1 && (nb || next == 0 || more)) step_barrier();
+                        if (nf == 2) { if (newg) bgl[rf] = rd(lane_lo, ug_n, rf * 2048); else if (anext) xl[rf] = rd(lane_lo, ux_n, rf * 2048); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {  // hi x hi
+                        const int rf = i / 3, nf = i % 3;
+                        mma_ip(bwh[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (rf == 2) { if (wnext) bwh[nf] = rd(lane_hi, ub_n, nf * 2048); else if (anext && nf < 2) wh[nf] = rd(lane_hi, ua_n, nf * 2048); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {  // lo x hi
+                        const int rf = i / 3, nf = i % 3;
+                        mma_ip(bwl[nf], bgh[rf], acc[rf][half * 3 + nf]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (nf == 2) { if (newg) bgh[rf] = rd(lane_hi, ug_n, rf * 2048); else if (anext) xh[rf] = rd(lane_hi, ux_n, rf * 2048); }
+                        if (rf == 2) { if (wnext) bwl[nf] = rd(lane_lo, ub_n, nf * 2048); else if (anext && nf < 2) wl[nf] = rd(lane_lo, ua_n, nf * 2048); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+#if FFD_PAIR_UNROLL
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+            for (int jb = 0; jb < NB / 2 - 1; ++jb) two_steps(jb, false);
+            two_steps(NB / 2 - 1, true);
+        };
+        const int npairs = nchunks >> 1;
+        for (int cp = 0; cp < npairs; ++cp) {
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) { pacc[rf][nf] = b1v[nf]; pacc1[rf][nf] = b1w[nf]; }
+            valu_settle(pacc);  // (VALU writes -> MFMA SrcC reads: the wait states the compiler cannot know an asm statement needs)
+            valu_settle(pacc1);
+            // ---- A-steps of both chunks, k-block by k-block
+#if FFD_PAIR_UNROLL
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+            for (int kbi = 0; kbi < NA - 1; ++kbi) {  // (one k-block's two steps; the last k-block apart: B-steps follow it)
+                a_step(pacc, 2 * kbi + 1, false, false);
+                a_step(pacc1, 2 * kbi + 2, true, false);
+            }
+            a_step(pacc, 2 * NA - 1, false, false);
+            a_step(pacc1, 2 * NA, true, true);
+            mfma_settle(pacc);
+            gelu_chunk(pacc);
+            step_barrier();  // the G tile is complete (the DMA waves pass it behind their barrier of step 2 NA)
+            load_b1x(2 * cp + 2, b1v);  // the next pair's biases, asked for while their sixteen registers are free
+            b_phase(2 * NA, 0, true);
+            mfma_settle(pacc1);
+            gelu_chunk(pacc1);
+            step_barrier();  // (behind the DMA waves' barrier of step 2 NA + NB)
+            load_b1x(2 * cp + 3, b1w);
+            b_phase(2 * NA + NB, 1, cp + 1 < npairs);
+        }
+        mfma_settle(acc);
+    } else {
 #if FFD_ROLL
     {
         // ROLLING FRAGMENT READS (round 5). In the loop below a step is [barrier | ten reads | wait | 18 / 27 MFMAs]: the reads' latency and the
@@ -767,12 +1016,13 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
         }
     }
 #endif
+    }
     // ---- LayerNorm epilogue: G is out of use once every wave is past its last B-step
     __syncthreads();  // E1
     layernorm_rows(p.gamma, p.beta, p.x_out, p.h_out, true);
 }
 
-template <bool PROJ>
+template <bool PROJ, bool PAIR>
 __device__ __forceinline__ void body(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -780,22 +1030,26 @@ __device__ __forceinline__ void body(const Params p) {
     const int m0 = blockIdx.x * BM;
     const int nchunks = p.F / CHUNK;
     const int c_rot = (int)(blockIdx.x & 7) % nchunks;  // the workgroups of an XCD walk the chunks in the same order
-    if (wv >= CW) dma_role<PROJ>(p, smem, wv - CW, lane, m0, nchunks, c_rot);
-    else compute_role<PROJ>(p, smem, wv, lane, m0, nchunks, c_rot);
+    if (wv >= CW) dma_role<PROJ, PAIR>(p, smem, wv - CW, lane, m0, nchunks, c_rot);
+    else compute_role<PROJ, PAIR>(p, smem, wv, lane, m0, nchunks, c_rot);
 }
 
-__global__ __launch_bounds__(THREADS) void ffn_dma_kernel(const Params p) { body<false>(p); }
-__global__ __launch_bounds__(THREADS) void proj_ffn_dma_kernel(const Params p) { body<true>(p); }
+__global__ __launch_bounds__(THREADS) void ffn_dma_kernel(const Params p) { body<false, false>(p); }
+__global__ __launch_bounds__(THREADS) void proj_ffn_dma_kernel(const Params p) { body<true, false>(p); }
+__global__ __launch_bounds__(THREADS) void ffn_dma_pair_kernel(const Params p) { body<false, true>(p); }
+__global__ __launch_bounds__(THREADS) void proj_ffn_dma_pair_kernel(const Params p) { body<true, true>(p); }
 
 }  // namespace ffd
 
 namespace ffs {
 // called from the entry points in pp_ffn_split.hip when the option "ffn_dma_waves" is on
 int launch_dma_form(const Params& p, bool proj, hipStream_t s) {
-    auto kern = proj ? ffd::proj_ffn_dma_kernel : ffd::ffn_dma_kernel;
+    // an even number of hidden chunks: the paired form (two chunks share every streamed x k-block); option "ffn_pair" = 0 or an odd count: one at a time
+    const bool pair = FFD_ROLL && option("ffn_pair") != 0 && (p.F / ffd::CHUNK) % 2 == 0;
+    auto kern = pair ? (proj ? ffd::proj_ffn_dma_pair_kernel : ffd::ffn_dma_pair_kernel) : (proj ? ffd::proj_ffn_dma_kernel : ffd::ffn_dma_kernel);
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ffd::LDS));
     hipLaunchKernelGGL(kern, dim3((p.M + ffd::BM - 1) / ffd::BM), dim3(ffd::THREADS), ffd::LDS, s, p);
-    PP_LAUNCH_CHECK();
+    PP_LAUNCH_CHECK_AS(pair ? "ffn_dma_pair" : "ffn_dma_single");
     return PP_OK;
 }
 }  // namespace ffs

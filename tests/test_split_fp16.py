@@ -503,15 +503,18 @@ def _ffn_pack(L, w1, w2, E, F_):
 
 @pytest.fixture
 def ffn_form(request):
-    """both forms of the fused feed-forward launch: 1 = twelve waves (pp_ffn_dma.hip, shipped), 0 = eight waves (pp_ffn_split.hip)"""
+    """the forms of the fused feed-forward launch: 2 = twelve waves, two hidden chunks per streamed x block (pp_ffn_dma.hip's pair kernels,
+    shipped for an even chunk count), 1 = twelve waves, one chunk at a time (pp_ffn_dma.hip), 0 = eight waves (pp_ffn_split.hip)"""
     L = _lib()
-    L.set_option("ffn_dma_waves", request.param)
+    L.set_option("ffn_dma_waves", min(request.param, 1))
+    L.set_option("ffn_pair", int(request.param == 2))
     yield request.param
     L.set_option("ffn_dma_waves", 1)
+    L.set_option("ffn_pair", 1)
 
 
 @gpu
-@pytest.mark.parametrize("ffn_form", [1, 0], indirect=True)
+@pytest.mark.parametrize("ffn_form", [2, 1, 0], indirect=True)
 @pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (24576, 1536)])
 def test_ffn_split_fused_vs_fp64(M, F_, ffn_form):
     """pp_ffn_split_residual_layernorm (fc1 - GELU - fc2 + residual + LayerNorm in one launch, hidden activation on the CU)
@@ -539,7 +542,7 @@ def test_ffn_split_fused_vs_fp64(M, F_, ffn_form):
 
 
 @gpu
-@pytest.mark.parametrize("ffn_form", [1, 0], indirect=True)
+@pytest.mark.parametrize("ffn_form", [2, 1, 0], indirect=True)
 def test_ffn_split_fused_in_place_and_errors(ffn_form):
     """residual aliasing x_out and h_in aliasing h_out (how the engine calls it), and the argument checks."""
     L = _lib()
@@ -571,7 +574,7 @@ def _proj_inputs(M, E=384, seed=80):
 
 
 @gpu
-@pytest.mark.parametrize("ffn_form", [1, 0], indirect=True)
+@pytest.mark.parametrize("ffn_form", [2, 1, 0], indirect=True)
 @pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (24576, 1536)])
 def test_proj_ffn_split_fused_vs_fp64(M, F_, ffn_form):
     """pp_proj_ffn_split_residual_layernorm (projection + residual + ln2 + FFN + residual + LayerNorm in one launch) against
@@ -647,7 +650,7 @@ def test_qkv_attention_split_fused_vs_fp64(n_seq, bias, pair):
 
 
 @gpu
-@pytest.mark.parametrize("ffn_form", [1, 0], indirect=True)
+@pytest.mark.parametrize("ffn_form", [2, 1, 0], indirect=True)
 def test_proj_ffn_split_two_streams_under_contention(ffn_form):
     """Two independent problems through pp_proj_ffn_split_residual_layernorm on two streams at once must each give the result
     they give alone, bit for bit. This is the condition bench.py's two steps in flight create; it caught counted vmcnt waits
@@ -691,13 +694,15 @@ def test_proj_ffn_split_two_streams_under_contention(ffn_form):
 
 
 @gpu
-@pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (24576, 1536)])
-def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_):
+@pytest.mark.parametrize("pair", [1, 0])
+@pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (96 * 2 + 5, 384), (24576, 1536)])
+def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_, pair):
     """pp_set_option("ffn_dma_waves", 1) routes both fused feed-forward entry points to the twelve-wave kernel (pp_ffn_dma.hip:
-    eight computing waves + four DMA waves). Held to the same fp64 references and tolerances as the eight-wave kernel above, in
-    place as the engine calls them, a ragged last tile included; the two forms agree to rounding (the same terms, summed in another
-    order since round 5); repeated launches bit-identical, also when two launches share
-    the chip (what two steps in flight create)."""
+    eight computing waves + four DMA waves); pp_set_option("ffn_pair", 1) to its paired-chunk form when the hidden width is an even
+    number of 128-column chunks (F = 384 - three chunks - runs the single-chunk kernel under either setting). Held to the same
+    fp64 references and tolerances as the eight-wave kernel above, in place as the engine calls them, a ragged last tile included;
+    the forms agree to rounding (the same terms, summed in another order); repeated launches bit-identical, also when two launches
+    share the chip (what two steps in flight create)."""
     L = _lib()
     E = 384
     h, r, w1, b1, w2, b2, g, be = _ffn_inputs(M, F_, seed=300)
@@ -734,7 +739,10 @@ def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_):
         L.set_option("ffn_dma_waves", 0)
         eight_f, eight_p = [t.cpu() for t in ffn()], [t.cpu() for t in proj()]
         L.set_option("ffn_dma_waves", 1)
+        L.set_option("ffn_pair", pair)
+        L.reset_launch_counts()
         want_f, want_p = [t.cpu() for t in ffn()], [t.cpu() for t in proj()]
+        assert L.launch_count("pp_ffn_dma.hip") == 2 and L.launch_count("ffn_dma_pair") == (2 if pair and (F_ // 128) % 2 == 0 else 0)
         torch.testing.assert_close(want_f[0].double(), x_ref, **TOL)
         torch.testing.assert_close(_unsp(want_f[1]), h_ref, **TOL)
         torch.testing.assert_close(_unsp(want_p[2]), h_mid, **TOL)
@@ -759,6 +767,7 @@ def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_):
                 assert same([t.cpu() for t in a], want_p) and same([t.cpu() for t in b], want_f), f"contended launch {it}"
     finally:
         L.set_option("ffn_dma_waves", 1)
+        L.set_option("ffn_pair", 1)
 
 
 @gpu
