@@ -192,6 +192,11 @@ def kernel_work_per_step(eng, B, passes, tag):
             by += L * (M * Fd * esz + 2 * M * E * 4 + M * E * esz)
             n += L
         return fl, by, n, f"_ZN2pp2rl18gemm_res_ln_kernelI{t}NS0_3CfgILi96ELi1ELi3ELi4ELi3EEEEEvNS0_6ParamsE"
+    if tag == "linear_fold":  # f16x3 without a fused layer kernel (ViT-B): qkv, proj, fc1, fc2 of every layer through pp_linear_ln_folded (LayerNorms
+        # folded in): operand-format rows in and out (4 bytes per element), the residual stream read and written by proj / fc2
+        fl = L * 2.0 * M * (3 * E * E + E * E + 2 * E * Fd)
+        by = L * 4 * M * ((E + 3 * E) + (E + 2 * E) + (E + Fd) + (Fd + 2 * E))
+        return fl, by, 4 * L, "_ZN2pp3ldm17linear_dma_kernelILi1EEEvNS0_6ParamsE|_ZN2pp3ldm17linear_dma_kernelILi2EEEvNS0_6ParamsE"
     if tag not in ("gemm_bf16out", "gemm_f32out"):
         return None
     # plain dense layers: qkv (+ fc1 when the FFN is not fused) write the operand dtype; the final 1x1 conv (+ the
@@ -213,9 +218,12 @@ def kernel_work_per_step(eng, B, passes, tag):
         if eng.precision == "f16x3" and (3 * E) % 192 == 0 and Fd % 192 == 0:
             from probpose_code_amd import _lib
             if _lib.get_option("linear_dma") != 0 and ((M + 191) // 192) * ((3 * E) // 192) >= 512:
-                # the twelve-wave persistent kernel (pp_linear_dma.hip: pp_gemm tries it FIRST, at every K >= 64 - at K = 384 it is level with
-                # pp_linear_ovl.hip, scripts/micro/linear_k384_bench.py): qkv = <ACT_NONE>, fc1 = <ACT_GELU>; both in this tag
-                return act_fl, act_by, act_n, "_ZN2pp3ldm28linear_dma_persistent_kernelILi0EEEvNS0_6ParamsE|_ZN2pp3ldm28linear_dma_persistent_kernelILi1EEEvNS0_6ParamsE"
+                # the twelve-wave kernel (pp_linear_dma.hip: pp_gemm tries it FIRST, at every K >= 64 - at K = 384 it is level with
+                # pp_linear_ovl.hip, scripts/micro/linear_k384_bench.py): one tile per workgroup, or round 4's persistent form under option
+                # "linear_persistent" (qkv = <ACT_NONE>, fc1 = <ACT_GELU>; both in this tag)
+                if _lib.get_option("linear_persistent") != 0:
+                    return act_fl, act_by, act_n, "_ZN2pp3ldm28linear_dma_persistent_kernelILi0EEEvNS0_6ParamsE|_ZN2pp3ldm28linear_dma_persistent_kernelILi1EEEvNS0_6ParamsE"
+                return act_fl, act_by, act_n, "_ZN2pp3ldm17linear_dma_kernelILi0EEEvNS0_6ParamsE"
         if eng.precision == "f16x3" and E >= 768 and (3 * E) % 192 == 0 and Fd % 192 == 0:
             # K >= 768: the wide-tile split kernel (256 x 192 tiles; the fp32-output Linear layers run on the same instantiation)
             return act_fl, act_by, act_n, "_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1ELi2ELb0ELb0EEEvNS_10GemmParamsE"
@@ -249,6 +257,13 @@ def pmc_traffic(kernel_mangled, precision, B, prefix=""):
             continue
         if "linear_dma_persistent_kernel" in kernel_mangled:  # two instantiations share the tag: launch-weighted mean of both
             hit = [v for k, v in ks.items() if "linear_dma_persistent_kernel<0>" in k or "linear_dma_persistent_kernel<1>" in k]
+            if hit:
+                n = sum(v["launches"] for v in hit)
+                return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / n), "profiles/" + name
+            continue
+        if "linear_dma_kernelILi" in kernel_mangled:  # the one-tile kernel's instantiations that share a tag (<1> + <2>: the folded-LayerNorm plan)
+            want = ["linear_dma_kernel<%s>" % m[len("linear_dma_kernelILi")] for m in kernel_mangled.split("|") for m in [m[m.index("linear_dma_kernelILi"):]]]
+            hit = [v for k, v in ks.items() if any(w in k for w in want)]
             if hit:
                 n = sum(v["launches"] for v in hit)
                 return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / n), "profiles/" + name

@@ -71,6 +71,8 @@ int pp_device_cu_count(void);
  *   "ksplit9_below" (1024)   pp_conv3x3_splitk_slices: output rows under which a small tower stage is cut into nine K-slices
  *   "linear_dma" (1)         0: large split-fp16 Linear layers (pp_gemm, N % 192 == 0, >= 512 tiles) stay on the wide-tile kernel instead of the
  *                            twelve-wave 192 x 192 kernels (pp_linear_dma.hip: persistent, finished tiles leave through the DMA waves)
+ *   "linear_persistent" (0)  1: twelve-wave Linear layers without a residual on the persistent kernel (finished tiles leave through the DMA
+ *                            waves; round 4's form - since the one-tile kernel has rolling fragment reads it is the faster of the two)
  *   "ffn_dma_waves" (1)      0: the fused f16x3 feed-forward launches run the eight-wave kernel (pp_ffn_split.hip) instead of the
  *                            twelve-wave one (pp_ffn_dma.hip: eight computing waves + four waves that only issue the LDS-DMA)
  *   "ffn_pair" (1)           twelve-wave feed-forward launch: hidden chunks in pairs that share every streamed x k-block (x rows streamed 6 instead of 12
@@ -117,7 +119,8 @@ enum {
     PP_WS_TOWER_PARTIAL = 11,/* (slices, 4, n_img, h, w, embed) fp32: split-K partial sums of tower stage `index`, slices =
                               * pp_conv3x3_splitk_slices(prec, n_img, h, w, embed, embed, 4)                                                    */
     PP_WS_TOWER_POOLED = 12, /* (4, n_img, h / ph, w / pw, embed) operand format: pooled output of tower stage `index`     */
-    PP_WS_WINOGRAD = 13      /* pp_conv3x3_winograd_maxpool_relu's scratch for the first tower stage (pp_winograd_scratch_bytes)  */
+    PP_WS_WINOGRAD = 13,     /* pp_conv3x3_winograd_maxpool_relu's scratch for the first tower stage (pp_winograd_scratch_bytes)  */
+    PP_WS_LN_STATS = 14      /* (n_img * n_tokens, embed / 96, 2) fp32: row statistics between two pp_linear_ln_folded launches   */
 };
 long long pp_workspace_bytes(int buffer, int index, const pp_plan_shape* shape);
 
@@ -219,6 +222,30 @@ enum { PP_CONV3X3 = 1, PP_DECONV4X4S2 = 2 };
 int pp_gemm(int prec, const void* act, const void* weight, const float* bias, const float* residual,
             int res_mod, void* out, int M, int N, int K, int lda, int ldw, int ldc, int act_fn,
             int out_bf16, int planar_P, void* stream);
+
+/* Dense layer of a ViT block (PP_PREC_F16X3 operands) with the LayerNorm in FRONT of it folded into the layer and the statistics of the
+ * LayerNorm BEHIND it emitted with the output rows: a block of mmpretrain's TransformerEncoderLayer [3P] (x = x + attn(ln1(x));
+ * x = ffn(ln2(x)) + x; call site mmpose/models/pose_estimators/base.py:206) then runs without a LayerNorm launch and with its residual
+ * stream in the operand format (the path ViT-B - BASELINE config 4 - takes; ViT-S at 192 tokens has its two-launch layer kernels).
+ *   out[m, n] = act_fn(sum_k a_hat[m, k] * weight[n, k] + bias[n]) + residual[m, n]
+ *   a_hat[m, :] = act[m, :]                                  without ln_stats
+ *               = (act[m, :] - mean[m]) * rstd[m]            with ln_stats: evaluated as rstd * (sum_k act weight - mean * ln_colsum[n]);
+ *                 the CALLER folds the affine part into the layer: weight[n, k] = W[n, k] * gamma[k], ln_colsum[n] = sum_k weight[n, k]
+ *                 (of the split-rounded weights), bias[n] = b[n] + sum_k W[n, k] * beta[k] (probpose_code_amd/weights.py::fold_layernorm)
+ * ln_stats : (M, K / 96, 2) fp32, per row and 96-column part (mean, sum of squared deviations from it) of the act rows - what the layer
+ *            that PRODUCED those rows left in its stats_out (its N = this K); mean / rstd (biased variance + ln_eps, as nn.LayerNorm)
+ *            are combined from the parts here. K % 192 == 0.
+ * stats_out: (M, N / 96, 2) fp32 or NULL: the same statistics of the OUTPUT rows (after activation and residual).
+ * residual : NULL, fp32 rows (residual_format PP_OUT_F32) or operand-format rows (PP_OUT_SPLIT: hi + lo, 22 significant bits; may alias
+ *            out - the residual stream updated in place). out_format PP_OUT_SPLIT or PP_OUT_F32. act must not alias out.
+ * Shapes: K % 32 == 0, K >= 64, N % 192 == 0 (192 x 192 tiles, twelve-wave kernel of pp_linear_dma.hip); ln_stats excludes residual and
+ * stats_out (the block has no such layer: qkv / fc1 take statistics, proj / fc2 make them); PP_ERR_UNSUPPORTED otherwise.
+ * pp_linear_ln_folded_supported: 0 = shape not served, 1 = served, 2 = served with at least two rounds of tiles on the chip (the size from
+ * which pp_gemm itself picks this kernel; callers use the folded plan from there and pp_gemm + pp_layernorm below). */
+int pp_linear_ln_folded(const void* act, const void* weight, const float* bias, const void* residual, int residual_format,
+                        void* out, int out_format, int M, int N, int K, int act_fn, const float* ln_stats,
+                        const float* ln_colsum, float ln_eps, float* stats_out, void* stream);
+int pp_linear_ln_folded_supported(int M, int N, int K, int with_ln_stats);
 
 /* Residual dense layer fused with the LayerNorm that follows it in the ViT block
  * (mmpretrain TransformerEncoderLayer [3P]: x = x + attn(ln1(x)); x = ffn(ln2(x)) + x; final ln1):

@@ -58,6 +58,8 @@ SIGNATURES = {
     "pp_reset_launch_counts": (c_int, []),
     "pp_workspace_bytes": (c_longlong, [c_int, c_int, _P]),
     "pp_conv3x3_splitk_slices": (c_int, [c_int] * 7),
+    "pp_linear_ln_folded": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P]),
+    "pp_linear_ln_folded_supported": (c_int, [c_int] * 4),
     "pp_clock_probe": (c_int, [_P, _P, ctypes.c_uint, _P]),
     "pp_probmap_decode": (
         c_int,
@@ -141,7 +143,7 @@ class PlanShape(ctypes.Structure):
 
 
 # PP_WS_* of the header
-WS = dict(patches=0, x=1, h=2, qkv=3, att=4, ln2=5, ffn=6, feat=7, logits=8, deconv=9, tower=10, tower_partial=11, tower_pooled=12, winograd=13)
+WS = dict(patches=0, x=1, h=2, qkv=3, att=4, ln2=5, ffn=6, feat=7, logits=8, deconv=9, tower=10, tower_partial=11, tower_pooled=12, winograd=13, ln_stats=14)
 
 
 def workspace_bytes(buffer: str, shape: "PlanShape", index: int = 0) -> int:

@@ -40,9 +40,15 @@ struct Params {
     const char* a;     // [M, K] split rows
     const char* w;     // [N, K] split rows
     const float* bias; // [N] or NULL
-    const float* residual;  // fp32 [*, ldres] or NULL
+    const float* residual;  // fp32 [*, ldres] or NULL; res_split: [M, N] split rows (may be `out`)
     char* out;         // [M, N]: split rows (out_split) or fp32
     int M, N, K, ldres, res_mod, act, out_split, ntn;
+    // LayerNorm folded around the layer (pp_linear_ln_folded): statistics of the activation rows in, of the output rows out
+    int res_split;           // residual rows are split rows
+    const float* ln_stats;   // [M, K / 96, 2]: per row and 96-column part (mean, sum of squared deviations) of the activation rows, or NULL
+    const float* ln_colsum;  // [N]: sum_k w[n, k] (of the split-rounded weights)
+    float ln_eps;
+    float* stats_out;        // [M, N / 96, 2]: the same statistics of the output rows, or NULL
 };
 
 #define LDM_WAITVM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
@@ -132,6 +138,10 @@ __device__ __forceinline__ void k_loop_roll(f32x4 (&acc)[3][6], const char* smem
     step(false);
 }
 
+// MODE 0: pp_gemm's epilogue; the two of pp_linear_ln_folded as their own instantiations (one epilogue with every option spills 20 registers):
+// MODE 1: LayerNorm statistics of the activation rows IN (qkv / fc1: no residual), MODE 2: residual rows in either format + statistics of the
+// output rows OUT (proj / fc2)
+template <int MODE>
 __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -171,6 +181,9 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + B_OFF + q * 1024), 16, v + (unsigned)(q * row8), kk * 128, 0, 0);
             }
         };
+        // (Measured and removed, round 5: pulling the residual tile towards the L2 from here - 18 extra LDS-DMA pieces into a junk KiB over the last
+        //  eight K-steps. The residual fetch costs a launch ~35 us (proj 214 us with it, 177 without: 170 MB at the speed of the HBM interface,
+        //  all workgroups asking at the same moment), but 256 tiles x 147 KB do not fit the 32 MB of L2 beside the operand streams: no gain.)
         issue(0, 0);
         issue(1, 1);
         int st_i = 2;
@@ -192,6 +205,62 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     const int lane_hi = f_row * 128 + ((f_kg ^ sw) << 4), lane_lo = f_row * 128 + (((4 + f_kg) ^ sw) << 4);
     auto opq = [](int v) { asm volatile("" : "+s"(v)); return v; };
     auto rd = [&](int lane_off, int uni, int imm) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + (lane_off + uni) + imm); };
+    // MODE 1: mean / rstd of this lane's three activation rows from the producer's 96-column parts - fetched HERE, in front of the K loop (the
+    // loads fly under the first stages; six registers live through the loop). Behind the loop they are two more memory round trips on a tile's
+    // critical path: +3.5 us per tile measured. Eight parts = 768 columns per round, a lane's twelve 16-byte loads in flight at once.
+    const int row0 = rg * 48 + f_row;  // + 16 i
+    float mu[3] = {0.f, 0.f, 0.f}, rs[3] = {1.f, 1.f, 1.f};
+    if (MODE == 1 && p.ln_stats) {
+        const int parts = p.K / 96;
+        const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ln_stats) + (size_t)m0 * parts * 2, 0,
+                                                                             (unsigned)rows_left * (unsigned)(parts * 8), 0x00020000);
+        float sm[3] = {0.f, 0.f, 0.f}, m2[3] = {0.f, 0.f, 0.f};
+        if (parts <= 8) {  // one round: mean and squared deviations from the same registers
+            f32x4 t[3][4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    t[i][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (2 * u < parts)  // (wave-uniform; parts is even: K % 192 == 0)
+                        t[i][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rst, (unsigned)(row0 + i * 16) * (unsigned)(parts * 8), 2 * u * 8, 0));
+                }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (2 * u < parts) sm[i] += t[i][u][0] + t[i][u][2];
+                mu[i] = sm[i] / (float)parts;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (2 * u < parts) {
+                        const float d0 = t[i][u][0] - mu[i], d1 = t[i][u][2] - mu[i];
+                        m2[i] += (t[i][u][1] + 96.f * d0 * d0) + (t[i][u][3] + 96.f * d1 * d1);
+                    }
+            }
+        } else {  // wider rows: two passes over the parts
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int q = 0; q < parts; q += 2) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rst, (unsigned)(row0 + i * 16) * (unsigned)(parts * 8), q * 8, 0));
+                        if (pass == 0) {
+                            sm[i] += t[0] + t[2];
+                        } else {
+                            const float d0 = t[0] - mu[i], d1 = t[2] - mu[i];
+                            m2[i] += (t[1] + 96.f * d0 * d0) + (t[3] + 96.f * d1 * d1);
+                        }
+                    }
+                }
+                if (pass == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) mu[i] = sm[i] / (float)parts;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rs[i] = 1.0f / sqrtf(m2[i] / (float)p.K + p.ln_eps);  // (rows past M read zeros: their stores are dropped)
+    }
     f32x4 acc[3][6];  // [row fragment i][column fragment j]: row 48 rg + 16 i + f_row, columns 96 cg + 16 j + 4 f_kg + (0..3)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -236,18 +305,57 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     // ---------------- epilogue: act_fn(sum + bias) + residual, rows out as split fp16 (two 8-byte halves per lane) or fp32 (16 bytes).
     // Output addressing through a buffer descriptor that ends at row M: the row part of the offset in the VGPR (range-checked), the
     // wave-uniform column part in the scalar offset.
-    const int row0 = rg * 48 + f_row;  // + 16 i
+    // With ln_stats the rows of `a` are RAW residual rows and the layer applies the LayerNorm in front of it here (the caller folded gamma
+    // into w and beta into the bias):  sum_k (a - mean) rstd w = rstd (acc - mean colsum(w)).  With stats_out the wave leaves (mean, sum of
+    // squared deviations) of its 96 columns of every output row for the layer that will do the same with THESE rows.
     const size_t ldo = (size_t)p.N * 4;  // bytes per output row in either format
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)m0 * ldo, 0, (unsigned)rows_left * (unsigned)ldo, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual) + (MODE == 2 && p.res_split ? (size_t)m0 * p.N : 0), 0,
+                                                                          MODE == 2 && p.res_split ? (unsigned)rows_left * (unsigned)ldo : 0u, 0x00020000);
+    // The residual values of all 18 fragments are fetched FIRST (72 registers: the operand fragments are dead): written inside the store loop
+    // each load sits behind the previous fragment's store - `residual` may alias `out`, the compiler must keep that order - and a tile pays 18
+    // memory round trips one after the other (measured: ~20 us per tile, as much as the K loop of the proj layer). A lane reads exactly the
+    // elements it writes, so the order between DIFFERENT fragments is free.
+    constexpr int JG = 6;
+    u32x4 resv[3][JG];
+    auto fetch_residual = [&](int j0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) {
+            const int n = n0 + cg * 96 + (j0 + jj) * 16;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int m = m0 + row0 + i * 16;
+                resv[i][jj] = u32x4{0u, 0u, 0u, 0u};
+                if (MODE == 2 && p.res_split) {
+                    const unsigned vrow = (unsigned)(row0 + i * 16) * (unsigned)ldo;
+                    const int so = (n >> 5) * 128 + (n & 16) * 2;
+                    // (row-pair form: the even lane of a pair fetches the hi chunk of both, the odd one the lo chunk; sorted out where they are used)
+                    resv[i][jj] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_s, vrow + (unsigned)(f_kg >> 1) * 16u + (unsigned)(f_kg & 1) * 64u, so, 0));
+                } else if (m < p.M) {
+                    const int rr = p.res_mod > 0 ? m % p.res_mod : m;
+                    resv[i][jj] = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(p.residual + (size_t)rr * p.ldres + n + f_kg * 4));
+                }
+            }
+        }
+    };
+    float rsum[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
+        if (MODE != 1 && p.residual && j % JG == 0) fetch_residual(j);
         const int n = n0 + cg * 96 + j * 16;  // (wave-uniform) first column of the fragment; the lane's four: n + 4 f_kg ..
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n + f_kg * 4);
+        if (MODE == 1 && p.ln_stats) cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n + f_kg * 4);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int m = m0 + row0 + i * 16;
-            f32x4 v = acc[i][j] + bv;
+            f32x4 v;
+            if (MODE == 1 && p.ln_stats) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rs[i] * (acc[i][j][e] - mu[i] * cs[e]) + bv[e];
+            } else {
+                v = acc[i][j] + bv;
+            }
             if (p.act == ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_erfc_as(v[e]);
@@ -255,23 +363,35 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (p.residual && m < p.M) {
-                const int rr = p.res_mod > 0 ? m % p.res_mod : m;
-                v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)rr * p.ldres + n + f_kg * 4);
-            }
             const unsigned vrow = (unsigned)(row0 + i * 16) * (unsigned)ldo;
-            if (p.out_split) {
-                f16x4 h, l;
+            const int so = (n >> 5) * 128 + (n & 16) * 2;  // split rows: the fragment's 16 hi halves inside their 32-element block (lo: + 64)
+            if (MODE == 2 && p.residual && p.res_split) {
+                const u32x4 rq = resv[i][j % JG];
+                const auto s0 = __builtin_amdgcn_permlane16_swap(rq[0], rq[2], false, false);  // -> (own hi, own lo) of values 0, 1
+                const auto s1 = __builtin_amdgcn_permlane16_swap(rq[1], rq[3], false, false);  //                         values 2, 3
+                const u32x2 rh = {s0[0], s1[0]}, rl = {s0[1], s1[1]};
+                const f16x4 h = __builtin_bit_cast(f16x4, rh), l = __builtin_bit_cast(f16x4, rl);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = v[e];
-                    split_pin(t);
-                    h[e] = split_hi(t);
-                    l[e] = split_lo(t, h[e]);
-                }
-                const int so = (n >> 5) * 128 + (n & 16) * 2;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), ro, vrow + (unsigned)f_kg * 8u, so, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l), ro, vrow + (unsigned)f_kg * 8u, so + 64, 0);
+                for (int e = 0; e < 4; ++e) v[e] += (float)h[e] + (float)l[e];
+            } else if (MODE != 1 && p.residual) {
+                v += __builtin_bit_cast(f32x4, resv[i][j % JG]);  // (rows past M: zeros, their stores are dropped)
+            }
+            if (MODE == 2 && p.stats_out) {
+                rsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
+                acc[i][j] = v;  // (kept for the second pass)
+            }
+            if (p.out_split) {
+                // (hi, lo) of the four values in eight VALU instructions (split_pair), then the row-pair form (pp_ffn_dma.hip): lanes f_kg, f_kg ^ 1
+                // exchange halves - the even one stores the 16-byte hi chunk of both, the odd one the lo chunk: ONE 16-byte store per fragment
+                // instead of two 8-byte ones (+ the wait states behind it, see below)
+                u32x2 hu, lu;
+                { unsigned h_, l_; split_pair(v[0], v[1], h_, l_); hu[0] = h_; lu[0] = l_; }
+                { unsigned h_, l_; split_pair(v[2], v[3], h_, l_); hu[1] = h_; lu[1] = l_; }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(hu[1], lu[1], false, false);
+                const u32x4 q = {s0[0], s1[0], s0[1], s1[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(q, ro, vrow + (unsigned)(f_kg >> 1) * 16u + (unsigned)(f_kg & 1) * 64u, so, 0);
+                asm volatile("s_nop 3" ::"v"(q));
             } else {
                 // (one 16-byte store + the wait states the compiler does not insert behind a buffer_store_dwordx4 with an SGPR offset:
                 //  its data registers are read a cycle late for lanes 12 - 15 of every row, scripts/micro/mubuf_store_hazard.hip)
@@ -279,6 +399,31 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
                 __builtin_amdgcn_raw_buffer_store_b128(q, ro, vrow + (unsigned)f_kg * 16u, n * 4, 0);
                 asm volatile("s_nop 3" ::"v"(q));
             }
+        }
+    }
+    if (MODE == 2 && p.stats_out) {
+        // two passes (mean, then squared deviations from it): no cancellation whatever the rows' offset is
+        const int parts = p.N / 96;
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.stats_out + (size_t)m0 * parts * 2, 0, (unsigned)rows_left * (unsigned)(parts * 8), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float sm = rsum[i];
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            const float mean = sm * (1.0f / 96.f);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dd = acc[i][j][e] - mean;
+                    q = __builtin_fmaf(dd, dd, q);
+                }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            if (f_kg == 0)
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, mean), __builtin_bit_cast(unsigned, q)}, rso,
+                                                      (unsigned)(row0 + i * 16) * (unsigned)(parts * 8), (tn * 2 + cg) * 8, 0);
         }
     }
 }
@@ -522,7 +667,7 @@ int linear_dma_gemm(const GemmParams& g, hipStream_t s) {
     p.out_split = g.out_bf16 == 2;
     p.ntn = g.N / ldm::BN;
     const int grid = p.ntn * ((g.M + ldm::BM - 1) / ldm::BM);
-    if (!g.residual) {  // persistent form: finished tiles leave through the DMA waves
+    if (!g.residual && option("linear_persistent") != 0) {  // persistent form: finished tiles leave through the DMA waves
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         auto kern = g.act == ACT_GELU ? ldm::linear_dma_persistent_kernel<ACT_GELU> : g.act == ACT_RELU ? ldm::linear_dma_persistent_kernel<ACT_RELU> : ldm::linear_dma_persistent_kernel<ACT_NONE>;
@@ -531,10 +676,61 @@ int linear_dma_gemm(const GemmParams& g, hipStream_t s) {
         PP_LAUNCH_CHECK_AS("linear_dma_persistent");
         return PP_OK;
     }
-    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldm::linear_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
-    hipLaunchKernelGGL(ldm::linear_dma_kernel, dim3(grid), dim3(ldm::THREADS), ldm::LDS, s, p);
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldm::linear_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
+    hipLaunchKernelGGL(ldm::linear_dma_kernel<0>, dim3(grid), dim3(ldm::THREADS), ldm::LDS, s, p);
     PP_LAUNCH_CHECK_AS("linear_dma_tile");
     return PP_OK;
 }
 
 }  // namespace pp
+
+// One Linear layer of a ViT block with the LayerNorm in front of it folded in and the statistics of the one behind it emitted (the
+// twelve-wave one-tile kernel above; include/probpose_mi355x.h). mmpretrain TransformerEncoderLayer [3P]: x = x + attn(ln1(x));
+// x = ffn(ln2(x)) + x - here ln1 / ln2 never run as launches and x lives in the operand format.
+extern "C" int pp_linear_ln_folded_supported(int M, int N, int K, int with_ln_stats) {
+    if (M <= 0 || N <= 0 || K < 64 || K % 32 != 0 || N % pp::ldm::BN != 0) return 0;
+    if (with_ln_stats && (K % 192 != 0)) return 0;  // (statistics come in 96-column parts, two per 192-column tile of their producer)
+    if ((size_t)pp::ldm::BM * K * 4 >= 0x7ffffff0u || (size_t)pp::ldm::BM * N * 4 >= 0x7ffffff0u) return 0;
+    const long long ntiles = (long long)(N / pp::ldm::BN) * ((M + pp::ldm::BM - 1) / pp::ldm::BM);
+    return ntiles >= 512 ? 2 : 1;  // 2: enough tiles for two rounds of the chip (what pp_gemm asks of this kernel); 1: runs, not recommended
+}
+
+extern "C" int pp_linear_ln_folded(const void* act, const void* weight, const float* bias, const void* residual, int residual_format,
+                                   void* out, int out_format, int M, int N, int K, int act_fn, const float* ln_stats,
+                                   const float* ln_colsum, float ln_eps, float* stats_out, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(act && weight && out, PP_ERR_INVALID_ARG, "pp_linear_ln_folded: act, weight and out must be non-NULL");
+    PP_REQUIRE(M > 0 && N > 0 && K > 0, PP_ERR_INVALID_ARG, "pp_linear_ln_folded: M, N and K must be positive");
+    PP_REQUIRE(out_format == PP_OUT_F32 || out_format == PP_OUT_SPLIT, PP_ERR_INVALID_ARG, "pp_linear_ln_folded: out_format is PP_OUT_F32 or PP_OUT_SPLIT");
+    PP_REQUIRE(!residual || residual_format == PP_OUT_F32 || residual_format == PP_OUT_SPLIT, PP_ERR_INVALID_ARG,
+               "pp_linear_ln_folded: residual_format is PP_OUT_F32 or PP_OUT_SPLIT");
+    PP_REQUIRE(act_fn == ACT_NONE || act_fn == ACT_GELU || act_fn == ACT_RELU, PP_ERR_INVALID_ARG, "pp_linear_ln_folded: unknown act_fn");
+    PP_REQUIRE(!ln_stats || ln_colsum, PP_ERR_INVALID_ARG, "pp_linear_ln_folded: ln_stats needs ln_colsum");
+    PP_REQUIRE(!ln_stats || (!residual && !stats_out), PP_ERR_UNSUPPORTED,
+               "pp_linear_ln_folded: a layer with ln_stats (qkv, fc1) takes no residual and emits no statistics - the block has none there");
+    PP_REQUIRE(act != out, PP_ERR_INVALID_ARG, "pp_linear_ln_folded: act must not alias out (a tile's rows are read by other workgroups)");
+    PP_REQUIRE(pp_linear_ln_folded_supported(M, N, K, ln_stats != nullptr) != 0, PP_ERR_UNSUPPORTED,
+               "pp_linear_ln_folded: needs K % 32 == 0 (K % 192 == 0 with ln_stats), K >= 64, N % 192 == 0");
+    ldm::Params p{};
+    p.a = reinterpret_cast<const char*>(act);
+    p.w = reinterpret_cast<const char*>(weight);
+    p.bias = bias;
+    p.residual = reinterpret_cast<const float*>(residual);
+    p.res_split = residual && residual_format == PP_OUT_SPLIT;
+    p.out = reinterpret_cast<char*>(out);
+    p.M = M; p.N = N; p.K = K;
+    p.ldres = N;
+    p.res_mod = 0;
+    p.act = act_fn;
+    p.out_split = out_format == PP_OUT_SPLIT;
+    p.ntn = N / ldm::BN;
+    p.ln_stats = ln_stats; p.ln_colsum = ln_colsum; p.ln_eps = ln_eps; p.stats_out = stats_out;
+    const int grid = p.ntn * ((M + ldm::BM - 1) / ldm::BM);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    auto kern = ln_stats ? ldm::linear_dma_kernel<1> : ldm::linear_dma_kernel<2>;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(ldm::THREADS), ldm::LDS, s, p);
+    PP_LAUNCH_CHECK_AS("linear_dma_fold");
+    return PP_OK;
+}
+

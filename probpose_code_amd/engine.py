@@ -37,7 +37,7 @@ CONV3X3, DECONV = 1, 2
 
 # launch-plan switches and their shipped values (fuse_resln: None = on for E = 384 only, True = also the E = 768 row-owner kernel)
 PLAN_DEFAULTS = dict(fuse_mlp=True, fuse_proj=True, fuse_qkv=True, split_k=True, fuse_attn=True, fuse_head=True, fuse_resln=None,
-                     fuse_pool=True, fuse_qkv_attn=True, winograd=True)
+                     fuse_pool=True, fuse_qkv_attn=True, winograd=True, ln_fold=True)
 
 
 def plan_from_env() -> Dict[str, object]:
@@ -142,6 +142,10 @@ class ProbPoseEngine:
         # f16x3, 192-token sequences of 32-dim heads: qkv Linear + attention of a layer in one launch, one workgroup per
         # (sequence, head); the qkv tensor never reaches HBM (pp_qkv_attn_split.hip). PP_FUSE_QKV_ATTN=0: pp_gemm + pp_attention
         self.fuse_qkv_attn = precision == "f16x3" and pl["fuse_qkv_attn"] and self.Np == 192 and self.hd == 32 and self.E == 384
+        # f16x3 widths without a fused layer kernel (ViT-B): ln1 / ln2 folded into qkv / fc1 (weights.fold_layernorm), the statistics emitted
+        # by proj / fc2, the residual stream in the operand format: no LayerNorm launch inside the layers (pp_linear_ln_folded)
+        self.ln_fold = bool(precision == "f16x3" and pl["ln_fold"] and not self._proj_packed and not self._ffn_packed
+                            and self.w.has("l0.qkv.wf") and self.E % 192 == 0 and self.w.ffn_dims % 192 == 0)
         # Which layer plan this geometry gets - said once, loudly, when a ViT-S-like model misses the two-launch layer only because of
         # its token count (pp_qkv_attn_split.hip is written for 192-token sequences of 32-dim heads; the projection + FFN launch takes
         # any row count): it then runs qkv Linear + attention (pp_attention) + the fused projection / FFN launch, three launches per layer
@@ -153,6 +157,9 @@ class ProbPoseEngine:
                 self.layer_plan = "three launches per layer (pp_gemm qkv + pp_attention + pp_proj_ffn_split_residual_layernorm)"
             else:
                 self.layer_plan = "generic (pp_gemm / pp_attention / pp_layernorm per layer)"
+                if self.ln_fold:
+                    self.layer_plan += ("; from the row count at which the twelve-wave Linear kernel engages: LayerNorm folded into the Linear "
+                                        "layers (pp_linear_ln_folded x4 + pp_attention per layer, residual stream in the operand format)")
             if pl["fuse_qkv_attn"] and not self.fuse_qkv_attn and self.E == 384 and self.hd == 32:
                 warnings.warn(
                     f"ProbPoseEngine: {self.Np}-token sequences ({img_size[0]}x{img_size[1]} input) miss the fused qkv + attention kernel, "
@@ -220,6 +227,9 @@ class ProbPoseEngine:
             f=None if (fused_layer or self._ffn_packed) else buf("ffn", (M, Fd)),
             att=buf("att", (M, E)) if self.fuse_qkv_attn else None,  # attention output of the fused qkv + attention launch
             hs=buf("ln2", (M, E)) if self._proj_packed else None,  # ln2 rows of the fused projection + FFN launch (scratch, parked in L2 / MALL)
+            # folded-LayerNorm plan: the residual stream in the operand format and the row statistics between its Linear layers
+            xs=buf("h", (M, E)) if self._ln_fold_at(M) else None,
+            lnst=buf("ln_stats", (M, E // 96, 2), f32) if self._ln_fold_at(M) else None,
             scalars=e(4, B, self.K, dt=f32), locs=e(B, self.K, 2, dt=f32),
             keypoints=e(B, self.K, 2, dt=torch.float64), scores=e(B, self.K, dt=f32),
             heatmaps=e(B, self.K, self.Hh, self.Wh, dt=f32),
@@ -244,6 +254,13 @@ class ProbPoseEngine:
             ws[f"p{j}"] = buf("tower_pooled", (4, nb, th // ph, tw // pw_, E), index=j)
         self._ws[key] = ws
         return ws
+
+    def _ln_fold_at(self, M: int) -> bool:
+        """The folded-LayerNorm layer plan runs from the row count at which pp_gemm itself would pick the twelve-wave Linear kernel for the
+        narrowest layer (proj: N = E); below it the generic plan (128 x 128 / wide tiles + pp_layernorm)."""
+        return (self.ln_fold and _lib.get_option("linear_dma") != 0
+                and _lib.lib.pp_linear_ln_folded_supported(int(M), self.E, self.E, 1) == 2
+                and _lib.lib.pp_linear_ln_folded_supported(int(M), self.E, self.w.ffn_dims, 0) == 2)
 
     def _check_options(self) -> None:
         """Library options (pp_set_option) decide kernel selection AND buffer sizes - the split-K slice count of the small tower
@@ -312,6 +329,8 @@ class ProbPoseEngine:
 
         res_ln(ws["patches"], w["patch_w"], w["patch_b"], Kp, w["l0.ln1.w"], w["l0.ln1.b"], ws["h"],
                residual=w["pos_embed"], res_mod=self.Np)
+        if self._ln_fold_at(M):
+            return self._layers_ln_folded(ws, st, B * passes, M)
         qkv_done = False  # the fused layer kernel has already produced this layer's qkv
         one_launch = (fused and E == 384 and self.precision == "bf16" and Fd % 128 == 0 and self.fuse_mlp and self.fuse_proj and self.fuse_attn
                       and self.Np == 192 and self.hd == 32)
@@ -385,6 +404,40 @@ class ProbPoseEngine:
             else:
                 self._gemm(st, ws["h"], w[f"l{i}.fc1.w"], w[f"l{i}.fc1.b"], ws["f"], M, Fd, E, act=ACT_GELU)
                 res_ln(ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], Fd, gn, bn, h_next)
+        return ws["feat"]
+
+    def _layers_ln_folded(self, ws, st, nb: int, M: int) -> torch.Tensor:
+        """The encoder layers with every inner LayerNorm folded into the Linear layer behind it (pp_linear_ln_folded): per layer qkv,
+        attention, proj, fc1, fc2 - five launches, none of them a LayerNorm. ws["x"] / ws["h"] hold the patch-embed output and ln1 of
+        layer 0 on entry (res_ln above); the residual stream then lives in ws["xs"] (operand format) until the last fc2 writes fp32 rows for
+        the final LayerNorm."""
+        E, Fd, w, L = self.E, self.w.ffn_dims, self.w, self.w.num_layers
+        F32, SPLIT = 0, 2
+        xs, stt, scale = ws["xs"], ws["lnst"], self.hd ** -0.5
+
+        def lin(a, wk, bias, out, N, K, act=ACT_NONE, residual=None, res_fmt=F32, out_fmt=SPLIT, ln=None, stats_out=None):
+            self._call("linear_fold", "pp_linear_ln_folded", a.data_ptr(), wk.data_ptr(), bias.data_ptr(), _lib.ptr(residual), res_fmt,
+                       out.data_ptr(), out_fmt, M, N, K, act, stt.data_ptr() if ln is not None else None, _lib.ptr(ln), self.ln_eps,
+                       stt.data_ptr() if stats_out else None, st)
+
+        for i in range(L):
+            if i == 0:  # ln1 of layer 0 came out of the patch-embed launch: the plain weights
+                lin(ws["h"], w["l0.qkv.w"], w["l0.qkv.b"], ws["qkv"], 3 * E, E)
+            else:
+                lin(xs, w[f"l{i}.qkv.wf"], w[f"l{i}.qkv.bf"], ws["qkv"], 3 * E, E, ln=w[f"l{i}.qkv.cf"])
+            if self.stage_hook is not None:
+                self.stage_hook("embed" if i == 0 else f"layer{i - 1}")
+            self._call("attention", "pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), nb, self.Np, self.heads, self.hd, scale, st)
+            # x <- x + att Wp^T + bp (layer 0: the fp32 rows of the patch embedding), statistics for ln2
+            lin(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], xs, E, E, residual=ws["x"] if i == 0 else xs, res_fmt=F32 if i == 0 else SPLIT,
+                stats_out=True)
+            lin(xs, w[f"l{i}.fc1.wf"], w[f"l{i}.fc1.bf"], ws["f"], Fd, E, act=ACT_GELU, ln=w[f"l{i}.fc1.cf"])
+            last = i + 1 == L
+            # x <- x + f W2^T + b2: statistics for the next layer's ln1, or fp32 rows for the final LayerNorm
+            lin(ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], ws["x"] if last else xs, E, Fd, residual=xs, res_fmt=SPLIT,
+                out_fmt=F32 if last else SPLIT, stats_out=not last)
+        self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), w["ln_f.w"].data_ptr(), w["ln_f.b"].data_ptr(), ws["feat"].data_ptr(), M, E,
+                   self.ln_eps, self.fmt, st)
         return ws["feat"]
 
     def heatmap_logits(self, feat: torch.Tensor, nb: int, ws, st) -> torch.Tensor:

@@ -44,6 +44,18 @@ def from_split(c: torch.Tensor) -> torch.Tensor:
     return (v[..., 0, :] + v[..., 1, :]).reshape(c.shape)
 
 
+def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """Linear(LayerNorm(x)) with the LayerNorm's affine part folded into the Linear layer, as pp_linear_ln_folded consumes it
+    (include/probpose_mi355x.h): ``W'[n, k] = W[n, k] gamma[k]`` in the split-fp16 container, ``colsum[n] = sum_k W'[n, k]`` of the
+    ROUNDED split values (what the MFMAs multiply the row mean with), ``bias'[n] = b[n] + sum_k W[n, k] beta[k]``; sums in fp64.
+    mmpretrain TransformerEncoderLayer [3P]: ``attn(ln1(x))`` / ``ffn(ln2(x))``."""
+    wd, g, be = w.double(), gamma.double(), beta.double()
+    wf = to_split((wd * g[None, :]).float().contiguous())
+    colsum = from_split(wf).double().sum(dim=1).float().contiguous()
+    bias = (b.double() + wd @ be).float().contiguous()
+    return wf, colsum, bias
+
+
 def normalize_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     if "state_dict" in sd and isinstance(sd["state_dict"], dict):
         sd = sd["state_dict"]
@@ -144,6 +156,14 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
         t[f"l{i}.fc1.b"] = f32(sd[p + "ffn.layers.0.0.bias"])
         t[f"l{i}.fc2.w"] = op(sd[p + "ffn.layers.1.weight"])
         t[f"l{i}.fc2.b"] = f32(sd[p + "ffn.layers.1.bias"])
+        if split and E % 192 == 0 and E != 384:
+            # widths without a fused layer kernel (ViT-B): the folded form of the two Linear layers that follow a LayerNorm (pp_linear_ln_folded;
+            # engine.py takes that plan from the row count at which the twelve-wave Linear kernel engages - the plain copies serve below it)
+            for name, wk, bk, ln in (("qkv", "attn.qkv.weight", "attn.qkv.bias", "ln1"), ("fc1", "ffn.layers.0.0.weight", "ffn.layers.0.0.bias", "ln2")):
+                bb = sd.get(p + bk)
+                wf, cs, bf = fold_layernorm(sd[p + wk].float(), bb.float() if bb is not None else torch.zeros(sd[p + wk].shape[0]),
+                                            sd[p + ln + ".weight"].float(), sd[p + ln + ".bias"].float())
+                t[f"l{i}.{name}.wf"], t[f"l{i}.{name}.cf"], t[f"l{i}.{name}.bf"] = wf.to(device), cs.to(device), bf.to(device)
     t["ln_f.w"] = f32(sd["backbone.ln1.weight"])
     t["ln_f.b"] = f32(sd["backbone.ln1.bias"])
 

@@ -280,9 +280,12 @@ def test_config4_bs32_graph_replay_default_plan():
     """BASELINE config 4 ON THE LAUNCH PLAN IT IS BENCHMARKED ON: ViT-B 384x288, f16x3, B = 32 crops with the flip
     pass (27 648 token rows: 576 tiles of 192 x 192 for proj / fc2, more for qkv / fc1 - every Linear layer clears the 512-tile threshold of
     pp_linear_dma.hip, as at bs 64), the 24 x 18 first tower stage in its Winograd form, captured as a hipGraph and REPLAYED. The library's
-    launch tally (pp_launch_count) proves which kernels the plan ran; keypoints / scalars of the replay against oracle.model_ref.predict on
-    the first 8 crops (crops are independent: eval-mode BatchNorm, per-crop decode) within 1e-3, no argmax flips
-    (reference workload: mmpose/models/heads/hybrid_heads/probmap_head.py:715-804 at heatmap 96 x 72)."""
+    launch tally (pp_launch_count) proves which kernels the plan ran: since round 5 the layers run with their LayerNorms FOLDED into the
+    Linear layers (pp_linear_ln_folded: 48 launches per forward, two LayerNorm launches left - behind the patch embedding and the final
+    one); plan switch ln_fold = False is round 4's plan (49 twelve-wave Linear launches + 25 LayerNorm launches) and must agree with it.
+    Keypoints / scalars of the replay against oracle.model_ref.predict on the first 8 crops (crops are independent: eval-mode
+    BatchNorm, per-crop decode) within 1e-3, no argmax flips (reference workload:
+    mmpose/models/heads/hybrid_heads/probmap_head.py:715-804 at heatmap 96 x 72)."""
     from oracle import model_ref as M
     from probpose_code_amd import ProbPoseEngine, _lib
     from probpose_code_amd import synthetic as S
@@ -292,35 +295,50 @@ def test_config4_bs32_graph_replay_default_plan():
     sd = S.synthetic_state_dict("base", img_size=img, seed=0, logit_scale=2.0)
     x = S.synthetic_crops(B, img_size=img, seed=3)
     ref = M.predict(sd, x[:NREF], 12, S.IMG_MEAN, S.IMG_STD, input_size=(288, 384))
-    eng = ProbPoseEngine(sd, 12, img_size=img, precision="f16x3", input_size=(288, 384))
-    assert eng.winograd, "the 24 x 18 tower stage must take the Winograd kernel"
     xd = x.cuda()
-    _lib.reset_launch_counts()
-    eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)  # warm-up launches + the capture
-    torch.cuda.synchronize()
     n_fwd = 3  # two eager warm-ups and the captured one (engine.capture)
-    assert _lib.launch_count("linear_dma_persistent") == 24 * n_fwd, "qkv / fc1 of every layer on the persistent twelve-wave kernel"
-    tally = {k: _lib.launch_count(k) for k in ("linear_dma_persistent", "linear_dma_tile", "winograd_gemm_pool", "pp_attention_dma.hip", "layernorm", "pp_gemm.hip", "pp_panel_split.hip")}
-    print("config 4 launch tally of three forwards:", tally)
-    assert _lib.launch_count("linear_dma_tile") == 25 * n_fwd, "patch embed + proj / fc2 of every layer on the twelve-wave kernel (one tile per workgroup)"
-    assert tally["pp_gemm.hip"] == 0, "no Linear layer of the plan on the 128 x 128 kernel"
-    assert tally["layernorm"] == 25 * n_fwd  # (E = 768 has no fused residual + LayerNorm in the default plan: DESIGN.md 4)
-    assert _lib.launch_count("winograd_gemm_pool") == n_fwd and _lib.launch_count("winograd_input_transform") == n_fwd
-    assert _lib.launch_count("pp_attention_dma.hip") == 12 * n_fwd, "432-token attention on the LDS-DMA kernel"
-    _lib.reset_launch_counts()
-    out = eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)  # a REPLAY: no host-side launch is tallied
-    torch.cuda.synchronize()
-    assert _lib.launch_count("linear_dma_persistent") == 0 and _lib.launch_count("pp_attention_dma.hip") == 0
-    kp = out["keypoints"].cpu().numpy()
-    assert np.isfinite(kp).all()
-    d = np.abs(kp[:NREF, None] - ref["keypoints_input_space"]).max(-1)
-    assert (d < 2.0).all() and d.max() <= 1e-3, f"config 4 bs {B} replay: {int((d >= 2).sum())} flips, L_inf {d[d < 2].max():.2e} px"
-    for i, name in enumerate(("keypoints_probs", "keypoints_visible", "keypoints_oks")):
-        assert np.abs(out["scalars"][i].cpu().numpy()[:NREF, None] - ref[name]).max() <= 1e-3, name
-    # the replay is deterministic and equals the eager plan bit for bit
-    eager = eng.forward(xd, True, S.COCO_FLIP_INDICES)
-    torch.cuda.synchronize()
-    assert torch.equal(eager["keypoints"], out["keypoints"])
+    results = {}
+    for fold in (True, False):
+        eng = ProbPoseEngine(sd, 12, img_size=img, precision="f16x3", input_size=(288, 384), plan=dict(ln_fold=fold))
+        assert eng.winograd, "the 24 x 18 tower stage must take the Winograd kernel"
+        assert eng.ln_fold == fold and ("LayerNorm folded" in eng.layer_plan) == fold
+        _lib.reset_launch_counts()
+        eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)  # warm-up launches + the capture
+        torch.cuda.synchronize()
+        tally = {k: _lib.launch_count(k) for k in ("linear_dma_fold", "linear_dma_persistent", "linear_dma_tile", "winograd_gemm_pool",
+                                                   "pp_attention_dma.hip", "layernorm", "pp_gemm.hip", "pp_panel_split.hip")}
+        print(f"config 4 launch tally of three forwards (ln_fold = {fold}):", tally)
+        if fold:
+            assert tally["linear_dma_fold"] == 48 * n_fwd, "qkv / proj / fc1 / fc2 of every layer through pp_linear_ln_folded"
+            assert tally["linear_dma_tile"] == 1 * n_fwd, "the patch embedding on the twelve-wave kernel (one tile per workgroup)"
+            assert tally["layernorm"] == 2 * n_fwd, "LayerNorm launches left: ln1 of layer 0 and the final one"
+        else:
+            assert tally["linear_dma_fold"] == 0 and tally["linear_dma_tile"] == 49 * n_fwd, "patch embed + the four Linear layers of every layer"
+            assert tally["layernorm"] == 25 * n_fwd
+        assert tally["linear_dma_persistent"] == 0, "(option linear_persistent = 0: round 4's persistent form is not in the plan)"
+        assert tally["pp_gemm.hip"] == 0, "no Linear layer of the plan on the 128 x 128 kernel"
+        assert _lib.launch_count("winograd_gemm_pool") == n_fwd and _lib.launch_count("winograd_input_transform") == n_fwd
+        assert _lib.launch_count("pp_attention_dma.hip") == 12 * n_fwd, "432-token attention on the LDS-DMA kernel"
+        _lib.reset_launch_counts()
+        out = eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)  # a REPLAY: no host-side launch is tallied
+        torch.cuda.synchronize()
+        assert _lib.launch_count("linear_dma_fold") == 0 and _lib.launch_count("linear_dma_tile") == 0 and _lib.launch_count("pp_attention_dma.hip") == 0
+        kp = out["keypoints"].cpu().numpy()
+        assert np.isfinite(kp).all()
+        d = np.abs(kp[:NREF, None] - ref["keypoints_input_space"]).max(-1)
+        assert (d < 2.0).all() and d.max() <= 1e-3, f"config 4 bs {B} replay (ln_fold = {fold}): {int((d >= 2).sum())} flips, L_inf {d[d < 2].max():.2e} px"
+        print(f"config 4 bs {B} replay (ln_fold = {fold}): L_inf {d.max():.2e} px vs the oracle")
+        for i, name in enumerate(("keypoints_probs", "keypoints_visible", "keypoints_oks")):
+            assert np.abs(out["scalars"][i].cpu().numpy()[:NREF, None] - ref[name]).max() <= 1e-3, name
+        # the replay is deterministic and equals the eager plan bit for bit
+        eager = eng.forward(xd, True, S.COCO_FLIP_INDICES)
+        torch.cuda.synchronize()
+        assert torch.equal(eager["keypoints"], out["keypoints"])
+        results[fold] = kp
+        del eng
+        torch.cuda.empty_cache()
+    dd = np.abs(results[True] - results[False]).max()
+    assert dd <= 1e-3, f"folded and stand-alone LayerNorm plans differ by {dd:.2e} px"
 
 
 def test_vit_small_384x288_layer_plan_is_named_and_within_1e3():

@@ -842,3 +842,89 @@ def test_conv3x3_maxpool_relu_split_fused_vs_two_launches(B):
     L.set_option("conv_pool_split", 1)
     torch.testing.assert_close(_unsp(outs[0]).permute(0, 1, 4, 2, 3), ref, **TOL)
     torch.testing.assert_close(_unsp(outs[0]), _unsp(outs[1]), **TOL)
+
+
+def _row_part_stats(y):
+    """(M, N) fp64 -> (M, N / 96, 2): per row and 96-column part (mean, sum of squared deviations from it) - pp_linear_ln_folded's stats_out."""
+    p = y.reshape(y.shape[0], -1, 96)
+    mean = p.mean(dim=2)
+    return torch.stack([mean, ((p - mean[..., None]) ** 2).sum(dim=2)], dim=2)
+
+
+@gpu
+@pytest.mark.parametrize("M", [192 * 3, 192 * 2 + 77, 24576])
+def test_linear_ln_folded_chain_vs_fp64(M):
+    """pp_linear_ln_folded: a ViT block's Linear layers with the LayerNorms folded in (mmpretrain TransformerEncoderLayer [3P]:
+    x = x + attn(ln1(x)); x = ffn(ln2(x)) + x). The chain the engine runs - proj (fp32 residual in, split rows + statistics out), fc1 on
+    the RAW rows with ln2 folded in (gamma into the weights, beta into the bias, mean / rstd from the statistics) + GELU, fc2 (split
+    residual in place, statistics out), and an fp32-output fc2 - against torch fp64 on the unrounded inputs with an explicit LayerNorm;
+    the rows carry an offset (mean / std ~ 3) so that the mean term is not small; a ragged last tile; the statistics themselves checked;
+    repeated launches bit-identical; shapes / aliasing it does not serve are refused."""
+    from probpose_code_amd.weights import fold_layernorm
+
+    L = _lib()
+    E, Fd, F32, eps = 768, 1536, 0, 1e-6
+    att = _rand(M, E, seed=700)
+    x0 = _rand(M, E, seed=701) + 3.0 * _rand(M, 1, seed=702)
+    wp, bp = _rand(E, E, seed=703, scale=1 / math.sqrt(E)), _rand(E, seed=704, scale=0.1)
+    g2, be2 = 1.0 + 0.2 * _rand(E, seed=705), 0.2 * _rand(E, seed=706)
+    w1, b1 = _rand(Fd, E, seed=707, scale=1 / math.sqrt(E)), _rand(Fd, seed=708, scale=0.1)
+    w2, b2 = _rand(E, Fd, seed=709, scale=1 / math.sqrt(Fd)), _rand(E, seed=710, scale=0.1)
+    # fp64 reference
+    x1 = x0.double() + att.double() @ wp.double().t() + bp.double()
+    h2 = F.layer_norm(x1, (E,), g2.double(), be2.double(), eps)
+    f = F.gelu(h2 @ w1.double().t() + b1.double())
+    x2 = x1 + f @ w2.double().t() + b2.double()
+    # device
+    w1f, c1, b1f = fold_layernorm(w1, b1, g2, be2)
+    d = dict(att=_sp(att), x0=x0.cuda(), wp=_sp(wp), bp=bp.cuda(), w1f=w1f.cuda(), c1=c1.cuda(), b1f=b1f.cuda(), w2=_sp(w2), b2=b2.cuda())
+
+    def chain():
+        xs = torch.full((M, E), float("nan"), device="cuda")
+        st = torch.full((M, E // 96, 2), float("nan"), device="cuda")
+        fbuf = torch.full((M, Fd), float("nan"), device="cuda")
+        xo = torch.full((M, E), float("nan"), device="cuda")
+        L.call("pp_linear_ln_folded", d["att"].data_ptr(), d["wp"].data_ptr(), d["bp"].data_ptr(), d["x0"].data_ptr(), F32, xs.data_ptr(), SPLIT,
+               M, E, E, 0, None, None, eps, st.data_ptr(), None)
+        x1_dev, st1 = _unsp(xs), st.cpu().double()
+        L.call("pp_linear_ln_folded", xs.data_ptr(), d["w1f"].data_ptr(), d["b1f"].data_ptr(), None, F32, fbuf.data_ptr(), SPLIT,
+               M, Fd, E, 1, st.data_ptr(), d["c1"].data_ptr(), eps, None, None)
+        L.call("pp_linear_ln_folded", fbuf.data_ptr(), d["w2"].data_ptr(), d["b2"].data_ptr(), xs.data_ptr(), SPLIT, xo.data_ptr(), F32,
+               M, E, Fd, 0, None, None, eps, None, None)   # the last layer's form: fp32 rows for the final LayerNorm
+        L.call("pp_linear_ln_folded", fbuf.data_ptr(), d["w2"].data_ptr(), d["b2"].data_ptr(), xs.data_ptr(), SPLIT, xs.data_ptr(), SPLIT,
+               M, E, Fd, 0, None, None, eps, st.data_ptr(), None)  # in place, statistics for the next ln1
+        return x1_dev, st1, _unsp(fbuf), xo.cpu().double(), _unsp(xs), st.cpu().double()
+
+    x1_dev, st1, f_dev, x2_f32, x2_split, st2 = chain()
+    torch.testing.assert_close(x1_dev, x1, **TOL)
+    torch.testing.assert_close(st1, _row_part_stats(x1), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(f_dev, f, rtol=3e-5, atol=3e-5)
+    torch.testing.assert_close(x2_f32, x2, rtol=3e-5, atol=3e-5)
+    torch.testing.assert_close(x2_split, x2, rtol=3e-5, atol=3e-5)
+    torch.testing.assert_close(st2, _row_part_stats(x2), rtol=1e-4, atol=1e-4)
+    again = chain()
+    for a, b in zip((x1_dev, st1, f_dev, x2_f32, x2_split, st2), again):
+        assert torch.equal(a, b), "run-to-run difference"
+    if M < 1000:  # rows wider than eight 96-column parts take the two-pass form of the statistics: fc2's rows (K = 1536) normalised in front of a layer
+        g3, be3 = 1.0 + 0.2 * _rand(Fd, seed=711), 0.2 * _rand(Fd, seed=712)
+        w3, b3 = _rand(192, Fd, seed=713, scale=1 / math.sqrt(Fd)), _rand(192, seed=714, scale=0.1)
+        fr = f + 2.0  # (an offset: the mean term must matter)
+        w3f, c3, b3f = [t.cuda() for t in fold_layernorm(w3, b3, g3, be3)]
+        frs, st3 = _sp(fr.float()), _row_part_stats(_unsp(_sp(fr.float()))).float().cuda()
+        o3 = torch.full((M, 192), float("nan"), device="cuda")
+        L.call("pp_linear_ln_folded", frs.data_ptr(), w3f.data_ptr(), b3f.data_ptr(), None, F32, o3.data_ptr(), F32, M, 192, Fd, 0, st3.data_ptr(),
+               c3.data_ptr(), eps, None, None)
+        ref3 = F.layer_norm(fr, (Fd,), g3.double(), be3.double(), eps) @ w3.double().t() + b3.double()
+        torch.testing.assert_close(o3.cpu().double(), ref3, rtol=3e-5, atol=3e-5)
+    assert L.lib.pp_linear_ln_folded_supported(M, E, E, 1) == (2 if M >= 24576 else 1)
+    assert L.lib.pp_linear_ln_folded_supported(M, 100, E, 0) == 0 and L.lib.pp_linear_ln_folded_supported(M, E, 800, 1) == 0
+    xs = torch.zeros((M, E), device="cuda")
+    with pytest.raises(L.ProbPoseLibraryError):  # act aliasing out
+        L.call("pp_linear_ln_folded", xs.data_ptr(), d["wp"].data_ptr(), d["bp"].data_ptr(), None, F32, xs.data_ptr(), SPLIT, M, E, E, 0, None, None,
+               eps, None, None)
+    with pytest.raises(L.ProbPoseLibraryError):  # statistics without the column sums
+        L.call("pp_linear_ln_folded", xs.data_ptr(), d["w1f"].data_ptr(), d["b1f"].data_ptr(), None, F32, d["x0"].data_ptr(), SPLIT, M, Fd, E, 1,
+               xs.data_ptr(), None, eps, None, None)
+    with pytest.raises(L.ProbPoseLibraryError):  # a layer with statistics in takes no residual
+        L.call("pp_linear_ln_folded", xs.data_ptr(), d["w1f"].data_ptr(), d["b1f"].data_ptr(), d["x0"].data_ptr(), F32, d["x0"].data_ptr(), SPLIT, M, E, E, 0,
+               xs.data_ptr(), d["c1"].data_ptr(), eps, None, None)
