@@ -158,11 +158,15 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
             const auto s32 = __builtin_amdgcn_permlane32_swap(mv, mv, false, false);
             mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
         }
-        const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);  // (first pair: exp2(-inf) = 0, nothing to rescale)
-        l_run *= alpha;
+        // (the running maximum of a query stops moving after its first few key blocks: when it has not moved for ANY query of the tile -
+        //  wave-uniform - alpha is exactly 1 for every lane and the rescale of O, 17 multiplications, is skipped)
+        if (__builtin_amdgcn_ballot_w64(mx != m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);  // (first pair: exp2(-inf) = 0, nothing to rescale)
+            l_run *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt) o[dt] *= alpha;
-        m_run = mx;
+            for (int dt = 0; dt < C::DT; ++dt) o[dt] *= alpha;
+            m_run = mx;
+        }
         const float mb = mx * scale_log2e;
         float sum = 0.f;
 #pragma unroll
@@ -179,12 +183,18 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
         for (int h = 0; h < 2; ++h) {
             const int st = 2 * pr + h;
             f16x8 ph, pl;
+            {   // (hi, lo) of the eight probabilities in 16 VALU instructions (split_pair) instead of 32
+                u32x4 phu, plu;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ph[j] = split_hi(sc[2 * h][j]);
-                pl[j] = split_lo(sc[2 * h][j], ph[j]);
-                ph[4 + j] = split_hi(sc[2 * h + 1][j]);
-                pl[4 + j] = split_lo(sc[2 * h + 1][j], ph[4 + j]);
+                for (int j = 0; j < 2; ++j) {
+                    unsigned h_, l_;
+                    split_pair(sc[2 * h][2 * j], sc[2 * h][2 * j + 1], h_, l_);
+                    phu[j] = h_; plu[j] = l_;
+                    split_pair(sc[2 * h + 1][2 * j], sc[2 * h + 1][2 * j + 1], h_, l_);
+                    phu[2 + j] = h_; plu[2 + j] = l_;
+                }
+                ph = __builtin_bit_cast(f16x8, phu);
+                pl = __builtin_bit_cast(f16x8, plu);
             }
             // two head-dim tiles (16 dims each) per group: eight transposing reads in flight, one wait, six MFMAs.
             // As asm: the BUILTIN carries no memory operand, so the compiler waits for every LDS-DMA in flight (vmcnt(0)) in front of
