@@ -341,6 +341,45 @@ def test_config4_bs32_graph_replay_default_plan():
     assert dd <= 1e-3, f"folded and stand-alone LayerNorm plans differ by {dd:.2e} px"
 
 
+def test_vit_base_256x192_bs64_folded_plan_within_1e3():
+    """ViT-B at the reference's own ViTPose-base geometry (configs/body_2d_keypoint/topdown_heatmap/coco/td-hm_ViTPose-base_8xb64-210e_coco-256x192.py:
+    46-61: 256x192 crops, 192 tokens of 12 heads x 64) with the ProbPose head, bs 64 + flip = 24 576 token rows: exactly the row count from
+    which the folded-LayerNorm plan runs (512 tiles for proj / fc2). The launch tally names the plan; keypoints / scalars of the hipGraph
+    replay against oracle.model_ref.predict on the first 6 crops within 1e-3, no argmax flips; one crop fewer (63) falls back to the
+    generic plan and must agree."""
+    from oracle import model_ref as M
+    from probpose_code_amd import ProbPoseEngine, _lib
+    from probpose_code_amd import synthetic as S
+
+    torch.set_num_threads(min(16, os.cpu_count()))
+    B, NREF = 64, 6
+    sd = S.synthetic_state_dict("base", seed=1, logit_scale=2.0)
+    x = S.synthetic_crops(B, seed=9)
+    ref = M.predict(sd, x[:NREF], 12, S.IMG_MEAN, S.IMG_STD)
+    eng = ProbPoseEngine(sd, 12, precision="f16x3")
+    xd = x.cuda()
+    _lib.reset_launch_counts()
+    out = eng.forward(xd, True, S.COCO_FLIP_INDICES)
+    torch.cuda.synchronize()
+    assert _lib.launch_count("linear_dma_fold") == 48 and _lib.launch_count("layernorm") == 2, "bs 64: the folded-LayerNorm plan"
+    rep = eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)
+    rep = eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)
+    rep = eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)
+    torch.cuda.synchronize()
+    assert torch.equal(rep["keypoints"], out["keypoints"])
+    kp = rep["keypoints"].cpu().numpy()
+    d = np.abs(kp[:NREF, None] - ref["keypoints_input_space"]).max(-1)
+    assert (d < 2.0).all() and d.max() <= 1e-3, f"ViT-B 256x192 bs 64: {int((d >= 2).sum())} flips, L_inf {d[d < 2].max():.2e} px"
+    for i, name in enumerate(("keypoints_probs", "keypoints_visible", "keypoints_oks")):
+        assert np.abs(rep["scalars"][i].cpu().numpy()[:NREF, None] - ref[name]).max() <= 1e-3, name
+    _lib.reset_launch_counts()
+    small = eng.forward(xd[:63].contiguous(), True, S.COCO_FLIP_INDICES)
+    torch.cuda.synchronize()
+    assert _lib.launch_count("linear_dma_fold") == 0 and _lib.launch_count("layernorm") == 25, "bs 63: below the threshold, the generic plan"
+    dd = (small["keypoints"][:NREF] - rep["keypoints"][:NREF]).abs().max().item()
+    assert dd <= 1e-3, f"generic and folded plans differ by {dd:.2e} px"
+
+
 def test_vit_small_384x288_layer_plan_is_named_and_within_1e3():
     """A ViT-S at another input size (432 tokens) misses the fused qkv + attention kernel, which is written for 192-token sequences:
     the engine says so ONCE, by name (RuntimeWarning + `layer_plan`), and runs three launches per layer - the projection + FFN launch
