@@ -219,10 +219,7 @@ def kernel_work_per_step(eng, B, passes, tag):
             from probpose_code_amd import _lib
             if _lib.get_option("linear_dma") != 0 and ((M + 191) // 192) * ((3 * E) // 192) >= 512:
                 # the twelve-wave kernel (pp_linear_dma.hip: pp_gemm tries it FIRST, at every K >= 64 - at K = 384 it is level with
-                # pp_linear_ovl.hip, scripts/micro/linear_k384_bench.py): one tile per workgroup, or round 4's persistent form under option
-                # "linear_persistent" (qkv = <ACT_NONE>, fc1 = <ACT_GELU>; both in this tag)
-                if _lib.get_option("linear_persistent") != 0:
-                    return act_fl, act_by, act_n, "_ZN2pp3ldm28linear_dma_persistent_kernelILi0EEEvNS0_6ParamsE|_ZN2pp3ldm28linear_dma_persistent_kernelILi1EEEvNS0_6ParamsE"
+                # pp_linear_ovl.hip, scripts/micro/linear_k384_bench.py)
                 return act_fl, act_by, act_n, "_ZN2pp3ldm17linear_dma_kernelILi0EEEvNS0_6ParamsE"
         if eng.precision == "f16x3" and E >= 768 and (3 * E) % 192 == 0 and Fd % 192 == 0:
             # K >= 768: the wide-tile split kernel (256 x 192 tiles; the fp32-output Linear layers run on the same instantiation)
@@ -254,12 +251,6 @@ def pmc_traffic(kernel_mangled, precision, B, prefix=""):
         try:
             ks = json.load(open(path))["kernels"]
         except Exception:  # noqa: BLE001
-            continue
-        if "linear_dma_persistent_kernel" in kernel_mangled:  # two instantiations share the tag: launch-weighted mean of both
-            hit = [v for k, v in ks.items() if "linear_dma_persistent_kernel<0>" in k or "linear_dma_persistent_kernel<1>" in k]
-            if hit:
-                n = sum(v["launches"] for v in hit)
-                return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / n), "profiles/" + name
             continue
         if "linear_dma_kernelILi" in kernel_mangled:  # the one-tile kernel's instantiations that share a tag (<1> + <2>: the folded-LayerNorm plan)
             want = ["linear_dma_kernel<%s>" % m[len("linear_dma_kernelILi")] for m in kernel_mangled.split("|") for m in [m[m.index("linear_dma_kernelILi"):]]]

@@ -70,9 +70,9 @@ int pp_device_cu_count(void);
  *   "qkv_attn_pair" (0)      1: pp_qkv_attention_split with a head pair per workgroup (measured slower; kept for A/B)
  *   "ksplit9_below" (1024)   pp_conv3x3_splitk_slices: output rows under which a small tower stage is cut into nine K-slices
  *   "linear_dma" (1)         0: large split-fp16 Linear layers (pp_gemm, N % 192 == 0, >= 512 tiles) stay on the wide-tile kernel instead of the
- *                            twelve-wave 192 x 192 kernels (pp_linear_dma.hip: persistent, finished tiles leave through the DMA waves)
- *   "linear_persistent" (0)  1: twelve-wave Linear layers without a residual on the persistent kernel (finished tiles leave through the DMA
- *                            waves; round 4's form - since the one-tile kernel has rolling fragment reads it is the faster of the two)
+ *                            twelve-wave 192 x 192 kernel (pp_linear_dma.hip: eight computing + four DMA-only waves)
+ *   "linear_loop" (1)        twelve-wave Linear kernel: one workgroup per CU walks a column of tiles, the next tile's first stages requested
+ *                            under this tile's epilogue; 0: a workgroup per tile
  *   "ffn_dma_waves" (1)      0: the fused f16x3 feed-forward launches run the eight-wave kernel (pp_ffn_split.hip) instead of the
  *                            twelve-wave one (pp_ffn_dma.hip: eight computing waves + four waves that only issue the LDS-DMA)
  *   "ffn_pair" (1)           twelve-wave feed-forward launch: hidden chunks in pairs that share every streamed x k-block (x rows streamed 6 instead of 12
@@ -87,8 +87,8 @@ int pp_get_option(const char* name, int* value);
 
 /* Diagnostics: kernel launches since the last reset, tallied on the host at launch time (a captured hipGraph counts once, at capture) under
  * the launching source file's name - "pp_winograd.hip", "pp_ffn_dma.hip", "pp_qkv_attn_split.hip", "pp_linear_dma.hip", "pp_gemm.hip" ... - and
- * for kernels that share a file under their own tag: "linear_dma_persistent" (twelve-wave Linear kernel, finished tiles through the DMA
- * waves), "linear_dma_tile" (its one-tile-per-workgroup form), "ffn_dma_pair" / "ffn_dma_single" (the twelve-wave feed-forward launch in its
+ * for kernels that share a file under their own tag: "linear_dma_tile" (twelve-wave Linear kernel under pp_gemm), "linear_dma_fold" (the same
+ * kernel under pp_linear_ln_folded), "ffn_dma_pair" / "ffn_dma_single" (the twelve-wave feed-forward launch in its
  * paired-chunk / one-chunk form), "winograd_input_transform", "winograd_gemm_pool", "layernorm". Lets a test
  * assert WHICH kernels a launch plan ran (the reference has no counterpart: kernel selection there is cuDNN's, mmpose/models/heads/
  * hybrid_heads/probmap_head.py:261-294 and mmpretrain's VisionTransformer only name the layers). Unknown names count 0. Not thread-safe. */

@@ -30,7 +30,7 @@ static Option g_options[] = {
     {"decode_wgs_per_cu", 3},  // most workgroups per CU the decode kernel sizes its band buffer for (5 .. 1): more than 3 measured slower at bs 64 (4.25 workgroups per CU are balanced by the dispatcher, not by residency; smaller buffers mean more bands)
     {"qkv_attn_pair", 0},      // 1: pp_qkv_attention_split with a head PAIR per workgroup (one workgroup per CU; measured slower)
     {"linear_dma", 1},         // large split-fp16 Linear layers (pp_gemm): 1 = the twelve-wave 192 x 192 kernels (pp_linear_dma.hip), 0 = the wide-tile kernel
-    {"linear_persistent", 0},  // twelve-wave Linear layers without a residual: 1 = the persistent kernel (finished tiles leave through the DMA waves; round 4), 0 = one tile per workgroup (faster since it has rolling reads)
+    {"linear_loop", 1},        // one-tile twelve-wave Linear kernel: 1 = one workgroup per CU walks a column of tiles, the next tile's first stages requested under this tile's epilogue; 0 = a workgroup per tile
     {"ffn_dma_waves", 1},      // fused f16x3 feed-forward launch: 1 = the twelve-wave form (pp_ffn_dma.hip: eight computing waves + four DMA waves), 0 = the eight-wave form (pp_ffn_split.hip)
     {"ffn_pair", 1},           // twelve-wave feed-forward launch: 1 = hidden chunks in PAIRS that share every streamed x k-block (x streamed 6 instead of 12 times per launch; even chunk counts only), 0 = one chunk at a time
     {"psplit_tail", 1},        // split-fp16 Linear layers on the wide-tile kernel: 0 = no second launch on 128 x 192 tiles for the rows of a ragged last round

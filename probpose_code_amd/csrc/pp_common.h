@@ -14,7 +14,7 @@ namespace pp {
 void set_error(const char* fmt, ...);
 int option(const char* name);  // explicit dev switches (pp_set_option); the library never reads the environment
 // Diagnostics (pp_launch_count): every kernel launch is tallied under its source file's name ("pp_winograd.hip") and, where a file holds
-// several kernel families, under an explicit tag as well ("linear_dma_persistent"). Host side, a few string compares per launch.
+// several kernel families, under an explicit tag as well ("linear_dma_tile"). Host side, a few string compares per launch.
 void count_launch(const char* file_or_tag);
 
 inline int fail(int code, const char* what) {

@@ -5,21 +5,24 @@
 // with arch 'base'). pp_gemm routes here before the wide-tile kernel (pp_panel_split.hip) when the shape allows it.
 //
 // The structure is pp_ffn_dma.hip's, applied to a plain GEMM:
-//   * one workgroup = one 192 x 192 output tile, 768 threads = 12 waves, three per SIMD, <= 168 registers, no scratch;
+//   * a workgroup works on one 192 x 192 output tile at a time, 768 threads = 12 waves, three per SIMD, <= 168 registers;
 //   * waves 0-7 compute: wave (rg, cg) = rows 48 rg .., columns 96 cg .. = 3 x 6 fragments (72 accumulator registers); per K-step
-//     (32 elements = one 128-byte block per row) one barrier, 18 fragment reads issued before the first MFMA, 54 MFMAs; they
-//     issue no memory instruction in the loop;
+//     (32 elements = one 128-byte block per row) one barrier, 18 fragment reads rolling under 54 MFMAs (k_loop_roll); they issue no
+//     memory instruction in the loop;
 //   * waves 8-11, one per SIMD, issue every buffer_load ... lds piece (a stage = 192 activation rows + 192 weight rows = 48 KiB =
 //     48 pieces of 8 rows x 128 B, 12 per wave) two stages ahead on a ring of three, and do the counted vmcnt wait in front of each
 //     barrier;
+//   * one workgroup per CU walks tiles id, id + CUs, ... (option "linear_loop"; 0: a workgroup per tile) with the ring turning across
+//     tiles: the next tile's first two stages are requested under this tile's epilogue;
 //   * tiles in bands of four row tiles, row tile fastest: the workgroups resident on one XCD share one row tile per band and half of the
 //     weight column tiles (see the kernel);
 //   * rows past M: the activation descriptor ends at row M (the DMA writes zeros), the output descriptor too (stores are dropped).
-// Two kernels: layers WITH a residual run the plain form above (every workgroup one tile; its epilogue - 147 KB through a store path of
-// ~8 B/clk = 9 us per tile - is exposed: whole launches 667 against 686 us for fc2 on the wide-tile kernel); layers without one run the
-// PERSISTENT form below, where finished tiles leave through the DMA waves. Step loop alone (scripts/micro/gemm12.hip, M = 55 296): 450 /
-// 583 / 622 us for (N, K) = (2304, 768) / (3072, 768) / (768, 3072); whole launches (scripts/micro/linear_forms_bench.py): qkv 519 - 529
-// against 549 - 557 us, fc1 + GELU 742 - 747 against 775 - 779; BASELINE config 4: 1 730 - 1 785 against 1 692 - 1 694 crops/s.
+// Three epilogues (template MODE): pp_gemm's, and the two of pp_linear_ln_folded (LayerNorm statistics in / out, residual rows in the
+// operand format). History: round 4 ran layers without a residual on a PERSISTENT form whose finished tiles left through the DMA waves
+// (qkv 519 - 529 against 549 - 557 us on the wide-tile kernel); with rolling fragment reads, row-pair stores and the tile loop the plain
+// kernel passed it (15.4 against 15.6 - 16.2 ms per config 4 step) and the form was removed in round 5 (its DMA waves spilled 66 - 75
+// SGPRs, and epilogue VALU shares the SIMDs with the MFMAs whichever wave issues it). Step loop alone (scripts/micro/gemm12.hip,
+// M = 55 296): 450 / 583 / 622 us for (N, K) = (2304, 768) / (3072, 768) / (768, 3072).
 #include "pp_common.h"
 #include "pp_gemm.h"
 #include "pp_split.h"
@@ -58,10 +61,6 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
 }
 
 
-#ifndef LDM_ROLL_PERSISTENT
-#define LDM_ROLL_PERSISTENT 0  // the persistent kernel keeps round 4's loop: with the rolling one its qkv / fc1 launches measured 1.3 % SLOWER (15.45 -> 15.65 ms
-                               // per config 4 step; the DMA waves hold 144 registers of tile there and spill 16 instead of 8), the one-tile kernel 3.7 % faster
-#endif
 #ifndef LDM_ROLL
 #define LDM_ROLL 1  // rolling fragment reads in the K loop (round 5, as pp_ffn_dma.hip): 0 = round 4's barrier | 18 reads | 54 MFMAs steps
 #endif
@@ -72,7 +71,7 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
 // by then this wave's reads of stage k (issued during step k - 1) have long returned, so the lgkmcnt(0) in front of the barrier costs
 // nothing, and what is read behind it comes from stage k + 1, landed. The DMA waves' protocol is unchanged (their barrier k = "stage k has
 // landed, stage k - 1 is read out"). `ks` >= 1 steps; stage s sits in ring slot s % NSTAGE.
-__device__ __forceinline__ void k_loop_roll(f32x4 (&acc)[3][6], const char* smem, int lane_hi, int lane_lo, int rg, int cg, int ks) {
+__device__ __forceinline__ void k_loop_roll(f32x4 (&acc)[3][6], const char* smem, int lane_hi, int lane_lo, int rg, int cg, int ks, int& slot) {
     auto opq = [](int v) { asm volatile("" : "+s"(v)); return v; };
     auto rd = [&](int lane_off, int uni, int imm) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + (lane_off + uni) + imm); };
     auto bar = []() {
@@ -82,9 +81,10 @@ __device__ __forceinline__ void k_loop_roll(f32x4 (&acc)[3][6], const char* smem
         __builtin_amdgcn_sched_barrier(0);
     };
     u32x4 ah[3], al[3], bh[6], bl[6];
+    int st = slot;  // ring slot of this tile's stage 0 (a workgroup that walks several tiles keeps the ring turning across them)
     bar();  // stage 0 has landed
     {
-        const int ua = opq(rg * 48 * 128), ub = opq(B_OFF + cg * 96 * 128);
+        const int ua = opq(st * STAGE + rg * 48 * 128), ub = opq(st * STAGE + B_OFF + cg * 96 * 128);
 #pragma unroll
         for (int j = 0; j < 6; ++j) bh[j] = rd(lane_hi, ub, j * 2048);
 #pragma unroll
@@ -94,7 +94,6 @@ __device__ __forceinline__ void k_loop_roll(f32x4 (&acc)[3][6], const char* smem
 #pragma unroll
         for (int j = 0; j < 6; ++j) bl[j] = rd(lane_lo, ub, j * 2048);
     }
-    int st = 0;
     auto step = [&](bool more) {
         const int sn = st + 1 == NSTAGE ? 0 : st + 1;
         const int ua = opq(sn * STAGE + rg * 48 * 128), ub = opq(sn * STAGE + B_OFF + cg * 96 * 128);
@@ -136,6 +135,7 @@ __device__ __forceinline__ void k_loop_roll(f32x4 (&acc)[3][6], const char* smem
     };
     for (int k = 0; k + 1 < ks; ++k) step(true);
     step(false);
+    slot = st;  // (the slot behind the last stage: the next tile's stage 0)
 }
 
 // MODE 0: pp_gemm's epilogue; the two of pp_linear_ln_folded as their own instantiations (one epilogue with every option spills 20 registers):
@@ -146,30 +146,37 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // tile of this workgroup: bands of 4 row tiles, row tile fastest inside a band. Consecutive ids go round the eight XCDs, so XCD x
-    // gets row tile x % 4 of every band and the column tiles of parity x / 4: the workgroups resident on an XCD share their
-    // activation rows and half of the weights in its L2
+    // Tiles: bands of 4 row tiles, row tile fastest inside a band. Consecutive ids go round the eight XCDs, so XCD x gets row tile x % 4 of
+    // every band and the column tiles of parity x / 4: the workgroups resident on an XCD share their activation rows and half of the weights
+    // in its L2. A workgroup takes tiles blockIdx.x, + gridDim.x, ...: one each when the grid is the tile count, or - option "linear_loop",
+    // grid = the CU count - a column of them with the ring turning ACROSS tiles: the DMA waves request the next tile's first two stages while
+    // the computing waves are in this tile's epilogue, so a tile no longer starts with a workgroup launch and two memory round trips
+    // (qkv / fc1 / proj of ViT-B have 24 K-steps per tile: ~20 % of a tile's time was not its K loop).
     const int ntm = (p.M + BM - 1) / BM;
-    const int t_lin = (int)blockIdx.x;
-    const int band = t_lin / (4 * p.ntn), r = t_lin % (4 * p.ntn);
-    const int rows_in_band = ntm - band * 4 < 4 ? ntm - band * 4 : 4;
-    const int tm = band * 4 + r % rows_in_band, tn = r / rows_in_band;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int ntiles = ntm * p.ntn;
     const int ksteps = p.K / 32;
-    const int rows_left = p.M - m0 < BM ? p.M - m0 : BM;
+    auto tile_origin = [&](int t_lin, int& m0, int& n0) {
+        const int band = t_lin / (4 * p.ntn), r = t_lin % (4 * p.ntn);
+        const int rows_in_band = ntm - band * 4 < 4 ? ntm - band * 4 : 4;
+        m0 = (band * 4 + r % rows_in_band) * BM;
+        n0 = (r / rows_in_band) * BN;
+    };
 
     if (wv >= CW) {
         // ---------------- DMA waves: a piece is 8 rows x 128 B; lane (row l = lane >> 3, physical chunk lane & 7) fetches logical chunk (lane & 7) ^ l
         const int d = wv - CW;
         const int x_l = lane >> 3;
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a) + (size_t)m0 * p.K * 4, 0, (unsigned)rows_left * (unsigned)(p.K * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w) + (size_t)n0 * p.K * 4, 0, (unsigned)BN * (unsigned)(p.K * 4), 0x00020000);
         const unsigned v = (unsigned)x_l * (unsigned)(p.K * 4) + (unsigned)(((lane & 7) ^ x_l) << 4);
         const int row8 = 8 * p.K * 4;
-        auto issue = [&](int k, int st) {
+        auto rsrc_a = [&](int m0) {
+            const int rows_left = p.M - m0 < BM ? p.M - m0 : BM;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a) + (size_t)m0 * p.K * 4, 0, (unsigned)rows_left * (unsigned)(p.K * 4), 0x00020000);
+        };
+        auto rsrc_w = [&](int n0) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w) + (size_t)n0 * p.K * 4, 0, (unsigned)BN * (unsigned)(p.K * 4), 0x00020000);
+        };
+        auto issue = [&](const __amdgpu_buffer_rsrc_t& ra, const __amdgpu_buffer_rsrc_t& rw, int kk, int st) {
             char* dst = smem + st * STAGE;
-            const bool live = k < ksteps;
-            const int kk = live ? k : 0;  // (past the end: a harmless re-read keeps the counts)
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
                 const int q = d + 4 * u;
@@ -184,16 +191,30 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
         // (Measured and removed, round 5: pulling the residual tile towards the L2 from here - 18 extra LDS-DMA pieces into a junk KiB over the last
         //  eight K-steps. The residual fetch costs a launch ~35 us (proj 214 us with it, 177 without: 170 MB at the speed of the HBM interface,
         //  all workgroups asking at the same moment), but 256 tiles x 147 KB do not fit the 32 MB of L2 beside the operand streams: no gain.)
-        issue(0, 0);
-        issue(1, 1);
+        int t = (int)blockIdx.x, m0, n0;
+        tile_origin(t, m0, n0);
+        __amdgpu_buffer_rsrc_t ra = rsrc_a(m0), rw = rsrc_w(n0);
+        issue(ra, rw, 0, 0);
+        issue(ra, rw, ksteps > 1 ? 1 : 0, 1);
         int st_i = 2;
-        for (int k = 0; k < ksteps; ++k) {
-            __builtin_amdgcn_sched_barrier(0);
-            LDM_WAITVM(12);  // stage k has landed: this wave's twelve pieces of stage k + 1 may be out
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            issue(k + 2, st_i);  // (all computing waves are past their reads of stage k - 1)
-            st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
+        for (; t < ntiles; t += (int)gridDim.x) {
+            const bool has_next = t + (int)gridDim.x < ntiles;
+            int m1 = m0, n1 = n0;
+            if (has_next) tile_origin(t + (int)gridDim.x, m1, n1);
+            const __amdgpu_buffer_rsrc_t ra_n = rsrc_a(m1), rw_n = rsrc_w(n1);
+            for (int k = 0; k < ksteps; ++k) {
+                __builtin_amdgcn_sched_barrier(0);
+                LDM_WAITVM(12);  // stage k has landed: this wave's twelve pieces of stage k + 1 may be out
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // stage k + 2 (all computing waves are past their reads of stage k - 1): of this tile, or the next tile's stage 0 / 1, or - behind
+                // the last tile - a harmless re-read that keeps the counts
+                if (k + 2 < ksteps) issue(ra, rw, k + 2, st_i);
+                else if (has_next) issue(ra_n, rw_n, k + 2 - ksteps < ksteps ? k + 2 - ksteps : 0, st_i);
+                else issue(ra, rw, 0, st_i);
+                st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
+            }
+            ra = ra_n; rw = rw_n; m0 = m1; n0 = n1;
         }
         LDM_WAITVM(0);
         return;
@@ -201,10 +222,18 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
 
     // ---------------- computing waves
     const int rg = wv >> 1, cg = wv & 1;
-    const int f_row = lane & 15, f_kg = lane >> 4, sw = f_row & 7;
-    const int lane_hi = f_row * 128 + ((f_kg ^ sw) << 4), lane_lo = f_row * 128 + (((4 + f_kg) ^ sw) << 4);
-    auto opq = [](int v) { asm volatile("" : "+s"(v)); return v; };
-    auto rd = [&](int lane_off, int uni, int imm) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + (lane_off + uni) + imm); };
+    const int lane_hi = (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) << 4), lane_lo = (lane & 15) * 128 + (((4 + (lane >> 4)) ^ (lane & 7)) << 4);
+    int slot = 0;  // ring slot of the next tile's stage 0
+    for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+    // (the lane's fragment coordinates from an OPAQUE copy of the lane id, per tile: as loop invariants the epilogue's per-fragment offsets are
+    //  hoisted out of the tile loop and held - 150 to 276 spilled registers - through every K loop)
+    int ln_ = lane;
+    asm volatile("" : "+v"(ln_));
+    const int f_row = ln_ & 15, f_kg = ln_ >> 4;
+    int m0, n0;
+    tile_origin(t, m0, n0);
+    const int tn = n0 / BN;
+    const int rows_left = p.M - m0 < BM ? p.M - m0 : BM;
     // MODE 1: mean / rstd of this lane's three activation rows from the producer's 96-column parts - fetched HERE, in front of the K loop (the
     // loads fly under the first stages; six registers live through the loop). Behind the loop they are two more memory round trips on a tile's
     // critical path: +3.5 us per tile measured. Eight parts = 768 columns per round, a lane's twelve 16-byte loads in flight at once.
@@ -267,9 +296,9 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #if LDM_ROLL
-    k_loop_roll(acc, smem, lane_hi, lane_lo, rg, cg, ksteps);
+    k_loop_roll(acc, smem, lane_hi, lane_lo, rg, cg, ksteps, slot);
 #else
-    int st = 0;
+    int st = slot;
     for (int k = 0; k < ksteps; ++k) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -299,6 +328,7 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
             for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], al[i], acc[i][j]);
         st = st + 1 == NSTAGE ? 0 : st + 1;
     }
+    slot = st;
 
 #endif
 
@@ -318,6 +348,10 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     // elements it writes, so the order between DIFFERENT fragments is free.
     constexpr int JG = 6;
     u32x4 resv[3][JG];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)  // (defined on every path: left to the fetch alone they become values carried round the tile loop, and spill)
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) resv[i][jj] = u32x4{0u, 0u, 0u, 0u};
     auto fetch_residual = [&](int j0) __attribute__((always_inline)) {
 #pragma unroll
         for (int jj = 0; jj < JG; ++jj) {
@@ -426,214 +460,16 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
                                                       (unsigned)(row0 + i * 16) * (unsigned)(parts * 8), (tn * 2 + cg) * 8, 0);
         }
     }
+    }  // tiles of this workgroup
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// PERSISTENT form (no residual): one workgroup per CU walks the tiles; a finished tile - bias added by the computing waves - is HANDED
-// to the four DMA waves through LDS (fp32, row pitch 784 B: the ring's 144 KiB + 6 KiB); each holds a quarter of it in 144 registers
-// per lane, applies the activation, splits and stores it while the computing waves are in the next tile's K loop: the ~9 us a
-// 192 x 192 tile takes to leave the CU (store path ~8 B/clk) and the activation's VALU work are no longer on the computing waves'
-// time line. The DMA waves' counted wait stays correct with stores in flight: loads retire in order among themselves, so "at most
-// the twelve pieces of the next stage outstanding" implies this stage has landed whatever else the count holds.
-constexpr int H_PITCH = 784;  // bytes per row of the hand-off tile: rows shift by four banks, eight lanes x 16 B never collide
-static_assert(BM * H_PITCH <= 160 * 1024, "hand-off tile");
-constexpr int LDS_P = BM * H_PITCH > LDS ? BM * H_PITCH : LDS;
-
-template <int ACT>
-__global__ __launch_bounds__(THREADS) void linear_dma_persistent_kernel(const Params p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntm = (p.M + BM - 1) / BM;
-    const int ntiles = ntm * p.ntn;
-    const int ksteps = p.K / 32;
-    // tiles in bands of four row tiles, row tile fastest (an XCD-grid order - XCD x owns a column quarter and a row parity, its
-    // share of the weights resident in its L2 - measured slower: 555 against 519 - 529 us for the qkv layer)
-    auto tile_m = [&](int t) { const int band = t / (4 * p.ntn), r = t % (4 * p.ntn); const int rib = ntm - band * 4 < 4 ? ntm - band * 4 : 4; return band * 4 + r % rib; };
-    auto tile_n = [&](int t) { const int band = t / (4 * p.ntn), r = t % (4 * p.ntn); const int rib = ntm - band * 4 < 4 ? ntm - band * 4 : 4; return r / rib; };
-    auto bar = []() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    const size_t ldo = (size_t)p.N * 4;
-
-    if (wv >= CW) {
-        // ================= DMA waves
-        const int d = wv - CW;
-        const int x_l = lane >> 3;
-        const unsigned v = (unsigned)x_l * (unsigned)(p.K * 4) + (unsigned)(((lane & 7) ^ x_l) << 4);
-        const int row8 = 8 * p.K * 4;
-        f32x4 hold[36];  // rows 48 d .. +47 of the previous tile, element (i * 256 + 4 lane) of the 48 x 192 block in chunk i
-        int pm0 = 0, pn0 = 0, prows = 0;
-        bool have = false;
-        // chunk i of the held tile: activation, split / fp32, store
-        auto finish = [&](int i) {
-            int ln = lane;
-            asm volatile("" : "+v"(ln));  // (opaque: the per-chunk offsets are computed here, not hoisted out of the K loop into 100 registers)
-            const int t = ln * 4 + (i % 3) * 64;               // element offset inside three rows' worth (768 = 4 x 192)
-            const int row = (i * 4) / 3 + (t >= 192 ? 1 : 0), col = t >= 192 ? t - 192 : t;
-            f32x4 x = hold[i];  // (the bias was added by the computing waves)
-            asm volatile("" : "+v"(x));  // (opaque: otherwise the activation is hoisted to the hand-off and the tile is held twice)
-            if (ACT == ACT_GELU) {  // one value at a time: this wave has 24 registers beside its quarter tile
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    x[e] = gelu_erfc_as(x[e]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else if (ACT == ACT_RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
-            }
-            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)pm0 * ldo, 0, (unsigned)prows * (unsigned)ldo, 0x00020000);
-            const unsigned vrow = (unsigned)(48 * d + row) * (unsigned)ldo;
-            const int n = pn0 + col;
-            if (p.out_split) {
-                f16x4 h, l;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float y = x[e];
-                    split_pin(y);
-                    h[e] = split_hi(y);
-                    l[e] = split_lo(y, h[e]);
-                }
-                const unsigned cb = (unsigned)((n >> 5) * 128 + (n & 31) * 2);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), ro, vrow + cb, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l), ro, vrow + cb + 64u, 0, 0);
-            } else {
-                const u32x4 q = __builtin_bit_cast(u32x4, x);
-                __builtin_amdgcn_raw_buffer_store_b128(q, ro, vrow + (unsigned)n * 4u, 0, 0);
-                asm volatile("s_nop 3" ::"v"(q));
-            }
-        };
-        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-            const int m0 = tile_m(t) * BM, n0 = tile_n(t) * BN;
-            const int rows_left = p.M - m0 < BM ? p.M - m0 : BM;
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a) + (size_t)m0 * p.K * 4, 0, (unsigned)rows_left * (unsigned)(p.K * 4), 0x00020000);
-            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w) + (size_t)n0 * p.K * 4, 0, (unsigned)BN * (unsigned)(p.K * 4), 0x00020000);
-            auto issue = [&](int k, int st) {
-                char* dst = smem + st * STAGE;
-                int r8 = row8;
-                asm volatile("" : "+s"(r8));  // (opaque: six hoisted offset registers are six registers of tile this wave cannot hold)
-#pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    const int q = d + 4 * u;
-                    const unsigned vq = v + (unsigned)(q * r8);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dst + q * 1024), 16, vq, k * 128, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + B_OFF + q * 1024), 16, vq, k * 128, 0, 0);
-                }
-            };
-            issue(0, 0);
-            issue(1, 1);
-            int st_i = 2;
-            for (int k = 0; k < ksteps; ++k) {
-                // the held tile leaves two chunks per step (statically indexed registers: a switch over the step)
-                if (have && k < 18) {
-                    switch (k) {
-#define LDM_CASE(K) case K: finish(2 * K); finish(2 * K + 1); break;
-                        LDM_CASE(0) LDM_CASE(1) LDM_CASE(2) LDM_CASE(3) LDM_CASE(4) LDM_CASE(5) LDM_CASE(6) LDM_CASE(7) LDM_CASE(8)
-                        LDM_CASE(9) LDM_CASE(10) LDM_CASE(11) LDM_CASE(12) LDM_CASE(13) LDM_CASE(14) LDM_CASE(15) LDM_CASE(16) LDM_CASE(17)
-#undef LDM_CASE
-                        default: break;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (k + 1 < ksteps) LDM_WAITVM(12); else LDM_WAITVM(0);  // stage k has landed (loads retire in order; stores only make the wait longer)
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                if (k + 2 < ksteps) issue(k + 2, st_i);
-                st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
-            }
-            if (have && ksteps < 18) {  // (short K: the rest of the held tile leaves here)
-#pragma unroll
-                for (int i = 0; i < 36; ++i)
-                    if (i >= 2 * ksteps) finish(i);
-            }
-            bar();  // X1: every computing wave is past its last fragment read
-            bar();  // X2: the tile is in LDS
-            {
-                const char* src = smem + (48 * d) * H_PITCH;
-#pragma unroll
-                for (int i = 0; i < 36; ++i) {
-                    int ln = lane;
-                    asm volatile("" : "+v"(ln));  // (opaque: see finish)
-                    const int tt = ln * 4 + (i % 3) * 64;
-                    const int row = (i * 4) / 3 + (tt >= 192 ? 1 : 0), col = tt >= 192 ? tt - 192 : tt;
-                    hold[i] = *reinterpret_cast<const f32x4*>(src + row * H_PITCH + col * 4);
-                }
-                __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));  // lgkmcnt(0)
-            }
-            bar();  // X3: the ring is free again
-            pm0 = m0; pn0 = n0; prows = rows_left; have = true;
-        }
-        if (have) {
-#pragma unroll
-            for (int i = 0; i < 36; ++i) finish(i);
-        }
-        return;
-    }
-
-    // ================= computing waves
-    const int rg = wv >> 1, cg = wv & 1;
-    const int f_row = lane & 15, f_kg = lane >> 4, sw = f_row & 7;
-    const int lane_hi = f_row * 128 + ((f_kg ^ sw) << 4), lane_lo = f_row * 128 + (((4 + f_kg) ^ sw) << 4);
-    auto opq = [](int v) { asm volatile("" : "+s"(v)); return v; };
-    auto rd = [&](int lane_off, int uni, int imm) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + (lane_off + uni) + imm); };
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        f32x4 acc[3][6];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if LDM_ROLL_PERSISTENT
-        k_loop_roll(acc, smem, lane_hi, lane_lo, rg, cg, ksteps);
-#else
-        int st = 0;
-        for (int k = 0; k < ksteps; ++k) {
-            bar();
-            const int ua = opq(st * STAGE + rg * 48 * 128), ub = opq(st * STAGE + B_OFF + cg * 96 * 128);
-            u32x4 ah[3], al[3], bh[6], bl[6];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) ah[i] = rd(lane_hi, ua, i * 2048);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) bh[j] = rd(lane_hi, ub, j * 2048);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) al[i] = rd(lane_lo, ua, i * 2048);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) bl[j] = rd(lane_lo, ub, j * 2048);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], ah[i], acc[i][j]);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = mma(bl[j], ah[i], acc[i][j]);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], al[i], acc[i][j]);
-            st = st + 1 == NSTAGE ? 0 : st + 1;
-        }
-#endif
-        bar();  // X1
-        {
-            char* dst = smem + (rg * 48 + f_row) * H_PITCH + (cg * 96 + f_kg * 4) * 4;
-            const int n0 = tile_n(t) * BN;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + cg * 96 + j * 16 + f_kg * 4);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(dst + i * 16 * H_PITCH + j * 64) = acc[i][j] + bv;
-            }
-            __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));  // lgkmcnt(0)
-        }
-        bar();  // X2
-        bar();  // X3
-    }
+// grid of the one-tile kernel: the tile count, or - option "linear_loop" - one workgroup per CU, each walking tiles id, id + CUs, ...
+static int loop_grid(int ntiles) {
+    if (option("linear_loop") == 0) return ntiles;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return ntiles < cus ? ntiles : cus;
 }
 
 }  // namespace ldm
@@ -667,17 +503,8 @@ int linear_dma_gemm(const GemmParams& g, hipStream_t s) {
     p.out_split = g.out_bf16 == 2;
     p.ntn = g.N / ldm::BN;
     const int grid = p.ntn * ((g.M + ldm::BM - 1) / ldm::BM);
-    if (!g.residual && option("linear_persistent") != 0) {  // persistent form: finished tiles leave through the DMA waves
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        auto kern = g.act == ACT_GELU ? ldm::linear_dma_persistent_kernel<ACT_GELU> : g.act == ACT_RELU ? ldm::linear_dma_persistent_kernel<ACT_RELU> : ldm::linear_dma_persistent_kernel<ACT_NONE>;
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS_P));
-        hipLaunchKernelGGL(kern, dim3(grid < cus ? grid : cus), dim3(ldm::THREADS), ldm::LDS_P, s, p);
-        PP_LAUNCH_CHECK_AS("linear_dma_persistent");
-        return PP_OK;
-    }
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldm::linear_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
-    hipLaunchKernelGGL(ldm::linear_dma_kernel<0>, dim3(grid), dim3(ldm::THREADS), ldm::LDS, s, p);
+    hipLaunchKernelGGL(ldm::linear_dma_kernel<0>, dim3(ldm::loop_grid(grid)), dim3(ldm::THREADS), ldm::LDS, s, p);
     PP_LAUNCH_CHECK_AS("linear_dma_tile");
     return PP_OK;
 }
@@ -729,7 +556,7 @@ extern "C" int pp_linear_ln_folded(const void* act, const void* weight, const fl
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     auto kern = ln_stats ? ldm::linear_dma_kernel<1> : ldm::linear_dma_kernel<2>;
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(ldm::THREADS), ldm::LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3(ldm::loop_grid(grid)), dim3(ldm::THREADS), ldm::LDS, s, p);
     PP_LAUNCH_CHECK_AS("linear_dma_fold");
     return PP_OK;
 }

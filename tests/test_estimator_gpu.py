@@ -305,7 +305,7 @@ def test_config4_bs32_graph_replay_default_plan():
         _lib.reset_launch_counts()
         eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)  # warm-up launches + the capture
         torch.cuda.synchronize()
-        tally = {k: _lib.launch_count(k) for k in ("linear_dma_fold", "linear_dma_persistent", "linear_dma_tile", "winograd_gemm_pool",
+        tally = {k: _lib.launch_count(k) for k in ("linear_dma_fold", "linear_dma_tile", "winograd_gemm_pool",
                                                    "pp_attention_dma.hip", "layernorm", "pp_gemm.hip", "pp_panel_split.hip")}
         print(f"config 4 launch tally of three forwards (ln_fold = {fold}):", tally)
         if fold:
@@ -315,7 +315,6 @@ def test_config4_bs32_graph_replay_default_plan():
         else:
             assert tally["linear_dma_fold"] == 0 and tally["linear_dma_tile"] == 49 * n_fwd, "patch embed + the four Linear layers of every layer"
             assert tally["layernorm"] == 25 * n_fwd
-        assert tally["linear_dma_persistent"] == 0, "(option linear_persistent = 0: round 4's persistent form is not in the plan)"
         assert tally["pp_gemm.hip"] == 0, "no Linear layer of the plan on the 128 x 128 kernel"
         assert _lib.launch_count("winograd_gemm_pool") == n_fwd and _lib.launch_count("winograd_input_transform") == n_fwd
         assert _lib.launch_count("pp_attention_dma.hip") == 12 * n_fwd, "432-token attention on the LDS-DMA kernel"
