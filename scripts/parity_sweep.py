@@ -44,6 +44,23 @@ torch.cuda.synchronize()
 r = dict(model="ProbPose-base (ViT-B) 384x288", weight_seed=0, crop_seed=1, batch=4, logit_scale=2.0, **compare(out, ref))
 rows.append(r)
 print(r, flush=True)
+del eng
+# ViT-B on the plan BASELINE config 4 is benchmarked on (bs 32 + flip: LayerNorms folded into the twelve-wave Linear layers), another seed,
+# the oracle on the first 8 crops (~1 s per 384x288 crop on the CPU), and at the reference's ViTPose-base geometry (256x192, bs 64)
+for model, im, B, nref, wseed, cseed in (("ProbPose-base (ViT-B) 384x288, folded-LayerNorm plan", (384, 288), 32, 8, 7, 17),
+                                         ("ProbPose-base (ViT-B) 256x192, folded-LayerNorm plan", (256, 192), 64, 8, 8, 18)):
+    sd = S.synthetic_state_dict("base", img_size=im, seed=wseed, logit_scale=2.0)
+    crops = S.synthetic_crops(B, img_size=im, seed=cseed)
+    ref = M.predict(sd, crops[:nref], 12, S.IMG_MEAN, S.IMG_STD, input_size=(im[1], im[0]))
+    eng = ProbPoseEngine(sd, 12, img_size=im, precision="f16x3", input_size=(im[1], im[0]))
+    assert "LayerNorm folded" in eng.layer_plan
+    out = eng.forward(crops.cuda(), True, S.COCO_FLIP_INDICES)
+    torch.cuda.synchronize()
+    sub = {"keypoints": out["keypoints"][:nref], "scalars": out["scalars"][:, :nref]}
+    r = dict(model=model, weight_seed=wseed, crop_seed=cseed, batch=B, compared_crops=nref, logit_scale=2.0, **compare(sub, ref))
+    rows.append(r)
+    print(r, flush=True)
+    del eng
 worst = max(x["keypoint_linf_px_same_argmax"] for x in rows)
 summary = {"precision": "f16x3", "against": "oracle/model_ref.py (fp32 CPU restatement of the reference path)", "runs": rows,
            "worst_keypoint_linf_px": worst, "total_argmax_flips": sum(x["argmax_flips"] for x in rows),
