@@ -73,6 +73,20 @@ __device__ __forceinline__ void wait_vm_lgkm() {
 
 // (hi, lo) of four values of an accumulator fragment, regrouped by the row swap of split_store4_rowpair: the even-row lane
 // (bit 4 of the lane id clear) gets the 16-byte hi chunk of the pair's eight elements, the odd-row lane the lo chunk
+// the value of lane ^ 16 / lane ^ 32 by v_permlane16_swap / v_permlane32_swap (swap(a, a): an even-row lane gets (own, partner's), an odd-row
+// lane (partner's, own))
+__device__ __forceinline__ float xor16(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned own_is_first = ((threadIdx.x >> 4) & 1u) == 0u;
+    return __builtin_bit_cast(float, own_is_first ? (unsigned)s[1] : (unsigned)s[0]);
+}
+__device__ __forceinline__ float xor32(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned own_is_first = ((threadIdx.x >> 5) & 1u) == 0u;
+    return __builtin_bit_cast(float, own_is_first ? (unsigned)s[1] : (unsigned)s[0]);
+}
 __device__ __forceinline__ u32x4 split_pair16(f32x4 v) {
     u32x2 hu, lu;
     { unsigned h__, l__; split_pair(v[0], v[1], h__, l__); hu[0] = h__; lu[0] = l__; }
@@ -252,8 +266,8 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[kt][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, xor16(mx));  // (the gfx950 row swaps - plain VALU - instead of trips through the LDS queue; same pairing, same bits)
+        mx = fmaxf(mx, xor32(mx));
         const float mb = mx * p.scale_log2e;
         float sum = 0.f;
 #pragma unroll
@@ -264,8 +278,8 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
                 s[kt][i] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum += xor16(sum);
+        sum += xor32(sum);
         // ---- O^T = V^T P^T: the K = 32 block `blk` takes keys 32 blk + 4 fg + (0..3) and 32 blk + 16 + 4 fg + (0..3) per lane -
         // the same permutation of the contraction index on both operands
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -490,8 +504,8 @@ __global__ __launch_bounds__(THREADS, 2) void qkv_attention_split2_kernel(const 
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[kt][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, xor16(mx));  // (the gfx950 row swaps - plain VALU - instead of trips through the LDS queue; same pairing, same bits)
+        mx = fmaxf(mx, xor32(mx));
         const float mb = mx * p.scale_log2e;
         float sum = 0.f;
 #pragma unroll
@@ -502,8 +516,8 @@ __global__ __launch_bounds__(THREADS, 2) void qkv_attention_split2_kernel(const 
                 s[kt][i] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum += xor16(sum);
+        sum += xor32(sum);
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int blk = 0; blk < NT / 2; ++blk) {
