@@ -73,6 +73,7 @@ int pp_device_cu_count(void);
  *                            twelve-wave 192 x 192 kernel (pp_linear_dma.hip: eight computing + four DMA-only waves)
  *   "linear_loop" (1)        twelve-wave Linear kernel: one workgroup per CU walks a column of tiles, the next tile's first stages requested
  *                            under this tile's epilogue; 0: a workgroup per tile
+ *   "psplit_deconv_weight_major" (0)  dev A/B: 1 = deconvolution tiles weight-set(phase)-major per XCD instead of row panel -> phase
  *   "ffn_dma_waves" (1)      0: the fused f16x3 feed-forward launches run the eight-wave kernel (pp_ffn_split.hip) instead of the
  *                            twelve-wave one (pp_ffn_dma.hip: eight computing waves + four waves that only issue the LDS-DMA)
  *   "ffn_pair" (1)           twelve-wave feed-forward launch: hidden chunks in pairs that share every streamed x k-block (x rows streamed 6 instead of 12

@@ -31,6 +31,7 @@ static Option g_options[] = {
     {"qkv_attn_pair", 0},      // 1: pp_qkv_attention_split with a head PAIR per workgroup (one workgroup per CU; measured slower)
     {"linear_dma", 1},         // large split-fp16 Linear layers (pp_gemm): 1 = the twelve-wave 192 x 192 kernels (pp_linear_dma.hip), 0 = the wide-tile kernel
     {"linear_loop", 1},        // one-tile twelve-wave Linear kernel: 1 = one workgroup per CU walks a column of tiles, the next tile's first stages requested under this tile's epilogue; 0 = a workgroup per tile
+    {"psplit_deconv_weight_major", 0},  // dev A/B: deconvolution tiles phase(weight set)-major per XCD instead of row panel -> phase (measured: DESIGN.md 4)
     {"ffn_dma_waves", 1},      // fused f16x3 feed-forward launch: 1 = the twelve-wave form (pp_ffn_dma.hip: eight computing waves + four DMA waves), 0 = the eight-wave form (pp_ffn_split.hip)
     {"ffn_pair", 1},           // twelve-wave feed-forward launch: 1 = hidden chunks in PAIRS that share every streamed x k-block (x streamed 6 instead of 12 times per launch; even chunk counts only), 0 = one chunk at a time
     {"psplit_tail", 1},        // split-fp16 Linear layers on the wide-tile kernel: 0 = no second launch on 128 x 192 tiles for the rows of a ragged last round

@@ -667,6 +667,7 @@ int panel_split_gemm(const GemmParams& p_in, int prec, int groups, hipStream_t s
     p.tap_inner = (p.gather == G_CONV3 && ti >= 1) || (p.gather == G_DECONV && ti >= 2) ? 1 : 0;
     PP_REQUIRE(p.ksplit <= 1 || p.tap_inner, PP_ERR_UNSUPPORTED, "pp panel split gemm: split-K slices are channel ranges walked taps-inner");
     p.tile_order = (p.gather == G_CONV3 && p.tap_inner && option("psplit_conv_weight_major") != 0) ? 1 : 0;
+    if (p.gather == G_DECONV && option("psplit_deconv_weight_major") != 0) p.tile_order = 1;  // dev A/B (is deconv2 + 1x1 traffic-bound?)
     if (p.gather == G_LINEAR) p.Cin = p.K;
     PP_REQUIRE(p.a_bytes > 0 && p.w_bytes > 0 && p.a_bytes < OOB && p.w_bytes < OOB, PP_ERR_UNSUPPORTED,
                "pp panel split gemm: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
