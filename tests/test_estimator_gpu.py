@@ -340,6 +340,32 @@ def test_config4_bs32_graph_replay_default_plan():
     assert dd <= 1e-3, f"folded and stand-alone LayerNorm plans differ by {dd:.2e} px"
 
 
+def test_config4_folded_plan_ragged_row_count_agrees_with_generic_plan():
+    """ViT-B 384x288 at B = 33 with flip: 28 512 token rows = 148.5 row tiles of the twelve-wave Linear kernel - the last tile of every layer
+    is half empty (buffer descriptors end at row M: statistics, residual rows and outputs past it are never touched). The folded-LayerNorm
+    plan against the generic plan (plan switch ln_fold = False) on the same crops: keypoints within 1e-3 px, scalars within 1e-5."""
+    from probpose_code_amd import ProbPoseEngine, _lib
+    from probpose_code_amd import synthetic as S
+
+    img, B = (384, 288), 33
+    sd = S.synthetic_state_dict("base", img_size=img, seed=2, logit_scale=2.0)
+    xd = S.synthetic_crops(B, img_size=img, seed=21).cuda()
+    outs = {}
+    for fold in (True, False):
+        eng = ProbPoseEngine(sd, 12, img_size=img, precision="f16x3", input_size=(288, 384), plan=dict(ln_fold=fold))
+        _lib.reset_launch_counts()
+        o = eng.forward(xd, True, S.COCO_FLIP_INDICES)
+        torch.cuda.synchronize()
+        assert (_lib.launch_count("linear_dma_fold") == 48) == fold
+        outs[fold] = {k: o[k].clone() for k in ("keypoints", "scalars")}
+        assert torch.isfinite(outs[fold]["keypoints"]).all() and torch.isfinite(outs[fold]["scalars"]).all()
+        del eng
+        torch.cuda.empty_cache()
+    d = (outs[True]["keypoints"] - outs[False]["keypoints"]).abs().max().item()
+    ds = (outs[True]["scalars"] - outs[False]["scalars"]).abs().max().item()
+    assert d <= 1e-3 and ds <= 1e-5, f"plans differ: keypoints {d:.2e} px, scalars {ds:.2e}"
+
+
 def test_vit_base_256x192_bs64_folded_plan_within_1e3():
     """ViT-B at the reference's own ViTPose-base geometry (configs/body_2d_keypoint/topdown_heatmap/coco/td-hm_ViTPose-base_8xb64-210e_coco-256x192.py:
     46-61: 256x192 crops, 192 tokens of 12 heads x 64) with the ProbPose head, bs 64 + flip = 24 576 token rows: exactly the row count from
