@@ -928,3 +928,37 @@ def test_linear_ln_folded_chain_vs_fp64(M):
     with pytest.raises(L.ProbPoseLibraryError):  # a layer with statistics in takes no residual
         L.call("pp_linear_ln_folded", xs.data_ptr(), d["w1f"].data_ptr(), d["b1f"].data_ptr(), d["x0"].data_ptr(), F32, d["x0"].data_ptr(), SPLIT, M, E, E, 0,
                xs.data_ptr(), d["c1"].data_ptr(), eps, None, None)
+
+
+@gpu
+@pytest.mark.parametrize("M,N,K,ln", [(1, 192, 64, False), (300, 384, 192, True), (50000, 192, 64, False), (50000, 192, 192, True), (777, 576, 1536, True)])
+def test_linear_ln_folded_edge_shapes_vs_fp64(M, N, K, ln):
+    """pp_linear_ln_folded at the edges of what it serves: a single row; K = 64 (two K-steps: the shortest ring walk); 261 tiles on 256 CUs (five
+    workgroups of the tile loop take a second tile, with K = 64 the next tile's stages are requested at the first barriers of this one); statistics
+    of 2 / 16 parts; with GELU, an fp32 residual, statistics out. Against torch fp64."""
+    from probpose_code_amd.weights import fold_layernorm
+
+    L = _lib()
+    eps = 1e-6
+    x = _rand(M, K, seed=800) + 1.5 * _rand(M, 1, seed=801)
+    w, b = _rand(N, K, seed=802, scale=1 / math.sqrt(K)), _rand(N, seed=803, scale=0.1)
+    res = _rand(M, N, seed=804)
+    xs = _sp(x)
+    if ln:
+        g, be = 1.0 + 0.2 * _rand(K, seed=805), 0.2 * _rand(K, seed=806)
+        wf, cs, bf = [t.cuda() for t in fold_layernorm(w, b, g, be)]
+        st = _row_part_stats(_unsp(xs)).float().cuda()
+        out = torch.full((M, N), float("nan"), device="cuda")
+        L.call("pp_linear_ln_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), None, 0, out.data_ptr(), SPLIT, M, N, K, 1, st.data_ptr(), cs.data_ptr(),
+               eps, None, None)
+        ref = F.gelu(F.layer_norm(x.double(), (K,), g.double(), be.double(), eps) @ w.double().t() + b.double())
+        torch.testing.assert_close(_unsp(out), ref, rtol=3e-5, atol=3e-5)
+    else:
+        wd, bd, rd = _sp(w), b.cuda(), res.cuda()
+        out = torch.full((M, N), float("nan"), device="cuda")
+        so = torch.full((M, N // 96, 2), float("nan"), device="cuda")
+        L.call("pp_linear_ln_folded", xs.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(), 0, out.data_ptr(), 0, M, N, K, 0, None, None, eps,
+               so.data_ptr(), None)
+        ref = x.double() @ w.double().t() + b.double() + res.double()
+        torch.testing.assert_close(out.cpu().double(), ref, **TOL)
+        torch.testing.assert_close(so.cpu().double(), _row_part_stats(ref), rtol=1e-4, atol=1e-4)
