@@ -51,6 +51,12 @@ static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must rep
 #ifndef FFD_DMA_PRIO
 #define FFD_DMA_PRIO 0  // dev A/B: priority of the DMA waves (s_setprio)
 #endif
+#ifndef FFD_STAMP
+#define FFD_STAMP 0  // dev: wave 0 of workgroups 0 and 131 leaves s_memtime stamps at the phase boundaries of the paired proj + FFN kernel (scripts/micro/ffd_stamps.sh)
+#endif
+#ifndef FFD_LN_PREFETCH
+#define FFD_LN_PREFETCH 1  // LayerNorm epilogues: gamma / beta of all column fragments fetched ahead of the store loop
+#endif
 #ifndef FFD_GELU_RELU_FORM
 #define FFD_GELU_RELU_FORM 1
 #endif
@@ -291,11 +297,27 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
 }
 
 // ---------------------------------------------------------------- computing waves
+#if FFD_STAMP
+__device__ unsigned long long g_ffd_stamps[2][64];
+#endif
 template <bool PROJ, bool PAIR>
 __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv, int lane, int m0, int nchunks, int c_rot) {
     const int rg = wv >> 2, cg = wv & 3;
     const int f_row = lane & 15, f_kg = lane >> 4;
     auto chunk_of = [&](int i) { const int c = i + c_rot; return c >= nchunks ? c - nchunks : c; };
+#if FFD_STAMP
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (wv == 0 && (blockIdx.x == 0 || blockIdx.x == 131)) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && n_stamp < 64) g_ffd_stamps[blockIdx.x == 0 ? 0 : 1][n_stamp] = t;
+            ++n_stamp;
+        }
+    };
+#else
+    auto stamp = []() {};
+#endif
+    stamp();  // 0: start
 
     // fragment reads: hi halves in 16-byte chunk f_kg, lo halves in chunk 4 + f_kg of a line, swizzled by line & 7. The register
     // budget has no room for an address register per line set: every read address is ONE of two per-lane offsets (hi / lo chunk of
@@ -425,10 +447,25 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             const float var = ((stat[4 * BM + r] + stat[5 * BM + r]) + (stat[6 * BM + r] + stat[7 * BM + r])) * (1.0f / E);
             rstd[rf] = 1.0f / sqrtf(var + p.eps);
         }
+#if FFD_LN_PREFETCH
+        // gamma / beta of all six column fragments in one round trip (48 registers: the operand fragments are dead): inside the store loop every
+        // pair of loads sits behind the previous fragment's buffer stores - six dependent trips to the L2 per LayerNorm
+        f32x4 gs_[6], bs_[6];
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) {
+            const int cb = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16;
+            gs_[cf] = *reinterpret_cast<const f32x4*>(gamma + cb + fk_ * 4);
+            bs_[cf] = *reinterpret_cast<const f32x4*>(beta + cb + fk_ * 4);
+        }
+#endif
 #pragma unroll
         for (int cf = 0; cf < 6; ++cf) {
             const int cb = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16;  // (wave-uniform)
+#if FFD_LN_PREFETCH
+            const f32x4 g = gs_[cf], b = bs_[cf];
+#else
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cb + fk_ * 4), b = *reinterpret_cast<const f32x4*>(beta + cb + fk_ * 4);
+#endif
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) {
                 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -502,6 +539,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             acc[rf][cf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, v_rowx + rf * (16 * E * 4), cb * 4, 0));  // (rows past M: zeros, never stored)
         }
 
+    stamp();  // 1: residual rows requested
     if constexpr (PROJ) {
         // ---- attention output projection + residual, then ln2:  acc <- x + att Wp^T + bp ;  h <- LN2(acc). 24 steps shaped like
         // the B-steps: step s = 2 kb + half takes the Wp half block from ring slot s & 3, the attention rows' k-block kb from G buffer kb & 3
@@ -573,11 +611,13 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
         }
+        stamp();  // 2: projection steps done
         __syncthreads();  // P1: the G buffers are out of use
         layernorm_rows(p.gamma2, p.beta2, nullptr, const_cast<void*>(p.h), false);
         // the rows must be in L2 before the DMA waves ask for them (a store counts in vmcnt until the L2 has acknowledged it)
         __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));
         __syncthreads();  // P2
+        stamp();  // 3: ln2 done, rows in L2
     }
 
     // + b2 (pp_ffn_split.hip adds it before the first B-step accumulates: same sum order)
@@ -835,16 +875,21 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             }
             a_step(pacc, 2 * NA - 1, false, false);
             a_step(pacc1, 2 * NA, true, true);
+            stamp();  // 4 + 5 cp: A-steps of the pair done
             mfma_settle(pacc);
             gelu_chunk(pacc);
             step_barrier();  // the G tile is complete (the DMA waves pass it behind their barrier of step 2 NA)
+            stamp();  // + 1: GELU of chunk 0
             load_b1x(2 * cp + 2, b1v);  // the next pair's biases, asked for while their sixteen registers are free
             b_phase(2 * NA, 0, true);
+            stamp();  // + 2: B-steps of chunk 0
             mfma_settle(pacc1);
             gelu_chunk(pacc1);
             step_barrier();  // (behind the DMA waves' barrier of step 2 NA + NB)
+            stamp();  // + 3: GELU of chunk 1
             load_b1x(2 * cp + 3, b1w);
             b_phase(2 * NA + NB, 1, cp + 1 < npairs);
+            stamp();  // + 4: B-steps of chunk 1
         }
         mfma_settle(acc);
     } else {
@@ -1019,7 +1064,9 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     }
     // ---- LayerNorm epilogue: G is out of use once every wave is past its last B-step
     __syncthreads();  // E1
+    stamp();  // last but one: every wave past its last step
     layernorm_rows(p.gamma, p.beta, p.x_out, p.h_out, true);
+    stamp();  // last: rows stored
 }
 
 template <bool PROJ, bool PAIR>
@@ -1040,6 +1087,12 @@ __global__ __launch_bounds__(THREADS) void ffn_dma_pair_kernel(const Params p) {
 __global__ __launch_bounds__(THREADS) void proj_ffn_dma_pair_kernel(const Params p) { body<true, true>(p); }
 
 }  // namespace ffd
+
+#if FFD_STAMP
+extern "C" int pp_dev_ffd_stamps(unsigned long long* out) {  // dev: 2 x 64 stamps of the last launch (host pointer)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::ffd::g_ffd_stamps), sizeof(unsigned long long) * 128, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 namespace ffs {
 // called from the entry points in pp_ffn_split.hip when the option "ffn_dma_waves" is on
