@@ -441,6 +441,9 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             if (fk_ == 0) stat[(4 + cg) * BM + r] = q;
         }
         __syncthreads();
+#if FFD_STAMP == 2
+        stamp();  // (fine) row statistics done
+#endif
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) {
             const int r = rows0_ + rf * 16;
@@ -613,9 +616,18 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
         }
         stamp();  // 2: projection steps done
         __syncthreads();  // P1: the G buffers are out of use
+#if FFD_STAMP == 2
+        stamp();  // (fine) P1 passed
+#endif
         layernorm_rows(p.gamma2, p.beta2, nullptr, const_cast<void*>(p.h), false);
+#if FFD_STAMP == 2
+        stamp();  // (fine) ln2 rows stored (issued)
+#endif
         // the rows must be in L2 before the DMA waves ask for them (a store counts in vmcnt until the L2 has acknowledged it)
         __builtin_amdgcn_s_waitcnt((7 << 4) | (0 << 8) | (0));
+#if FFD_STAMP == 2
+        stamp();  // (fine) stores acknowledged
+#endif
         __syncthreads();  // P2
         stamp();  // 3: ln2 done, rows in L2
     }

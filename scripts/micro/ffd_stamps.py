@@ -21,10 +21,12 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 128)()
 L.lib.pp_dev_ffd_stamps.restype = ctypes.c_int
 assert L.lib.pp_dev_ffd_stamps(buf) == 0
-names = ["start -> residual rows requested", "projection: 24 steps", "ln2 + rows to L2"]
+fine = len(sys.argv) > 1 and sys.argv[1] == "fine"   # library built with -DFFD_STAMP=2: the LayerNorm phases in pieces
+names = ["start -> residual rows requested", "projection: 24 steps"] + (["ln2: wait for every wave (P1)", "ln2: row statistics", "ln2: normalise, split, stores issued",
+         "ln2: stores acknowledged by the L2", "ln2: wait for every wave (P2)"] if fine else ["ln2 + rows to L2"])
 for cp in range(6):
     names += [f"pair {cp}: 24 A-steps", f"pair {cp}: GELU chunk 0", f"pair {cp}: 8 B-steps chunk 0", f"pair {cp}: GELU chunk 1", f"pair {cp}: 8 B-steps chunk 1"]
-names += ["wait for every wave (E1)", "final LayerNorm + stores"]
+names += ["wait for every wave (E1)"] + (["final LayerNorm: row statistics", "final LayerNorm: normalise, split, stores issued"] if fine else ["final LayerNorm + stores"])
 for wg, tag in ((0, "workgroup 0"), (1, "workgroup 131")):
     t = [buf[wg * 64 + i] for i in range(64)]
     n = len(names) + 1
