@@ -96,6 +96,12 @@ __device__ __forceinline__ u32x4 split_pair16(f32x4 v) {
     return u32x4{s0[0], s1[0], s0[1], s1[1]};
 }
 
+#ifndef QKA_STAMP
+#define QKA_STAMP 0  // dev: s_memtime stamps of waves 0 and 7 of workgroups 0 and 777 at the phase boundaries (scripts/micro/qka_stamps.py)
+#endif
+#if QKA_STAMP
+__device__ unsigned long long g_qka_stamps[4][16];
+#endif
 struct TagF { static constexpr bool value = false; };
 struct TagT { static constexpr bool value = true; };
 
@@ -107,6 +113,19 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
     const int fr = lane & 15, fg = lane >> 4;
     const int sw = fr & 7;
 
+#if QKA_STAMP
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if ((wv == 0 || wv == 7) && (blockIdx.x == 0 || blockIdx.x == 777)) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && n_stamp < 16) g_qka_stamps[(blockIdx.x == 0 ? 0 : 2) + (wv == 0 ? 0 : 1)][n_stamp] = t;
+            ++n_stamp;
+        }
+    };
+#else
+    auto stamp = []() {};
+#endif
+    stamp();  // 0: start
     int id = blockIdx.x;
     const int nblk = gridDim.x;
     if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);  // the heads of a sequence on one XCD, one after the other
@@ -155,6 +174,7 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
     issue_stage(1, 1);
     if (wv < 4) wait_vm_lgkm<5>(); else wait_vm_lgkm<4>();  // the first stage has landed
     __builtin_amdgcn_s_barrier();
+    stamp();  // 1: first stage landed
     u32x4 ah[3], wh[3], al[3], wl[3];
 #pragma unroll
     for (int cf = 0; cf < 3; ++cf) wh[cf] = frag_w(0, 0, cf);
@@ -197,6 +217,7 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
         }
     };
     if (cg == 0) k_loop(TagF{}); else k_loop(TagT{});
+    stamp();  // 2: the twelve K-steps of the qkv projection
     // (every wave passed the last barrier with all its reads of the ring complete: the ring may be overwritten)
 
     // ---- + bias, out to LDS: q and k as split lines [token][32 hi | 32 lo] (chunk-swizzled like the staged blocks), V^T planes
@@ -237,7 +258,9 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
             }
         }
     }
+    stamp();  // 3: this wave's q / k / V^T staged
     __syncthreads();
+    stamp();  // 4: every wave's
     if (DBG & 1) return;
 
     // ================= phase 2: attention of the head over the sequence; query tiles w and w + 8
@@ -307,7 +330,9 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
         const size_t oidx = ((size_t)seq * S + qt * 16 + fr) * E + head * HD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) split_store4_rowpair(p.out, oidx + dt * 16 + 4 * fg, o[dt] * inv, true);
+        stamp();  // 5, 6: a query tile done
     }
+    stamp();  // last
 }
 
 
@@ -548,6 +573,12 @@ __global__ __launch_bounds__(THREADS, 2) void qkv_attention_split2_kernel(const 
 }
 
 }  // namespace qka
+
+#if QKA_STAMP
+extern "C" int pp_dev_qka_stamps(unsigned long long* out) {  // dev: 4 x 16 stamps of the last launch (host pointer)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::qka::g_qka_stamps), sizeof(unsigned long long) * 64, 0, hipMemcpyDeviceToHost);
+}
+#endif
 }  // namespace pp
 
 extern "C" int pp_qkv_attention_split(const void* h_in, const void* wqkv, const float* bqkv, void* out, int n_seq, int seq_len,
