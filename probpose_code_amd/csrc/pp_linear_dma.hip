@@ -138,11 +138,27 @@ __device__ __forceinline__ void k_loop_roll(f32x4 (&acc)[3][6], const char* smem
     slot = st;  // (the slot behind the last stage: the next tile's stage 0)
 }
 
+#ifndef LDM_STAMP
+#define LDM_STAMP 0  // dev: s_memtime stamps of wave 0 of workgroups 0 and 100 around the K loop and the epilogue of their first tiles (scripts/micro/ldm_stamps.py)
+#endif
+#ifndef LDM_SKIP_STORES
+#define LDM_SKIP_STORES 0  // dev, with LDM_STAMP: only fragment (0, 0) of a tile is stored (wrong results: what does an epilogue cost without its store instructions?)
+#endif
+#if LDM_STAMP
+__device__ unsigned long long g_ldm_stamps[2][64];
+#endif
 // MODE 0: pp_gemm's epilogue; the two of pp_linear_ln_folded as their own instantiations (one epilogue with every option spills 20 registers):
 // MODE 1: LayerNorm statistics of the activation rows IN (qkv / fc1: no residual), MODE 2: residual rows in either format + statistics of the
 // output rows OUT (proj / fc2)
-template <int MODE>
+// ACT / OUTS / RES / STATS: -1 = read from the parameters at run time (the generic instantiation); a value = the epilogue's switches folded at
+// compile time. The generic epilogue is 18 fragments x ~8 wave-uniform branches (150 s_cbranch, 360 v_mov at their joins: ~3 k of its ~12 k
+// cycles per tile, round 5 stamps); the shapes a launch plan actually uses get their own instantiation (launch_tile below).
+template <int MODE, int ACT = -1, int OUTS = -1, int RES = -1, int STATS = -1>
 __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
+    const int k_act = ACT < 0 ? p.act : ACT;
+    const bool k_out_split = OUTS < 0 ? p.out_split != 0 : OUTS != 0;
+    const int k_res = RES < 0 ? (p.residual ? ((MODE == 2 && p.res_split) ? 2 : 1) : 0) : RES;  // 0 none, 1 fp32 rows, 2 split rows
+    const bool k_stats = MODE == 2 && (STATS < 0 ? p.stats_out != nullptr : STATS != 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -224,7 +240,20 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     const int rg = wv >> 1, cg = wv & 1;
     const int lane_hi = (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) << 4), lane_lo = (lane & 15) * 128 + (((4 + (lane >> 4)) ^ (lane & 7)) << 4);
     int slot = 0;  // ring slot of the next tile's stage 0
+#if LDM_STAMP
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (wv == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+            const unsigned long long ts = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && n_stamp < 64) g_ldm_stamps[blockIdx.x == 0 ? 0 : 1][n_stamp] = ts;
+            ++n_stamp;
+        }
+    };
+#else
+    auto stamp = []() {};
+#endif
     for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+    stamp();  // 3 i: tile i begins
     // (the lane's fragment coordinates from an OPAQUE copy of the lane id, per tile: as loop invariants the epilogue's per-fragment offsets are
     //  hoisted out of the tile loop and held - 150 to 276 spilled registers - through every K loop)
     int ln_ = lane;
@@ -239,7 +268,7 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     // critical path: +3.5 us per tile measured. Eight parts = 768 columns per round, a lane's twelve 16-byte loads in flight at once.
     const int row0 = rg * 48 + f_row;  // + 16 i
     float mu[3] = {0.f, 0.f, 0.f}, rs[3] = {1.f, 1.f, 1.f};
-    if (MODE == 1 && p.ln_stats) {
+    if (MODE == 1) {
         const int parts = p.K / 96;
         const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ln_stats) + (size_t)m0 * parts * 2, 0,
                                                                              (unsigned)rows_left * (unsigned)(parts * 8), 0x00020000);
@@ -332,6 +361,7 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
 
 #endif
 
+    stamp();  // 3 i + 1: K loop done
     // ---------------- epilogue: act_fn(sum + bias) + residual, rows out as split fp16 (two 8-byte halves per lane) or fp32 (16 bytes).
     // Output addressing through a buffer descriptor that ends at row M: the row part of the offset in the VGPR (range-checked), the
     // wave-uniform column part in the scalar offset.
@@ -340,8 +370,8 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     // squared deviations) of its 96 columns of every output row for the layer that will do the same with THESE rows.
     const size_t ldo = (size_t)p.N * 4;  // bytes per output row in either format
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)m0 * ldo, 0, (unsigned)rows_left * (unsigned)ldo, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual) + (MODE == 2 && p.res_split ? (size_t)m0 * p.N : 0), 0,
-                                                                          MODE == 2 && p.res_split ? (unsigned)rows_left * (unsigned)ldo : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual) + (k_res == 2 ? (size_t)m0 * p.N : 0), 0,
+                                                                          k_res == 2 ? (unsigned)rows_left * (unsigned)ldo : 0u, 0x00020000);
     // The residual values of all 18 fragments are fetched FIRST (72 registers: the operand fragments are dead): written inside the store loop
     // each load sits behind the previous fragment's store - `residual` may alias `out`, the compiler must keep that order - and a tile pays 18
     // memory round trips one after the other (measured: ~20 us per tile, as much as the K loop of the proj layer). A lane reads exactly the
@@ -360,7 +390,7 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
             for (int i = 0; i < 3; ++i) {
                 const int m = m0 + row0 + i * 16;
                 resv[i][jj] = u32x4{0u, 0u, 0u, 0u};
-                if (MODE == 2 && p.res_split) {
+                if (k_res == 2) {
                     const unsigned vrow = (unsigned)(row0 + i * 16) * (unsigned)ldo;
                     const int so = (n >> 5) * 128 + (n & 16) * 2;
                     // (row-pair form: the even lane of a pair fetches the hi chunk of both, the odd one the lo chunk; sorted out where they are used)
@@ -375,31 +405,31 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     float rsum[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        if (MODE != 1 && p.residual && j % JG == 0) fetch_residual(j);
+        if (MODE != 1 && k_res != 0 && j % JG == 0) fetch_residual(j);
         const int n = n0 + cg * 96 + j * 16;  // (wave-uniform) first column of the fragment; the lane's four: n + 4 f_kg ..
         f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n + f_kg * 4);
-        if (MODE == 1 && p.ln_stats) cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n + f_kg * 4);
+        if (MODE == 1) cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n + f_kg * 4);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int m = m0 + row0 + i * 16;
             f32x4 v;
-            if (MODE == 1 && p.ln_stats) {
+            if (MODE == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = rs[i] * (acc[i][j][e] - mu[i] * cs[e]) + bv[e];
             } else {
                 v = acc[i][j] + bv;
             }
-            if (p.act == ACT_GELU) {
+            if (k_act == ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_erfc_as(v[e]);
-            } else if (p.act == ACT_RELU) {
+            } else if (k_act == ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             const unsigned vrow = (unsigned)(row0 + i * 16) * (unsigned)ldo;
             const int so = (n >> 5) * 128 + (n & 16) * 2;  // split rows: the fragment's 16 hi halves inside their 32-element block (lo: + 64)
-            if (MODE == 2 && p.residual && p.res_split) {
+            if (MODE == 2 && k_res == 2) {
                 const u32x4 rq = resv[i][j % JG];
                 const auto s0 = __builtin_amdgcn_permlane16_swap(rq[0], rq[2], false, false);  // -> (own hi, own lo) of values 0, 1
                 const auto s1 = __builtin_amdgcn_permlane16_swap(rq[1], rq[3], false, false);  //                         values 2, 3
@@ -407,14 +437,14 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
                 const f16x4 h = __builtin_bit_cast(f16x4, rh), l = __builtin_bit_cast(f16x4, rl);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += (float)h[e] + (float)l[e];
-            } else if (MODE != 1 && p.residual) {
+            } else if (MODE != 1 && k_res == 1) {
                 v += __builtin_bit_cast(f32x4, resv[i][j % JG]);  // (rows past M: zeros, their stores are dropped)
             }
-            if (MODE == 2 && p.stats_out) {
+            if (k_stats) {
                 rsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
                 acc[i][j] = v;  // (kept for the second pass)
             }
-            if (p.out_split) {
+            if (k_out_split) {
                 // (hi, lo) of the four values in eight VALU instructions (split_pair), then the row-pair form (pp_ffn_dma.hip): lanes f_kg, f_kg ^ 1
                 // exchange halves - the even one stores the 16-byte hi chunk of both, the odd one the lo chunk: ONE 16-byte store per fragment
                 // instead of two 8-byte ones (+ the wait states behind it, see below)
@@ -424,6 +454,9 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
                 const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(hu[1], lu[1], false, false);
                 const u32x4 q = {s0[0], s1[0], s0[1], s1[1]};
+#if LDM_SKIP_STORES
+                if (i != 0 || j != 0) { asm volatile("" ::"v"(q)); continue; }
+#endif
                 __builtin_amdgcn_raw_buffer_store_b128(q, ro, vrow + (unsigned)(f_kg >> 1) * 16u + (unsigned)(f_kg & 1) * 64u, so, 0);
                 asm volatile("s_nop 3" ::"v"(q));
             } else {
@@ -435,7 +468,7 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
             }
         }
     }
-    if (MODE == 2 && p.stats_out) {
+    if (k_stats) {
         // two passes (mean, then squared deviations from it): no cancellation whatever the rows' offset is
         const int parts = p.N / 96;
         const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.stats_out + (size_t)m0 * parts * 2, 0, (unsigned)rows_left * (unsigned)(parts * 8), 0x00020000);
@@ -460,6 +493,7 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
                                                       (unsigned)(row0 + i * 16) * (unsigned)(parts * 8), (tn * 2 + cg) * 8, 0);
         }
     }
+    stamp();  // 3 i + 2: epilogue issued
     }  // tiles of this workgroup
 }
 
@@ -503,8 +537,14 @@ int linear_dma_gemm(const GemmParams& g, hipStream_t s) {
     p.out_split = g.out_bf16 == 2;
     p.ntn = g.N / ldm::BN;
     const int grid = p.ntn * ((g.M + ldm::BM - 1) / ldm::BM);
-    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldm::linear_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
-    hipLaunchKernelGGL(ldm::linear_dma_kernel<0>, dim3(ldm::loop_grid(grid)), dim3(ldm::THREADS), ldm::LDS, s, p);
+    // pp_gemm's shapes of the ViT plans get their epilogue switches at compile time: qkv (split rows out), fc1 (+ GELU), proj / fc2 / patch embed
+    // (fp32 rows out + fp32 residual); anything else the generic instantiation
+    void (*kern)(const ldm::Params) = ldm::linear_dma_kernel<0>;
+    if (!p.residual && p.out_split && p.act == ACT_NONE) kern = ldm::linear_dma_kernel<0, ACT_NONE, 1, 0>;
+    else if (!p.residual && p.out_split && p.act == ACT_GELU) kern = ldm::linear_dma_kernel<0, ACT_GELU, 1, 0>;
+    else if (p.residual && !p.out_split && p.act == ACT_NONE) kern = ldm::linear_dma_kernel<0, ACT_NONE, 0, 1>;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
+    hipLaunchKernelGGL(kern, dim3(ldm::loop_grid(grid)), dim3(ldm::THREADS), ldm::LDS, s, p);
     PP_LAUNCH_CHECK_AS("linear_dma_tile");
     return PP_OK;
 }
@@ -554,10 +594,20 @@ extern "C" int pp_linear_ln_folded(const void* act, const void* weight, const fl
     p.ln_stats = ln_stats; p.ln_colsum = ln_colsum; p.ln_eps = ln_eps; p.stats_out = stats_out;
     const int grid = p.ntn * ((M + ldm::BM - 1) / ldm::BM);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    auto kern = ln_stats ? ldm::linear_dma_kernel<1> : ldm::linear_dma_kernel<2>;
+    // the layers of the folded plan with their epilogue switches at compile time: qkv / fc1 (statistics in, split rows out), proj / fc2 (split
+    // residual in place, statistics out); the first proj (fp32 residual), the last fc2 (fp32 rows out) and anything else: generic
+    void (*kern)(const ldm::Params) = ln_stats ? ldm::linear_dma_kernel<1> : ldm::linear_dma_kernel<2>;
+    if (ln_stats && p.out_split && p.act == ACT_NONE) kern = ldm::linear_dma_kernel<1, ACT_NONE, 1, 0, 0>;
+    else if (ln_stats && p.out_split && p.act == ACT_GELU) kern = ldm::linear_dma_kernel<1, ACT_GELU, 1, 0, 0>;
+    else if (!ln_stats && p.res_split && p.out_split && p.act == ACT_NONE && stats_out) kern = ldm::linear_dma_kernel<2, ACT_NONE, 1, 2, 1>;
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldm::LDS));
     hipLaunchKernelGGL(kern, dim3(ldm::loop_grid(grid)), dim3(ldm::THREADS), ldm::LDS, s, p);
     PP_LAUNCH_CHECK_AS("linear_dma_fold");
     return PP_OK;
 }
 
+#if LDM_STAMP
+extern "C" int pp_dev_ldm_stamps(unsigned long long* out) {  // dev: 2 x 64 stamps of the last launch (host pointer)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::ldm::g_ldm_stamps), sizeof(unsigned long long) * 128, 0, hipMemcpyDeviceToHost);
+}
+#endif
