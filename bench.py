@@ -252,9 +252,10 @@ def pmc_traffic(kernel_mangled, precision, B, prefix=""):
             ks = json.load(open(path))["kernels"]
         except Exception:  # noqa: BLE001
             continue
-        if "linear_dma_kernelILi" in kernel_mangled:  # the one-tile kernel's instantiations that share a tag (<1> + <2>: the folded-LayerNorm plan)
-            want = ["linear_dma_kernel<%s>" % m[len("linear_dma_kernelILi")] for m in kernel_mangled.split("|") for m in [m[m.index("linear_dma_kernelILi"):]]]
-            hit = [v for k, v in ks.items() if any(w in k for w in want)]
+        if "linear_dma_kernelILi" in kernel_mangled:  # the twelve-wave Linear kernel's instantiations that share a tag (MODE 1 + MODE 2 of the
+            # folded-LayerNorm plan, each with its compile-time epilogue switches: rocprofv3 lists them as linear_dma_kernel<1, 0, 1, 0, 0> ...)
+            modes = [m[m.index("linear_dma_kernelILi") + len("linear_dma_kernelILi")] for m in kernel_mangled.split("|")]
+            hit = [v for k, v in ks.items() if any(("linear_dma_kernel<%s," % md) in k or ("linear_dma_kernel<%s>" % md) in k for md in modes)]
             if hit:
                 n = sum(v["launches"] for v in hit)
                 return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / n), "profiles/" + name
