@@ -506,17 +506,15 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 // handful of stale 4-byte words per launch on a full chip (first behind the v_permlane16_swap below and wrongly blamed
                 // on the swap; then in pp_linear_dma.hip's fp32 rows, where no swap is involved). Every 16-byte buffer store of this
                 // file is followed by an explicit s_nop that depends on its data.
-                f16x4 h, l;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    h[j] = split_hi(hv[j]);
-                    l[j] = split_lo(hv[j], h[j]);
-                }
+                // (hi, lo) of the four values by split_pair: eight VALU instructions instead of fourteen (the stamps of round 5 found the LayerNorm
+                // epilogues still on the one-value-at-a-time split)
+                u32x2_t hu, lu;
+                { unsigned h__, l__; split_pair(hv[0], hv[1], h__, l__); hu[0] = h__; lu[0] = l__; }
+                { unsigned h__, l__; split_pair(hv[2], hv[3], h__, l__); hu[1] = h__; lu[1] = l__; }
                 const int so = (cb >> 5) * 128 + (cb & 16) * 2;
 #if FFD_H128
                 {   // the row-pair form of split_store4_rowpair (lanes fk_, fk_ ^ 1 exchange halves: the even one stores the 16-byte hi chunk,
                     // the odd one the lo chunk), as ONE 16-byte buffer store followed by the wait states the compiler does not insert
-                    const u32x2_t hu = __builtin_bit_cast(u32x2_t, h), lu = __builtin_bit_cast(u32x2_t, l);
                     const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(hu[1], lu[1], false, false);
                     u32x4 q = {s0[0], s1[0], s0[1], s1[1]};
@@ -524,8 +522,8 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                     asm volatile("s_nop 3" ::"v"(q));
                 }
 #else
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, h), rh, v_rowh + rf * (16 * E * 4), so, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, l), rh, v_rowh + rf * (16 * E * 4), so + 64, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(hu, rh, v_rowh + rf * (16 * E * 4), so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(lu, rh, v_rowh + rf * (16 * E * 4), so + 64, 0);
 #endif
             }
         }

@@ -384,13 +384,18 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
                         for (int kb2 = 0; kb2 < 2; ++kb2) {
                             f32x4 v0 = acc[2 * kb2][rf] + bias_r[2 * kb2], v1 = acc[2 * kb2 + 1][rf] + bias_r[2 * kb2 + 1];
                             f16x8 ph, pl;
+                            {   // (hi, lo) of the eight ReLU'd values by split_pair: 16 VALU instructions instead of ~28
+                                u32x4 phu, plu;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float a0 = fmaxf(v0[j], 0.f), a1 = fmaxf(v1[j], 0.f);
-                                ph[j] = split_hi(a0);
-                                pl[j] = split_lo(a0, ph[j]);
-                                ph[4 + j] = split_hi(a1);
-                                pl[4 + j] = split_lo(a1, ph[4 + j]);
+                                for (int j = 0; j < 2; ++j) {
+                                    unsigned h_, l_;
+                                    split_pair(fmaxf(v0[2 * j], 0.f), fmaxf(v0[2 * j + 1], 0.f), h_, l_);
+                                    phu[j] = h_; plu[j] = l_;
+                                    split_pair(fmaxf(v1[2 * j], 0.f), fmaxf(v1[2 * j + 1], 0.f), h_, l_);
+                                    phu[2 + j] = h_; plu[2 + j] = l_;
+                                }
+                                ph = __builtin_bit_cast(f16x8, phu);
+                                pl = __builtin_bit_cast(f16x8, plu);
                             }
                             o0 = split_mma(__builtin_bit_cast(f16x8, hw[kb2][0][0]), __builtin_bit_cast(f16x8, hw[kb2][0][1]), ph, pl, o0);
                             o1 = split_mma(__builtin_bit_cast(f16x8, hw[kb2][1][0]), __builtin_bit_cast(f16x8, hw[kb2][1][1]), ph, pl, o1);
@@ -538,12 +543,18 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
                         *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.C) + eoff) = ov;
                     } else if (p.out_bf16 == 2) {
                         f16x8 hv, lv;
+                        {
+                            u32x4 hu, lu;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            hv[j] = split_hi(v0[j]);
-                            lv[j] = split_lo(v0[j], hv[j]);
-                            hv[4 + j] = split_hi(v1[j]);
-                            lv[4 + j] = split_lo(v1[j], hv[4 + j]);
+                            for (int j = 0; j < 2; ++j) {
+                                unsigned h_, l_;
+                                split_pair(v0[2 * j], v0[2 * j + 1], h_, l_);
+                                hu[j] = h_; lu[j] = l_;
+                                split_pair(v1[2 * j], v1[2 * j + 1], h_, l_);
+                                hu[2 + j] = h_; lu[2 + j] = l_;
+                            }
+                            hv = __builtin_bit_cast(f16x8, hu);
+                            lv = __builtin_bit_cast(f16x8, lu);
                         }
                         char* o = split_addr(p.C, eoff);
                         *reinterpret_cast<f16x8*>(o) = hv;
