@@ -386,6 +386,15 @@ int pp_ffn_split_residual_layernorm(const void* h_in, const void* w_packed, cons
 int pp_qkv_attention_split(const void* h_in, const void* wqkv, const float* bqkv, void* out, int n_seq, int seq_len, int heads,
                            int head_dim, float scale, void* stream);
 
+/* The same launch with the LayerNorm in front of it (ln1 of the block; mmpretrain TransformerEncoderLayer [3P]: x + attn(ln1(x))) folded into the
+ * projection: x_in holds the RAW residual rows in the operand format, wqkv_folded / bqkv_folded carry gamma / beta
+ * (probpose_code_amd/weights.py::fold_layernorm: W' = W gamma, b' = b + W beta), ln_colsum[n] = sum_k W'[n, k] of the split-rounded weights, and
+ * ln_stats holds (mean, rstd) of every row - (n_seq * seq_len, 2) fp32, as pp_proj_ffn_split_folded leaves them. q / k / v are evaluated as
+ * rstd (x W'^T - mean colsum) + b' where the unfolded launch adds its bias. Same shapes, same restrictions as pp_qkv_attention_split. */
+int pp_qkv_attention_split_folded(const void* x_in, const void* wqkv_folded, const float* bqkv_folded, const float* ln_stats,
+                                  const float* ln_colsum, void* out, int n_seq, int seq_len, int heads, int head_dim, float scale,
+                                  void* stream);
+
 /* The second half of a ViT layer in ONE launch in the parity precision (PP_PREC_F16X3): attention output projection +
  * residual, ln2, the feed-forward block + residual, and the LayerNorm that follows the layer:
  *   x_mid = residual + att Wp^T + bp ;  h = LayerNorm(x_mid; gamma2, beta2, eps)

@@ -97,6 +97,7 @@ SIGNATURES = {
     "pp_ffn_split_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "pp_ffn_split_residual_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, _P]),
     "pp_qkv_attention_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "pp_qkv_attention_split_folded": (c_int, [_P] * 6 + [c_int] * 4 + [c_float, _P]),
     "pp_proj_split_packed_bytes": (c_longlong, [c_int]),
     "pp_proj_split_pack_weights": (c_int, [_P, _P, c_int, _P]),
     "pp_proj_ffn_split_residual_layernorm": (

@@ -59,6 +59,10 @@ struct Params {
     int n_seq, heads;
     unsigned h_bytes, w_bytes;
     float scale_log2e;
+    // LayerNorm folded into the projection (pp_qkv_attention_split_folded): h holds the RAW residual rows (operand format), w / bias carry
+    // gamma / beta (weights.fold_layernorm), and mean / rstd of every row come with them
+    const float* ln_stats;   // [n_seq * 192, 2]: (mean, rstd) per row
+    const float* ln_colsum;  // [1152]: sum_k w[n, k] of the split-rounded folded weights
 };
 
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
@@ -105,7 +109,8 @@ __device__ unsigned long long g_qka_stamps[4][16];
 struct TagF { static constexpr bool value = false; };
 struct TagT { static constexpr bool value = true; };
 
-__global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const Params p) {
+template <bool FOLD>
+__device__ __forceinline__ void qkv_attention_body(const Params& p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -221,6 +226,12 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
     // (every wave passed the last barrier with all its reads of the ring complete: the ring may be overwritten)
 
     // ---- + bias, out to LDS: q and k as split lines [token][32 hi | 32 lo] (chunk-swizzled like the staged blocks), V^T planes
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t st_n[3] = {f32x2_t{0.f, 1.f}, f32x2_t{0.f, 1.f}, f32x2_t{0.f, 1.f}};  // (mean, rstd) of this lane's tokens 48 rg + 16 rf + fr
+    if (FOLD) {
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) st_n[rf] = *reinterpret_cast<const f32x2_t*>(p.ln_stats + ((size_t)seq * S + 48 * rg + 16 * rf + fr) * 2);
+    }
     {
         char* Qs = smem + OFF_Q;
         char* Ks = smem + OFF_K;
@@ -232,23 +243,39 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
             const int c = 3 * cg + cf;  // 16-column fragment of the 96 outputs: 0, 1 = q; 2, 3 = k; 4, 5 = v
             if (c < 4) {
                 const int which = c >> 1, d0 = (c & 1) * 16;  // dims d0 + 4 fg + (0..3)
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + which * E + head * HD + d0 + 4 * fg);
+                if (FOLD) cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + which * E + head * HD + d0 + 4 * fg);
                 char* dstb = which == 0 ? Qs : Ks;
                 const int chunk = (d0 >> 3) + (fg >> 1);  // the pair (fg, fg ^ 1) fills one 8-dim chunk
 #pragma unroll
                 for (int rf = 0; rf < 3; ++rf) {
                     const int t = 48 * rg + 16 * rf + fr;
-                    const u32x4 q = split_pair16(acc[cf][rf] + bv);
+                    f32x4 val = acc[cf][rf] + bv;
+                    if (FOLD) {  // LayerNorm(x) W^T = rstd (x W'^T - mean colsum(W')) + b': this lane's token
+                        const float mu = st_n[rf][0], rs = st_n[rf][1];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) val[e] = rs * (acc[cf][rf][e] - mu * cs[e]) + bv[e];
+                    }
+                    const u32x4 q = split_pair16(val);
                     *reinterpret_cast<u32x4*>(dstb + t * 128 + ((((odd ? 4 : 0) + chunk) ^ sw) << 4)) = q;
                 }
             } else {
                 const int d = (c - 4) * 16 + fr;
                 const float bs = p.bias ? p.bias[2 * E + head * HD + d] : 0.f;
+                const float csd = FOLD ? p.ln_colsum[2 * E + head * HD + d] : 0.f;
 #pragma unroll
                 for (int rf = 0; rf < 3; ++rf) {
                     const int t0 = 48 * rg + 16 * rf + 4 * fg;
-                    const f32x4 v = acc[cf][rf] + bs;
+                    f32x4 v = acc[cf][rf] + bs;
+                    if (FOLD) {  // (transposed fragment: the lane's four values are four TOKENS of one v dim)
+                        const f32x4 s01 = *reinterpret_cast<const f32x4*>(p.ln_stats + ((size_t)seq * S + t0) * 2);
+                        const f32x4 s23 = *reinterpret_cast<const f32x4*>(p.ln_stats + ((size_t)seq * S + t0) * 2 + 4);
+                        v[0] = s01[1] * (acc[cf][rf][0] - s01[0] * csd) + bs;
+                        v[1] = s01[3] * (acc[cf][rf][1] - s01[2] * csd) + bs;
+                        v[2] = s23[1] * (acc[cf][rf][2] - s23[0] * csd) + bs;
+                        v[3] = s23[3] * (acc[cf][rf][3] - s23[2] * csd) + bs;
+                    }
                     u32x2 hv, lv;
                     { unsigned h__, l__; split_pair(v[0], v[1], h__, l__); hv[0] = h__; lv[0] = l__; }
                     { unsigned h__, l__; split_pair(v[2], v[3], h__, l__); hv[1] = h__; lv[1] = l__; }
@@ -334,6 +361,9 @@ __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const P
     }
     stamp();  // last
 }
+
+__global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const Params p) { qkv_attention_body<false>(p); }
+__global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_folded_kernel(const Params p) { qkv_attention_body<true>(p); }
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -581,8 +611,23 @@ extern "C" int pp_dev_qka_stamps(unsigned long long* out) {  // dev: 4 x 16 stam
 #endif
 }  // namespace pp
 
+static int qkv_attention_launch(const void* h_in, const void* wqkv, const float* bqkv, const float* ln_stats, const float* ln_colsum, void* out,
+                                int n_seq, int seq_len, int heads, int head_dim, float scale, void* stream);
+
 extern "C" int pp_qkv_attention_split(const void* h_in, const void* wqkv, const float* bqkv, void* out, int n_seq, int seq_len,
                                       int heads, int head_dim, float scale, void* stream) {
+    return qkv_attention_launch(h_in, wqkv, bqkv, nullptr, nullptr, out, n_seq, seq_len, heads, head_dim, scale, stream);
+}
+
+extern "C" int pp_qkv_attention_split_folded(const void* x_in, const void* wqkv_folded, const float* bqkv_folded, const float* ln_stats,
+                                             const float* ln_colsum, void* out, int n_seq, int seq_len, int heads, int head_dim, float scale,
+                                             void* stream) {
+    PP_REQUIRE(ln_stats && ln_colsum && bqkv_folded, PP_ERR_INVALID_ARG, "pp_qkv_attention_split_folded: statistics, column sums and the folded bias are required");
+    return qkv_attention_launch(x_in, wqkv_folded, bqkv_folded, ln_stats, ln_colsum, out, n_seq, seq_len, heads, head_dim, scale, stream);
+}
+
+static int qkv_attention_launch(const void* h_in, const void* wqkv, const float* bqkv, const float* ln_stats, const float* ln_colsum, void* out,
+                                int n_seq, int seq_len, int heads, int head_dim, float scale, void* stream) {
     using namespace pp;
     PP_REQUIRE(h_in && wqkv && out, PP_ERR_INVALID_ARG, "pp_qkv_attention_split: NULL argument");
     PP_REQUIRE(n_seq > 0, PP_ERR_INVALID_ARG, "pp_qkv_attention_split: n_seq must be positive");
@@ -600,7 +645,14 @@ extern "C" int pp_qkv_attention_split(const void* h_in, const void* wqkv, const 
     p.h_bytes = (unsigned)((size_t)n_seq * qka::S * qka::E * 4);
     p.w_bytes = (unsigned)((size_t)3 * qka::E * qka::E * 4);
     p.scale_log2e = scale * 1.44269504088896340736f;
-    if (pp::option("qkv_attn_pair") != 0 && heads % 2 == 0) {  // two heads per workgroup (opt-in: measured slower, see above)
+    p.ln_stats = ln_stats;
+    p.ln_colsum = ln_colsum;
+    if (ln_stats) {
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qka::qkv_attention_split_folded_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, qka::LDS));
+        hipLaunchKernelGGL(qka::qkv_attention_split_folded_kernel, dim3(n_seq * heads), dim3(qka::THREADS), qka::LDS,
+                           reinterpret_cast<hipStream_t>(stream), p);
+    } else if (pp::option("qkv_attn_pair") != 0 && heads % 2 == 0) {  // two heads per workgroup (opt-in: measured slower, see above)
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qka::qkv_attention_split2_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, qka::two::LDS2));
         hipLaunchKernelGGL(qka::qkv_attention_split2_kernel, dim3(n_seq * (heads / 2)), dim3(qka::THREADS), qka::two::LDS2,

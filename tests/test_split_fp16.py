@@ -650,6 +650,45 @@ def test_qkv_attention_split_fused_vs_fp64(n_seq, bias, pair):
 
 
 @gpu
+@pytest.mark.parametrize("n_seq", [3, 128])
+def test_qkv_attention_split_folded_vs_fp64(n_seq):
+    """pp_qkv_attention_split_folded: the same launch on RAW residual rows with ln1 folded into the projection (gamma into the weights, beta into
+    the bias, mean / rstd per row applied where the bias is added) against torch fp64 with an explicit LayerNorm; rows with an offset (mean / std
+    ~ 2); the unfolded launch on the normalised rows must agree; repeated launches bit-identical."""
+    from probpose_code_amd.weights import fold_layernorm
+
+    L = _lib()
+    S, E, H, hd, eps = 192, 384, 12, 32, 1e-6
+    M = n_seq * S
+    x = _rand(M, E, seed=190) * 1.3 + 2.5 * _rand(M, 1, seed=191)
+    g, be = 1.0 + 0.2 * _rand(E, seed=192), 0.2 * _rand(E, seed=193)
+    w, b = _rand(3 * E, E, seed=194, scale=1 / math.sqrt(E)), _rand(3 * E, seed=195, scale=0.3)
+    xs = _sp(x)
+    xq = _unsp(xs)  # the rows the kernel multiplies: split-rounded
+    hn = F.layer_norm(x.double(), (E,), g.double(), be.double(), eps)
+    qkv = hn @ w.double().t() + b.double()
+    q, k, v = qkv.reshape(n_seq, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(M, E)
+    stats = torch.stack([xq.mean(dim=1), 1.0 / torch.sqrt(xq.var(dim=1, unbiased=False) + eps)], dim=1).float().cuda()
+    wf, cs, bf = [t.cuda() for t in fold_layernorm(w, b, g, be)]
+    outs = []
+    for _ in range(3):
+        out = torch.full((M, E), float("nan"), device="cuda")
+        L.call("pp_qkv_attention_split_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), stats.data_ptr(), cs.data_ptr(), out.data_ptr(), n_seq, S, H,
+               hd, hd ** -0.5, None)
+        outs.append(out.cpu())
+    torch.testing.assert_close(_unsp(outs[0]), ref, rtol=3e-5, atol=3e-5)
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int32), outs[0].view(torch.int32))
+    plain = torch.full((M, E), float("nan"), device="cuda")
+    hs, wd, bd = _sp(hn.float()), _sp(w), b.cuda()
+    L.call("pp_qkv_attention_split", hs.data_ptr(), wd.data_ptr(), bd.data_ptr(), plain.data_ptr(), n_seq, S, H, hd, hd ** -0.5, None)
+    torch.testing.assert_close(_unsp(outs[0]), _unsp(plain.cpu()), rtol=3e-5, atol=3e-5)
+    with pytest.raises(L.ProbPoseLibraryError):
+        L.call("pp_qkv_attention_split_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), None, cs.data_ptr(), out.data_ptr(), n_seq, S, H, hd, 0.1, None)
+
+
+@gpu
 @pytest.mark.parametrize("ffn_form", [2, 1, 0], indirect=True)
 def test_proj_ffn_split_two_streams_under_contention(ffn_form):
     """Two independent problems through pp_proj_ffn_split_residual_layernorm on two streams at once must each give the result
