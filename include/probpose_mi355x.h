@@ -89,8 +89,8 @@ int pp_get_option(const char* name, int* value);
 /* Diagnostics: kernel launches since the last reset, tallied on the host at launch time (a captured hipGraph counts once, at capture) under
  * the launching source file's name - "pp_winograd.hip", "pp_ffn_dma.hip", "pp_qkv_attn_split.hip", "pp_linear_dma.hip", "pp_gemm.hip" ... - and
  * for kernels that share a file under their own tag: "linear_dma_tile" (twelve-wave Linear kernel under pp_gemm), "linear_dma_fold" (the same
- * kernel under pp_linear_ln_folded), "ffn_dma_pair" / "ffn_dma_single" (the twelve-wave feed-forward launch in its
- * paired-chunk / one-chunk form), "winograd_input_transform", "winograd_gemm_pool", "layernorm". Lets a test
+ * kernel under pp_linear_ln_folded), "ffn_dma_pair" / "ffn_dma_single" / "ffn_dma_fold" (the twelve-wave feed-forward launch in its
+ * paired-chunk / one-chunk form / under pp_proj_ffn_split_folded), "winograd_input_transform", "winograd_gemm_pool", "layernorm". Lets a test
  * assert WHICH kernels a launch plan ran (the reference has no counterpart: kernel selection there is cuDNN's, mmpose/models/heads/
  * hybrid_heads/probmap_head.py:261-294 and mmpretrain's VisionTransformer only name the layers). Unknown names count 0. Not thread-safe. */
 long long pp_launch_count(const char* kernel);
@@ -413,6 +413,19 @@ int pp_proj_ffn_split_residual_layernorm(const void* att, const void* wproj_pack
                                          const float* b1, const float* b2, const float* residual, float* x_out,
                                          const float* gamma, const float* beta, float eps, void* h_out, int M, int E,
                                          int F, void* stream);
+
+/* The same launch inside a chain of layers whose ln1 is folded into the qkv projection (pp_qkv_attention_split_folded):
+ *   residual_format PP_OUT_SPLIT: `residual` holds the residual rows in the operand format (hi + lo: 22 significant bits), PP_OUT_F32: fp32 rows;
+ *   fold_out != 0: the LayerNorm behind the FFN is NOT applied - the new residual rows leave ONCE, in the operand format, to h_out (which may alias
+ *                  `residual`), with (mean, rstd) of every row in stats_out ((M, 2) fp32); x_out, gamma, beta are not used. A workgroup writes
+ *                  288 KiB less per 96 rows (the store path of a CU is what the epilogue waits for);
+ *   fold_out == 0: x_out (fp32) and h_out = LayerNorm(x_out; gamma, beta) as in the plain launch (the last layer: ln_f).
+ * Twelve-wave paired kernel only: F / 128 even, option "ffn_dma_waves" != 0 - PP_ERR_UNSUPPORTED otherwise (callers keep the plain launches). The
+ * pair's launches are tallied as "ffn_dma_fold". */
+int pp_proj_ffn_split_folded(const void* att, const void* wproj_packed, const float* bproj, const float* gamma2, const float* beta2,
+                             void* h_scratch, const void* w_packed, const float* b1, const float* b2, const void* residual,
+                             int residual_format, int fold_out, float* x_out, const float* gamma, const float* beta, float eps, void* h_out,
+                             float* stats_out, int M, int E, int F, void* stream);
 
 /* Last deconvolution of the heatmap branch fused with the 1x1 convolution that follows it (bf16 operands):
  *   ConvTranspose2d(Cin -> 256, k4, s2, p1) + BN + ReLU  ->  Conv2d(256 -> K, k1)

@@ -102,6 +102,8 @@ SIGNATURES = {
     "pp_proj_split_pack_weights": (c_int, [_P, _P, c_int, _P]),
     "pp_proj_ffn_split_residual_layernorm": (
         c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, _P]),
+    "pp_proj_ffn_split_folded": (
+        c_int, [_P] * 10 + [c_int, c_int, _P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, _P]),
     "pp_conv3x3_splitk": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_int, _P]),
     "pp_sum_maxpool_relu_nhwc": (c_int, [_P, c_int, c_longlong, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pp_warp_affine_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),

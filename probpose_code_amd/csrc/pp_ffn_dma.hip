@@ -300,7 +300,11 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
 #if FFD_STAMP
 __device__ unsigned long long g_ffd_stamps[2][64];
 #endif
-template <bool PROJ, bool PAIR>
+struct TagF { static constexpr bool value = false; };
+struct TagT { static constexpr bool value = true; };
+// FOLD (bit 0: the residual rows come in the operand format; bit 1: the final LayerNorm is left to the next layer - rows out once, in the operand
+// format, with their statistics): pp_proj_ffn_split_folded, the paired projection kernel only
+template <bool PROJ, bool PAIR, int FOLD = 0>
 __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv, int lane, int m0, int nchunks, int c_rot) {
     const int rg = wv >> 2, cg = wv & 3;
     const int f_row = lane & 15, f_kg = lane >> 4;
@@ -391,7 +395,10 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     // Stores as buffer stores: the row part of the address (and the lane's column part) in the VGPR offset - rows past M fall out
     // of the descriptor's extent and are dropped by the hardware (the range check covers the VGPR offset, not the scalar one) -
     // the wave-uniform column part in the scalar offset: two address registers for the whole epilogue.
-    auto layernorm_rows = [&](const float* gamma, const float* beta, float* x_dst, void* h_dst, bool store_x) {
+    // fold_c (std::true_type-like tag): the rows are NOT normalised - they leave once, in the operand format, to h_dst, with (mean, rstd) per row in
+    // p.stats_out: the LayerNorm is applied by the layer that consumes them (pp_qkv_attention_split_folded)
+    auto layernorm_rows = [&](const float* gamma, const float* beta, float* x_dst, void* h_dst, bool store_x, auto fold_c) {
+        constexpr bool FO = decltype(fold_c)::value;
         // (row offsets recomputed here from an opaque copy of the lane id: kept as kernel-long constants they cost three registers the paired
         // A-steps do not have)
         unsigned ones_ = ~0u;
@@ -449,6 +456,10 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             const int r = rows0_ + rf * 16;
             const float var = ((stat[4 * BM + r] + stat[5 * BM + r]) + (stat[6 * BM + r] + stat[7 * BM + r])) * (1.0f / E);
             rstd[rf] = 1.0f / sqrtf(var + p.eps);
+            if (FO && fk_ == 0 && cg == 0 && m0 + r < p.M) {
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<f32x2_t*>(p.stats_out + (size_t)(m0 + r) * 2) = f32x2_t{mean[rf], rstd[rf]};
+            }
         }
 #if FFD_LN_PREFETCH
         // gamma / beta of all six column fragments in one round trip (48 registers: the operand fragments are dead): inside the store loop every
@@ -457,8 +468,8 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
         for (int cf = 0; cf < 6; ++cf) {
             const int cb = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16;
-            gs_[cf] = *reinterpret_cast<const f32x4*>(gamma + cb + fk_ * 4);
-            bs_[cf] = *reinterpret_cast<const f32x4*>(beta + cb + fk_ * 4);
+            gs_[cf] = FO ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(gamma + cb + fk_ * 4);
+            bs_[cf] = FO ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(beta + cb + fk_ * 4);
         }
 #endif
 #pragma unroll
@@ -467,7 +478,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #if FFD_LN_PREFETCH
             const f32x4 g = gs_[cf], b = bs_[cf];
 #else
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cb + fk_ * 4), b = *reinterpret_cast<const f32x4*>(beta + cb + fk_ * 4);
+            const f32x4 g = FO ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(gamma + cb + fk_ * 4), b = FO ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(beta + cb + fk_ * 4);
 #endif
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) {
@@ -478,6 +489,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 asm("" : "+v"(mu));  // (a second, opaque copy: with the same value as in the variance pass the compiler keeps all 72 differences v - mean alive from there to here)
                 f32x4 hv = {(v[0] - mu) * rs * g[0] + b[0], (v[1] - mu) * rs * g[1] + b[1], (v[2] - mu) * rs * g[2] + b[2],
                             (v[3] - mu) * rs * g[3] + b[3]};
+                if (FO) hv = v;  // (the raw rows)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { float t = hv[j]; split_pin(t); hv[j] = t; }
 #if FFD_STORE16
@@ -537,7 +549,19 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
         for (int cf = 0; cf < 6; ++cf) {
             const int cb = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16;
-            acc[rf][cf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, v_rowx + rf * (16 * E * 4), cb * 4, 0));  // (rows past M: zeros, never stored)
+            if constexpr ((FOLD & 1) != 0) {
+                // operand-format rows, row-pair form: the even lane of a pair (f_kg, f_kg ^ 1) fetches the 16-byte hi chunk of both lanes' values, the odd
+                // one the lo chunk; two row swaps give every lane its own (hi, lo) halves; x = hi + lo (22 significant bits)
+                const unsigned vsp = (unsigned)(m0 + rows0) * (unsigned)(E * 4) + (unsigned)(f_kg >> 1) * 16u + (unsigned)(f_kg & 1) * 64u;
+                const u32x4 q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, vsp + rf * (16 * E * 4), (cb >> 5) * 128 + (cb & 16) * 2, 0));
+                const auto s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const f16x4 hh = __builtin_bit_cast(f16x4, u32x2_t{s0[0], s1[0]}), ll = __builtin_bit_cast(f16x4, u32x2_t{s0[1], s1[1]});
+                acc[rf][cf] = f32x4{(float)hh[0] + (float)ll[0], (float)hh[1] + (float)ll[1], (float)hh[2] + (float)ll[2], (float)hh[3] + (float)ll[3]};
+            } else {
+                acc[rf][cf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, v_rowx + rf * (16 * E * 4), cb * 4, 0));  // (rows past M: zeros, never stored)
+            }
         }
 
     stamp();  // 1: residual rows requested
@@ -617,7 +641,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #if FFD_STAMP == 2
         stamp();  // (fine) P1 passed
 #endif
-        layernorm_rows(p.gamma2, p.beta2, nullptr, const_cast<void*>(p.h), false);
+        layernorm_rows(p.gamma2, p.beta2, nullptr, const_cast<void*>(p.h), false, TagF{});
 #if FFD_STAMP == 2
         stamp();  // (fine) ln2 rows stored (issued)
 #endif
@@ -1075,11 +1099,12 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     // ---- LayerNorm epilogue: G is out of use once every wave is past its last B-step
     __syncthreads();  // E1
     stamp();  // last but one: every wave past its last step
-    layernorm_rows(p.gamma, p.beta, p.x_out, p.h_out, true);
+    if constexpr ((FOLD & 2) != 0) layernorm_rows(nullptr, nullptr, nullptr, p.h_out, false, TagT{});
+    else layernorm_rows(p.gamma, p.beta, p.x_out, p.h_out, true, TagF{});
     stamp();  // last: rows stored
 }
 
-template <bool PROJ, bool PAIR>
+template <bool PROJ, bool PAIR, int FOLD = 0>
 __device__ __forceinline__ void body(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1088,13 +1113,16 @@ __device__ __forceinline__ void body(const Params p) {
     const int nchunks = p.F / CHUNK;
     const int c_rot = (int)(blockIdx.x & 7) % nchunks;  // the workgroups of an XCD walk the chunks in the same order
     if (wv >= CW) dma_role<PROJ, PAIR>(p, smem, wv - CW, lane, m0, nchunks, c_rot);
-    else compute_role<PROJ, PAIR>(p, smem, wv, lane, m0, nchunks, c_rot);
+    else compute_role<PROJ, PAIR, FOLD>(p, smem, wv, lane, m0, nchunks, c_rot);
 }
 
 __global__ __launch_bounds__(THREADS) void ffn_dma_kernel(const Params p) { body<false, false>(p); }
 __global__ __launch_bounds__(THREADS) void proj_ffn_dma_kernel(const Params p) { body<true, false>(p); }
 __global__ __launch_bounds__(THREADS) void ffn_dma_pair_kernel(const Params p) { body<false, true>(p); }
 __global__ __launch_bounds__(THREADS) void proj_ffn_dma_pair_kernel(const Params p) { body<true, true>(p); }
+__global__ __launch_bounds__(THREADS) void proj_ffn_dma_pair_fold1_kernel(const Params p) { body<true, true, 1>(p); }  // split residual in, LayerNorm out (last layer)
+__global__ __launch_bounds__(THREADS) void proj_ffn_dma_pair_fold2_kernel(const Params p) { body<true, true, 2>(p); }  // fp32 residual in (first layer), folded out
+__global__ __launch_bounds__(THREADS) void proj_ffn_dma_pair_fold3_kernel(const Params p) { body<true, true, 3>(p); }  // split in, folded out
 
 }  // namespace ffd
 
@@ -1110,9 +1138,13 @@ int launch_dma_form(const Params& p, bool proj, hipStream_t s) {
     // an even number of hidden chunks: the paired form (two chunks share every streamed x k-block); option "ffn_pair" = 0 or an odd count: one at a time
     const bool pair = FFD_ROLL && option("ffn_pair") != 0 && (p.F / ffd::CHUNK) % 2 == 0;
     auto kern = pair ? (proj ? ffd::proj_ffn_dma_pair_kernel : ffd::ffn_dma_pair_kernel) : (proj ? ffd::proj_ffn_dma_kernel : ffd::ffn_dma_kernel);
+    const int fold = (p.res_split ? 1 : 0) | (p.fold_out ? 2 : 0);
+    if (fold) {  // pp_proj_ffn_split_folded: the paired projection kernel only (its entry point checks)
+        kern = fold == 1 ? ffd::proj_ffn_dma_pair_fold1_kernel : fold == 2 ? ffd::proj_ffn_dma_pair_fold2_kernel : ffd::proj_ffn_dma_pair_fold3_kernel;
+    }
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ffd::LDS));
     hipLaunchKernelGGL(kern, dim3((p.M + ffd::BM - 1) / ffd::BM), dim3(ffd::THREADS), ffd::LDS, s, p);
-    PP_LAUNCH_CHECK_AS(pair ? "ffn_dma_pair" : "ffn_dma_single");
+    PP_LAUNCH_CHECK_AS(fold ? "ffn_dma_fold" : pair ? "ffn_dma_pair" : "ffn_dma_single");
     return PP_OK;
 }
 }  // namespace ffs

@@ -27,6 +27,11 @@ struct Params {
     const float* gamma2;   // ln2
     const float* beta2;
     unsigned att_bytes, wproj_bytes;
+    // Folded form (pp_proj_ffn_split_folded, twelve-wave paired kernel only): res_split - `residual` holds operand-format rows; fold_out - the final
+    // LayerNorm is NOT applied: the new residual rows leave ONCE, in the operand format, to h_out, with (mean, rstd) per row in stats_out - the next
+    // layer's pp_qkv_attention_split_folded applies them (x_out, gamma, beta unused)
+    int res_split, fold_out;
+    float* stats_out;      // [M, 2]
 };
 
 }  // namespace ffs

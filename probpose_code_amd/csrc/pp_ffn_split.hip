@@ -936,3 +936,54 @@ extern "C" int pp_proj_ffn_split_residual_layernorm(const void* att, const void*
     p.wproj_bytes = (unsigned)(2 * ffs::KB * ffs::B_BLOCK);
     return ffs::launch<true>(p, reinterpret_cast<hipStream_t>(stream));
 }
+
+// The projection + FFN launch inside a chain of layers whose LayerNorm in front of the qkv projection is folded into that projection
+// (pp_qkv_attention_split_folded): the residual rows arrive and / or leave in the operand format, and with fold_out the final LayerNorm of this
+// launch is NOT applied - the rows leave once (h_out: x in the operand format) with (mean, rstd) per row (stats_out). Twelve-wave paired kernel only.
+extern "C" int pp_proj_ffn_split_folded(const void* att, const void* wproj_packed, const float* bproj, const float* gamma2, const float* beta2,
+                                        void* h_scratch, const void* w_packed, const float* b1, const float* b2, const void* residual,
+                                        int residual_format, int fold_out, float* x_out, const float* gamma, const float* beta, float eps, void* h_out,
+                                        float* stats_out, int M, int E, int F, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(att && wproj_packed && bproj && gamma2 && beta2 && h_scratch && w_packed && b1 && b2 && residual && h_out, PP_ERR_INVALID_ARG,
+               "pp_proj_ffn_split_folded: NULL argument");
+    PP_REQUIRE(residual_format == PP_OUT_F32 || residual_format == PP_OUT_SPLIT, PP_ERR_INVALID_ARG, "pp_proj_ffn_split_folded: residual_format is PP_OUT_F32 or PP_OUT_SPLIT");
+    PP_REQUIRE(fold_out ? stats_out != nullptr : (x_out && gamma && beta), PP_ERR_INVALID_ARG,
+               "pp_proj_ffn_split_folded: fold_out needs stats_out; without it x_out, gamma and beta are required");
+    PP_REQUIRE(E == ffs::E, PP_ERR_UNSUPPORTED, "pp_proj_ffn_split_folded: built for embed dim 384 (ViT-S)");
+    PP_REQUIRE(M > 0 && F > 0 && F % ffs::CHUNK == 0 && (F / ffs::CHUNK) % 2 == 0, PP_ERR_UNSUPPORTED,
+               "pp_proj_ffn_split_folded: hidden width must be an even number of 128-column chunks (the paired twelve-wave kernel)");
+    PP_REQUIRE(option("ffn_dma_waves") != 0, PP_ERR_UNSUPPORTED, "pp_proj_ffn_split_folded: needs the twelve-wave kernel (option ffn_dma_waves)");
+    PP_REQUIRE((size_t)M * E * 4 < ffs::OOB && (size_t)(F / ffs::CHUNK) * ffs::CHUNK_BYTES < ffs::OOB, PP_ERR_UNSUPPORTED,
+               "pp_proj_ffn_split_folded: operand exceeds 2 GiB");
+    PP_REQUIRE(h_scratch != att && h_scratch != h_out && h_scratch != residual, PP_ERR_INVALID_ARG,
+               "pp_proj_ffn_split_folded: h_scratch must not alias the attention rows, the residual rows or h_out");
+    ffs::Params p{};
+    p.h = h_scratch;
+    p.wpack = w_packed;
+    p.b1 = b1;
+    p.b2 = b2;
+    p.residual = reinterpret_cast<const float*>(residual);
+    p.x_out = x_out;
+    p.gamma = gamma;
+    p.beta = beta;
+    p.h_out = h_out;
+    p.M = M;
+    p.F = F;
+    p.h_bytes = (unsigned)((size_t)M * E * 4);
+    p.w_bytes = (unsigned)((size_t)(F / ffs::CHUNK) * ffs::CHUNK_BYTES);
+    p.eps = eps;
+    p.trace = ffs::g_trace;
+    p.att = att;
+    p.wproj = wproj_packed;
+    p.bp = bproj;
+    p.gamma2 = gamma2;
+    p.beta2 = beta2;
+    p.att_bytes = p.h_bytes;
+    p.wproj_bytes = (unsigned)(2 * ffs::KB * ffs::B_BLOCK);
+    p.res_split = residual_format == PP_OUT_SPLIT;
+    p.fold_out = fold_out != 0;
+    p.stats_out = stats_out;
+    return ffs::launch_dma_form(p, true, reinterpret_cast<hipStream_t>(stream));
+}
+

@@ -1001,3 +1001,68 @@ def test_linear_ln_folded_edge_shapes_vs_fp64(M, N, K, ln):
         ref = x.double() @ w.double().t() + b.double() + res.double()
         torch.testing.assert_close(out.cpu().double(), ref, **TOL)
         torch.testing.assert_close(so.cpu().double(), _row_part_stats(ref), rtol=1e-4, atol=1e-4)
+
+
+@gpu
+@pytest.mark.parametrize("M", [96 * 3, 96 * 2 - 40, 24576])
+def test_proj_ffn_split_folded_vs_plain_launch(M):
+    """pp_proj_ffn_split_folded (the projection + FFN launch with the residual rows in the operand format and / or its final LayerNorm left to the next
+    layer's pp_qkv_attention_split_folded) against the plain launch on the same numbers: operand-format residual rows in (x = hi + lo is exact in
+    fp32: bit-identical x_out / h_out to the plain launch on those rounded rows); folded out: h_out holds the new residual rows in the operand
+    format (= the plain launch's x_out to 2^-22), stats_out (mean, rstd) per row against fp64; both at once, in place; a ragged last block; the
+    bs 64 shape; repeated launches bit-identical; shapes it does not serve are refused."""
+    from probpose_code_amd.weights import from_split
+
+    L = _lib()
+    E, F_, F32, eps = 384, 1536, 0, 1e-6
+    h, r, w1, b1, w2, b2, g, be = _ffn_inputs(M, F_, seed=600)
+    att, wp, bp, g2, be2 = _proj_inputs(M, seed=620)
+    packed = _ffn_pack(L, w1, w2, E, F_)
+    wpp = torch.empty(E * E, dtype=torch.float32, device="cuda")
+    wps = _sp(wp)
+    L.call("pp_proj_split_pack_weights", wps.data_ptr(), wpp.data_ptr(), E, None)
+    dev = [t.cuda() for t in (bp, g2, be2, b1, b2, g, be)]
+    rs = _sp(r)                               # residual rows in the operand format
+    rq = from_split(rs.cpu()).cuda()          # ... and their value as fp32 rows (hi + lo: exact)
+    ad = _sp(att)
+
+    def plain(res32):
+        xo, ho, sc = (torch.full((M, E), float("nan"), device="cuda") for _ in range(3))
+        L.call("pp_proj_ffn_split_residual_layernorm", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), sc.data_ptr(),
+               packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), res32.data_ptr(), xo.data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(), eps, ho.data_ptr(),
+               M, E, F_, None)
+        return xo.cpu(), ho.cpu()
+
+    def folded(res, res_fmt, fold_out, in_place=False):
+        xo, sc = (torch.full((M, E), float("nan"), device="cuda") for _ in range(2))
+        ho = res if in_place else torch.full((M, E), float("nan"), device="cuda")
+        st = torch.full((M, 2), float("nan"), device="cuda")
+        L.call("pp_proj_ffn_split_folded", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), sc.data_ptr(),
+               packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), res.data_ptr(), res_fmt, int(fold_out), None if fold_out else xo.data_ptr(),
+               None if fold_out else dev[5].data_ptr(), None if fold_out else dev[6].data_ptr(), eps, ho.data_ptr(), st.data_ptr() if fold_out else None,
+               M, E, F_, None)
+        return xo.cpu(), ho.cpu(), st.cpu()
+
+    want_x, want_h = plain(rq)
+    # 1: operand-format residual in, LayerNorm out (the last layer of a folded chain)
+    x1, h1, _ = folded(rs, SPLIT, False)
+    assert torch.equal(x1, want_x) and torch.equal(h1.view(torch.int32), want_h.view(torch.int32)), "split residual in: must equal the plain launch on hi + lo"
+    # 2: fp32 residual in, folded out (the first layer)
+    _, h2, st2 = folded(rq, F32, True)
+    torch.testing.assert_close(_unsp(h2), want_x.double(), rtol=5e-7, atol=5e-7)
+    ref_stats = torch.stack([want_x.double().mean(dim=1), 1.0 / torch.sqrt(want_x.double().var(dim=1, unbiased=False) + eps)], dim=1)
+    torch.testing.assert_close(st2.double(), ref_stats, rtol=2e-5, atol=2e-5)
+    # 3: both, in place (the layers in between): the residual buffer becomes the new rows
+    rs3 = rs.clone()
+    _, h3, st3 = folded(rs3, SPLIT, True, in_place=True)
+    assert torch.equal(h3.view(torch.int32), h2.view(torch.int32)) and torch.equal(st3, st2)
+    rs4 = rs.clone()
+    _, h4, st4 = folded(rs4, SPLIT, True, in_place=True)
+    assert torch.equal(h4.view(torch.int32), h3.view(torch.int32)) and torch.equal(st4, st3), "run-to-run difference"
+    assert L.launch_count("ffn_dma_fold") >= 4
+    with pytest.raises(L.ProbPoseLibraryError):  # an odd number of hidden chunks: no paired kernel
+        L.call("pp_proj_ffn_split_folded", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), rs4.data_ptr(),
+               packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), rs.data_ptr(), SPLIT, 1, None, None, None, eps, rs3.data_ptr(), st4.cuda().data_ptr(), M, E, 384, None)
+    with pytest.raises(L.ProbPoseLibraryError):  # folded out without a statistics buffer
+        L.call("pp_proj_ffn_split_folded", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), rs4.data_ptr(),
+               packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), rs.data_ptr(), SPLIT, 1, None, None, None, eps, rs3.data_ptr(), None, M, E, F_, None)
