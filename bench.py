@@ -175,7 +175,11 @@ def kernel_work_per_step(eng, B, passes, tag):
         pair = _lib.get_option("ffn_pair") != 0 and (Fd // 128) % 2 == 0
         name = ("_ZN2pp3ffd24proj_ffn_dma_pair_kernelENS_3ffs6ParamsE" if pair else "_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE") if dma else \
             "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE"
-        return L * (4.0 * M * E * Fd + 2.0 * M * E * E), L * 4 * M * E * 4, L, name
+        by = L * 4 * M * E * 4
+        if dma and getattr(eng, "ln_fold_fused", False):  # the folded chain: fold2 (first layer), fold3 (layers between), fold1 (last) of the paired kernel;
+            name = "_ZN2pp3ffd30proj_ffn_dma_pair_fold3_kernelENS_3ffs6ParamsE"  # every layer but the last writes its rows ONCE (operand format, + 8 B of statistics)
+            by = (3 * (L - 1) + 4) * M * E * 4 + (L - 1) * M * 8
+        return L * (4.0 * M * E * Fd + 2.0 * M * E * E), by, L, name
     if tag == "qkv_attention":  # f16x3: qkv Linear + attention per (sequence, head); LayerNorm rows in, attention rows out
         att_fl = 4.0 * (B * passes) * eng.heads * eng.Np * eng.Np * eng.hd
         return L * (2.0 * M * 3 * E * E + att_fl), L * 2 * M * E * 4, L, "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE"
@@ -251,6 +255,12 @@ def pmc_traffic(kernel_mangled, precision, B, prefix=""):
         try:
             ks = json.load(open(path))["kernels"]
         except Exception:  # noqa: BLE001
+            continue
+        if "proj_ffn_dma_pair_fold" in kernel_mangled:  # the three instantiations of the folded chain share the tag: launch-weighted mean
+            hit = [v for k, v in ks.items() if "proj_ffn_dma_pair_fold" in k]
+            if hit:
+                n = sum(v["launches"] for v in hit)
+                return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / n), "profiles/" + name
             continue
         if "linear_dma_kernelILi" in kernel_mangled:  # the twelve-wave Linear kernel's instantiations that share a tag (MODE 1 + MODE 2 of the
             # folded-LayerNorm plan, each with its compile-time epilogue switches: rocprofv3 lists them as linear_dma_kernel<1, 0, 1, 0, 0> ...)

@@ -221,17 +221,32 @@ __device__ __forceinline__ void qkv_attention_body(const Params& p) {
             }
         }
     };
-    if (cg == 0) k_loop(TagF{}); else k_loop(TagT{});
-    stamp();  // 2: the twelve K-steps of the qkv projection
-    // (every wave passed the last barrier with all its reads of the ring complete: the ring may be overwritten)
-
-    // ---- + bias, out to LDS: q and k as split lines [token][32 hi | 32 lo] (chunk-swizzled like the staged blocks), V^T planes
+    // FOLD: (mean, rstd) of the tokens this lane's fragments belong to. Normal fragments: the lane's token 48 rg + 16 rf + fr; transposed ones
+    // (V^T, waves of column half 1): four consecutive tokens 48 rg + 16 rf + 4 fg + (0..3) per fragment row
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    f32x2_t st_n[3] = {f32x2_t{0.f, 1.f}, f32x2_t{0.f, 1.f}, f32x2_t{0.f, 1.f}};  // (mean, rstd) of this lane's tokens 48 rg + 16 rf + fr
+    if (cg == 0) k_loop(TagF{}); else k_loop(TagT{});
+    // (requested here, all at once: kept through the K loop they cost 6 - 35 spilled registers at the kernel's 128; one pair per fragment inside the
+    //  store loop below is a chain of trips to the L2)
+    f32x2_t st_n[3] = {f32x2_t{0.f, 1.f}, f32x2_t{0.f, 1.f}, f32x2_t{0.f, 1.f}};
     if (FOLD) {
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) st_n[rf] = *reinterpret_cast<const f32x2_t*>(p.ln_stats + ((size_t)seq * S + 48 * rg + 16 * rf + fr) * 2);
     }
+    f32x4 st_t[3][2];
+#pragma unroll
+    for (int rf = 0; rf < 3; ++rf) st_t[rf][0] = st_t[rf][1] = f32x4{0.f, 1.f, 0.f, 1.f};
+    if (FOLD && cg == 1) {
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            const float* sp = p.ln_stats + ((size_t)seq * S + 48 * rg + 16 * rf + 4 * fg) * 2;
+            st_t[rf][0] = *reinterpret_cast<const f32x4*>(sp);
+            st_t[rf][1] = *reinterpret_cast<const f32x4*>(sp + 4);
+        }
+    }
+    stamp();  // 2: the twelve K-steps of the qkv projection
+    // (every wave passed the last barrier with all its reads of the ring complete: the ring may be overwritten)
+
+    // ---- + bias, out to LDS: q and k as split lines [token][32 hi | 32 lo] (chunk-swizzled like the staged blocks), V^T planes
     {
         char* Qs = smem + OFF_Q;
         char* Ks = smem + OFF_K;
@@ -269,8 +284,7 @@ __device__ __forceinline__ void qkv_attention_body(const Params& p) {
                     const int t0 = 48 * rg + 16 * rf + 4 * fg;
                     f32x4 v = acc[cf][rf] + bs;
                     if (FOLD) {  // (transposed fragment: the lane's four values are four TOKENS of one v dim)
-                        const f32x4 s01 = *reinterpret_cast<const f32x4*>(p.ln_stats + ((size_t)seq * S + t0) * 2);
-                        const f32x4 s23 = *reinterpret_cast<const f32x4*>(p.ln_stats + ((size_t)seq * S + t0) * 2 + 4);
+                        const f32x4 s01 = st_t[rf][0], s23 = st_t[rf][1];
                         v[0] = s01[1] * (acc[cf][rf][0] - s01[0] * csd) + bs;
                         v[1] = s01[3] * (acc[cf][rf][1] - s01[2] * csd) + bs;
                         v[2] = s23[1] * (acc[cf][rf][2] - s23[0] * csd) + bs;

@@ -146,6 +146,11 @@ class ProbPoseEngine:
         # by proj / fc2, the residual stream in the operand format: no LayerNorm launch inside the layers (pp_linear_ln_folded)
         self.ln_fold = bool(precision == "f16x3" and pl["ln_fold"] and not self._proj_packed and not self._ffn_packed
                             and self.w.has("l0.qkv.wf") and self.E % 192 == 0 and self.w.ffn_dims % 192 == 0)
+        # the ViT-S chain of fused layer kernels with ln1 of layers 1 .. L - 1 folded into the qkv projection: a layer's projection + FFN launch leaves
+        # its rows once, in the operand format, with (mean, rstd) per row (pp_proj_ffn_split_folded), the next qkv + attention launch applies them
+        # (pp_qkv_attention_split_folded): 288 KiB less to store per 96 rows and launch (the paired twelve-wave kernel only)
+        self.ln_fold_fused = bool(precision == "f16x3" and pl["ln_fold"] and self.fuse_qkv_attn and self._proj_packed and self.w.has("l1.qkv.wf")
+                                  and (self.w.ffn_dims // 128) % 2 == 0 and self.w.num_layers >= 2)
         # Which layer plan this geometry gets - said once, loudly, when a ViT-S-like model misses the two-launch layer only because of
         # its token count (pp_qkv_attn_split.hip is written for 192-token sequences of 32-dim heads; the projection + FFN launch takes
         # any row count): it then runs qkv Linear + attention (pp_attention) + the fused projection / FFN launch, three launches per layer
@@ -153,6 +158,8 @@ class ProbPoseEngine:
         if precision == "f16x3":
             if self.fuse_qkv_attn and self._proj_packed:
                 self.layer_plan = "two launches per layer (pp_qkv_attention_split + pp_proj_ffn_split_residual_layernorm)"
+                if self.ln_fold_fused:
+                    self.layer_plan += "; ln1 of layers 1 .. L - 1 folded into the qkv projection (pp_proj_ffn_split_folded -> pp_qkv_attention_split_folded)"
             elif self._proj_packed:
                 self.layer_plan = "three launches per layer (pp_gemm qkv + pp_attention + pp_proj_ffn_split_residual_layernorm)"
             else:
@@ -230,6 +237,7 @@ class ProbPoseEngine:
             # folded-LayerNorm plan: the residual stream in the operand format and the row statistics between its Linear layers
             xs=buf("h", (M, E)) if self._ln_fold_at(M) else None,
             lnst=buf("ln_stats", (M, E // 96, 2), f32) if self._ln_fold_at(M) else None,
+            rowst=e(M, 2, dt=f32) if self.ln_fold_fused else None,  # (mean, rstd) per row between pp_proj_ffn_split_folded and pp_qkv_attention_split_folded
             scalars=e(4, B, self.K, dt=f32), locs=e(B, self.K, 2, dt=f32),
             keypoints=e(B, self.K, 2, dt=torch.float64), scores=e(B, self.K, dt=f32),
             heatmaps=e(B, self.K, self.Hh, self.Wh, dt=f32),
@@ -357,7 +365,12 @@ class ProbPoseEngine:
                 qcur, qnext = qnext, qcur
                 continue
             qkv_done = False
-            if self.fuse_qkv_attn:
+            fold = self.ln_fold_fused and _lib.get_option("ffn_dma_waves") != 0
+            if self.fuse_qkv_attn and fold and i >= 1:
+                # ws["h"] holds the RAW rows the previous layer left (operand format), ws["rowst"] their statistics
+                self._call("qkv_attention", "pp_qkv_attention_split_folded", ws["h"].data_ptr(), w[f"l{i}.qkv.wf"].data_ptr(), w[f"l{i}.qkv.bf"].data_ptr(),
+                           ws["rowst"].data_ptr(), w[f"l{i}.qkv.cf"].data_ptr(), att.data_ptr(), B * passes, self.Np, self.heads, self.hd, scale, st)
+            elif self.fuse_qkv_attn:
                 self._call("qkv_attention", "pp_qkv_attention_split", ws["h"].data_ptr(), w[f"l{i}.qkv.w"].data_ptr(),
                            w[f"l{i}.qkv.b"].data_ptr(), att.data_ptr(), B * passes, self.Np, self.heads, self.hd, scale, st)
             else:
@@ -380,6 +393,16 @@ class ProbPoseEngine:
                            None if nq else h_next.data_ptr(), nq[0].data_ptr() if nq else None,
                            nq[1].data_ptr() if nq else None, qcur.data_ptr() if nq else None, M, E, Fd, st)
                 qkv_done = nq is not None
+                continue
+            if i in self._proj_packed and self.fuse_qkv_attn and fold:
+                # the same launch in the folded chain: residual rows fp32 (layer 0: the patch embedding's) or operand format; every layer but the last
+                # leaves its rows once, in the operand format, in ws["h"] with their statistics; the last applies ln_f as before
+                res, res_fmt = (ws["x"], 0) if i == 0 else (ws["h"], 2)
+                self._call("proj_ffn_split", "pp_proj_ffn_split_folded", att.data_ptr(), self._proj_packed[i].data_ptr(), w[f"l{i}.proj.b"].data_ptr(),
+                           w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(), ws["hs"].data_ptr(), self._ffn_packed[i].data_ptr(),
+                           w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(), res.data_ptr(), res_fmt, 0 if last else 1,
+                           ws["x"].data_ptr() if last else None, gn.data_ptr() if last else None, bn.data_ptr() if last else None, self.ln_eps,
+                           h_next.data_ptr(), None if last else ws["rowst"].data_ptr(), M, E, Fd, st)
                 continue
             if i in self._proj_packed:
                 # f16x3: projection + residual, ln2, FFN + residual, next LayerNorm in one kernel

@@ -156,6 +156,13 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
         t[f"l{i}.fc1.b"] = f32(sd[p + "ffn.layers.0.0.bias"])
         t[f"l{i}.fc2.w"] = op(sd[p + "ffn.layers.1.weight"])
         t[f"l{i}.fc2.b"] = f32(sd[p + "ffn.layers.1.bias"])
+        if split and E == 384 and i >= 1:
+            # ViT-S chain of fused layer kernels: ln1 of layers 1 .. L - 1 folded into the qkv projection (pp_qkv_attention_split_folded; the layer in front
+            # leaves raw rows + statistics, pp_proj_ffn_split_folded)
+            bb = sd.get(p + "attn.qkv.bias")
+            wf, cs, bf = fold_layernorm(sd[p + "attn.qkv.weight"].float(), bb.float() if bb is not None else torch.zeros(3 * E),
+                                        sd[p + "ln1.weight"].float(), sd[p + "ln1.bias"].float())
+            t[f"l{i}.qkv.wf"], t[f"l{i}.qkv.cf"], t[f"l{i}.qkv.bf"] = wf.to(device), cs.to(device), bf.to(device)
         if split and E % 192 == 0 and E != 384:
             # widths without a fused layer kernel (ViT-B): the folded form of the two Linear layers that follow a LayerNorm (pp_linear_ln_folded;
             # engine.py takes that plan from the row count at which the twelve-wave Linear kernel engages - the plain copies serve below it)

@@ -340,6 +340,37 @@ def test_config4_bs32_graph_replay_default_plan():
     assert dd <= 1e-3, f"folded and stand-alone LayerNorm plans differ by {dd:.2e} px"
 
 
+def test_vit_small_folded_chain_is_the_default_plan_and_agrees_with_the_plain_chain():
+    """The headline workload's layer plan (round 5): ln1 of layers 1 .. 11 folded into the qkv projection - every projection + FFN launch but the
+    last leaves its rows once, in the operand format, with (mean, rstd) per row (pp_proj_ffn_split_folded, tallied "ffn_dma_fold"), the next
+    qkv + attention launch applies them (pp_qkv_attention_split_folded). The launch tally names the plan; plan switch ln_fold = False is the plain
+    chain (round 4) and must agree within 1e-3 px / 1e-5 on the scalar heads; the hipGraph replay equals the eager launches bit for bit."""
+    from probpose_code_amd import ProbPoseEngine, _lib
+    from probpose_code_amd import synthetic as S
+
+    sd = S.synthetic_state_dict("small", seed=4, logit_scale=2.0)
+    xd = S.synthetic_crops(64, seed=44).cuda()
+    outs = {}
+    for fold in (True, False):
+        eng = ProbPoseEngine(sd, 12, precision="f16x3", plan=dict(ln_fold=fold))
+        assert eng.ln_fold_fused == fold and ("folded into the qkv projection" in eng.layer_plan) == fold
+        _lib.reset_launch_counts()
+        o = eng.forward(xd, True, S.COCO_FLIP_INDICES)
+        torch.cuda.synchronize()
+        assert _lib.launch_count("ffn_dma_fold") == (12 if fold else 0) and _lib.launch_count("ffn_dma_pair") == (0 if fold else 12)
+        assert _lib.launch_count("pp_qkv_attn_split.hip") == 12 and _lib.launch_count("layernorm") == 0
+        outs[fold] = {k: o[k].clone() for k in ("keypoints", "scalars")}
+        for _ in range(3):
+            rep = eng.forward_graph(xd, True, S.COCO_FLIP_INDICES)
+        torch.cuda.synchronize()
+        assert torch.equal(rep["keypoints"], outs[fold]["keypoints"]) and torch.equal(rep["scalars"], outs[fold]["scalars"])
+        del eng
+        torch.cuda.empty_cache()
+    d = (outs[True]["keypoints"] - outs[False]["keypoints"]).abs().max().item()
+    ds = (outs[True]["scalars"] - outs[False]["scalars"]).abs().max().item()
+    assert d <= 1e-3 and ds <= 1e-5, f"plans differ: keypoints {d:.2e} px, scalars {ds:.2e}"
+
+
 def test_config4_folded_plan_ragged_row_count_agrees_with_generic_plan():
     """ViT-B 384x288 at B = 33 with flip: 28 512 token rows = 148.5 row tiles of the twelve-wave Linear kernel - the last tile of every layer
     is half empty (buffer descriptors end at row M: statistics, residual rows and outputs past it are never touched). The folded-LayerNorm
