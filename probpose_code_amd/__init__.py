@@ -10,7 +10,7 @@ operator interface for this path and nothing else.
 from . import _lib  # noqa: F401  (fails loudly when the HIP library is missing)
 from .codecs import BaseKeypointCodec, ProbMap, oks_kernel_taps  # noqa: F401
 from .config import Config  # noqa: F401
-from .engine import ProbPoseEngine  # noqa: F401
+from .engine import ProbPoseEngine, domain_report  # noqa: F401
 from .pipeline import StepPipeline  # noqa: F401
 from .pose_estimators import (  # noqa: F401
     PoseDataPreprocessor,

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         float* fscr = reinterpret_cast<float*>(smem);
         SmxStat* sscr = reinterpret_cast<SmxStat*>(smem + 64);
         f32x4 z0[NV], z1[NV];
-        float m0 = -__builtin_inff(), m1 = -__builtin_inff();
+        float m0 = -__builtin_inff(), m1 = -__builtin_inff(), chk = 0.f;
         // a division costs nine VALU instructions, the row has 24 per thread: multiply when the temperature is a normal power of two
         const unsigned t_bits = __builtin_bit_cast(unsigned, temperature);
         const bool t_pow2 = (t_bits & 0x007fffffu) == 0 && (t_bits >> 23) >= 2 && (t_bits >> 23) <= 252;
@@ -351,9 +351,29 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
             for (int j = 0; j < 4; ++j) {
                 m0 = fmaxf(m0, z0[e][j]);
                 m1 = fmaxf(m1, z1[e][j]);
+                if (ok) {  // x * 0 is NaN for x = +-inf / NaN: one fma per logit finds a non-finite input (fmaxf would skip a NaN)
+                    chk = __builtin_fmaf(z0[e][j], 0.f, chk);
+                    if (HAS_FLIP) chk = __builtin_fmaf(z1[e][j], 0.f, chk);
+                }
             }
         }
+        if (chk != chk) m0 = __builtin_inff();
         block_max2(m0, m1, fscr);
+        // A non-finite logit (an operand beyond the split-fp16 range upstream - numeric domain, include/probpose_mi355x.h - or a NaN input) must not
+        // decode to pixel 0 with a plausible score: the keypoint comes out as NaN, which the host mirror turns into a FloatingPointError.
+        if (!(fabsf(m0) < __builtin_inff()) || (HAS_FLIP && !(fabsf(m1) < __builtin_inff()))) {  // (workgroup-uniform)
+            const float qnan = __builtin_nanf("");
+            if (avg_out)
+                for (int i = tid; i < HW; i += DEC_THREADS) avg_out[(size_t)bk * HW + i] = qnan;
+            if (conv_out)
+                for (int i = tid; i < HW; i += DEC_THREADS) conv_out[(size_t)bk * HW + i] = qnan;
+            if (tid == 0) {
+                locs[2 * bk + 0] = locs[2 * bk + 1] = qnan;
+                keypoints[2 * bk + 0] = keypoints[2 * bk + 1] = (double)qnan;
+                scores[bk] = qnan;
+            }
+            return;
+        }
         // normalize < 0 stands for the head's `normalize=None` (probmap_head.py:249,642-646): no Sparsemax, the map is
         // clamp(x / T, 0, 1) - the same code with threshold 0, no shift and scale 1
         const bool smx = normalize >= 0.f;

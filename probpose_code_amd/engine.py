@@ -93,6 +93,9 @@ class ProbPoseEngine:
         self._flip: Dict[tuple, torch.Tensor] = {}
         self._graphs: Dict[tuple, tuple] = {}  # insertion order = least recently used first (see capture / forward_graph)
         self.max_graphs = 8  # captured graphs kept (each pins a static input and, per batch size and slot, a workspace)
+        self._tick = 0  # forward / forward_graph calls so far; _graph_tick: the call at which a captured graph last replayed
+        self._graph_tick: Dict[tuple, int] = {}
+        self.graph_captures = 0  # captures so far (diagnostics; tests assert it stays bounded when more sizes recur than graphs are kept)
         self._opt_epoch = _lib.option_epoch()
         # Launch-plan switches: every fusion below is on in the shipped plan; `plan` (constructor argument) turns single ones off
         # for A/B timing and for the tests of the unfused kernels, PP_FUSE_* environment variables do the same from outside a
@@ -280,6 +283,7 @@ class ProbPoseEngine:
             self._opt_epoch = _lib.option_epoch()
             self._ws.clear()
             self._graphs.clear()
+            self._graph_tick.clear()
 
     def _flip_indices(self, flip_indices) -> torch.Tensor:
         key = tuple(int(i) for i in flip_indices)
@@ -614,6 +618,7 @@ class ProbPoseEngine:
         tensors (views into the cached workspace, valid until the next call with the same batch size):
         ``keypoints`` (B,K,2) f64 input-pixel space, ``scores`` (B,K) f32 (keypoints_conf), ``locs``,
         ``scalars`` (4,B,K) f32 [probability, visibility, oks, raw error], optionally ``heatmaps``."""
+        self._tick += 1
         feat = self.run_backbone(imgs, flip_test, slot)
         out = self.run_head(feat, flip_test, flip_indices, return_heatmaps, slot, shift_heatmap)
         if return_features:
@@ -633,7 +638,11 @@ class ProbPoseEngine:
             return self._graphs[key][1]
         while len(self._graphs) >= max(1, int(self.max_graphs)):  # least recently used out, with the workspace nothing else replays from
             old_key = next(iter(self._graphs))
+            # the victim may still be replaying on another slot's stream (StepPipeline depth >= 2): its exec graph and the buffers it reads go
+            # back to the allocator below, so the device must be through with it first (an eviction is rare; the capture syncs anyway)
+            torch.cuda.synchronize(self.device)
             del self._graphs[old_key]
+            self._graph_tick.pop(old_key, None)
             passes_old = 2 if old_key[1] else 1
             if not any(k[0] == old_key[0] and k[-1] == old_key[-1] and (2 if k[1] else 1) == passes_old for k in self._graphs):
                 self._ws.pop((old_key[0], passes_old, old_key[-1]), None)
@@ -649,16 +658,94 @@ class ProbPoseEngine:
         with torch.cuda.graph(graph):
             out = self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot, shift_heatmap=shift_heatmap)
         self._graphs[key] = (graph, static_in, out)
+        self._graph_tick[key] = self._tick
+        self.graph_captures += 1
         return static_in
+
+    @staticmethod
+    def _graph_key(B, flip_test, flip_indices, return_heatmaps, shift_heatmap, slot):
+        return (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps, bool(shift_heatmap), slot)
+
+    def has_graph(self, B: int, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False, slot: int = 0,
+                  shift_heatmap: bool = False) -> bool:
+        self._check_options()
+        return self._graph_key(B, flip_test, flip_indices, return_heatmaps, shift_heatmap, slot) in self._graphs
+
+    def capture_would_thrash(self) -> bool:
+        """True when a new capture would evict a graph that replayed within the last ``4 * max_graphs`` calls: with more recurring batch sizes
+        than graphs kept (the person counts of a video: 0 .. 20 per frame) every call would otherwise evict, re-allocate a workspace, warm up,
+        capture, synchronise the device and replay - several times the cost of launching kernel by kernel, for ever. The caller then runs this
+        size eagerly; a graph nobody replays any more ages out and makes room."""
+        if len(self._graphs) < max(1, int(self.max_graphs)):
+            return False
+        victim = next(iter(self._graphs))
+        return self._tick - self._graph_tick.get(victim, 0) <= 4 * max(1, int(self.max_graphs))
 
     def forward_graph(self, imgs: torch.Tensor, flip_test: bool = True, flip_indices=None,
                       return_heatmaps: bool = False, slot: int = 0, shift_heatmap: bool = False) -> Dict[str, torch.Tensor]:
         """Same contract as ``forward`` for uint8 crops, replaying the captured graph (on torch's current stream)."""
         B = imgs.shape[0]
         static_in = self.capture(B, flip_test, flip_indices, return_heatmaps, slot, shift_heatmap)
-        key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps, bool(shift_heatmap), slot)
+        key = self._graph_key(B, flip_test, flip_indices, return_heatmaps, shift_heatmap, slot)
         graph, _, out = self._graphs[key]
+        self._tick += 1
+        self._graph_tick[key] = self._tick
         if imgs.data_ptr() != static_in.data_ptr():
             static_in.copy_(imgs, non_blocking=True)
         graph.replay()
         return out
+
+
+# numeric domain of the split-fp16 operand format (include/probpose_mi355x.h, "numeric domain"; csrc/pp_split.h)
+F16X3_MAX_OPERAND = 65504.0     # |x| beyond it: the high half is inf, products NaN -> NaN keypoints (pp_probmap_decode_flags), FloatingPointError in predict
+F16X3_FULL_PRECISION_MIN = 0.125  # below it the low half is an fp16 subnormal: absolute 2^-25 instead of relative 2^-22
+F16X3_FOLD_MEAN_OVER_STD = 30.0  # LayerNorm fold: rstd (acc - mean colsum) cancels ~ log2(|mean| / std) of the 22 operand bits (1e-4 relative at 30)
+
+
+@torch.no_grad()
+def domain_report(state_dict: Dict[str, torch.Tensor], crops_u8: torch.Tensor, num_heads: int, img_size=(256, 192), device="cuda",
+                  **engine_kw) -> Dict[str, object]:
+    """Does a checkpoint stay inside the numeric domain of ``precision="f16x3"`` on these crops? Runs the network once in the fp32 mode
+    (fp32 operands, the generic launch plan: every activation passes through HBM) and reads, layer by layer, what the f16x3 kernels would
+    be handed as MFMA operands: the residual rows (raw rows are operands since the LayerNorm fold), the LayerNorm output, qkv, the FFN's hidden
+    activation, the features. Returns ``{"layers": [...], "max_operand": .., "max_mean_over_std": .., "ok": bool, "advice": str}``.
+    A diagnostic for a new checkpoint (run once), not part of the hot path."""
+    eng = ProbPoseEngine(state_dict, num_heads, img_size=img_size, precision="f32", device=device, **engine_kw)
+    rows: list = []
+    crops_u8 = crops_u8.to(eng.device)
+    B = crops_u8.shape[0]
+    ws = eng._workspace(B, 1, 0)
+
+    def stat(name, t):
+        t = t.float()
+        return {name + "_absmax": float(t.abs().max())}
+
+    def hook(stage):
+        torch.cuda.synchronize(eng.device)
+        x = ws["x"].float()
+        sd_ = x.std(dim=1, unbiased=False).clamp_min(1e-12)
+        r = dict(stage=stage, residual_absmax=float(x.abs().max()), residual_mean_over_std=float((x.mean(dim=1).abs() / sd_).max()))
+        r.update(stat("ln_out", ws["h"]))
+        r.update(stat("qkv", ws["qkv"]))
+        if ws.get("f") is not None and stage != "embed":
+            r.update(stat("ffn_hidden", ws["f"]))
+        rows.append(r)
+
+    eng.stage_hook = hook
+    out = eng.forward(crops_u8, False, None)
+    torch.cuda.synchronize(eng.device)
+    eng.stage_hook = None
+    feat_abs = float(ws["feat"].float().abs().max())
+    worst = max(max(v for k, v in r.items() if k.endswith("_absmax")) for r in rows)
+    worst = max(worst, feat_abs)
+    ratio = max(r["residual_mean_over_std"] for r in rows[1:]) if len(rows) > 1 else 0.0  # (layer 0's ln1 is never folded)
+    finite = bool(torch.isfinite(out["keypoints"]).all())
+    ok = finite and worst <= F16X3_MAX_OPERAND / 2 and ratio <= F16X3_FOLD_MEAN_OVER_STD
+    advice = "inside the f16x3 domain"
+    if not finite or worst > F16X3_MAX_OPERAND / 2:
+        advice = (f"an operand reaches {worst:.3g} (limit 65504, a factor 2 kept in hand): run precision='f32', or rescale the layer that "
+                  "produces it")
+    elif ratio > F16X3_FOLD_MEAN_OVER_STD:
+        advice = (f"token rows reach |mean| / std = {ratio:.1f}: the folded LayerNorm loses ~log2 of that in bits - build the model with "
+                  "plan=dict(ln_fold=False) (LayerNorm applied before the split, no cancellation)")
+    return dict(layers=rows, features_absmax=feat_abs, max_operand=worst, max_mean_over_std=ratio, ok=ok, advice=advice)

@@ -317,6 +317,12 @@ class ProbMapHead(nn.Module):
         the record ONCE; the per-crop ``InstanceData`` hold (1, K[, 2]) views of those batch arrays - no per-crop copies."""
         eng = self._engine
         B, C = rec.shape[:2]
+        if not np.isfinite(rec).all():
+            bad = np.argwhere(~np.isfinite(rec).all(axis=(1, 2))).ravel().tolist()
+            raise FloatingPointError(
+                f"non-finite keypoints / scores for crop(s) {bad[:8]} of this batch: a value left the numeric domain of precision="
+                f"{eng.precision!r} (f16x3: operands are fp16 pairs, |x| <= 65504 - include/probpose_mi355x.h, 'numeric domain'; "
+                "ProbPoseEngine.domain_report(crops) shows the layer). Run the model with precision='f32' or rescale the checkpoint")
         kpts = np.ascontiguousarray(rec[..., :2])  # float64, like the reference's decode (codecs/probmap.py:218)
         sc = np.ascontiguousarray(np.moveaxis(rec[..., 2:7], -1, 0).astype(np.float32))  # (5, B, K): conf, prob, vis, oks, err
         conf, probabilities, visibilities, oks, errors = (sc[i].reshape(B, 1, C) for i in range(5))
@@ -510,7 +516,12 @@ class TopdownPoseEstimator(nn.Module):
         self._sizes_seen[key] = seen + 1
         shift = self._shift_heatmap
         eng.max_graphs = self.max_graphs
-        if self.graph_replay and seen + 1 >= self.graph_capture_after and inputs.dtype == torch.uint8:
+        # replay a captured graph; capture a new one only when that does not evict a graph still in use (more recurring batch sizes than
+        # graphs kept - the person counts of a video - would otherwise capture on every call: engine.capture_would_thrash)
+        use_graph = self.graph_replay and inputs.dtype == torch.uint8 and (
+            eng.has_graph(B, flip, flip_indices, want_hm, 0, shift)
+            or (seen + 1 >= self.graph_capture_after and not eng.capture_would_thrash()))
+        if use_graph:
             out = eng.forward_graph(inputs, flip, flip_indices, return_heatmaps=want_hm, shift_heatmap=shift)
         else:
             out = eng.forward(inputs, flip, flip_indices, return_heatmaps=want_hm, shift_heatmap=shift)

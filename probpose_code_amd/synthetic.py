@@ -29,9 +29,88 @@ ARCHS = {
 }
 
 
+TRAINED_MASSIVE = (250.0, -120.0, 60.0)  # residual-stream values of the massive-activation channels (stats="trained")
+
+
+def _trained_like(sd: Dict[str, torch.Tensor], E: int, L: int, heads: int, g: torch.Generator,
+                  massive=TRAINED_MASSIVE, row_offset: float = 8.0, gamma_decades: float = 2.0,
+                  small_rows: float = 1e-2) -> Dict[str, torch.Tensor]:
+    """Re-parametrise the O(1) network above into the statistics a TRAINED ViT shows (the published ``ProbPose-s.pth``,
+    ``README.md:119-120``, cannot be fetched; this is what its numerics must survive) - in place, same key names:
+
+      * massive activations (Sun et al. 2024): ``len(massive)`` channels of the residual stream sit at 60 .. 250x the
+        typical magnitude from the second layer on - injected through that layer's ``fc2`` bias, its ``fc2`` rows for
+        those channels 20x wider so that the values also vary per token; every LayerNorm behind it carries a small
+        gamma there and a gamma ~ row std on the ordinary channels (what training arrives at: the normalised ordinary
+        channels would otherwise shrink to 1 / std);
+      * LayerNorm gamma log-uniform over ``gamma_decades`` decades, the Linear layer behind it with the inverse column
+        scale (function preserved, the stored weights are what changes);
+      * a per-token offset of the whole row of up to ``row_offset`` (token mean / std up to ~ ``row_offset`` in the first
+        layers) through ``pos_embed``;
+      * weight rows down to ``small_rows`` of their width: q rows scaled by s with the k rows of the same head
+        dimension by 1 / s, v rows by s with the ``proj`` columns by 1 / s, ``fc1`` rows by s with the ``fc2`` columns
+        by 1 / sqrt(s) (fp16 subnormal low halves in the split format).
+    """
+    u = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
+    hd = E // heads
+    n_mass = len(massive)
+    chans = torch.randperm(E, generator=g)[:n_mass]
+    inject = min(1, L - 1)
+    mass_std = math.sqrt(sum(m * m for m in massive) / E)  # what the massive channels add to a row's std
+    sd["backbone.pos_embed"] = sd["backbone.pos_embed"] + (u(1, sd["backbone.pos_embed"].shape[1], 1) * 2 - 1) * row_offset
+    p = f"backbone.layers.{inject}."
+    sd[p + "ffn.layers.1.bias"][chans] += torch.tensor(massive)
+    sd[p + "ffn.layers.1.weight"][chans] *= 20.0
+
+    def widen(depth):
+        """What a LayerNorm behind the injection must multiply the ordinary channels with to hand on what the O(1) network's
+        LayerNorm would: row std with the massive channels / row std without (the latter grows ~ 0.8 + 0.38 per layer)."""
+        return math.sqrt(1.0 + (mass_std / (0.8 + 0.38 * depth)) ** 2)
+
+    def regamma(ln_key, lin_keys, depth, after_massive):
+        gam = 10.0 ** ((u(E) - 0.5) * gamma_decades)
+        comp = 1.0 / gam  # the Linear behind sees gamma * norm(x): keep the product
+        sd[ln_key + ".bias"] = sd[ln_key + ".bias"] * gam
+        if after_massive:
+            gam = gam * widen(depth)
+            gam[chans] = 0.02 + 0.08 * u(n_mass)
+            comp[chans] = 1.0
+        sd[ln_key + ".weight"] = sd[ln_key + ".weight"] * gam
+        for k in lin_keys:
+            sd[k] = sd[k] * comp[None, :]
+
+    for i in range(L):
+        p = f"backbone.layers.{i}."
+        regamma(p + "ln1", [p + "attn.qkv.weight"], i, i > inject)
+        regamma(p + "ln2", [p + "ffn.layers.0.0.weight"], i + 0.5, i > inject)
+        # small rows, function preserved
+        s = small_rows ** u(heads, hd)  # log-uniform in [small_rows, 1]
+        wq = sd[p + "attn.qkv.weight"].reshape(3, heads, hd, E)
+        bq = sd[p + "attn.qkv.bias"].reshape(3, heads, hd)
+        sv = small_rows ** u(heads, hd)
+        for part, sc in ((0, s), (1, 1.0 / s), (2, sv)):
+            wq[part] *= sc[..., None]
+            bq[part] *= sc
+        sd[p + "attn.proj.weight"] = sd[p + "attn.proj.weight"] / sv.reshape(1, E)
+        sf = small_rows ** u(sd[p + "ffn.layers.0.0.weight"].shape[0])
+        sd[p + "ffn.layers.0.0.weight"] = sd[p + "ffn.layers.0.0.weight"] * sf[:, None]
+        sd[p + "ffn.layers.0.0.bias"] = sd[p + "ffn.layers.0.0.bias"] * sf
+        sd[p + "ffn.layers.1.weight"] = sd[p + "ffn.layers.1.weight"] / sf.sqrt()[None, :]
+    # the final LayerNorm feeds the head: small gamma on the massive channels, ordinary channels back at O(1)
+    if L > inject + 1:
+        gf = sd["backbone.ln1.weight"] * widen(L)
+        gf[chans] = 0.02 + 0.08 * u(n_mass)
+        sd["backbone.ln1.weight"] = gf
+    return sd
+
+
 def synthetic_state_dict(arch: str = "small", img_size=(256, 192), num_keypoints: int = 17,
                          deconv_out_channels: Sequence[int] = (256, 256), seed: int = 0,
-                         logit_scale: float = 3.0) -> Dict[str, torch.Tensor]:
+                         logit_scale: float = 3.0, stats: str = "unit", **trained_kw) -> Dict[str, torch.Tensor]:
+    """``stats="unit"``: activations O(1) everywhere (the weights every round-1..5 parity figure was taken on);
+    ``stats="trained"``: the same network re-parametrised to a trained ViT's statistics (``_trained_like``)."""
+    if stats not in ("unit", "trained"):
+        raise ValueError(f"stats must be 'unit' or 'trained', got {stats!r}")
     a = ARCHS[arch] if isinstance(arch, str) else arch
     E, L, Fd = a["embed_dims"], a["num_layers"], a["feedforward_channels"]
     g = torch.Generator().manual_seed(seed)
@@ -82,6 +161,8 @@ def synthetic_state_dict(arch: str = "small", img_size=(256, 192), num_keypoints
             bn(f"head.{t}_layers.{4 * j + 1}", E)
         sd[f"head.{t}_layers.12.weight"] = n(num_keypoints, E, 1, 1, std=1.0 / math.sqrt(E))
         sd[f"head.{t}_layers.12.bias"] = n(num_keypoints, std=0.3)
+    if stats == "trained":
+        _trained_like(sd, E, L, a["num_heads"], g, **trained_kw)
     return sd
 
 

@@ -44,12 +44,28 @@ def from_split(c: torch.Tensor) -> torch.Tensor:
     return (v[..., 0, :] + v[..., 1, :]).reshape(c.shape)
 
 
-def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+SPLIT_MAX = 65504.0  # largest fp16: the high half of a split-fp16 operand (csrc/pp_split.h; numeric domain in include/probpose_mi355x.h)
+
+
+def check_split_range(name: str, x: torch.Tensor) -> None:
+    """Refuse a weight tensor the split-fp16 container cannot hold: a non-finite value, or |w| > 65504 (its high half would be inf and every
+    product with it NaN). Raised by name, at load time - the alternative is a NaN heatmap at the first batch."""
+    x = x.detach()
+    if not bool(torch.isfinite(x).all()):
+        raise ValueError(f"weight tensor {name!r} holds non-finite values")
+    m = float(x.abs().max()) if x.numel() else 0.0
+    if m > SPLIT_MAX:
+        raise ValueError(f"weight tensor {name!r}: max |w| = {m:.4g} exceeds the split-fp16 operand range (65504); the f16x3 mode cannot "
+                         "represent it - use precision='f32', or rescale the checkpoint (include/probpose_mi355x.h, numeric domain)")
+
+
+def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, name: str = "folded weights"):
     """Linear(LayerNorm(x)) with the LayerNorm's affine part folded into the Linear layer, as pp_linear_ln_folded consumes it
     (include/probpose_mi355x.h): ``W'[n, k] = W[n, k] gamma[k]`` in the split-fp16 container, ``colsum[n] = sum_k W'[n, k]`` of the
     ROUNDED split values (what the MFMAs multiply the row mean with), ``bias'[n] = b[n] + sum_k W[n, k] beta[k]``; sums in fp64.
     mmpretrain TransformerEncoderLayer [3P]: ``attn(ln1(x))`` / ``ffn(ln2(x))``."""
     wd, g, be = w.double(), gamma.double(), beta.double()
+    check_split_range(name, wd * g[None, :])
     wf = to_split((wd * g[None, :]).float().contiguous())
     colsum = from_split(wf).double().sum(dim=1).float().contiguous()
     bias = (b.double() + wd @ be).float().contiguous()
@@ -130,16 +146,18 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
     sd = {k: v.detach().cpu() for k, v in normalize_state_dict(sd).items()}
     f32 = lambda x: x.float().contiguous().to(device)  # noqa: E731
     if split:
-        op = lambda x: to_split(x.float().contiguous()).to(device)  # noqa: E731
+        def op(x, name="weights"):
+            check_split_range(name, x)
+            return to_split(x.float().contiguous()).to(device)
     else:
-        op = lambda x: x.float().contiguous().to(dtype).to(device)  # noqa: E731
+        op = lambda x, name=None: x.float().contiguous().to(dtype).to(device)  # noqa: E731
     pw = sd["backbone.patch_embed.projection.weight"]
     E = pw.shape[0]
     L = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("backbone.layers."))
     Fd = sd["backbone.layers.0.ffn.layers.0.0.weight"].shape[0]
     K = sd["head.final_layer.weight"].shape[0]
     t: Dict[str, torch.Tensor] = {}
-    t["patch_w"] = op(pw.reshape(E, -1))
+    t["patch_w"] = op(pw.reshape(E, -1), "patch_w")
     t["patch_b"] = f32(sd["backbone.patch_embed.projection.bias"])
     t["pos_embed"] = f32(sd["backbone.pos_embed"].reshape(-1, E))
     for i in range(L):
@@ -147,21 +165,21 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
         for ln in ("ln1", "ln2"):
             t[f"l{i}.{ln}.w"] = f32(sd[p + ln + ".weight"])
             t[f"l{i}.{ln}.b"] = f32(sd[p + ln + ".bias"])
-        t[f"l{i}.qkv.w"] = op(sd[p + "attn.qkv.weight"])
+        t[f"l{i}.qkv.w"] = op(sd[p + "attn.qkv.weight"], f"l{i}.qkv.w")
         qb = sd.get(p + "attn.qkv.bias")
         t[f"l{i}.qkv.b"] = f32(qb if qb is not None else torch.zeros(3 * E))
-        t[f"l{i}.proj.w"] = op(sd[p + "attn.proj.weight"])
+        t[f"l{i}.proj.w"] = op(sd[p + "attn.proj.weight"], f"l{i}.proj.w")
         t[f"l{i}.proj.b"] = f32(sd[p + "attn.proj.bias"])
-        t[f"l{i}.fc1.w"] = op(sd[p + "ffn.layers.0.0.weight"])
+        t[f"l{i}.fc1.w"] = op(sd[p + "ffn.layers.0.0.weight"], f"l{i}.fc1.w")
         t[f"l{i}.fc1.b"] = f32(sd[p + "ffn.layers.0.0.bias"])
-        t[f"l{i}.fc2.w"] = op(sd[p + "ffn.layers.1.weight"])
+        t[f"l{i}.fc2.w"] = op(sd[p + "ffn.layers.1.weight"], f"l{i}.fc2.w")
         t[f"l{i}.fc2.b"] = f32(sd[p + "ffn.layers.1.bias"])
         if split and E == 384 and i >= 1:
             # ViT-S chain of fused layer kernels: ln1 of layers 1 .. L - 1 folded into the qkv projection (pp_qkv_attention_split_folded; the layer in front
             # leaves raw rows + statistics, pp_proj_ffn_split_folded)
             bb = sd.get(p + "attn.qkv.bias")
             wf, cs, bf = fold_layernorm(sd[p + "attn.qkv.weight"].float(), bb.float() if bb is not None else torch.zeros(3 * E),
-                                        sd[p + "ln1.weight"].float(), sd[p + "ln1.bias"].float())
+                                        sd[p + "ln1.weight"].float(), sd[p + "ln1.bias"].float(), name=f"l{i}.qkv.wf")
             t[f"l{i}.qkv.wf"], t[f"l{i}.qkv.cf"], t[f"l{i}.qkv.bf"] = wf.to(device), cs.to(device), bf.to(device)
         if split and E % 192 == 0 and E != 384:
             # widths without a fused layer kernel (ViT-B): the folded form of the two Linear layers that follow a LayerNorm (pp_linear_ln_folded;
@@ -169,7 +187,7 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
             for name, wk, bk, ln in (("qkv", "attn.qkv.weight", "attn.qkv.bias", "ln1"), ("fc1", "ffn.layers.0.0.weight", "ffn.layers.0.0.bias", "ln2")):
                 bb = sd.get(p + bk)
                 wf, cs, bf = fold_layernorm(sd[p + wk].float(), bb.float() if bb is not None else torch.zeros(sd[p + wk].shape[0]),
-                                            sd[p + ln + ".weight"].float(), sd[p + ln + ".bias"].float())
+                                            sd[p + ln + ".weight"].float(), sd[p + ln + ".bias"].float(), name=f"l{i}.{name}.wf")
                 t[f"l{i}.{name}.wf"], t[f"l{i}.{name}.cf"], t[f"l{i}.{name}.bf"] = wf.to(device), cs.to(device), bf.to(device)
     t["ln_f.w"] = f32(sd["backbone.ln1.weight"])
     t["ln_f.b"] = f32(sd["backbone.ln1.bias"])
@@ -190,16 +208,16 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
                     for tx in range(2):
                         tap = ty * 2 + tx
                         ph[py, px, :, tap * cin : (tap + 1) * cin] = w[:, :, 3 - 2 * ty - py, 3 - 2 * tx - px].t()
-        t[f"deconv{j}.w"] = op(ph)
+        t[f"deconv{j}.w"] = op(ph, f"deconv{j}.w")
         t[f"deconv{j}.b"] = f32(shift)
         deconv_channels.append(cout)
         j += 1
-    t["final.w"] = op(sd["head.final_layer.weight"].reshape(K, -1))
+    t["final.w"] = op(sd["head.final_layer.weight"].reshape(K, -1), "final.w")
     t["final.b"] = f32(sd["head.final_layer.bias"])
     if K <= 32:  # zero-padded to 32 rows: the MFMA operand of the 1x1 conv fused into the last deconvolution (pp_deconv_head)
         wpad = torch.zeros((32, t["final.w"].shape[1]), dtype=torch.float32)
         wpad[:K] = sd["head.final_layer.weight"].reshape(K, -1).float()
-        t["final.w_pad"] = op(wpad)
+        t["final.w_pad"] = op(wpad, "final.w_pad")
         if split and wpad.shape[1] == 256:
             t["final.w_head"] = pack_head_split(wpad).to(device)
 
@@ -217,8 +235,8 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
             if c == 0 and split:
                 wino.append(winograd_weights(w))
         if c == 0 and split and w.shape[1] % 128 == 0 and w.shape[0] % 96 == 0:
-            t["tower0.wino"] = op(torch.stack(wino))  # (4, 16, Cout, Cin): the first stage's Winograd form (pp_conv3x3_winograd_maxpool_relu)
-        t[f"tower{c}.w"] = op(torch.stack(ws))
+            t["tower0.wino"] = op(torch.stack(wino), "tower0.wino")  # (4, 16, Cout, Cin): the first stage's Winograd form (pp_conv3x3_winograd_maxpool_relu)
+        t[f"tower{c}.w"] = op(torch.stack(ws), f"tower{c}.w")
         t[f"tower{c}.b"] = f32(torch.stack(bs))
     t["tower_out.w"] = f32(torch.stack([sd[f"head.{tw}_layers.12.weight"].float().reshape(K, -1) for tw in TOWERS]))
     t["tower_out.b"] = f32(torch.stack([sd[f"head.{tw}_layers.12.bias"].float() for tw in TOWERS]))
