@@ -163,20 +163,16 @@ def kernel_work_per_step(eng, B, passes, tag):
         return L * 4.0 * M * E * Fd, L * (M * E * 2 + 2 * M * E * 4 + M * E * 2), L, "_ZN2pp3mlp17mlp_res_ln_kernelILb0ELb0ELb0EEEvNS0_6ParamsE"
     if tag == "ffn_split":  # f16x3: fc1 + GELU + fc2 + residual + LN per layer; h in, residual in, x out, h out (4 bytes each)
         from probpose_code_amd import _lib
-        dma = _lib.get_option("ffn_dma_waves") != 0  # the twelve-wave form (pp_ffn_dma.hip) or the eight-wave one (pp_ffn_split.hip)
         pair = _lib.get_option("ffn_pair") != 0 and (Fd // 128) % 2 == 0  # (launch_dma_form's choice: hidden chunks in pairs)
-        name = ("_ZN2pp3ffd19ffn_dma_pair_kernelENS_3ffs6ParamsE" if pair else "_ZN2pp3ffd14ffn_dma_kernelENS_3ffs6ParamsE") if dma else \
-            "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE"
+        name = "_ZN2pp3ffd19ffn_dma_pair_kernelENS_3ffs6ParamsE" if pair else "_ZN2pp3ffd14ffn_dma_kernelENS_3ffs6ParamsE"
         return L * 4.0 * M * E * Fd, L * 4 * M * E * 4, L, name
     if tag == "proj_ffn_split":  # f16x3: proj + residual + ln2 + fc1 + GELU + fc2 + residual + LN per layer; attention rows in,
         # residual in, x out, h out (4 bytes each); the ln2 rows a workgroup parks in L2 and streams back are not algorithmic bytes
         from probpose_code_amd import _lib
-        dma = _lib.get_option("ffn_dma_waves") != 0
         pair = _lib.get_option("ffn_pair") != 0 and (Fd // 128) % 2 == 0
-        name = ("_ZN2pp3ffd24proj_ffn_dma_pair_kernelENS_3ffs6ParamsE" if pair else "_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE") if dma else \
-            "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE"
+        name = "_ZN2pp3ffd24proj_ffn_dma_pair_kernelENS_3ffs6ParamsE" if pair else "_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE"
         by = L * 4 * M * E * 4
-        if dma and getattr(eng, "ln_fold_fused", False):  # the folded chain: fold2 (first layer), fold3 (layers between), fold1 (last) of the paired kernel;
+        if getattr(eng, "ln_fold_fused", False):  # the folded chain: fold2 (first layer), fold3 (layers between), fold1 (last) of the paired kernel;
             name = "_ZN2pp3ffd30proj_ffn_dma_pair_fold3_kernelENS_3ffs6ParamsE"  # every layer but the last writes its rows ONCE (operand format, + 8 B of statistics)
             by = (3 * (L - 1) + 4) * M * E * 4 + (L - 1) * M * 8
         return L * (4.0 * M * E * Fd + 2.0 * M * E * E), by, L, name
@@ -222,16 +218,11 @@ def kernel_work_per_step(eng, B, passes, tag):
         if eng.precision == "f16x3" and (3 * E) % 192 == 0 and Fd % 192 == 0:
             from probpose_code_amd import _lib
             if _lib.get_option("linear_dma") != 0 and ((M + 191) // 192) * ((3 * E) // 192) >= 512:
-                # the twelve-wave kernel (pp_linear_dma.hip: pp_gemm tries it FIRST, at every K >= 64 - at K = 384 it is level with
-                # pp_linear_ovl.hip, scripts/micro/linear_k384_bench.py)
+                # the twelve-wave kernel (pp_linear_dma.hip: pp_gemm tries it FIRST, at every K >= 64 - scripts/micro/linear_k384_bench.py)
                 return act_fl, act_by, act_n, "_ZN2pp3ldm17linear_dma_kernelILi0EEEvNS0_6ParamsE"
         if eng.precision == "f16x3" and E >= 768 and (3 * E) % 192 == 0 and Fd % 192 == 0:
             # K >= 768: the wide-tile split kernel (256 x 192 tiles; the fp32-output Linear layers run on the same instantiation)
             return act_fl, act_by, act_n, "_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1ELi2ELb0ELb0EEEvNS_10GemmParamsE"
-        if eng.precision == "f16x3" and (3 * E) % 192 == 0 and Fd % 192 == 0 and ((M + 191) // 192) * ((3 * E) // 192) >= 512:
-            # the Linear layers with long output rows run on 192 x 192 tiles with the epilogue of one tile under the K-loop of
-            # the next (pp_linear_ovl.hip; rocprofv3 lists it demangled: pp::lovl::linear_ovl_kernel(pp::GemmParams))
-            return act_fl, act_by, act_n, "_ZN2pp4lovl17linear_ovl_kernelENS_10GemmParamsE"
         return act_fl, act_by, act_n, f"_ZN2pp11gemm_kernelI{t}Li0ELi{op_fmt}EEEvNS_10GemmParamsE"
     return res_fl, res_by, res_n, f"_ZN2pp11gemm_kernelI{t}Li0ELi0EEEvNS_10GemmParamsE"
 
@@ -240,10 +231,7 @@ def pmc_traffic(kernel_mangled, precision, B, prefix=""):
     """HBM bytes per launch of `kernel_mangled` from the committed rocprofv3 --pmc passes (profiles/), or None."""
     if B != 64:
         return None, None
-    short = {"_ZN2pp4lovl17linear_ovl_kernelENS_10GemmParamsE": "pp::lovl::linear_ovl_kernel(",
-             "_ZN2pp3ffs16ffn_split_kernelENS0_6ParamsE": "pp::ffs::ffn_split_kernel(",
-             "_ZN2pp3ffs21proj_ffn_split_kernelENS0_6ParamsE": "pp::ffs::proj_ffn_split_kernel(",
-             "_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE": "pp::ffd::proj_ffn_dma_kernel(",
+    short = {"_ZN2pp3ffd19proj_ffn_dma_kernelENS_3ffs6ParamsE": "pp::ffd::proj_ffn_dma_kernel(",
              "_ZN2pp3ffd24proj_ffn_dma_pair_kernelENS_3ffs6ParamsE": "pp::ffd::proj_ffn_dma_pair_kernel(",
              "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE": "pp::qka::qkv_attention_split_kernel("}.get(kernel_mangled)
     short = short or {"_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1ELi2ELb0ELb0EEEvNS_10GemmParamsE": "void pp::psplit::panel_split_kernel<0, 8, 3, true, 2, false, false>("}.get(kernel_mangled)

@@ -28,10 +28,38 @@
 extern "C" {
 #endif
 
-/* 3: + pp_launch_count / pp_reset_launch_counts (diagnostics: which kernels a launch plan really ran).
+/* 4 (round 6): the numeric domain of PP_PREC_F16X3 stated and guarded (below); power-of-two WEIGHT SCALES: + pp_gemm_ws, pp_linear_ln_folded_ws,
+ *    pp_qkv_attention_split_ws, pp_ffn_split_residual_layernorm_ws, pp_proj_ffn_split_residual_layernorm_ws (the unsuffixed entry points = scale 1);
+ *    CHANGED signatures: pp_qkv_attention_split_folded (centered rows, no column sums, + w_inv_scale), pp_proj_ffn_split_folded (+ residual_stats,
+ *    + three weight scales; the rows it leaves are centered); pp_probmap_decode_flags writes NaN results for a map with a non-finite logit;
+ *    + pp_skinny_* (the launch plan of small batches); REMOVED: the eight-wave feed-forward kernel and the overlapped-epilogue Linear kernel with
+ *    their options "ffn_dma_waves" / "linear_ovl".
+ * 3: + pp_launch_count / pp_reset_launch_counts (diagnostics: which kernels a launch plan really ran); pp_linear_ln_folded, the *_folded launches
+ *    and PP_WS_LN_STATS (round 5).
  * 2: + pp_clock_probe, pp_conv3x3_splitk_slices, pp_conv3x3_winograd_maxpool_relu, pp_winograd_scratch_bytes, pp_probmap_decode_flags, option "ksplit9_below"; PP_WS_TOWER_PARTIAL sized for the slice count the
  *    library itself picks (round 3 added pp_workspace_bytes / pp_set_option / the split-fp16 layer kernels under version 1). */
-#define PP_ABI_VERSION 3
+#define PP_ABI_VERSION 4
+
+/* NUMERIC DOMAIN of PP_PREC_F16X3 (the parity mode: every parity figure of the repo is taken in it).
+ * An operand x is carried as hi = fp16(x), lo = fp16(x - hi) (csrc/pp_split.h); a product is three fp16 MFMAs with fp32 accumulation.
+ *   range      |x| <= 65504 for EVERY MFMA operand: activations (LayerNorm outputs, q / k / v, the FFN's hidden activation, features, deconvolution
+ *              maps) and - since the LayerNorm fold - the residual rows themselves (centered per row in the ViT-S chain, raw in ViT-B's
+ *              pp_linear_ln_folded plan). Beyond it hi = inf, the product NaN: it reaches the heatmap logits as NaN / inf, pp_probmap_decode_flags
+ *              then writes NaN keypoints / scores (never "pixel 0 with a score"), and the host mirror raises FloatingPointError.
+ *   precision  hi + lo has 22 significant bits while lo is a NORMAL fp16 number: |x| >= 2^-3. Below that lo is subnormal and the pair is exact
+ *              to an ABSOLUTE 2^-25 only (no bits at all below 2^-25). Harmless for activations next to O(1) neighbours, fatal for weights,
+ *              which are small numbers throughout (trained ViT weights ~ 0.02: 17 bits; rows of 1e-3: 13 bits - measured, tests/
+ *              test_trained_stats.py). Linear weights are therefore stored SCALED by a power of two, the tensor's largest element in
+ *              [2^12, 2^13) (probpose_code_amd/weights.py), and the kernels multiply their accumulators by the inverse (the *_ws entry points,
+ *              `w_inv_scale`: exact). Elements down to 2^-16 of a tensor's largest keep all 22 bits.
+ *   weights    a weight (after the BatchNorm / LayerNorm-gamma folds) with |w| > 65504 or non-finite is refused at load (weights.check_split_range).
+ *   LayerNorm fold   ViT-S chain: rows travel CENTERED, the folded projection is rstd * ((x - mean) W'^T) + b' - the accuracy of a plain LayerNorm.
+ *              ViT-B plan (pp_linear_ln_folded): rstd * (x W'^T - mean * colsum) + b' on raw rows loses ~ log2(1 + |mean| / std) bits of the fp32
+ *              accumulator: 2 - 5e-6 relative at |mean| / std <= 1 (a trained ViT's rows), 3e-5 at 10, 5e-4 at 150; engine plan ln_fold=False
+ *              applies the LayerNorm before the split instead.
+ *   diagnosis  probpose_code_amd.domain_report(state_dict, crops, heads) runs a checkpoint once in fp32 and reports every operand's range and the
+ *              rows' |mean| / std per layer.
+ * PP_PREC_F32 has fp32's range and no such limits (16x slower MFMA); PP_PREC_BF16 has fp32's range and 8 bits. */
 
 enum {
     PP_OK = 0,
@@ -57,7 +85,6 @@ int pp_device_cu_count(void);
  * call and on these switches, which exist for A/B timing and default to the shipped plan:
  *   "panel" (1)              0: every GEMM / convolution on the 128 x 128-tile kernel
  *   "conv_halo" (1)          0: first tower convolution (bf16) on the implicit-GEMM kernel
- *   "linear_ovl" (1)         0: split-fp16 Linear layers without the overlapped-epilogue kernel
  *   "psplit_nst" (0)         2 / 3: force the two- / three-stage form of the wide-tile split kernel
  *   "panel_linear_mink" (0)  > 0: shortest K of a bf16 Linear layer that takes the wide-tile kernel
  *   "psplit_bf16_conv" (0)   1: bf16 convolutions through the split kernel's bf16 instantiation
@@ -74,8 +101,6 @@ int pp_device_cu_count(void);
  *   "linear_loop" (1)        twelve-wave Linear kernel: one workgroup per CU walks a column of tiles, the next tile's first stages requested
  *                            under this tile's epilogue; 0: a workgroup per tile
  *   "psplit_deconv_weight_major" (0)  dev A/B: 1 = deconvolution tiles weight-set(phase)-major per XCD instead of row panel -> phase
- *   "ffn_dma_waves" (1)      0: the fused f16x3 feed-forward launches run the eight-wave kernel (pp_ffn_split.hip) instead of the
- *                            twelve-wave one (pp_ffn_dma.hip: eight computing waves + four waves that only issue the LDS-DMA)
  *   "ffn_pair" (1)           twelve-wave feed-forward launch: hidden chunks in pairs that share every streamed x k-block (x rows streamed 6 instead of 12
  *                            times per launch; taken when F / 128 is even); 0: one chunk at a time
  *   "psplit_tail" (1)        0: split-fp16 Linear layers never send the rows of a ragged last round to a second launch on 128 x 192 tiles
@@ -223,6 +248,11 @@ enum { PP_CONV3X3 = 1, PP_DECONV4X4S2 = 2 };
 int pp_gemm(int prec, const void* act, const void* weight, const float* bias, const float* residual,
             int res_mod, void* out, int M, int N, int K, int lda, int ldw, int ldc, int act_fn,
             int out_bf16, int planar_P, void* stream);
+/* ... with PP_PREC_F16X3 weights stored as W * 2^e (numeric domain above): w_inv_scale = 2^-e multiplies the sums in front of the bias. A power
+ * of two in [2^-40, 2^40]; 1 for the other precisions. */
+int pp_gemm_ws(int prec, const void* act, const void* weight, const float* bias, const float* residual,
+               int res_mod, void* out, int M, int N, int K, int lda, int ldw, int ldc, int act_fn,
+               int out_bf16, int planar_P, float w_inv_scale, void* stream);
 
 /* Dense layer of a ViT block (PP_PREC_F16X3 operands) with the LayerNorm in FRONT of it folded into the layer and the statistics of the
  * LayerNorm BEHIND it emitted with the output rows: a block of mmpretrain's TransformerEncoderLayer [3P] (x = x + attn(ln1(x));
@@ -246,6 +276,10 @@ int pp_gemm(int prec, const void* act, const void* weight, const float* bias, co
 int pp_linear_ln_folded(const void* act, const void* weight, const float* bias, const void* residual, int residual_format,
                         void* out, int out_format, int M, int N, int K, int act_fn, const float* ln_stats,
                         const float* ln_colsum, float ln_eps, float* stats_out, void* stream);
+/* ... with the weights stored as W' * 2^e (ln_colsum then sums the STORED weights): w_inv_scale = 2^-e. */
+int pp_linear_ln_folded_ws(const void* act, const void* weight, const float* bias, const void* residual, int residual_format,
+                           void* out, int out_format, int M, int N, int K, int act_fn, const float* ln_stats,
+                           const float* ln_colsum, float ln_eps, float* stats_out, float w_inv_scale, void* stream);
 int pp_linear_ln_folded_supported(int M, int N, int K, int with_ln_stats);
 
 /* Residual dense layer fused with the LayerNorm that follows it in the ViT block
@@ -373,6 +407,10 @@ int pp_ffn_split_pack_weights(const void* w1_split, const void* w2_split, void* 
 int pp_ffn_split_residual_layernorm(const void* h_in, const void* w_packed, const float* b1, const float* b2,
                                     const float* residual, float* x_out, const float* gamma, const float* beta,
                                     float eps, void* h_out, int M, int E, int F, void* stream);
+/* ... with W1 / W2 packed from tensors stored as W * 2^e: their inverse scales (powers of two). */
+int pp_ffn_split_residual_layernorm_ws(const void* h_in, const void* w_packed, const float* b1, const float* b2,
+                                       const float* residual, float* x_out, const float* gamma, const float* beta,
+                                       float eps, void* h_out, int M, int E, int F, float w1_inv_scale, float w2_inv_scale, void* stream);
 
 /* The first half of a ViT layer in ONE launch in the parity precision (PP_PREC_F16X3): the qkv Linear layer and the
  * multi-head self-attention behind it; the (M, 3E) qkv tensor never reaches HBM:
@@ -385,15 +423,19 @@ int pp_ffn_split_residual_layernorm(const void* h_in, const void* w_packed, cons
  * use pp_gemm + pp_attention). out must not alias h_in. */
 int pp_qkv_attention_split(const void* h_in, const void* wqkv, const float* bqkv, void* out, int n_seq, int seq_len, int heads,
                            int head_dim, float scale, void* stream);
+/* ... with Wqkv stored as W * 2^e: w_inv_scale = 2^-e. */
+int pp_qkv_attention_split_ws(const void* h_in, const void* wqkv, const float* bqkv, void* out, int n_seq, int seq_len, int heads,
+                              int head_dim, float scale, float w_inv_scale, void* stream);
 
 /* The same launch with the LayerNorm in front of it (ln1 of the block; mmpretrain TransformerEncoderLayer [3P]: x + attn(ln1(x))) folded into the
- * projection: x_in holds the RAW residual rows in the operand format, wqkv_folded / bqkv_folded carry gamma / beta
- * (probpose_code_amd/weights.py::fold_layernorm: W' = W gamma, b' = b + W beta), ln_colsum[n] = sum_k W'[n, k] of the split-rounded weights, and
- * ln_stats holds (mean, rstd) of every row - (n_seq * seq_len, 2) fp32, as pp_proj_ffn_split_folded leaves them. q / k / v are evaluated as
- * rstd (x W'^T - mean colsum) + b' where the unfolded launch adds its bias. Same shapes, same restrictions as pp_qkv_attention_split. */
-int pp_qkv_attention_split_folded(const void* x_in, const void* wqkv_folded, const float* bqkv_folded, const float* ln_stats,
-                                  const float* ln_colsum, void* out, int n_seq, int seq_len, int heads, int head_dim, float scale,
-                                  void* stream);
+ * projection: x_centered holds the residual rows MINUS THEIR ROW MEAN in the operand format, wqkv_folded / bqkv_folded carry gamma / beta
+ * (probpose_code_amd/weights.py::fold_layernorm: W' = W gamma * 2^e, b' = b + W beta), and ln_stats holds (mean, rstd) of every row -
+ * (n_seq * seq_len, 2) fp32, as pp_proj_ffn_split_folded leaves both. q / k / v are evaluated as  rstd * w_inv_scale * ((x - mean) W'^T) + b'
+ * where the unfolded launch adds its bias: no  mean * colsum  correction, hence the accuracy of a LayerNorm applied before the split (ABI 3 took raw
+ * rows and column sums: 2 - 5x the error at |mean| / std <= 1, a digit more per decade beyond). Same shapes and restrictions as
+ * pp_qkv_attention_split. */
+int pp_qkv_attention_split_folded(const void* x_centered, const void* wqkv_folded, const float* bqkv_folded, const float* ln_stats, void* out,
+                                  int n_seq, int seq_len, int heads, int head_dim, float scale, float w_inv_scale, void* stream);
 
 /* The second half of a ViT layer in ONE launch in the parity precision (PP_PREC_F16X3): attention output projection +
  * residual, ln2, the feed-forward block + residual, and the LayerNorm that follows the layer:
@@ -413,19 +455,28 @@ int pp_proj_ffn_split_residual_layernorm(const void* att, const void* wproj_pack
                                          const float* b1, const float* b2, const float* residual, float* x_out,
                                          const float* gamma, const float* beta, float eps, void* h_out, int M, int E,
                                          int F, void* stream);
+/* ... with Wp / W1 / W2 packed from tensors stored as W * 2^e: their inverse scales (powers of two). */
+int pp_proj_ffn_split_residual_layernorm_ws(const void* att, const void* wproj_packed, const float* bproj,
+                                            const float* gamma2, const float* beta2, void* h_scratch, const void* w_packed,
+                                            const float* b1, const float* b2, const float* residual, float* x_out,
+                                            const float* gamma, const float* beta, float eps, void* h_out, int M, int E,
+                                            int F, float wp_inv_scale, float w1_inv_scale, float w2_inv_scale, void* stream);
 
-/* The same launch inside a chain of layers whose ln1 is folded into the qkv projection (pp_qkv_attention_split_folded):
- *   residual_format PP_OUT_SPLIT: `residual` holds the residual rows in the operand format (hi + lo: 22 significant bits), PP_OUT_F32: fp32 rows;
- *   fold_out != 0: the LayerNorm behind the FFN is NOT applied - the new residual rows leave ONCE, in the operand format, to h_out (which may alias
- *                  `residual`), with (mean, rstd) of every row in stats_out ((M, 2) fp32); x_out, gamma, beta are not used. A workgroup writes
- *                  288 KiB less per 96 rows (the store path of a CU is what the epilogue waits for);
+/* The same launch inside a chain of layers whose ln1 is folded into the qkv projection (pp_qkv_attention_split_folded). Rows that travel between
+ * the launches of the chain are CENTERED rows: x - mean(x) in the operand format, with (mean, rstd) per row beside them.
+ *   residual_format PP_OUT_SPLIT: `residual` holds centered rows, residual_stats ((M, 2) fp32: mean, rstd) their means - x = (hi + lo) + mean;
+ *                   PP_OUT_F32: fp32 rows (the first layer: the patch embedding's), residual_stats unused;
+ *   fold_out != 0: the LayerNorm behind the FFN is NOT applied - the new rows leave ONCE, centered, in the operand format, to h_out (which may alias
+ *                  `residual`), with (mean, rstd) of every row in stats_out ((M, 2) fp32; may alias residual_stats: a workgroup owns its rows);
+ *                  x_out, gamma, beta are not used. A workgroup writes 288 KiB less per 96 rows (the store path is what the epilogue waits for);
  *   fold_out == 0: x_out (fp32) and h_out = LayerNorm(x_out; gamma, beta) as in the plain launch (the last layer: ln_f).
- * Twelve-wave paired kernel only: F / 128 even, option "ffn_dma_waves" != 0 - PP_ERR_UNSUPPORTED otherwise (callers keep the plain launches). The
- * pair's launches are tallied as "ffn_dma_fold". */
+ *   w*_inv_scale:  inverse power-of-two scales of Wp / W1 / W2 (1 for unscaled weights).
+ * Paired kernel only: F / 128 even - PP_ERR_UNSUPPORTED otherwise (callers keep the plain launches). Tallied as "ffn_dma_fold". */
 int pp_proj_ffn_split_folded(const void* att, const void* wproj_packed, const float* bproj, const float* gamma2, const float* beta2,
                              void* h_scratch, const void* w_packed, const float* b1, const float* b2, const void* residual,
-                             int residual_format, int fold_out, float* x_out, const float* gamma, const float* beta, float eps, void* h_out,
-                             float* stats_out, int M, int E, int F, void* stream);
+                             int residual_format, const float* residual_stats, int fold_out, float* x_out, const float* gamma,
+                             const float* beta, float eps, void* h_out, float* stats_out, int M, int E, int F, float wp_inv_scale,
+                             float w1_inv_scale, float w2_inv_scale, void* stream);
 
 /* Last deconvolution of the heatmap branch fused with the 1x1 convolution that follows it (bf16 operands):
  *   ConvTranspose2d(Cin -> 256, k4, s2, p1) + BN + ReLU  ->  Conv2d(256 -> K, k1)

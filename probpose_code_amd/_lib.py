@@ -59,6 +59,7 @@ SIGNATURES = {
     "pp_workspace_bytes": (c_longlong, [c_int, c_int, _P]),
     "pp_conv3x3_splitk_slices": (c_int, [c_int] * 7),
     "pp_linear_ln_folded": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P]),
+    "pp_linear_ln_folded_ws": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_float, _P]),
     "pp_linear_ln_folded_supported": (c_int, [c_int] * 4),
     "pp_clock_probe": (c_int, [_P, _P, ctypes.c_uint, _P]),
     "pp_probmap_decode": (
@@ -83,6 +84,10 @@ SIGNATURES = {
         c_int,
         [c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     ),
+    "pp_gemm_ws": (
+        c_int,
+        [c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
+    ),
     "pp_gemm_residual_layernorm": (
         c_int,
         [c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
@@ -96,14 +101,18 @@ SIGNATURES = {
     "pp_ffn_split_packed_bytes": (c_longlong, [c_int, c_int]),
     "pp_ffn_split_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "pp_ffn_split_residual_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, _P]),
+    "pp_ffn_split_residual_layernorm_ws": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_float, c_float, _P]),
     "pp_qkv_attention_split": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
-    "pp_qkv_attention_split_folded": (c_int, [_P] * 6 + [c_int] * 4 + [c_float, _P]),
+    "pp_qkv_attention_split_ws": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    "pp_qkv_attention_split_folded": (c_int, [_P] * 5 + [c_int] * 4 + [c_float, c_float, _P]),
     "pp_proj_split_packed_bytes": (c_longlong, [c_int]),
     "pp_proj_split_pack_weights": (c_int, [_P, _P, c_int, _P]),
     "pp_proj_ffn_split_residual_layernorm": (
         c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, _P]),
+    "pp_proj_ffn_split_residual_layernorm_ws": (
+        c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P]),
     "pp_proj_ffn_split_folded": (
-        c_int, [_P] * 10 + [c_int, c_int, _P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, _P]),
+        c_int, [_P] * 10 + [c_int, _P, c_int, _P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P]),
     "pp_conv3x3_splitk": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_int, _P]),
     "pp_sum_maxpool_relu_nhwc": (c_int, [_P, c_int, c_longlong, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "pp_warp_affine_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),

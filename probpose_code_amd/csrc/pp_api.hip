@@ -19,7 +19,6 @@ struct Option { const char* name; int value; };
 static Option g_options[] = {
     {"panel", 1},              // 0: every GEMM / convolution on the 128 x 128 kernel (pp_gemm.hip)
     {"conv_halo", 1},          // 0: first tower convolution (bf16) on the implicit-GEMM kernel instead of pp_conv_halo.hip
-    {"linear_ovl", 1},         // 0: split-fp16 Linear layers on pp_panel_split.hip instead of pp_linear_ovl.hip
     {"psplit_nst", 0},         // 2 / 3: force the two- / three-stage form of pp_panel_split.hip (0: by shape)
     {"panel_linear_mink", 0},  // > 0: shortest K of a bf16 Linear layer that takes the wide-tile kernel (0: built-in thresholds)
     {"psplit_bf16_conv", 0},   // 1: bf16 convolutions through pp_panel_split.hip instead of pp_panel_gemm.hip
@@ -32,7 +31,6 @@ static Option g_options[] = {
     {"linear_dma", 1},         // large split-fp16 Linear layers (pp_gemm): 1 = the twelve-wave 192 x 192 kernels (pp_linear_dma.hip), 0 = the wide-tile kernel
     {"linear_loop", 1},        // one-tile twelve-wave Linear kernel: 1 = one workgroup per CU walks a column of tiles, the next tile's first stages requested under this tile's epilogue; 0 = a workgroup per tile
     {"psplit_deconv_weight_major", 0},  // dev A/B: deconvolution tiles phase(weight set)-major per XCD instead of row panel -> phase (measured: DESIGN.md 4)
-    {"ffn_dma_waves", 1},      // fused f16x3 feed-forward launch: 1 = the twelve-wave form (pp_ffn_dma.hip: eight computing waves + four DMA waves), 0 = the eight-wave form (pp_ffn_split.hip)
     {"ffn_pair", 1},           // twelve-wave feed-forward launch: 1 = hidden chunks in PAIRS that share every streamed x k-block (x streamed 6 instead of 12 times per launch; even chunk counts only), 0 = one chunk at a time
     {"psplit_tail", 1},        // split-fp16 Linear layers on the wide-tile kernel: 0 = no second launch on 128 x 192 tiles for the rows of a ragged last round
     {"wino_order", 8},         // pp_conv3x3_winograd_maxpool_relu: column tiles per 32-workgroup super tile (0: column tiles fastest over an XCD's run: 1.19 GB fetched per launch at bs 64; 8 = 4 row blocks x 8 column tiles: 0.72 GB, same launch time)

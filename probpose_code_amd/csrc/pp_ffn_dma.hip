@@ -1,6 +1,5 @@
-// The fused f16x3 feed-forward launch of pp_ffn_split.hip (same packed weight streams, same sums in the same order; the two agree
-// to rounding - the GELU here is written max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2), two instructions shorter) with the LDS-DMA issue
-// taken OUT of the computing waves:
+// The fused f16x3 feed-forward launch (entry points, packed weight streams: pp_ffn_split.hip) with the LDS-DMA issue in waves of its own - the
+// eight-wave kernel of round 3 issued it from the computing waves (GELU written max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2)):
 //     [x <- x + att Wp^T + bp ; h <- LN2(x)]   x <- x + GELU(h W1^T + b1) W2^T + b2 ;   h_next <- LayerNorm(x)
 // (mmpretrain TransformerEncoderLayer [3P]; call site mmpose/models/pose_estimators/base.py:206).
 //
@@ -489,7 +488,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 asm("" : "+v"(mu));  // (a second, opaque copy: with the same value as in the variance pass the compiler keeps all 72 differences v - mean alive from there to here)
                 f32x4 hv = {(v[0] - mu) * rs * g[0] + b[0], (v[1] - mu) * rs * g[1] + b[1], (v[2] - mu) * rs * g[2] + b[2],
                             (v[3] - mu) * rs * g[3] + b[3]};
-                if (FO) hv = v;  // (the raw rows)
+                if (FO) hv = f32x4{v[0] - mu, v[1] - mu, v[2] - mu, v[3] - mu};  // (the CENTERED rows: the consumer's projection needs no mean * colsum term)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { float t = hv[j]; split_pin(t); hv[j] = t; }
 #if FFD_STORE16
@@ -542,6 +541,14 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     };
 
     // the residual rows, straight into the accumulators
+    float res_mean[3] = {0.f, 0.f, 0.f};
+    if constexpr ((FOLD & 1) != 0) {
+#pragma unroll
+        for (int rf = 0; rf < 3; ++rf) {
+            const int r = m0 + rows0 + rf * 16;
+            res_mean[rf] = r < p.M ? p.res_stats[(size_t)r * 2] : 0.f;
+        }
+    }
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, p.h_bytes, 0x00020000);
     const unsigned v_rowx = (unsigned)(m0 + rows0) * (unsigned)(E * 4) + (unsigned)f_kg * 16u;  // (dead after these loads)
 #pragma unroll
@@ -558,13 +565,27 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 const auto s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
                 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
                 const f16x4 hh = __builtin_bit_cast(f16x4, u32x2_t{s0[0], s1[0]}), ll = __builtin_bit_cast(f16x4, u32x2_t{s0[1], s1[1]});
-                acc[rf][cf] = f32x4{(float)hh[0] + (float)ll[0], (float)hh[1] + (float)ll[1], (float)hh[2] + (float)ll[2], (float)hh[3] + (float)ll[3]};
+                // (centered rows: the row's mean comes back here - after hi + lo, the order the producer's x - mean inverts)
+                const float mu = res_mean[rf];
+                acc[rf][cf] = f32x4{((float)hh[0] + (float)ll[0]) + mu, ((float)hh[1] + (float)ll[1]) + mu, ((float)hh[2] + (float)ll[2]) + mu,
+                                    ((float)hh[3] + (float)ll[3]) + mu};
             } else {
                 acc[rf][cf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, v_rowx + rf * (16 * E * 4), cb * 4, 0));  // (rows past M: zeros, never stored)
             }
         }
 
     stamp();  // 1: residual rows requested
+    // the accumulators collect products with weights stored as w * s: the fp32 values they start from are scaled to match (exact: powers of two)
+    {
+        const float s_in = PROJ ? p.s_p : p.s_2;
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) {
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!PROJ) bv = *reinterpret_cast<const f32x4*>(p.b2 + (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4);
+#pragma unroll
+            for (int rf = 0; rf < 3; ++rf) acc[rf][cf] = (acc[rf][cf] + bv) * s_in;  // (!PROJ: + b2 before the first B-step accumulates)
+        }
+    }
     if constexpr (PROJ) {
         // ---- attention output projection + residual, then ln2:  acc <- x + att Wp^T + bp ;  h <- LN2(acc). 24 steps shaped like
         // the B-steps: step s = 2 kb + half takes the Wp half block from ring slot s & 3, the attention rows' k-block kb from G buffer kb & 3
@@ -634,7 +655,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
         for (int cf = 0; cf < 6; ++cf) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bp + (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4);
 #pragma unroll
-            for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
+            for (int rf = 0; rf < 3; ++rf) acc[rf][cf] = acc[rf][cf] * p.inv_p + bv;
         }
         stamp();  // 2: projection steps done
         __syncthreads();  // P1: the G buffers are out of use
@@ -654,12 +675,14 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
         stamp();  // 3: ln2 done, rows in L2
     }
 
-    // + b2 (pp_ffn_split.hip adds it before the first B-step accumulates: same sum order)
+    // + b2 before the first B-step accumulates, in the scale of the W2 products
+    if constexpr (PROJ) {
 #pragma unroll
-    for (int cf = 0; cf < 6; ++cf) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b2 + (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4);
+        for (int cf = 0; cf < 6; ++cf) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.b2 + (cf / 3) * 192 + cg * 48 + (cf % 3) * 16 + f_kg * 4);
 #pragma unroll
-        for (int rf = 0; rf < 3; ++rf) acc[rf][cf] += bv;
+            for (int rf = 0; rf < 3; ++rf) acc[rf][cf] = (acc[rf][cf] + bv) * p.s_2;
+        }
     }
     auto load_b1 = [&](int ci) {
         const int c = chunk_of(ci < nchunks ? ci : 0);
@@ -698,7 +721,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 unsigned hq[2], lq[2];
 #pragma unroll
                 for (int u0 = 0; u0 < 2; ++u0) {
-                    const f32x2 x = {pa[rf][nf][2 * u0], pa[rf][nf][2 * u0 + 1]};
+                    const f32x2 x = f32x2{pa[rf][nf][2 * u0], pa[rf][nf][2 * u0 + 1]} * p.inv_1;
                     const f32x2 ax = __builtin_elementwise_abs(x);
                     const f32x2 d = ax * 0.23164189265f + 1.0f;  // 0.3275911 / sqrt 2
                     const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
@@ -729,7 +752,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 f16x4 hv, lv;
                 float x[4], z[4], tt[4], qq[4], e[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = pa[rf][nf][u];
+                for (int u = 0; u < 4; ++u) x[u] = pa[rf][nf][u] * p.inv_1;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) z[u] = fabsf(x[u]) * 0.70710678118654752440f;
 #pragma unroll
@@ -894,7 +917,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf) { pacc[rf][nf] = b1v[nf]; pacc1[rf][nf] = b1w[nf]; }
+                for (int nf = 0; nf < 2; ++nf) { pacc[rf][nf] = b1v[nf] * p.s_1; pacc1[rf][nf] = b1w[nf] * p.s_1; }
             valu_settle(pacc);  // (VALU writes -> MFMA SrcC reads: the wait states the compiler cannot know an asm statement needs)
             valu_settle(pacc1);
             // ---- A-steps of both chunks, k-block by k-block
@@ -953,7 +976,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
-                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf];
+                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf] * p.s_1;
             load_b1(ci + 1);
             // ---- A-steps: P += x[:, kb] W1[chunk, kb]^T, wave tile 48 rows x 32 units
 #pragma unroll
@@ -1043,7 +1066,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
-            for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf];
+            for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf] * p.s_1;
         load_b1(ci + 1);
         // ---- A-steps: P += x[:, kb] W1[chunk, kb]^T, wave tile 48 rows x 32 units
 #pragma unroll
@@ -1099,6 +1122,10 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     // ---- LayerNorm epilogue: G is out of use once every wave is past its last B-step
     __syncthreads();  // E1
     stamp();  // last but one: every wave past its last step
+#pragma unroll
+    for (int rf = 0; rf < 3; ++rf)
+#pragma unroll
+        for (int cf = 0; cf < 6; ++cf) acc[rf][cf] *= p.inv_2;  // (the W2 products carried the scale of W2)
     if constexpr ((FOLD & 2) != 0) layernorm_rows(nullptr, nullptr, nullptr, p.h_out, false, TagT{});
     else layernorm_rows(p.gamma, p.beta, p.x_out, p.h_out, true, TagF{});
     stamp();  // last: rows stored
@@ -1133,7 +1160,7 @@ extern "C" int pp_dev_ffd_stamps(unsigned long long* out) {  // dev: 2 x 64 stam
 #endif
 
 namespace ffs {
-// called from the entry points in pp_ffn_split.hip when the option "ffn_dma_waves" is on
+// called from the entry points in pp_ffn_split.hip
 int launch_dma_form(const Params& p, bool proj, hipStream_t s) {
     // an even number of hidden chunks: the paired form (two chunks share every streamed x k-block); option "ffn_pair" = 0 or an odd count: one at a time
     const bool pair = FFD_ROLL && option("ffn_pair") != 0 && (p.F / ffd::CHUNK) % 2 == 0;

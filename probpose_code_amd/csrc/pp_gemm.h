@@ -34,6 +34,9 @@ struct GemmParams {
     int tile_order;         // pp_panel_split.hip: 0 row panel -> group -> column tile (activations shared per XCD), 1 weight set -> row panels
     int planar_P;           // >0: store planar, out[((m / P) * N + n) * P + m % P]  (NHWC rows -> (B, N, P) planes)
     unsigned a_bytes, w_bytes;  // extent of the activation / weight tensor of ONE group (buffer-descriptor bound)
+    float w_inv = 1.0f;     // PP_PREC_F16X3 Linear layers: the weights are stored as w * 2^e (weights.py: the tensor's largest element in [2^12, 2^13),
+                            // so that the low halves of its small elements are normal fp16 numbers); the accumulators are multiplied by 2^-e = w_inv
+                            // in front of bias / residual / activation (exact: a power of two)
     long long strideA_z, strideW_z, strideC_z, strideBias_z;  // grouped launch (blockIdx.z), in elements
 };
 
@@ -55,11 +58,5 @@ int panel_split_gemm(const GemmParams& p, int prec, int groups, hipStream_t s);
 // pp_linear_dma.hip: twelve-wave 192 x 192 tiles (eight computing waves + four DMA-only waves) for the large PP_PREC_F16X3 Linear layers
 bool linear_dma_supported(const GemmParams& p, int prec, int groups);
 int linear_dma_gemm(const GemmParams& p, hipStream_t s);
-
-
-// pp_linear_ovl.hip: split-fp16 Linear layers (qkv / fc1 of the f16x3 mode) on 192 x 192 tiles with two accumulator sets - the
-// epilogue of tile t (activation, split, stores) runs under the K-loop of tile t + 1
-bool linear_ovl_supported(const GemmParams& p, int prec, int groups);
-int linear_ovl_gemm(const GemmParams& p, hipStream_t s);
 
 }  // namespace pp

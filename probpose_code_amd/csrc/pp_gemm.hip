@@ -277,7 +277,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
             }
         }
         auto finish = [&](f32x4 v, int nf) -> f32x4 {
-            v += bvec[nf];
+            v = v * p.w_inv + bvec[nf];  // (w_inv: the power-of-two scale of split-fp16 Linear weights, 1 otherwise - exact)
             if (p.act == ACT_GELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = __is_same(T, SplitH) ? gelu_erfc_as(v[j]) : gelu_erf(v[j]);
@@ -500,9 +500,23 @@ static bool panel_enabled() {
 extern "C" int pp_gemm(int prec, const void* act, const void* weight, const float* bias, const float* residual,
                        int res_mod, void* out, int M, int N, int K, int lda, int ldw, int ldc, int act_fn,
                        int out_bf16, int planar_P, void* stream) {
+    return pp_gemm_ws(prec, act, weight, bias, residual, res_mod, out, M, N, K, lda, ldw, ldc, act_fn, out_bf16, planar_P, 1.0f, stream);
+}
+
+extern "C" int pp_gemm_ws(int prec, const void* act, const void* weight, const float* bias, const float* residual,
+                          int res_mod, void* out, int M, int N, int K, int lda, int ldw, int ldc, int act_fn,
+                          int out_bf16, int planar_P, float w_inv_scale, void* stream) {
     using namespace pp;
     PP_REQUIRE(act && weight && out, PP_ERR_INVALID_ARG, "pp_gemm: act, weight and out must be non-NULL");
+    {
+        unsigned u;
+        __builtin_memcpy(&u, &w_inv_scale, 4);
+        PP_REQUIRE((u >> 31) == 0 && (u & 0x007fffffu) == 0 && ((u >> 23) & 0xffu) >= 127 - 40 && ((u >> 23) & 0xffu) <= 127 + 40, PP_ERR_INVALID_ARG,
+                   "pp_gemm: the weight scale must be a power of two in [2^-40, 2^40]");
+        PP_REQUIRE(w_inv_scale == 1.0f || prec == PP_PREC_F16X3, PP_ERR_INVALID_ARG, "pp_gemm: weight scales belong to the split-fp16 mode");
+    }
     GemmParams p{};
+    p.w_inv = w_inv_scale;
     p.A = act; p.W = weight; p.C = out; p.bias = bias; p.residual = residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
     p.act = act_fn; p.out_bf16 = out_bf16; p.gather = G_LINEAR;
@@ -514,7 +528,6 @@ extern "C" int pp_gemm(int prec, const void* act, const void* weight, const floa
     p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
     PP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, PP_ERR_UNSUPPORTED, "pp_gemm: lda/ldw must be multiples of 8 elements");
     if (panel_enabled() && linear_dma_supported(p, prec, 1)) return linear_dma_gemm(p, reinterpret_cast<hipStream_t>(stream));
-    if (panel_enabled() && linear_ovl_supported(p, prec, 1)) return linear_ovl_gemm(p, reinterpret_cast<hipStream_t>(stream));
     if (panel_enabled() && panel_split_supported(p, prec, 1)) return panel_split_gemm(p, prec, 1, reinterpret_cast<hipStream_t>(stream));
     return gemm(p, prec, 1, reinterpret_cast<hipStream_t>(stream));
 }

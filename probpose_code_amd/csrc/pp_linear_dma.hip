@@ -52,6 +52,7 @@ struct Params {
     const float* ln_colsum;  // [N]: sum_k w[n, k] (of the split-rounded weights)
     float ln_eps;
     float* stats_out;        // [M, N / 96, 2]: the same statistics of the output rows, or NULL
+    float w_inv = 1.0f;      // the weights are stored as w * 2^e (weights.py): accumulators * 2^-e in front of bias / activation / residual (exact)
 };
 
 #define LDM_WAITVM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
@@ -415,10 +416,11 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
             const int m = m0 + row0 + i * 16;
             f32x4 v;
             if (MODE == 1) {
+                const float rsw = rs[i] * p.w_inv;  // (colsum is the sum of the STORED - scaled - weights: the difference carries the scale)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rs[i] * (acc[i][j][e] - mu[i] * cs[e]) + bv[e];
+                for (int e = 0; e < 4; ++e) v[e] = rsw * (acc[i][j][e] - mu[i] * cs[e]) + bv[e];
             } else {
-                v = acc[i][j] + bv;
+                v = acc[i][j] * p.w_inv + bv;
             }
             if (k_act == ACT_GELU) {
 #pragma unroll
@@ -519,7 +521,7 @@ bool linear_dma_supported(const GemmParams& p, int prec, int groups) {
     // two rounds of the chip at least; smaller problems stay with the 128 x 128 / wide-tile kernels. No lower bound on K beyond two stages: at
     // the ViT-S shapes (K = 384; reached when the fused layer kernels are off or the token count is not 192) it is level with the
     // overlapped-epilogue kernel it shadows - 71.5 / 111.2 / 160.8 / 255.7 us against 71.1 / 104.7 / 174.7 / 256.7 us for qkv / fc1 at
-    // M = 24 576 / 55 296 (scripts/micro/linear_k384_bench.py); option "linear_dma" = 0 hands those shapes back to pp_linear_ovl.hip
+    // M = 24 576 / 55 296 (scripts/micro/linear_k384_bench.py); option "linear_dma" = 0 hands those shapes to the wide-tile kernel (pp_panel_split.hip)
     return ntiles >= 512;
 }
 
@@ -536,6 +538,7 @@ int linear_dma_gemm(const GemmParams& g, hipStream_t s) {
     p.act = g.act;
     p.out_split = g.out_bf16 == 2;
     p.ntn = g.N / ldm::BN;
+    p.w_inv = g.w_inv;
     const int grid = p.ntn * ((g.M + ldm::BM - 1) / ldm::BM);
     // pp_gemm's shapes of the ViT plans get their epilogue switches at compile time: qkv (split rows out), fc1 (+ GELU), proj / fc2 / patch embed
     // (fp32 rows out + fp32 residual); anything else the generic instantiation
@@ -565,7 +568,20 @@ extern "C" int pp_linear_ln_folded_supported(int M, int N, int K, int with_ln_st
 extern "C" int pp_linear_ln_folded(const void* act, const void* weight, const float* bias, const void* residual, int residual_format,
                                    void* out, int out_format, int M, int N, int K, int act_fn, const float* ln_stats,
                                    const float* ln_colsum, float ln_eps, float* stats_out, void* stream) {
+    return pp_linear_ln_folded_ws(act, weight, bias, residual, residual_format, out, out_format, M, N, K, act_fn, ln_stats, ln_colsum, ln_eps, stats_out,
+                                  1.0f, stream);
+}
+
+extern "C" int pp_linear_ln_folded_ws(const void* act, const void* weight, const float* bias, const void* residual, int residual_format,
+                                      void* out, int out_format, int M, int N, int K, int act_fn, const float* ln_stats,
+                                      const float* ln_colsum, float ln_eps, float* stats_out, float w_inv_scale, void* stream) {
     using namespace pp;
+    {
+        unsigned u;
+        __builtin_memcpy(&u, &w_inv_scale, 4);
+        PP_REQUIRE((u >> 31) == 0 && (u & 0x007fffffu) == 0 && ((u >> 23) & 0xffu) >= 127 - 40 && ((u >> 23) & 0xffu) <= 127 + 40, PP_ERR_INVALID_ARG,
+                   "pp_linear_ln_folded: the weight scale must be a power of two in [2^-40, 2^40]");
+    }
     PP_REQUIRE(act && weight && out, PP_ERR_INVALID_ARG, "pp_linear_ln_folded: act, weight and out must be non-NULL");
     PP_REQUIRE(M > 0 && N > 0 && K > 0, PP_ERR_INVALID_ARG, "pp_linear_ln_folded: M, N and K must be positive");
     PP_REQUIRE(out_format == PP_OUT_F32 || out_format == PP_OUT_SPLIT, PP_ERR_INVALID_ARG, "pp_linear_ln_folded: out_format is PP_OUT_F32 or PP_OUT_SPLIT");
@@ -592,6 +608,7 @@ extern "C" int pp_linear_ln_folded(const void* act, const void* weight, const fl
     p.out_split = out_format == PP_OUT_SPLIT;
     p.ntn = N / ldm::BN;
     p.ln_stats = ln_stats; p.ln_colsum = ln_colsum; p.ln_eps = ln_eps; p.stats_out = stats_out;
+    p.w_inv = w_inv_scale;
     const int grid = p.ntn * ((M + ldm::BM - 1) / ldm::BM);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // the layers of the folded plan with their epilogue switches at compile time: qkv / fc1 (statistics in, split rows out), proj / fc2 (split

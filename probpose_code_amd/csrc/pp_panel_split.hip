@@ -459,7 +459,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
 #pragma unroll
                     for (int r2 = 0; r2 < RF / 2; ++r2) {
                         const int rf = (q & 1) * (RF / 2) + r2;
-                        f32x4 v = acc[cf][rf] + bv;
+                        f32x4 v = acc[cf][rf] * p.w_inv + bv;  // (w_inv: power-of-two scale of a split-fp16 Linear layer's weights, 1 otherwise)
                         if (p.act == ACT_RELU) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);

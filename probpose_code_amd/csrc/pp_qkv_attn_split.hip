@@ -61,8 +61,10 @@ struct Params {
     float scale_log2e;
     // LayerNorm folded into the projection (pp_qkv_attention_split_folded): h holds the RAW residual rows (operand format), w / bias carry
     // gamma / beta (weights.fold_layernorm), and mean / rstd of every row come with them
+    // The rows are CENTERED (x - mean, the producer pp_proj_ffn_split_folded subtracts the mean it has just computed): LayerNorm(x) W^T + b =
+    // rstd ((x - mean) W'^T) + b' with no  - mean * colsum(W')  term - that fp32 difference was the folded form's whole excess error.
     const float* ln_stats;   // [n_seq * 192, 2]: (mean, rstd) per row
-    const float* ln_colsum;  // [1152]: sum_k w[n, k] of the split-rounded folded weights
+    float w_inv;             // the weights are stored as w * 2^e (weights.py): accumulators * 2^-e in front of the bias (exact)
 };
 
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
@@ -258,37 +260,32 @@ __device__ __forceinline__ void qkv_attention_body(const Params& p) {
             const int c = 3 * cg + cf;  // 16-column fragment of the 96 outputs: 0, 1 = q; 2, 3 = k; 4, 5 = v
             if (c < 4) {
                 const int which = c >> 1, d0 = (c & 1) * 16;  // dims d0 + 4 fg + (0..3)
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + which * E + head * HD + d0 + 4 * fg);
-                if (FOLD) cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + which * E + head * HD + d0 + 4 * fg);
                 char* dstb = which == 0 ? Qs : Ks;
                 const int chunk = (d0 >> 3) + (fg >> 1);  // the pair (fg, fg ^ 1) fills one 8-dim chunk
 #pragma unroll
                 for (int rf = 0; rf < 3; ++rf) {
                     const int t = 48 * rg + 16 * rf + fr;
-                    f32x4 val = acc[cf][rf] + bv;
-                    if (FOLD) {  // LayerNorm(x) W^T = rstd (x W'^T - mean colsum(W')) + b': this lane's token
-                        const float mu = st_n[rf][0], rs = st_n[rf][1];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) val[e] = rs * (acc[cf][rf][e] - mu * cs[e]) + bv[e];
-                    }
+                    // LayerNorm(x) W^T + b = rstd ((x - mean) W'^T) + b' on centered rows (this lane's token); * w_inv: the weights' power-of-two scale
+                    const float rs = (FOLD ? st_n[rf][1] : 1.0f) * p.w_inv;
+                    const f32x4 val = acc[cf][rf] * rs + bv;
                     const u32x4 q = split_pair16(val);
                     *reinterpret_cast<u32x4*>(dstb + t * 128 + ((((odd ? 4 : 0) + chunk) ^ sw) << 4)) = q;
                 }
             } else {
                 const int d = (c - 4) * 16 + fr;
                 const float bs = p.bias ? p.bias[2 * E + head * HD + d] : 0.f;
-                const float csd = FOLD ? p.ln_colsum[2 * E + head * HD + d] : 0.f;
 #pragma unroll
                 for (int rf = 0; rf < 3; ++rf) {
                     const int t0 = 48 * rg + 16 * rf + 4 * fg;
-                    f32x4 v = acc[cf][rf] + bs;
+                    f32x4 v = acc[cf][rf] * p.w_inv + bs;
                     if (FOLD) {  // (transposed fragment: the lane's four values are four TOKENS of one v dim)
                         const f32x4 s01 = st_t[rf][0], s23 = st_t[rf][1];
-                        v[0] = s01[1] * (acc[cf][rf][0] - s01[0] * csd) + bs;
-                        v[1] = s01[3] * (acc[cf][rf][1] - s01[2] * csd) + bs;
-                        v[2] = s23[1] * (acc[cf][rf][2] - s23[0] * csd) + bs;
-                        v[3] = s23[3] * (acc[cf][rf][3] - s23[2] * csd) + bs;
+                        v[0] = (s01[1] * p.w_inv) * acc[cf][rf][0] + bs;
+                        v[1] = (s01[3] * p.w_inv) * acc[cf][rf][1] + bs;
+                        v[2] = (s23[1] * p.w_inv) * acc[cf][rf][2] + bs;
+                        v[3] = (s23[3] * p.w_inv) * acc[cf][rf][3] + bs;
                     }
                     u32x2 hv, lv;
                     { unsigned h__, l__; split_pair(v[0], v[1], h__, l__); hv[0] = h__; lv[0] = l__; }
@@ -524,7 +521,7 @@ __global__ __launch_bounds__(THREADS, 2) void qkv_attention_split2_kernel(const 
 #pragma unroll
                 for (int rf = 0; rf < 6; ++rf) {
                     const int t = 96 * rg + 16 * rf + fr;
-                    const u32x4 q = split_pair16(acc[cf][rf] + bv);
+                    const u32x4 q = split_pair16(acc[cf][rf] * p.w_inv + bv);
                     *reinterpret_cast<u32x4*>(dstb + t * 128 + ((((odd ? 4 : 0) + chunk) ^ sw) << 4)) = q;
                 }
             } else {
@@ -533,7 +530,7 @@ __global__ __launch_bounds__(THREADS, 2) void qkv_attention_split2_kernel(const 
 #pragma unroll
                 for (int rf = 0; rf < 6; ++rf) {
                     const int t0 = 96 * rg + 16 * rf + 4 * fg;
-                    const f32x4 v = acc[cf][rf] + bs;
+                    const f32x4 v = acc[cf][rf] * p.w_inv + bs;
                     f16x4 hv, lv;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -625,24 +622,35 @@ extern "C" int pp_dev_qka_stamps(unsigned long long* out) {  // dev: 4 x 16 stam
 #endif
 }  // namespace pp
 
-static int qkv_attention_launch(const void* h_in, const void* wqkv, const float* bqkv, const float* ln_stats, const float* ln_colsum, void* out,
-                                int n_seq, int seq_len, int heads, int head_dim, float scale, void* stream);
+static int qkv_attention_launch(const void* h_in, const void* wqkv, const float* bqkv, const float* ln_stats, void* out, int n_seq, int seq_len,
+                                int heads, int head_dim, float scale, float w_inv_scale, void* stream);
+
+extern "C" int pp_qkv_attention_split_ws(const void* h_in, const void* wqkv, const float* bqkv, void* out, int n_seq, int seq_len, int heads,
+                                         int head_dim, float scale, float w_inv_scale, void* stream) {
+    return qkv_attention_launch(h_in, wqkv, bqkv, nullptr, out, n_seq, seq_len, heads, head_dim, scale, w_inv_scale, stream);
+}
 
 extern "C" int pp_qkv_attention_split(const void* h_in, const void* wqkv, const float* bqkv, void* out, int n_seq, int seq_len,
                                       int heads, int head_dim, float scale, void* stream) {
-    return qkv_attention_launch(h_in, wqkv, bqkv, nullptr, nullptr, out, n_seq, seq_len, heads, head_dim, scale, stream);
+    return qkv_attention_launch(h_in, wqkv, bqkv, nullptr, out, n_seq, seq_len, heads, head_dim, scale, 1.0f, stream);
 }
 
-extern "C" int pp_qkv_attention_split_folded(const void* x_in, const void* wqkv_folded, const float* bqkv_folded, const float* ln_stats,
-                                             const float* ln_colsum, void* out, int n_seq, int seq_len, int heads, int head_dim, float scale,
+extern "C" int pp_qkv_attention_split_folded(const void* x_centered, const void* wqkv_folded, const float* bqkv_folded, const float* ln_stats,
+                                             void* out, int n_seq, int seq_len, int heads, int head_dim, float scale, float w_inv_scale,
                                              void* stream) {
-    PP_REQUIRE(ln_stats && ln_colsum && bqkv_folded, PP_ERR_INVALID_ARG, "pp_qkv_attention_split_folded: statistics, column sums and the folded bias are required");
-    return qkv_attention_launch(x_in, wqkv_folded, bqkv_folded, ln_stats, ln_colsum, out, n_seq, seq_len, heads, head_dim, scale, stream);
+    PP_REQUIRE(ln_stats && bqkv_folded, PP_ERR_INVALID_ARG, "pp_qkv_attention_split_folded: the row statistics and the folded bias are required");
+    return qkv_attention_launch(x_centered, wqkv_folded, bqkv_folded, ln_stats, out, n_seq, seq_len, heads, head_dim, scale, w_inv_scale, stream);
 }
 
-static int qkv_attention_launch(const void* h_in, const void* wqkv, const float* bqkv, const float* ln_stats, const float* ln_colsum, void* out,
-                                int n_seq, int seq_len, int heads, int head_dim, float scale, void* stream) {
+static int qkv_attention_launch(const void* h_in, const void* wqkv, const float* bqkv, const float* ln_stats, void* out, int n_seq, int seq_len,
+                                int heads, int head_dim, float scale, float w_inv_scale, void* stream) {
     using namespace pp;
+    {
+        unsigned u;
+        __builtin_memcpy(&u, &w_inv_scale, 4);
+        PP_REQUIRE((u >> 31) == 0 && (u & 0x007fffffu) == 0 && ((u >> 23) & 0xffu) >= 127 - 40 && ((u >> 23) & 0xffu) <= 127 + 40, PP_ERR_INVALID_ARG,
+                   "pp_qkv_attention_split: the weight scale must be a power of two in [2^-40, 2^40]");
+    }
     PP_REQUIRE(h_in && wqkv && out, PP_ERR_INVALID_ARG, "pp_qkv_attention_split: NULL argument");
     PP_REQUIRE(n_seq > 0, PP_ERR_INVALID_ARG, "pp_qkv_attention_split: n_seq must be positive");
     PP_REQUIRE(seq_len == qka::S && head_dim == qka::HD && heads * head_dim == qka::E, PP_ERR_UNSUPPORTED,
@@ -660,7 +668,7 @@ static int qkv_attention_launch(const void* h_in, const void* wqkv, const float*
     p.w_bytes = (unsigned)((size_t)3 * qka::E * qka::E * 4);
     p.scale_log2e = scale * 1.44269504088896340736f;
     p.ln_stats = ln_stats;
-    p.ln_colsum = ln_colsum;
+    p.w_inv = w_inv_scale;
     if (ln_stats) {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qka::qkv_attention_split_folded_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, qka::LDS));

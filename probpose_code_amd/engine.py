@@ -148,7 +148,7 @@ class ProbPoseEngine:
         # f16x3 widths without a fused layer kernel (ViT-B): ln1 / ln2 folded into qkv / fc1 (weights.fold_layernorm), the statistics emitted
         # by proj / fc2, the residual stream in the operand format: no LayerNorm launch inside the layers (pp_linear_ln_folded)
         self.ln_fold = bool(precision == "f16x3" and pl["ln_fold"] and not self._proj_packed and not self._ffn_packed
-                            and self.w.has("l0.qkv.wf") and self.E % 192 == 0 and self.w.ffn_dims % 192 == 0)
+                            and self.w.has("l0.fc1.wf") and self.E % 192 == 0 and self.w.ffn_dims % 192 == 0)
         # the ViT-S chain of fused layer kernels with ln1 of layers 1 .. L - 1 folded into the qkv projection: a layer's projection + FFN launch leaves
         # its rows once, in the operand format, with (mean, rstd) per row (pp_proj_ffn_split_folded), the next qkv + attention launch applies them
         # (pp_qkv_attention_split_folded): 288 KiB less to store per 96 rows and launch (the paired twelve-wave kernel only)
@@ -306,11 +306,12 @@ class ProbPoseEngine:
         self.profile.setdefault(tag, []).append((a, b))
 
     def _gemm(self, st, a, w, bias, out, M, N, K, act=ACT_NONE, residual=None, res_mod=0, out_bf16=None, planar=0,
-              ldc=None):
-        """``out_bf16``: PP_OUT_* format of ``out``; default = the operand format of the precision mode."""
+              ldc=None, winv: float = 1.0):
+        """``out_bf16``: PP_OUT_* format of ``out``; default = the operand format of the precision mode. ``winv``: inverse power-of-two scale of
+        a split-fp16 Linear weight tensor (``PackedWeights.inv``)."""
         ob = self.fmt if out_bf16 is None else out_bf16
-        self._call("gemm_bf16out" if ob else "gemm_f32out", "pp_gemm", self.prec, a.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(residual),
-                   res_mod, out.data_ptr(), M, N, K, K, K, N if ldc is None else ldc, act, ob, planar, st)
+        self._call("gemm_bf16out" if ob else "gemm_f32out", "pp_gemm_ws", self.prec, a.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(residual),
+                   res_mod, out.data_ptr(), M, N, K, K, K, N if ldc is None else ldc, act, ob, planar, float(winv), st)
 
     def backbone(self, imgs_u8: torch.Tensor, passes: int, ws, st) -> torch.Tensor:
         """uint8 (B,3,H,W) -> final-LN features, token-major (passes*B*Np, E) == NHWC (passes*B, Hp, Wp, E)."""
@@ -327,15 +328,17 @@ class ProbPoseEngine:
         fused = self.fuse_resln and (E == 384 or (E == 768 and self._resln_768))
         L = w.num_layers
 
-        def res_ln(a, wk, bk, K, gamma, beta, h_out, residual=None, res_mod=0):
-            """x <- residual + a @ wk^T + bk ; h_out <- LN(x)."""
+        def res_ln(a, wk, bk, K, gamma, beta, h_out, residual=None, res_mod=0, winv=1.0):
+            """x <- residual + a @ wk^T + bk ; h_out <- LN(x). (A weight tensor stored with a scale - winv != 1 - takes the two-launch route: the
+            row-owner kernel of pp_gemm_ln.hip starts its accumulators from residual + bias and knows no scale; only launch plans with a fusion
+            switched off get here with one.)"""
             residual = ws["x"] if residual is None else residual
-            if fused:
+            if fused and winv == 1.0:
                 self._call("gemm_res_ln", "pp_gemm_residual_layernorm", self.prec, a.data_ptr(), wk.data_ptr(),
                            bk.data_ptr(), residual.data_ptr(), res_mod, ws["x"].data_ptr(), gamma.data_ptr(),
                            beta.data_ptr(), self.ln_eps, h_out.data_ptr(), ob, M, E, K, K, K, st)
             else:
-                self._gemm(st, a, wk, bk, ws["x"], M, E, K, residual=residual, res_mod=res_mod, out_bf16=0)
+                self._gemm(st, a, wk, bk, ws["x"], M, E, K, residual=residual, res_mod=res_mod, out_bf16=0, winv=winv)
                 self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                            h_out.data_ptr(), M, E, self.ln_eps, ob, st)
 
@@ -350,7 +353,7 @@ class ProbPoseEngine:
         att = ws["att"] if self.fuse_qkv_attn else ws["h"]  # where a layer's attention output goes
         for i in range(L):
             if not qkv_done and not self.fuse_qkv_attn:
-                self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], qcur, M, 3 * E, E)
+                self._gemm(st, ws["h"], w[f"l{i}.qkv.w"], w[f"l{i}.qkv.b"], qcur, M, 3 * E, E, winv=w.inv(f"l{i}.qkv.w"))
             if self.stage_hook is not None:
                 self.stage_hook("embed" if i == 0 else f"layer{i - 1}")
             if one_launch:
@@ -369,14 +372,14 @@ class ProbPoseEngine:
                 qcur, qnext = qnext, qcur
                 continue
             qkv_done = False
-            fold = self.ln_fold_fused and _lib.get_option("ffn_dma_waves") != 0
+            fold = self.ln_fold_fused
             if self.fuse_qkv_attn and fold and i >= 1:
-                # ws["h"] holds the RAW rows the previous layer left (operand format), ws["rowst"] their statistics
+                # ws["h"] holds the CENTERED rows the previous layer left (operand format), ws["rowst"] their (mean, rstd)
                 self._call("qkv_attention", "pp_qkv_attention_split_folded", ws["h"].data_ptr(), w[f"l{i}.qkv.wf"].data_ptr(), w[f"l{i}.qkv.bf"].data_ptr(),
-                           ws["rowst"].data_ptr(), w[f"l{i}.qkv.cf"].data_ptr(), att.data_ptr(), B * passes, self.Np, self.heads, self.hd, scale, st)
+                           ws["rowst"].data_ptr(), att.data_ptr(), B * passes, self.Np, self.heads, self.hd, scale, w.inv(f"l{i}.qkv.wf"), st)
             elif self.fuse_qkv_attn:
-                self._call("qkv_attention", "pp_qkv_attention_split", ws["h"].data_ptr(), w[f"l{i}.qkv.w"].data_ptr(),
-                           w[f"l{i}.qkv.b"].data_ptr(), att.data_ptr(), B * passes, self.Np, self.heads, self.hd, scale, st)
+                self._call("qkv_attention", "pp_qkv_attention_split_ws", ws["h"].data_ptr(), w[f"l{i}.qkv.w"].data_ptr(),
+                           w[f"l{i}.qkv.b"].data_ptr(), att.data_ptr(), B * passes, self.Np, self.heads, self.hd, scale, w.inv(f"l{i}.qkv.w"), st)
             else:
                 self._call("attention", "pp_attention", self.prec, qcur.data_ptr(), ws["h"].data_ptr(), B * passes,
                            self.Np, self.heads, self.hd, scale, st)
@@ -404,24 +407,25 @@ class ProbPoseEngine:
                 res, res_fmt = (ws["x"], 0) if i == 0 else (ws["h"], 2)
                 self._call("proj_ffn_split", "pp_proj_ffn_split_folded", att.data_ptr(), self._proj_packed[i].data_ptr(), w[f"l{i}.proj.b"].data_ptr(),
                            w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(), ws["hs"].data_ptr(), self._ffn_packed[i].data_ptr(),
-                           w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(), res.data_ptr(), res_fmt, 0 if last else 1,
-                           ws["x"].data_ptr() if last else None, gn.data_ptr() if last else None, bn.data_ptr() if last else None, self.ln_eps,
-                           h_next.data_ptr(), None if last else ws["rowst"].data_ptr(), M, E, Fd, st)
+                           w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(), res.data_ptr(), res_fmt, None if i == 0 else ws["rowst"].data_ptr(),
+                           0 if last else 1, ws["x"].data_ptr() if last else None, gn.data_ptr() if last else None, bn.data_ptr() if last else None,
+                           self.ln_eps, h_next.data_ptr(), None if last else ws["rowst"].data_ptr(), M, E, Fd, w.inv(f"l{i}.proj.w"),
+                           w.inv(f"l{i}.fc1.w"), w.inv(f"l{i}.fc2.w"), st)
                 continue
             if i in self._proj_packed:
                 # f16x3: projection + residual, ln2, FFN + residual, next LayerNorm in one kernel
-                self._call("proj_ffn_split", "pp_proj_ffn_split_residual_layernorm", att.data_ptr(), self._proj_packed[i].data_ptr(),
+                self._call("proj_ffn_split", "pp_proj_ffn_split_residual_layernorm_ws", att.data_ptr(), self._proj_packed[i].data_ptr(),
                            w[f"l{i}.proj.b"].data_ptr(), w[f"l{i}.ln2.w"].data_ptr(), w[f"l{i}.ln2.b"].data_ptr(), ws["hs"].data_ptr(),
                            self._ffn_packed[i].data_ptr(), w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(),
                            ws["x"].data_ptr(), ws["x"].data_ptr(), gn.data_ptr(), bn.data_ptr(), self.ln_eps, h_next.data_ptr(),
-                           M, E, Fd, st)
+                           M, E, Fd, w.inv(f"l{i}.proj.w"), w.inv(f"l{i}.fc1.w"), w.inv(f"l{i}.fc2.w"), st)
                 continue
-            res_ln(att, w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"])
+            res_ln(att, w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], E, w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["h"], winv=w.inv(f"l{i}.proj.w"))
             if i in self._ffn_packed:
                 # f16x3: whole FFN + residual + next LayerNorm in one kernel, hidden activation on the CU
-                self._call("ffn_split", "pp_ffn_split_residual_layernorm", ws["h"].data_ptr(), self._ffn_packed[i].data_ptr(),
+                self._call("ffn_split", "pp_ffn_split_residual_layernorm_ws", ws["h"].data_ptr(), self._ffn_packed[i].data_ptr(),
                            w[f"l{i}.fc1.b"].data_ptr(), w[f"l{i}.fc2.b"].data_ptr(), ws["x"].data_ptr(), ws["x"].data_ptr(),
-                           gn.data_ptr(), bn.data_ptr(), self.ln_eps, h_next.data_ptr(), M, E, Fd, st)
+                           gn.data_ptr(), bn.data_ptr(), self.ln_eps, h_next.data_ptr(), M, E, Fd, w.inv(f"l{i}.fc1.w"), w.inv(f"l{i}.fc2.w"), st)
             elif fuse_ffn:
                 # whole FFN + residual + next LayerNorm in one kernel: the 4x-wide hidden activation stays on the CU
                 self._call("mlp_res_ln", "pp_mlp_residual_layernorm", ws["h"].data_ptr(), w[f"l{i}.fc1.w"].data_ptr(),
@@ -429,8 +433,8 @@ class ProbPoseEngine:
                            ws["x"].data_ptr(), ws["x"].data_ptr(), gn.data_ptr(), bn.data_ptr(), self.ln_eps,
                            h_next.data_ptr(), M, E, Fd, st)
             else:
-                self._gemm(st, ws["h"], w[f"l{i}.fc1.w"], w[f"l{i}.fc1.b"], ws["f"], M, Fd, E, act=ACT_GELU)
-                res_ln(ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], Fd, gn, bn, h_next)
+                self._gemm(st, ws["h"], w[f"l{i}.fc1.w"], w[f"l{i}.fc1.b"], ws["f"], M, Fd, E, act=ACT_GELU, winv=w.inv(f"l{i}.fc1.w"))
+                res_ln(ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], Fd, gn, bn, h_next, winv=w.inv(f"l{i}.fc2.w"))
         return ws["feat"]
 
     def _layers_ln_folded(self, ws, st, nb: int, M: int) -> torch.Tensor:
@@ -442,26 +446,26 @@ class ProbPoseEngine:
         F32, SPLIT = 0, 2
         xs, stt, scale = ws["xs"], ws["lnst"], self.hd ** -0.5
 
-        def lin(a, wk, bias, out, N, K, act=ACT_NONE, residual=None, res_fmt=F32, out_fmt=SPLIT, ln=None, stats_out=None):
-            self._call("linear_fold", "pp_linear_ln_folded", a.data_ptr(), wk.data_ptr(), bias.data_ptr(), _lib.ptr(residual), res_fmt,
+        def lin(a, wname, bias, out, N, K, act=ACT_NONE, residual=None, res_fmt=F32, out_fmt=SPLIT, ln=None, stats_out=None):
+            self._call("linear_fold", "pp_linear_ln_folded_ws", a.data_ptr(), w[wname].data_ptr(), bias.data_ptr(), _lib.ptr(residual), res_fmt,
                        out.data_ptr(), out_fmt, M, N, K, act, stt.data_ptr() if ln is not None else None, _lib.ptr(ln), self.ln_eps,
-                       stt.data_ptr() if stats_out else None, st)
+                       stt.data_ptr() if stats_out else None, w.inv(wname), st)
 
         for i in range(L):
             if i == 0:  # ln1 of layer 0 came out of the patch-embed launch: the plain weights
-                lin(ws["h"], w["l0.qkv.w"], w["l0.qkv.b"], ws["qkv"], 3 * E, E)
+                lin(ws["h"], "l0.qkv.w", w["l0.qkv.b"], ws["qkv"], 3 * E, E)
             else:
-                lin(xs, w[f"l{i}.qkv.wf"], w[f"l{i}.qkv.bf"], ws["qkv"], 3 * E, E, ln=w[f"l{i}.qkv.cf"])
+                lin(xs, f"l{i}.qkv.wf", w[f"l{i}.qkv.bf"], ws["qkv"], 3 * E, E, ln=w[f"l{i}.qkv.cf"])
             if self.stage_hook is not None:
                 self.stage_hook("embed" if i == 0 else f"layer{i - 1}")
             self._call("attention", "pp_attention", self.prec, ws["qkv"].data_ptr(), ws["h"].data_ptr(), nb, self.Np, self.heads, self.hd, scale, st)
             # x <- x + att Wp^T + bp (layer 0: the fp32 rows of the patch embedding), statistics for ln2
-            lin(ws["h"], w[f"l{i}.proj.w"], w[f"l{i}.proj.b"], xs, E, E, residual=ws["x"] if i == 0 else xs, res_fmt=F32 if i == 0 else SPLIT,
+            lin(ws["h"], f"l{i}.proj.w", w[f"l{i}.proj.b"], xs, E, E, residual=ws["x"] if i == 0 else xs, res_fmt=F32 if i == 0 else SPLIT,
                 stats_out=True)
-            lin(xs, w[f"l{i}.fc1.wf"], w[f"l{i}.fc1.bf"], ws["f"], Fd, E, act=ACT_GELU, ln=w[f"l{i}.fc1.cf"])
+            lin(xs, f"l{i}.fc1.wf", w[f"l{i}.fc1.bf"], ws["f"], Fd, E, act=ACT_GELU, ln=w[f"l{i}.fc1.cf"])
             last = i + 1 == L
             # x <- x + f W2^T + b2: statistics for the next layer's ln1, or fp32 rows for the final LayerNorm
-            lin(ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], ws["x"] if last else xs, E, Fd, residual=xs, res_fmt=SPLIT,
+            lin(ws["f"], f"l{i}.fc2.w", w[f"l{i}.fc2.b"], ws["x"] if last else xs, E, Fd, residual=xs, res_fmt=SPLIT,
                 out_fmt=F32 if last else SPLIT, stats_out=not last)
         self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), w["ln_f.w"].data_ptr(), w["ln_f.b"].data_ptr(), ws["feat"].data_ptr(), M, E,
                    self.ln_eps, self.fmt, st)

@@ -14,6 +14,7 @@ Packing (all on the host, once, in fp32; then cast to the operand precision):
   * tower Conv2d(k3, p1) + BatchNorm -> folded, [tower][n, (ky*3+kx)*Cin + c];
   * tower Conv1x1 -> [tower][K, C] fp32.
 """
+import math
 from dataclasses import dataclass, field
 from typing import Dict, List
 
@@ -59,14 +60,25 @@ def check_split_range(name: str, x: torch.Tensor) -> None:
                          "represent it - use precision='f32', or rescale the checkpoint (include/probpose_mi355x.h, numeric domain)")
 
 
-def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, name: str = "folded weights"):
+def weight_scale_exponent(w: torch.Tensor) -> int:
+    """e such that the largest element of ``w * 2^e`` lies in [2^12, 2^13): the power-of-two scale a split-fp16 Linear weight tensor is stored
+    with (include/probpose_mi355x.h, numeric domain). The low half of a split value is a normal fp16 number only for |x| >= 2^-3: trained ViT
+    weights (~ 0.02, rows down to 1e-3) sit far below and would keep 13 - 17 of the format's 22 bits; scaled, every element down to 2^-16 of the
+    tensor's largest keeps them all. The kernels multiply their accumulators by 2^-e (exact)."""
+    m = float(w.detach().abs().max()) if w.numel() else 0.0
+    if not m > 0.0 or not math.isfinite(m):
+        return 0
+    return max(-40, min(40, 12 - math.floor(math.log2(m))))
+
+
+def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, name: str = "folded weights", scale_exp: int = 0):
     """Linear(LayerNorm(x)) with the LayerNorm's affine part folded into the Linear layer, as pp_linear_ln_folded consumes it
-    (include/probpose_mi355x.h): ``W'[n, k] = W[n, k] gamma[k]`` in the split-fp16 container, ``colsum[n] = sum_k W'[n, k]`` of the
-    ROUNDED split values (what the MFMAs multiply the row mean with), ``bias'[n] = b[n] + sum_k W[n, k] beta[k]``; sums in fp64.
-    mmpretrain TransformerEncoderLayer [3P]: ``attn(ln1(x))`` / ``ffn(ln2(x))``."""
+    (include/probpose_mi355x.h): ``W'[n, k] = W[n, k] gamma[k] 2^scale_exp`` in the split-fp16 container, ``colsum[n] = sum_k W'[n, k]`` of the
+    ROUNDED split values (what the MFMAs multiply the row mean with: it carries the scale too), ``bias'[n] = b[n] + sum_k W[n, k] beta[k]``; sums
+    in fp64. mmpretrain TransformerEncoderLayer [3P]: ``attn(ln1(x))`` / ``ffn(ln2(x))``."""
     wd, g, be = w.double(), gamma.double(), beta.double()
     check_split_range(name, wd * g[None, :])
-    wf = to_split((wd * g[None, :]).float().contiguous())
+    wf = to_split((wd * g[None, :] * 2.0 ** scale_exp).float().contiguous())
     colsum = from_split(wf).double().sum(dim=1).float().contiguous()
     bias = (b.double() + wd @ be).float().contiguous()
     return wf, colsum, bias
@@ -94,9 +106,15 @@ class PackedWeights:
     num_keypoints: int
     deconv_channels: List[int]
     t: Dict[str, torch.Tensor] = field(default_factory=dict)
+    # name -> 2^-e of the split-fp16 Linear weight tensors stored as w * 2^e (weight_scale_exponent); absent = 1.0
+    inv_scale: Dict[str, float] = field(default_factory=dict)
 
     def __getitem__(self, k):
         return self.t[k]
+
+    def inv(self, k) -> float:
+        """What a kernel multiplies its accumulators with for weight tensor ``k`` (the ``*_ws`` entry points' ``w_inv_scale``)."""
+        return float(self.inv_scale.get(k, 1.0))
 
     def has(self, k) -> bool:
         return k in self.t
@@ -140,17 +158,24 @@ def winograd_weights(w: torch.Tensor) -> torch.Tensor:
     return u.reshape(16, w.shape[0], w.shape[1]).float()
 
 
-def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = False) -> PackedWeights:
+def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = False, scale_linear: bool = True) -> PackedWeights:
     """``dtype``: operand dtype of the MFMA kernels (bf16 / fp32); ``split=True``: split-fp16 operands in a float32
-    container (``to_split``)."""
+    container (``to_split``); with it ``scale_linear``: the backbone's Linear weights (qkv, proj, fc1, fc2 and their LayerNorm-folded forms) are
+    stored times a power of two per tensor, ``PackedWeights.inv(name)`` is what the ``*_ws`` launches are handed (``weight_scale_exponent``)."""
     sd = {k: v.detach().cpu() for k, v in normalize_state_dict(sd).items()}
     f32 = lambda x: x.float().contiguous().to(device)  # noqa: E731
+    inv_scale: Dict[str, float] = {}
     if split:
-        def op(x, name="weights"):
+        def op(x, name="weights", scaled=False):
             check_split_range(name, x)
-            return to_split(x.float().contiguous()).to(device)
+            x = x.float()
+            if scaled and scale_linear:
+                e = weight_scale_exponent(x)
+                x = x * 2.0 ** e  # exact
+                inv_scale[name] = 2.0 ** -e
+            return to_split(x.contiguous()).to(device)
     else:
-        op = lambda x, name=None: x.float().contiguous().to(dtype).to(device)  # noqa: E731
+        op = lambda x, name=None, scaled=False: x.float().contiguous().to(dtype).to(device)  # noqa: E731
     pw = sd["backbone.patch_embed.projection.weight"]
     E = pw.shape[0]
     L = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("backbone.layers."))
@@ -165,30 +190,35 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
         for ln in ("ln1", "ln2"):
             t[f"l{i}.{ln}.w"] = f32(sd[p + ln + ".weight"])
             t[f"l{i}.{ln}.b"] = f32(sd[p + ln + ".bias"])
-        t[f"l{i}.qkv.w"] = op(sd[p + "attn.qkv.weight"], f"l{i}.qkv.w")
+        t[f"l{i}.qkv.w"] = op(sd[p + "attn.qkv.weight"], f"l{i}.qkv.w", scaled=True)
         qb = sd.get(p + "attn.qkv.bias")
         t[f"l{i}.qkv.b"] = f32(qb if qb is not None else torch.zeros(3 * E))
-        t[f"l{i}.proj.w"] = op(sd[p + "attn.proj.weight"], f"l{i}.proj.w")
+        t[f"l{i}.proj.w"] = op(sd[p + "attn.proj.weight"], f"l{i}.proj.w", scaled=True)
         t[f"l{i}.proj.b"] = f32(sd[p + "attn.proj.bias"])
-        t[f"l{i}.fc1.w"] = op(sd[p + "ffn.layers.0.0.weight"], f"l{i}.fc1.w")
+        t[f"l{i}.fc1.w"] = op(sd[p + "ffn.layers.0.0.weight"], f"l{i}.fc1.w", scaled=True)
         t[f"l{i}.fc1.b"] = f32(sd[p + "ffn.layers.0.0.bias"])
-        t[f"l{i}.fc2.w"] = op(sd[p + "ffn.layers.1.weight"], f"l{i}.fc2.w")
+        t[f"l{i}.fc2.w"] = op(sd[p + "ffn.layers.1.weight"], f"l{i}.fc2.w", scaled=True)
         t[f"l{i}.fc2.b"] = f32(sd[p + "ffn.layers.1.bias"])
         if split and E == 384 and i >= 1:
             # ViT-S chain of fused layer kernels: ln1 of layers 1 .. L - 1 folded into the qkv projection (pp_qkv_attention_split_folded; the layer in front
             # leaves raw rows + statistics, pp_proj_ffn_split_folded)
             bb = sd.get(p + "attn.qkv.bias")
-            wf, cs, bf = fold_layernorm(sd[p + "attn.qkv.weight"].float(), bb.float() if bb is not None else torch.zeros(3 * E),
-                                        sd[p + "ln1.weight"].float(), sd[p + "ln1.bias"].float(), name=f"l{i}.qkv.wf")
-            t[f"l{i}.qkv.wf"], t[f"l{i}.qkv.cf"], t[f"l{i}.qkv.bf"] = wf.to(device), cs.to(device), bf.to(device)
+            e = weight_scale_exponent(sd[p + "attn.qkv.weight"].double() * sd[p + "ln1.weight"].double()[None, :]) if scale_linear else 0
+            wf, _, bf = fold_layernorm(sd[p + "attn.qkv.weight"].float(), bb.float() if bb is not None else torch.zeros(3 * E),
+                                       sd[p + "ln1.weight"].float(), sd[p + "ln1.bias"].float(), name=f"l{i}.qkv.wf", scale_exp=e)
+            # (no column sums: the rows this projection is handed are centered, pp_qkv_attention_split_folded)
+            t[f"l{i}.qkv.wf"], t[f"l{i}.qkv.bf"] = wf.to(device), bf.to(device)
+            inv_scale[f"l{i}.qkv.wf"] = 2.0 ** -e
         if split and E % 192 == 0 and E != 384:
             # widths without a fused layer kernel (ViT-B): the folded form of the two Linear layers that follow a LayerNorm (pp_linear_ln_folded;
             # engine.py takes that plan from the row count at which the twelve-wave Linear kernel engages - the plain copies serve below it)
             for name, wk, bk, ln in (("qkv", "attn.qkv.weight", "attn.qkv.bias", "ln1"), ("fc1", "ffn.layers.0.0.weight", "ffn.layers.0.0.bias", "ln2")):
                 bb = sd.get(p + bk)
+                e = weight_scale_exponent(sd[p + wk].double() * sd[p + ln + ".weight"].double()[None, :]) if scale_linear else 0
                 wf, cs, bf = fold_layernorm(sd[p + wk].float(), bb.float() if bb is not None else torch.zeros(sd[p + wk].shape[0]),
-                                            sd[p + ln + ".weight"].float(), sd[p + ln + ".bias"].float(), name=f"l{i}.{name}.wf")
+                                            sd[p + ln + ".weight"].float(), sd[p + ln + ".bias"].float(), name=f"l{i}.{name}.wf", scale_exp=e)
                 t[f"l{i}.{name}.wf"], t[f"l{i}.{name}.cf"], t[f"l{i}.{name}.bf"] = wf.to(device), cs.to(device), bf.to(device)
+                inv_scale[f"l{i}.{name}.wf"] = 2.0 ** -e
     t["ln_f.w"] = f32(sd["backbone.ln1.weight"])
     t["ln_f.b"] = f32(sd["backbone.ln1.bias"])
 
@@ -241,4 +271,4 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
     t["tower_out.w"] = f32(torch.stack([sd[f"head.{tw}_layers.12.weight"].float().reshape(K, -1) for tw in TOWERS]))
     t["tower_out.b"] = f32(torch.stack([sd[f"head.{tw}_layers.12.bias"].float() for tw in TOWERS]))
     return PackedWeights(dtype=dtype, embed_dims=E, num_layers=L, ffn_dims=Fd, num_keypoints=K,
-                         deconv_channels=deconv_channels, t=t)
+                         deconv_channels=deconv_channels, t=t, inv_scale=inv_scale)

@@ -25,7 +25,7 @@ def test_python_binding_covers_header(lib_built):
     from probpose_code_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
-    assert _lib.lib.pp_abi_version() == 3
+    assert _lib.lib.pp_abi_version() == 4
     assert _lib.lib.pp_status_string(-2) == b"PP_ERR_UNSUPPORTED"
 
 

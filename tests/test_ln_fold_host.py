@@ -47,3 +47,52 @@ def test_fold_layernorm_identity_affine_is_plain_linear():
     wf, colsum, bias = fold_layernorm(w, b, torch.ones(K), torch.zeros(K))
     assert torch.equal(wf, to_split(w)) and torch.equal(bias, b)
     torch.testing.assert_close(colsum.double(), from_split(to_split(w)).double().sum(dim=1), rtol=1e-7, atol=1e-6)
+
+
+def test_weight_scale_exponent_and_pack_scales():
+    """weights.weight_scale_exponent: the tensor's largest element lands in [2^12, 2^13); pack(split=True) stores the backbone's Linear weights that
+    way and remembers 2^-e; the stored values times 2^-e are the weights to the split format's 2^-22 - also for rows of 1e-3 of the width, whose low
+    halves would be fp16 subnormals unscaled."""
+    from probpose_code_amd import synthetic as S
+    from probpose_code_amd import weights as W
+
+    for m in (1e-4, 0.03, 0.9, 1.0, 4096.0, 7000.0, 9000.0):
+        e = W.weight_scale_exponent(torch.tensor([m, -m / 3]))
+        assert 2.0 ** 12 <= m * 2.0 ** e < 2.0 ** 13, (m, e)
+    assert W.weight_scale_exponent(torch.zeros(4)) == 0
+    arch = dict(embed_dims=384, num_layers=2, num_heads=12, feedforward_channels=1536)
+    sd = S.synthetic_state_dict(arch, seed=0, stats="trained")
+    pw = W.pack(sd, torch.float32, "cpu", split=True)
+    plain = W.pack(sd, torch.float32, "cpu", split=True, scale_linear=False)
+    assert all(v == 1.0 for v in plain.inv_scale.values()) and plain.inv("l1.fc1.w") == 1.0
+    for name, key in (("l1.qkv.w", "attn.qkv.weight"), ("l1.proj.w", "attn.proj.weight"), ("l1.fc1.w", "ffn.layers.0.0.weight"),
+                      ("l1.fc2.w", "ffn.layers.1.weight")):
+        w = sd["backbone.layers.1." + key].double()
+        inv = pw.inv(name)
+        assert inv < 1.0 and math.log2(inv) == round(math.log2(inv))
+        got = from_split(pw[name]).double() * inv
+        got_plain = from_split(plain[name]).double()
+        small = w.abs() < 0.125 * w.abs().max() * 2.0 ** -10  # elements whose unscaled low halves are deep in the subnormals
+        err_s, err_p = (got - w).abs(), (got_plain - w).abs()
+        assert (err_s <= w.abs() * 2.0 ** -21 + 2.0 ** -25 * inv).all()
+        assert err_s[small].max() <= err_p[small].max() / 8, "scaling must buy the small elements their low halves back"
+    assert "l1.qkv.wf" in pw.inv_scale and "l1.qkv.cf" not in pw.t  # the ViT-S chain's folded projection: centered rows, no column sums
+
+
+def test_centered_fold_is_linear_of_layernorm_without_a_mean_term():
+    """The ViT-S chain's form (pp_proj_ffn_split_folded -> pp_qkv_attention_split_folded): rows travel as x - mean with (mean, rstd) beside them, the
+    projection is rstd * ((x - mean) @ W'^T) * 2^-e + b'. Against Linear(LayerNorm(x)) in fp64, rows with |mean| / std = 100."""
+    from probpose_code_amd.weights import weight_scale_exponent
+
+    M, K, N, eps = 29, 384, 96, 1e-6
+    x = _rand(M, K, seed=11) * 1.3 + 130.0
+    w, b = _rand(N, K, seed=13, scale=1 / math.sqrt(K)), _rand(N, seed=14, scale=0.1)
+    gamma, beta = 1.0 + 0.3 * _rand(K, seed=15), 0.3 * _rand(K, seed=16)
+    ref = F.layer_norm(x.double(), (K,), gamma.double(), beta.double(), eps) @ w.double().t() + b.double()
+    e = weight_scale_exponent(w.double() * gamma.double()[None, :])
+    wf, _, bias = fold_layernorm(w, b, gamma, beta, scale_exp=e)
+    mean = x.double().mean(dim=1, keepdim=True)
+    xc = from_split(to_split((x.double() - mean).float())).double()
+    rstd = 1.0 / torch.sqrt(x.double().var(dim=1, unbiased=False, keepdim=True) + eps)
+    got = rstd * (xc @ from_split(wf).double().t()) * 2.0 ** -e + bias.double()
+    torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)

@@ -416,15 +416,13 @@ def test_linear_dma_twelve_wave_tiles(act, split_out, res, res_mod, bias, K):
     torch.testing.assert_close(outs[0][1], outs[2][1], rtol=3e-6, atol=3e-6)
 
 
-# ---- the overlapped-epilogue kernel (pp_linear_ovl.hip) takes split Linear layers without residual once there are at least two
-# 192 x 192 tiles per CU (qkv / fc1 of the ViT at bs 64): tail rows, the three activations, both output formats, and a bias
-# that must come out of LDS for every column tile
+# ---- large split Linear layers without residual (qkv / fc1 of the ViT at bs 64: the twelve-wave tile kernel since round 5; the overlapped-epilogue
+# kernel these shapes were written for was retired in round 6): tail rows, the three activations, both output formats, uneven tile counts per
+# workgroup - and a WEIGHT SCALE: the weights stored times 2^e, pp_gemm_ws handed 2^-e, must give the same bits as the unscaled launch
 @gpu
 @pytest.mark.parametrize("act,split_out,N,K,M", [(1, 1, 1536, 384, 192 * 86 + 77), (0, 1, 1152, 384, 192 * 86 + 77), (2, 0, 1152, 192, 192 * 86 + 77),
                                                   (0, 0, 1536, 768, 192 * 86 + 77), (1, 1, 1536, 384, 24576), (0, 1, 1152, 384, 24576)])
-def test_linear_overlapped_epilogue(act, split_out, N, K, M):
-    # 87 row tiles (the last one 77 rows) x 6 or 8 column tiles = 522 / 696 tiles: 2 - 3 per workgroup, uneven; and the bs 64
-    # shapes of the path (128 row tiles: 768 / 1024 tiles, 3 / 4 per workgroup), repeated to catch races between the waves
+def test_linear_large_tiles_and_weight_scale(act, split_out, N, K, M):
     L = _lib()
     a, w, b = _rand(M, K, seed=61), _rand(N, K, seed=62, scale=1 / math.sqrt(K)), _rand(N, seed=63)
     ref = a.double() @ w.double().t() + b.double()
@@ -437,11 +435,22 @@ def test_linear_overlapped_epilogue(act, split_out, N, K, M):
     assert not torch.isnan(got).any(), "rows or columns left unwritten"
     torch.testing.assert_close(got, ref, **TOL)
     first = out.clone()
-    for _ in range(5):  # the same launch again: bit-identical every time (no wave reads a staging buffer another one is rewriting)
+    for _ in range(3):  # the same launch again: bit-identical every time (no wave reads a staging buffer another one is rewriting)
         out.fill_(float("nan"))
         L.call("pp_gemm", F16X3, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, 0, out.data_ptr(), M, N, K, K, K, N, act,
                SPLIT if split_out else 0, 0, None)
         assert torch.equal(out, first)
+    # weights * 2^17 (their low halves leave the fp16 subnormals), sums * 2^-17: at least as close to fp64, and close to the unscaled result
+    ws = _sp(w * 2.0 ** 17)
+    out.fill_(float("nan"))
+    L.call("pp_gemm_ws", F16X3, ad.data_ptr(), ws.data_ptr(), bd.data_ptr(), None, 0, out.data_ptr(), M, N, K, K, K, N, act,
+           SPLIT if split_out else 0, 0, 2.0 ** -17, None)
+    got_s = _unsp(out) if split_out else out.cpu().double()
+    torch.testing.assert_close(got_s, ref, **TOL)
+    assert (got_s - ref).abs().max() <= (got - ref).abs().max() * 1.5 + 1e-7
+    with pytest.raises(L.ProbPoseLibraryError):  # not a power of two
+        L.call("pp_gemm_ws", F16X3, ad.data_ptr(), ws.data_ptr(), bd.data_ptr(), None, 0, out.data_ptr(), M, N, K, K, K, N, act,
+               SPLIT if split_out else 0, 0, 0.3, None)
 
 
 @gpu
@@ -503,18 +512,16 @@ def _ffn_pack(L, w1, w2, E, F_):
 
 @pytest.fixture
 def ffn_form(request):
-    """the forms of the fused feed-forward launch: 2 = twelve waves, two hidden chunks per streamed x block (pp_ffn_dma.hip's pair kernels,
-    shipped for an even chunk count), 1 = twelve waves, one chunk at a time (pp_ffn_dma.hip), 0 = eight waves (pp_ffn_split.hip)"""
+    """the forms of the fused feed-forward launch (pp_ffn_dma.hip, twelve waves): 2 = two hidden chunks per streamed x block (the pair kernels,
+    shipped for an even chunk count), 1 = one chunk at a time (the eight-wave kernel of round 3 - form 0 - was retired in round 6)"""
     L = _lib()
-    L.set_option("ffn_dma_waves", min(request.param, 1))
     L.set_option("ffn_pair", int(request.param == 2))
     yield request.param
-    L.set_option("ffn_dma_waves", 1)
     L.set_option("ffn_pair", 1)
 
 
 @gpu
-@pytest.mark.parametrize("ffn_form", [2, 1, 0], indirect=True)
+@pytest.mark.parametrize("ffn_form", [2, 1], indirect=True)
 @pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (24576, 1536)])
 def test_ffn_split_fused_vs_fp64(M, F_, ffn_form):
     """pp_ffn_split_residual_layernorm (fc1 - GELU - fc2 + residual + LayerNorm in one launch, hidden activation on the CU)
@@ -542,7 +549,7 @@ def test_ffn_split_fused_vs_fp64(M, F_, ffn_form):
 
 
 @gpu
-@pytest.mark.parametrize("ffn_form", [2, 1, 0], indirect=True)
+@pytest.mark.parametrize("ffn_form", [2, 1], indirect=True)
 def test_ffn_split_fused_in_place_and_errors(ffn_form):
     """residual aliasing x_out and h_in aliasing h_out (how the engine calls it), and the argument checks."""
     L = _lib()
@@ -574,7 +581,7 @@ def _proj_inputs(M, E=384, seed=80):
 
 
 @gpu
-@pytest.mark.parametrize("ffn_form", [2, 1, 0], indirect=True)
+@pytest.mark.parametrize("ffn_form", [2, 1], indirect=True)
 @pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (24576, 1536)])
 def test_proj_ffn_split_fused_vs_fp64(M, F_, ffn_form):
     """pp_proj_ffn_split_residual_layernorm (projection + residual + ln2 + FFN + residual + LayerNorm in one launch) against
@@ -652,10 +659,11 @@ def test_qkv_attention_split_fused_vs_fp64(n_seq, bias, pair):
 @gpu
 @pytest.mark.parametrize("n_seq", [3, 128])
 def test_qkv_attention_split_folded_vs_fp64(n_seq):
-    """pp_qkv_attention_split_folded: the same launch on RAW residual rows with ln1 folded into the projection (gamma into the weights, beta into
-    the bias, mean / rstd per row applied where the bias is added) against torch fp64 with an explicit LayerNorm; rows with an offset (mean / std
-    ~ 2); the unfolded launch on the normalised rows must agree; repeated launches bit-identical."""
-    from probpose_code_amd.weights import fold_layernorm
+    """pp_qkv_attention_split_folded: the same launch on CENTERED residual rows (x - mean, what pp_proj_ffn_split_folded leaves) with ln1 folded into
+    the projection (gamma into the weights, beta into the bias, rstd per row applied where the bias is added) and the weights stored with a power-of-two
+    scale, against torch fp64 with an explicit LayerNorm; rows with an offset (mean / std ~ 2: it must not matter any more); the unfolded launch on the
+    normalised rows must agree; repeated launches bit-identical."""
+    from probpose_code_amd.weights import fold_layernorm, weight_scale_exponent
 
     L = _lib()
     S, E, H, hd, eps = 192, 384, 12, 32, 1e-6
@@ -663,33 +671,44 @@ def test_qkv_attention_split_folded_vs_fp64(n_seq):
     x = _rand(M, E, seed=190) * 1.3 + 2.5 * _rand(M, 1, seed=191)
     g, be = 1.0 + 0.2 * _rand(E, seed=192), 0.2 * _rand(E, seed=193)
     w, b = _rand(3 * E, E, seed=194, scale=1 / math.sqrt(E)), _rand(3 * E, seed=195, scale=0.3)
-    xs = _sp(x)
-    xq = _unsp(xs)  # the rows the kernel multiplies: split-rounded
-    hn = F.layer_norm(x.double(), (E,), g.double(), be.double(), eps)
+    mean = x.mean(dim=1, keepdim=True)
+    xs = _sp(x - mean)          # the rows as the producer leaves them
+    xq = _unsp(xs) + mean.double()  # ... and the values they stand for
+    hn = F.layer_norm(xq, (E,), g.double(), be.double(), eps)
     qkv = hn @ w.double().t() + b.double()
     q, k, v = qkv.reshape(n_seq, S, 3, H, hd).permute(2, 0, 3, 1, 4)
     ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(M, E)
     stats = torch.stack([xq.mean(dim=1), 1.0 / torch.sqrt(xq.var(dim=1, unbiased=False) + eps)], dim=1).float().cuda()
-    wf, cs, bf = [t.cuda() for t in fold_layernorm(w, b, g, be)]
+    e = weight_scale_exponent(w.double() * g.double()[None, :])
+    assert e >= 10
+    wf, _, bf = [t.cuda() for t in fold_layernorm(w, b, g, be, scale_exp=e)]
     outs = []
     for _ in range(3):
         out = torch.full((M, E), float("nan"), device="cuda")
-        L.call("pp_qkv_attention_split_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), stats.data_ptr(), cs.data_ptr(), out.data_ptr(), n_seq, S, H,
-               hd, hd ** -0.5, None)
+        L.call("pp_qkv_attention_split_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), stats.data_ptr(), out.data_ptr(), n_seq, S, H,
+               hd, hd ** -0.5, 2.0 ** -e, None)
         outs.append(out.cpu())
-    torch.testing.assert_close(_unsp(outs[0]), ref, rtol=3e-5, atol=3e-5)
+    torch.testing.assert_close(_unsp(outs[0]), ref, rtol=1e-5, atol=1e-5)
     for o in outs[1:]:
         assert torch.equal(o.view(torch.int32), outs[0].view(torch.int32))
     plain = torch.full((M, E), float("nan"), device="cuda")
     hs, wd, bd = _sp(hn.float()), _sp(w), b.cuda()
     L.call("pp_qkv_attention_split", hs.data_ptr(), wd.data_ptr(), bd.data_ptr(), plain.data_ptr(), n_seq, S, H, hd, hd ** -0.5, None)
-    torch.testing.assert_close(_unsp(outs[0]), _unsp(plain.cpu()), rtol=3e-5, atol=3e-5)
+    torch.testing.assert_close(_unsp(outs[0]), _unsp(plain.cpu()), rtol=1e-5, atol=1e-5)
+    # the unfolded launch with a weight scale
+    e2 = weight_scale_exponent(w)
+    plain2 = torch.full((M, E), float("nan"), device="cuda")
+    L.call("pp_qkv_attention_split_ws", hs.data_ptr(), _sp(w * 2.0 ** e2).data_ptr(), bd.data_ptr(), plain2.data_ptr(), n_seq, S, H, hd, hd ** -0.5,
+           2.0 ** -e2, None)
+    torch.testing.assert_close(_unsp(plain2.cpu()), ref, rtol=1e-5, atol=1e-5)
     with pytest.raises(L.ProbPoseLibraryError):
-        L.call("pp_qkv_attention_split_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), None, cs.data_ptr(), out.data_ptr(), n_seq, S, H, hd, 0.1, None)
+        L.call("pp_qkv_attention_split_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), None, out.data_ptr(), n_seq, S, H, hd, 0.1, 1.0, None)
+    with pytest.raises(L.ProbPoseLibraryError):  # a scale that is no power of two
+        L.call("pp_qkv_attention_split_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), stats.data_ptr(), out.data_ptr(), n_seq, S, H, hd, 0.1, 0.7, None)
 
 
 @gpu
-@pytest.mark.parametrize("ffn_form", [2, 1, 0], indirect=True)
+@pytest.mark.parametrize("ffn_form", [2, 1], indirect=True)
 def test_proj_ffn_split_two_streams_under_contention(ffn_form):
     """Two independent problems through pp_proj_ffn_split_residual_layernorm on two streams at once must each give the result
     they give alone, bit for bit. This is the condition bench.py's two steps in flight create; it caught counted vmcnt waits
@@ -735,13 +754,13 @@ def test_proj_ffn_split_two_streams_under_contention(ffn_form):
 @gpu
 @pytest.mark.parametrize("pair", [1, 0])
 @pytest.mark.parametrize("M,F_", [(96 * 3, 1536), (96 * 2 - 40, 256), (96 * 2 + 5, 384), (24576, 1536)])
-def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_, pair):
-    """pp_set_option("ffn_dma_waves", 1) routes both fused feed-forward entry points to the twelve-wave kernel (pp_ffn_dma.hip:
-    eight computing waves + four DMA waves); pp_set_option("ffn_pair", 1) to its paired-chunk form when the hidden width is an even
-    number of 128-column chunks (F = 384 - three chunks - runs the single-chunk kernel under either setting). Held to the same
-    fp64 references and tolerances as the eight-wave kernel above, in place as the engine calls them, a ragged last tile included;
-    the forms agree to rounding (the same terms, summed in another order); repeated launches bit-identical, also when two launches
-    share the chip (what two steps in flight create)."""
+def test_ffn_dma_waves_form_vs_fp64_and_weight_scales(M, F_, pair):
+    """Both fused feed-forward entry points on the twelve-wave kernel (pp_ffn_dma.hip: eight computing waves + four DMA waves);
+    pp_set_option("ffn_pair", 1): its paired-chunk form when the hidden width is an even number of 128-column chunks (F = 384 - three
+    chunks - runs the single-chunk kernel under either setting). Against fp64, in place as the engine calls them, a ragged last tile
+    included; repeated launches bit-identical, also when two launches share the chip (what two steps in flight create); and with WEIGHT
+    SCALES: Wp / W1 / W2 stored times three different powers of two, the *_ws launches handed the inverses - the same numbers to rounding
+    (power-of-two factors commute with every rounding; only the weights' low halves gain bits)."""
     L = _lib()
     E = 384
     h, r, w1, b1, w2, b2, g, be = _ffn_inputs(M, F_, seed=300)
@@ -775,9 +794,6 @@ def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_, pair):
         return all(torch.equal(u.view(torch.int32), v.view(torch.int32)) for u, v in zip(a, b))
 
     try:
-        L.set_option("ffn_dma_waves", 0)
-        eight_f, eight_p = [t.cpu() for t in ffn()], [t.cpu() for t in proj()]
-        L.set_option("ffn_dma_waves", 1)
         L.set_option("ffn_pair", pair)
         L.reset_launch_counts()
         want_f, want_p = [t.cpu() for t in ffn()], [t.cpu() for t in proj()]
@@ -787,10 +803,24 @@ def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_, pair):
         torch.testing.assert_close(_unsp(want_p[2]), h_mid, **TOL)
         torch.testing.assert_close(want_p[0].double(), xp_ref, rtol=3e-5, atol=3e-5)
         torch.testing.assert_close(_unsp(want_p[1]), hp_ref, rtol=3e-5, atol=3e-5)
-        # (round 5: the twelve-wave kernel adds a block's hi x lo product FIRST - rolling fragment reads - the eight-wave one last: the same
-        # terms in another order; 2 of 9.4 M outputs of the bs 64 shape differ by 2.9e-6, the rest by < 2e-6)
-        torch.testing.assert_close(want_f[0], eight_f[0], rtol=5e-6, atol=5e-6)
-        torch.testing.assert_close(want_p[0], eight_p[0], rtol=5e-6, atol=5e-6)
+        # weight scales: 2^15 / 2^17 / 2^16 on Wp / W1 / W2
+        packed_s = _ffn_pack(L, w1 * 2.0 ** 17, w2 * 2.0 ** 16, E, F_)
+        wpp_s = torch.empty(E * E, dtype=torch.float32, device="cuda")
+        L.call("pp_proj_split_pack_weights", _sp(wp * 2.0 ** 15).data_ptr(), wpp_s.data_ptr(), E, None)
+        hd, xd = _sp(h), r.cuda()
+        L.call("pp_ffn_split_residual_layernorm_ws", hd.data_ptr(), packed_s.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), xd.data_ptr(),
+               xd.data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(), 1e-6, hd.data_ptr(), M, E, F_, 2.0 ** -17, 2.0 ** -16, None)
+        torch.testing.assert_close(xd.cpu().double(), x_ref, **TOL)
+        torch.testing.assert_close(xd.cpu(), want_f[0], rtol=3e-6, atol=3e-6)
+        assert (xd.cpu().double() - x_ref).abs().max() <= (want_f[0].double() - x_ref).abs().max() * 1.5 + 1e-7
+        ad, xd = _sp(att), r.cuda()
+        scratch = torch.full((M, E), float("nan"), device="cuda")
+        L.call("pp_proj_ffn_split_residual_layernorm_ws", ad.data_ptr(), wpp_s.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(),
+               dev[2].data_ptr(), scratch.data_ptr(), packed_s.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), xd.data_ptr(),
+               xd.data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(), 1e-6, ad.data_ptr(), M, E, F_, 2.0 ** -15, 2.0 ** -17, 2.0 ** -16, None)
+        torch.testing.assert_close(xd.cpu().double(), xp_ref, rtol=3e-5, atol=3e-5)
+        torch.testing.assert_close(_unsp(ad), hp_ref, rtol=3e-5, atol=3e-5)
+        torch.testing.assert_close(xd.cpu(), want_p[0], rtol=5e-6, atol=5e-6)
         for _ in range(3):
             assert same([t.cpu() for t in ffn()], want_f), "FFN form: run-to-run difference"
             assert same([t.cpu() for t in proj()], want_p), "projection + FFN form: run-to-run difference"
@@ -805,7 +835,6 @@ def test_ffn_dma_waves_form_vs_fp64_and_eight_wave_form(M, F_, pair):
                 torch.cuda.synchronize()
                 assert same([t.cpu() for t in a], want_p) and same([t.cpu() for t in b], want_f), f"contended launch {it}"
     finally:
-        L.set_option("ffn_dma_waves", 1)
         L.set_option("ffn_pair", 1)
 
 
@@ -1006,24 +1035,27 @@ def test_linear_ln_folded_edge_shapes_vs_fp64(M, N, K, ln):
 @gpu
 @pytest.mark.parametrize("M", [96 * 3, 96 * 2 - 40, 24576])
 def test_proj_ffn_split_folded_vs_plain_launch(M):
-    """pp_proj_ffn_split_folded (the projection + FFN launch with the residual rows in the operand format and / or its final LayerNorm left to the next
-    layer's pp_qkv_attention_split_folded) against the plain launch on the same numbers: operand-format residual rows in (x = hi + lo is exact in
-    fp32: bit-identical x_out / h_out to the plain launch on those rounded rows); folded out: h_out holds the new residual rows in the operand
-    format (= the plain launch's x_out to 2^-22), stats_out (mean, rstd) per row against fp64; both at once, in place; a ragged last block; the
-    bs 64 shape; repeated launches bit-identical; shapes it does not serve are refused."""
+    """pp_proj_ffn_split_folded (the projection + FFN launch inside the folded chain: CENTERED operand-format rows in and / or out, the final LayerNorm
+    left to the next layer's pp_qkv_attention_split_folded) against the plain launch on the same numbers: centered residual rows + their means in
+    ((hi + lo) + mean: the plain launch's results on those fp32 rows, bit for bit); folded out: h_out holds x - mean in the operand format, stats_out
+    (mean, rstd) per row - together the plain launch's x_out to 2^-22; both at once, in place, statistics in place; weight scales; a ragged last
+    block; the bs 64 shape; repeated launches bit-identical; shapes it does not serve are refused."""
     from probpose_code_amd.weights import from_split
 
     L = _lib()
     E, F_, F32, eps = 384, 1536, 0, 1e-6
     h, r, w1, b1, w2, b2, g, be = _ffn_inputs(M, F_, seed=600)
+    r = r + 3.0 * _rand(M, 1, seed=601)  # rows with an offset: centering must really happen
     att, wp, bp, g2, be2 = _proj_inputs(M, seed=620)
     packed = _ffn_pack(L, w1, w2, E, F_)
     wpp = torch.empty(E * E, dtype=torch.float32, device="cuda")
     wps = _sp(wp)
     L.call("pp_proj_split_pack_weights", wps.data_ptr(), wpp.data_ptr(), E, None)
     dev = [t.cuda() for t in (bp, g2, be2, b1, b2, g, be)]
-    rs = _sp(r)                               # residual rows in the operand format
-    rq = from_split(rs.cpu()).cuda()          # ... and their value as fp32 rows (hi + lo: exact)
+    rmean = r.mean(dim=1, keepdim=True)
+    rs = _sp(r - rmean)                                        # centered residual rows in the operand format
+    rst = torch.cat([rmean, torch.ones_like(rmean)], dim=1).contiguous().cuda()  # (mean, rstd): only the mean is read back
+    rq = (from_split(rs.cpu()) + rmean).cuda()                 # ... and the fp32 rows they stand for: (hi + lo) + mean, one rounding
     ad = _sp(att)
 
     def plain(res32):
@@ -1033,36 +1065,50 @@ def test_proj_ffn_split_folded_vs_plain_launch(M):
                M, E, F_, None)
         return xo.cpu(), ho.cpu()
 
-    def folded(res, res_fmt, fold_out, in_place=False):
+    def folded(res, res_fmt, fold_out, in_place=False, res_stats=None, wpk=None, pk=None, scales=(1.0, 1.0, 1.0)):
         xo, sc = (torch.full((M, E), float("nan"), device="cuda") for _ in range(2))
         ho = res if in_place else torch.full((M, E), float("nan"), device="cuda")
-        st = torch.full((M, 2), float("nan"), device="cuda")
-        L.call("pp_proj_ffn_split_folded", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), sc.data_ptr(),
-               packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), res.data_ptr(), res_fmt, int(fold_out), None if fold_out else xo.data_ptr(),
+        st = res_stats if (in_place and res_stats is not None) else torch.full((M, 2), float("nan"), device="cuda")
+        L.call("pp_proj_ffn_split_folded", ad.data_ptr(), (wpk if wpk is not None else wpp).data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(),
+               sc.data_ptr(), (pk if pk is not None else packed).data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), res.data_ptr(), res_fmt,
+               res_stats.data_ptr() if res_stats is not None else None, int(fold_out), None if fold_out else xo.data_ptr(),
                None if fold_out else dev[5].data_ptr(), None if fold_out else dev[6].data_ptr(), eps, ho.data_ptr(), st.data_ptr() if fold_out else None,
-               M, E, F_, None)
+               M, E, F_, scales[0], scales[1], scales[2], None)
         return xo.cpu(), ho.cpu(), st.cpu()
 
     want_x, want_h = plain(rq)
-    # 1: operand-format residual in, LayerNorm out (the last layer of a folded chain)
-    x1, h1, _ = folded(rs, SPLIT, False)
-    assert torch.equal(x1, want_x) and torch.equal(h1.view(torch.int32), want_h.view(torch.int32)), "split residual in: must equal the plain launch on hi + lo"
-    # 2: fp32 residual in, folded out (the first layer)
+    # 1: centered operand-format residual in, LayerNorm out (the last layer of a folded chain)
+    x1, h1, _ = folded(rs, SPLIT, False, res_stats=rst)
+    assert torch.equal(x1, want_x) and torch.equal(h1.view(torch.int32), want_h.view(torch.int32)), "centered residual in: must equal the plain launch on (hi + lo) + mean"
+    # 2: fp32 residual in, folded out (the first layer): centered rows + statistics
     _, h2, st2 = folded(rq, F32, True)
-    torch.testing.assert_close(_unsp(h2), want_x.double(), rtol=5e-7, atol=5e-7)
     ref_stats = torch.stack([want_x.double().mean(dim=1), 1.0 / torch.sqrt(want_x.double().var(dim=1, unbiased=False) + eps)], dim=1)
     torch.testing.assert_close(st2.double(), ref_stats, rtol=2e-5, atol=2e-5)
-    # 3: both, in place (the layers in between): the residual buffer becomes the new rows
-    rs3 = rs.clone()
-    _, h3, st3 = folded(rs3, SPLIT, True, in_place=True)
+    torch.testing.assert_close(_unsp(h2) + st2[:, :1].double(), want_x.double(), rtol=5e-7, atol=5e-7)
+    assert _unsp(h2).mean(dim=1).abs().max() < 1e-5, "the rows that leave must be centered"
+    # 3: both, in place (the layers in between): the residual buffer becomes the new rows, the statistics buffer the new statistics
+    rs3, rst3 = rs.clone(), rst.clone()
+    _, h3, st3 = folded(rs3, SPLIT, True, in_place=True, res_stats=rst3)
     assert torch.equal(h3.view(torch.int32), h2.view(torch.int32)) and torch.equal(st3, st2)
-    rs4 = rs.clone()
-    _, h4, st4 = folded(rs4, SPLIT, True, in_place=True)
+    rs4, rst4 = rs.clone(), rst.clone()
+    _, h4, st4 = folded(rs4, SPLIT, True, in_place=True, res_stats=rst4)
     assert torch.equal(h4.view(torch.int32), h3.view(torch.int32)) and torch.equal(st4, st3), "run-to-run difference"
-    assert L.launch_count("ffn_dma_fold") >= 4
+    # 4: weight scales (Wp 2^15, W1 2^17, W2 2^16): the same rows to rounding
+    pk_s = _ffn_pack(L, w1 * 2.0 ** 17, w2 * 2.0 ** 16, E, F_)
+    wpp_s = torch.empty(E * E, dtype=torch.float32, device="cuda")
+    L.call("pp_proj_split_pack_weights", _sp(wp * 2.0 ** 15).data_ptr(), wpp_s.data_ptr(), E, None)
+    _, h5, st5 = folded(rs, SPLIT, True, res_stats=rst, wpk=wpp_s, pk=pk_s, scales=(2.0 ** -15, 2.0 ** -17, 2.0 ** -16))
+    torch.testing.assert_close(_unsp(h5) + st5[:, :1].double(), _unsp(h2) + st2[:, :1].double(), rtol=5e-6, atol=5e-6)
+    assert L.launch_count("ffn_dma_fold") >= 5
     with pytest.raises(L.ProbPoseLibraryError):  # an odd number of hidden chunks: no paired kernel
         L.call("pp_proj_ffn_split_folded", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), rs4.data_ptr(),
-               packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), rs.data_ptr(), SPLIT, 1, None, None, None, eps, rs3.data_ptr(), st4.cuda().data_ptr(), M, E, 384, None)
+               packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), rs.data_ptr(), SPLIT, rst.data_ptr(), 1, None, None, None, eps, rs3.data_ptr(),
+               rst4.data_ptr(), M, E, 384, 1.0, 1.0, 1.0, None)
     with pytest.raises(L.ProbPoseLibraryError):  # folded out without a statistics buffer
         L.call("pp_proj_ffn_split_folded", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), rs4.data_ptr(),
-               packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), rs.data_ptr(), SPLIT, 1, None, None, None, eps, rs3.data_ptr(), None, M, E, F_, None)
+               packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), rs.data_ptr(), SPLIT, rst.data_ptr(), 1, None, None, None, eps, rs3.data_ptr(), None,
+               M, E, F_, 1.0, 1.0, 1.0, None)
+    with pytest.raises(L.ProbPoseLibraryError):  # centered rows without their means
+        L.call("pp_proj_ffn_split_folded", ad.data_ptr(), wpp.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), rs4.data_ptr(),
+               packed.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), rs.data_ptr(), SPLIT, None, 1, None, None, None, eps, rs3.data_ptr(), rst4.data_ptr(),
+               M, E, F_, 1.0, 1.0, 1.0, None)

@@ -189,18 +189,19 @@ def _offset_rows(M, E, ratio, outliers, seed):
     return x, g
 
 
-# measured on the MI355X (round 6, printed by these tests) and bounded just above: the folded form's error grows with the row's |mean| / std
-# - the product  acc - mean * colsum  cancels that many leading bits of a 22-bit operand
-QKV_FOLD_TOL = {(0, False): 3e-5, (10, False): 3e-5, (50, False): 1.5e-4, (150, False): 4e-4, (10, True): 3e-5}
-LIN_FOLD_TOL = {(0, False): 3e-5, (10, False): 3e-5, (50, False): 1.5e-4, (150, False): 4e-4, (10, True): 3e-5}
+# measured on the MI355X (round 6, printed by these tests) and bounded just above. ViT-S chain (centered rows): no dependence on the offset. ViT-B's
+# pp_linear_ln_folded takes RAW rows (its statistics arrive in parts from several workgroups): rstd (acc - mean colsum) cancels ~ log2(|mean| / std) bits of fp32
+QKV_FOLD_TOL = {(0, False): 1e-5, (10, False): 1e-5, (50, False): 1e-5, (150, False): 1e-5, (10, True): 3e-5}  # centered rows: no growth with the offset
+LIN_FOLD_TOL = {(0, False): 1e-5, (10, False): 5e-5, (50, False): 2.5e-4, (150, False): 7e-4, (10, True): 5e-5}  # raw rows: measured 5.0e-6 / 3.3e-5 / 1.8e-4 / 4.9e-4 / 3.3e-5
 
 
 @gpu
 @pytest.mark.parametrize("ratio,outliers", list(QKV_FOLD_TOL))
 def test_qkv_attention_split_folded_row_offsets_vs_fp64(ratio, outliers):
-    """pp_qkv_attention_split_folded (the ViT-S chain's qkv + attention launch on RAW rows) at row mean / std = ratio, with and without outlier
-    columns, against torch fp64 with an explicit LayerNorm - and beside it the unfolded launch on the normalised rows (what `ln_fold=False` runs)."""
-    from probpose_code_amd.weights import fold_layernorm
+    """pp_qkv_attention_split_folded (the ViT-S chain's qkv + attention launch on CENTERED rows) at row mean / std = ratio, with and without outlier
+    columns, against torch fp64 with an explicit LayerNorm - and beside it the unfolded launch on the normalised rows (what `ln_fold=False` runs).
+    Centered, the fold has no cancellation left: the offset must not show."""
+    from probpose_code_amd.weights import fold_layernorm, weight_scale_exponent
 
     L = _lib()
     S_, E, H, hd, eps, n_seq = 192, 384, 12, 32, 1e-6, 8
@@ -208,23 +209,26 @@ def test_qkv_attention_split_folded_row_offsets_vs_fp64(ratio, outliers):
     x, g = _offset_rows(M, E, ratio, outliers, seed=900 + ratio)
     be = 0.2 * _rand(E, seed=893)
     w, b = _rand(3 * E, E, seed=894, scale=1 / math.sqrt(E)), _rand(3 * E, seed=895, scale=0.3)
-    xs = _sp(x)
-    xq = _unsp(xs)
-    hn = F.layer_norm(xq, (E,), g.double(), be.double(), eps)  # of the rows the kernel is handed (their split rounding is the producer's, not this launch's)
+    mean = x.mean(dim=1, keepdim=True)
+    xs = _sp(x - mean)
+    xq = _unsp(xs) + mean.double()  # the rows the producer's (centered rows, mean) stand for
+    hn = F.layer_norm(xq, (E,), g.double(), be.double(), eps)
     qkv = hn @ w.double().t() + b.double()
     q, k, v = qkv.reshape(n_seq, S_, 3, H, hd).permute(2, 0, 3, 1, 4)
     ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(M, E)
     stats = torch.stack([xq.mean(dim=1), 1.0 / torch.sqrt(xq.var(dim=1, unbiased=False) + eps)], dim=1).float().cuda()
-    wf, cs, bf = [t.cuda() for t in fold_layernorm(w, b, g, be)]
+    e = weight_scale_exponent(w.double() * g.double()[None, :])
+    wf, _, bf = [t.cuda() for t in fold_layernorm(w, b, g, be, scale_exp=e)]
     out = torch.full((M, E), float("nan"), device="cuda")
-    L.call("pp_qkv_attention_split_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), stats.data_ptr(), cs.data_ptr(), out.data_ptr(), n_seq, S_, H,
-           hd, hd ** -0.5, None)
+    L.call("pp_qkv_attention_split_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), stats.data_ptr(), out.data_ptr(), n_seq, S_, H,
+           hd, hd ** -0.5, 2.0 ** -e, None)
     plain = torch.full((M, E), float("nan"), device="cuda")
-    hs, wd, bd = _sp(hn.float()), _sp(w), b.cuda()
-    L.call("pp_qkv_attention_split", hs.data_ptr(), wd.data_ptr(), bd.data_ptr(), plain.data_ptr(), n_seq, S_, H, hd, hd ** -0.5, None)
+    e2 = weight_scale_exponent(w)
+    hs, wd, bd = _sp(hn.float()), _sp(w * 2.0 ** e2), b.cuda()
+    L.call("pp_qkv_attention_split_ws", hs.data_ptr(), wd.data_ptr(), bd.data_ptr(), plain.data_ptr(), n_seq, S_, H, hd, hd ** -0.5, 2.0 ** -e2, None)
     e_fold = (_unsp(out) - ref).abs().max().item()
     e_plain = (_unsp(plain) - ref).abs().max().item()
-    print(f"[trained-stats] qkv+attention folded, mean/std {ratio}, outliers {outliers}: |err| folded {e_fold:.2e}, plain LayerNorm {e_plain:.2e} (outputs O({ref.abs().max():.1f}))")
+    print(f"[trained-stats] qkv+attention folded (centered), mean/std {ratio}, outliers {outliers}: |err| folded {e_fold:.2e}, plain LayerNorm {e_plain:.2e} (outputs O({ref.abs().max():.1f}))")
     assert e_fold <= QKV_FOLD_TOL[(ratio, outliers)]
     assert e_plain <= 3e-5
 
@@ -247,10 +251,13 @@ def test_linear_ln_folded_row_offsets_vs_fp64(ratio, outliers):
     p = xq.reshape(M, -1, 96)
     pm = p.mean(dim=2)
     st = torch.stack([pm, ((p - pm[..., None]) ** 2).sum(dim=2)], dim=2).float().cuda()
-    wf, cs, bf = [t.cuda() for t in fold_layernorm(w, b, g, be)]
+    from probpose_code_amd.weights import weight_scale_exponent
+
+    e = weight_scale_exponent(w.double() * g.double()[None, :])
+    wf, cs, bf = [t.cuda() for t in fold_layernorm(w, b, g, be, scale_exp=e)]
     out = torch.full((M, N), float("nan"), device="cuda")
-    L.call("pp_linear_ln_folded", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), None, 0, out.data_ptr(), SPLIT, M, N, E, 0, st.data_ptr(), cs.data_ptr(),
-           eps, None, None)
+    L.call("pp_linear_ln_folded_ws", xs.data_ptr(), wf.data_ptr(), bf.data_ptr(), None, 0, out.data_ptr(), SPLIT, M, N, E, 0, st.data_ptr(), cs.data_ptr(),
+           eps, None, 2.0 ** -e, None)
     err = (_unsp(out) - ref).abs().max().item()
     print(f"[trained-stats] linear_ln_folded, mean/std {ratio}, outliers {outliers}: |err| {err:.2e} (outputs O({ref.abs().max():.1f}))")
     assert err <= LIN_FOLD_TOL[(ratio, outliers)]
