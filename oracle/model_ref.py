@@ -136,12 +136,16 @@ def head_forward(sd, feat, **kw):
 # --------------------------------------------------------------------------- estimator
 def predict(sd, imgs_u8_bgr: torch.Tensor, num_heads: int, mean, std, input_size=(192, 256), flip_test=True,
             flip_indices=D.COCO_FLIP_INDICES, input_center=None, input_scale=None, decode_backend="scipy",
-            normalize=1.0, freeze_oks=False, shift_heatmap=False) -> Dict[str, np.ndarray]:
+            normalize=1.0, freeze_oks=False, shift_heatmap=False, dtype=torch.float32) -> Dict[str, np.ndarray]:
     """TopdownPoseEstimator.predict (topdown.py:86-126) + ProbMapHead.predict (probmap_head.py:715-804)
     + add_pred_to_datasample (topdown.py:128-194), batched; returns the pred_instances fields stacked
-    over the batch plus the intermediate tensors parity tests compare."""
+    over the batch plus the intermediate tensors parity tests compare. ``dtype=torch.float64`` runs the SAME network in double precision
+    (not what the reference does - it is the yardstick that says how far the fp32 reference itself sits from the exact result, i.e. what
+    two correct fp32 implementations may differ by); the maps go to the decode as float32 like the reference's."""
+    if dtype != torch.float32:
+        sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     with torch.no_grad():
-        x = preprocess(imgs_u8_bgr, mean, std)
+        x = preprocess(imgs_u8_bgr, mean, std).to(dtype)
         feat = vit_forward(sd, x, num_heads)
         htm, prob, vis, oks, err = head_forward(sd, feat, normalize=normalize)
         if flip_test:
@@ -159,6 +163,7 @@ def predict(sd, imgs_u8_bgr: torch.Tensor, num_heads: int, mean, std, input_size
         else:
             heat = htm
     B, K, H, W = heat.shape
+    heat, prob, vis, oks, err, feat = (t.float() for t in (heat, prob, vis, oks, err, feat))
     heat_np = heat.numpy()
     kpts, conf = [], []
     for b in range(B):  # base_head.py:69-77: per-sample loop

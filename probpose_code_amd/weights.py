@@ -71,6 +71,44 @@ def weight_scale_exponent(w: torch.Tensor) -> int:
     return max(-40, min(40, 12 - math.floor(math.log2(m))))
 
 
+def balance_attention_dims(sd: Dict[str, torch.Tensor], prefix: str, heads: int) -> None:
+    """Exact re-parametrisation of one attention block for the split-fp16 format, in place: per head dimension d a power of two moves magnitude
+    between the q row and the k row (q_d k_d is what the logits see: q_d * 2^a and k_d * 2^-a leave every product unchanged) and between the v row
+    and the projection's column d (att_d = sum_t P_t v_td is linear in v_d). Chosen so that the two partners' largest weights agree to a factor
+    of two. Why: the format carries a VALUE to an absolute 2^-25 below 2^-3 (include/probpose_mi355x.h, numeric domain). A checkpoint whose q
+    dimension is 1000x smaller than the k dimension it meets computes the same logits in fp32, but its q activations sit in the split format's
+    subnormal band while they are multiplied with k values of the hundreds - measured (scripts/r06/trained_stats_ablation.py, weight rows down to
+    1e-3): features 2.6e-4 off, keypoints 1.6e-3 px, one argmax flip; balanced: the O(1) network's figures. mmpretrain MultiheadAttention [3P]:
+    qkv rows [q | k | v], each (heads, head_dim)."""
+    wq = sd[prefix + "attn.qkv.weight"]
+    E = wq.shape[1]
+    hd = E // heads
+    w = wq.detach().clone().double().reshape(3, heads, hd, E)
+    bq = sd.get(prefix + "attn.qkv.bias")
+    b = bq.detach().clone().double().reshape(3, heads, hd) if bq is not None else None
+    wp = sd[prefix + "attn.proj.weight"].detach().clone().double()  # (E, E): column h * hd + d multiplies att dim d of head h
+
+    def exps(n_small, n_big):
+        ok = (n_small > 0) & (n_big > 0)
+        a = torch.zeros_like(n_small)
+        a[ok] = torch.round(0.5 * torch.log2(n_big[ok] / n_small[ok]))
+        return a.clamp(-30, 30)
+
+    a_qk = exps(w[0].abs().amax(dim=-1), w[1].abs().amax(dim=-1))  # (heads, hd): q * 2^a, k * 2^-a
+    a_vp = exps(w[2].abs().amax(dim=-1), wp.abs().amax(dim=0).reshape(heads, hd))  # v * 2^a, proj column * 2^-a
+    w[0] *= (2.0 ** a_qk)[..., None]
+    w[1] *= (2.0 ** -a_qk)[..., None]
+    w[2] *= (2.0 ** a_vp)[..., None]
+    wp *= (2.0 ** -a_vp).reshape(1, E)
+    if b is not None:
+        b[0] *= 2.0 ** a_qk
+        b[1] *= 2.0 ** -a_qk
+        b[2] *= 2.0 ** a_vp
+        sd[prefix + "attn.qkv.bias"] = b.reshape(-1).to(bq.dtype)
+    sd[prefix + "attn.qkv.weight"] = w.reshape(3 * E, E).to(wq.dtype)
+    sd[prefix + "attn.proj.weight"] = wp.to(wq.dtype)
+
+
 def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, name: str = "folded weights", scale_exp: int = 0):
     """Linear(LayerNorm(x)) with the LayerNorm's affine part folded into the Linear layer, as pp_linear_ln_folded consumes it
     (include/probpose_mi355x.h): ``W'[n, k] = W[n, k] gamma[k] 2^scale_exp`` in the split-fp16 container, ``colsum[n] = sum_k W'[n, k]`` of the
@@ -158,11 +196,18 @@ def winograd_weights(w: torch.Tensor) -> torch.Tensor:
     return u.reshape(16, w.shape[0], w.shape[1]).float()
 
 
-def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = False, scale_linear: bool = True) -> PackedWeights:
+def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = False, scale_linear: bool = True,
+         num_heads: int = 0) -> PackedWeights:
     """``dtype``: operand dtype of the MFMA kernels (bf16 / fp32); ``split=True``: split-fp16 operands in a float32
     container (``to_split``); with it ``scale_linear``: the backbone's Linear weights (qkv, proj, fc1, fc2 and their LayerNorm-folded forms) are
-    stored times a power of two per tensor, ``PackedWeights.inv(name)`` is what the ``*_ws`` launches are handed (``weight_scale_exponent``)."""
+    stored times a power of two per tensor, ``PackedWeights.inv(name)`` is what the ``*_ws`` launches are handed (``weight_scale_exponent``), and
+    - given ``num_heads`` - every attention block's q / k and v / proj dimensions are balanced by exact powers of two (``balance_attention_dims``)."""
     sd = {k: v.detach().cpu() for k, v in normalize_state_dict(sd).items()}
+    if split and scale_linear and num_heads > 0:
+        n_layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("backbone.layers."))
+        for i in range(n_layers):
+            if sd[f"backbone.layers.{i}.attn.qkv.weight"].shape[1] % num_heads == 0:
+                balance_attention_dims(sd, f"backbone.layers.{i}.", num_heads)
     f32 = lambda x: x.float().contiguous().to(device)  # noqa: E731
     inv_scale: Dict[str, float] = {}
     if split:

@@ -82,7 +82,11 @@ def test_pack_refuses_weights_beyond_the_split_range():
 
 
 # ------------------------------------------------------------------------------------------------- GPU, end to end
-def _kp_check(out, ref, tag):
+def _kp_check(out, ref, tag, ref64=None):
+    if ref64 is not None:  # the yardstick: how far the fp32 reference itself, and this path, sit from the same network in double precision
+        kp = out["keypoints"].cpu().numpy()[:, None]
+        d_ours, d_ref = np.abs(kp - ref64["keypoints_input_space"]).max(-1), np.abs(ref["keypoints_input_space"] - ref64["keypoints_input_space"]).max(-1)
+        print(f"[trained-stats] {tag}: vs the fp64 network: this path {d_ours[d_ours < 2].max():.2e} px, the fp32 reference {d_ref[d_ref < 2].max():.2e} px")
     d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
     flips = int((d >= 2.0).sum())
     worst = float(d[d < 2.0].max())
@@ -108,11 +112,12 @@ def test_vit_s_bs64_trained_statistics_within_1e3(ln_fold):
     sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0, stats="trained")
     crops = S.synthetic_crops(64, seed=100)
     ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD)
+    ref64 = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD, dtype=torch.float64) if ln_fold else None
     eng = ProbPoseEngine(sd, 12, precision="f16x3", plan=dict(ln_fold=ln_fold))
     assert eng.ln_fold_fused == ln_fold and eng.fuse_qkv_attn
     out = eng.forward_graph(crops.cuda(), True, S.COCO_FLIP_INDICES)
     torch.cuda.synchronize()
-    _kp_check(out, ref, f"ViT-S bs64 ln_fold={ln_fold}")
+    _kp_check(out, ref, f"ViT-S bs64 ln_fold={ln_fold}", ref64)
 
 
 @gpu
