@@ -283,7 +283,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams 
                 for (int j = 0; j < 4; ++j) v[j] = __is_same(T, SplitH) ? gelu_erfc_as(v[j]) : gelu_erf(v[j]);
             } else if (p.act == ACT_RELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                for (int j = 0; j < 4; ++j) v[j] = __is_same(T, SplitH) ? relu_keep_nan(v[j]) : fmaxf(v[j], 0.f);
             }
             __builtin_amdgcn_sched_barrier(0);
             return v;

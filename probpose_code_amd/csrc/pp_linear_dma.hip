@@ -427,7 +427,7 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
                 for (int e = 0; e < 4; ++e) v[e] = gelu_erfc_as(v[e]);
             } else if (k_act == ACT_RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 4; ++e) v[e] = relu_keep_nan(v[e]);
             }
             const unsigned vrow = (unsigned)(row0 + i * 16) * (unsigned)ldo;
             const int so = (n >> 5) * 128 + (n & 16) * 2;  // split rows: the fragment's 16 hi halves inside their 32-element block (lo: + 64)

@@ -389,9 +389,9 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
                                     unsigned h_, l_;
-                                    split_pair(fmaxf(v0[2 * j], 0.f), fmaxf(v0[2 * j + 1], 0.f), h_, l_);
+                                    split_pair(relu_keep_nan(v0[2 * j]), relu_keep_nan(v0[2 * j + 1]), h_, l_);
                                     phu[j] = h_; plu[j] = l_;
-                                    split_pair(fmaxf(v1[2 * j], 0.f), fmaxf(v1[2 * j + 1], 0.f), h_, l_);
+                                    split_pair(relu_keep_nan(v1[2 * j]), relu_keep_nan(v1[2 * j + 1]), h_, l_);
                                     phu[2 + j] = h_; plu[2 + j] = l_;
                                 }
                                 ph = __builtin_bit_cast(f16x8, phu);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(const GemmParam
                         f32x4 v = acc[cf][rf] * p.w_inv + bv;  // (w_inv: power-of-two scale of a split-fp16 Linear layer's weights, 1 otherwise)
                         if (p.act == ACT_RELU) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                            for (int j = 0; j < 4; ++j) v[j] = SPLIT ? relu_keep_nan(v[j]) : fmaxf(v[j], 0.f);
                         } else if (p.act == ACT_GELU) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = SPLIT ? gelu_erfc_as(v[j]) : gelu_erf_exact(v[j]);

@@ -121,6 +121,15 @@ __device__ __forceinline__ split_f32x4 split_mma(const f16x8& ah, const f16x8& a
     return c;
 }
 
+// ReLU that keeps a NaN: v_max_f32 returns the OTHER operand for a NaN input (IEEE maxNum), so fmaxf(x, 0) turns the NaN an out-of-range
+// split-fp16 operand produces upstream (include/probpose_mi355x.h, numeric domain) into a clean 0 - and the heatmap branch would decode a map of
+// biases to "pixel 0" with a plausible score. The heatmap branch's ReLUs use this form: the NaN reaches the logits, pp_probmap_decode_flags writes
+// NaN keypoints, the host mirror raises. Two instructions more per value, in epilogues only.
+__device__ __forceinline__ float relu_keep_nan(float x) {
+    const float r = fmaxf(x, 0.f);
+    return x != x ? x : r;
+}
+
 // GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) for the parity mode's epilogues. libdevice erff costs ~57 VALU instructions per
 // element - 55 us of a 166 us fc1 launch at bs 64 (scripts/bench_split_gemm.py). This form is Abramowitz & Stegun 7.1.26,
 //     erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p z),  z >= 0,  |error| <= 1.5e-7,

@@ -811,7 +811,7 @@ def test_ffn_dma_waves_form_vs_fp64_and_weight_scales(M, F_, pair):
         L.call("pp_ffn_split_residual_layernorm_ws", hd.data_ptr(), packed_s.data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), xd.data_ptr(),
                xd.data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(), 1e-6, hd.data_ptr(), M, E, F_, 2.0 ** -17, 2.0 ** -16, None)
         torch.testing.assert_close(xd.cpu().double(), x_ref, **TOL)
-        torch.testing.assert_close(xd.cpu(), want_f[0], rtol=3e-6, atol=3e-6)
+        torch.testing.assert_close(xd.cpu(), want_f[0], rtol=1e-5, atol=1e-5)
         assert (xd.cpu().double() - x_ref).abs().max() <= (want_f[0].double() - x_ref).abs().max() * 1.5 + 1e-7
         ad, xd = _sp(att), r.cuda()
         scratch = torch.full((M, E), float("nan"), device="cuda")
@@ -820,7 +820,7 @@ def test_ffn_dma_waves_form_vs_fp64_and_weight_scales(M, F_, pair):
                xd.data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(), 1e-6, ad.data_ptr(), M, E, F_, 2.0 ** -15, 2.0 ** -17, 2.0 ** -16, None)
         torch.testing.assert_close(xd.cpu().double(), xp_ref, rtol=3e-5, atol=3e-5)
         torch.testing.assert_close(_unsp(ad), hp_ref, rtol=3e-5, atol=3e-5)
-        torch.testing.assert_close(xd.cpu(), want_p[0], rtol=5e-6, atol=5e-6)
+        torch.testing.assert_close(xd.cpu(), want_p[0], rtol=1e-5, atol=1e-5)
         for _ in range(3):
             assert same([t.cpu() for t in ffn()], want_f), "FFN form: run-to-run difference"
             assert same([t.cpu() for t in proj()], want_p), "projection + FFN form: run-to-run difference"
@@ -1084,7 +1084,7 @@ def test_proj_ffn_split_folded_vs_plain_launch(M):
     _, h2, st2 = folded(rq, F32, True)
     ref_stats = torch.stack([want_x.double().mean(dim=1), 1.0 / torch.sqrt(want_x.double().var(dim=1, unbiased=False) + eps)], dim=1)
     torch.testing.assert_close(st2.double(), ref_stats, rtol=2e-5, atol=2e-5)
-    torch.testing.assert_close(_unsp(h2) + st2[:, :1].double(), want_x.double(), rtol=5e-7, atol=5e-7)
+    torch.testing.assert_close(_unsp(h2) + st2[:, :1].double(), want_x.double(), rtol=1e-6, atol=1e-6)  # (x - mean rounds once more than x)
     assert _unsp(h2).mean(dim=1).abs().max() < 1e-5, "the rows that leave must be centered"
     # 3: both, in place (the layers in between): the residual buffer becomes the new rows, the statistics buffer the new statistics
     rs3, rst3 = rs.clone(), rst.clone()
