@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 /* 4 (round 6): the numeric domain of PP_PREC_F16X3 stated and guarded (below); power-of-two WEIGHT SCALES: + pp_gemm_ws, pp_linear_ln_folded_ws,
- *    pp_qkv_attention_split_ws, pp_ffn_split_residual_layernorm_ws, pp_proj_ffn_split_residual_layernorm_ws (the unsuffixed entry points = scale 1);
+ *    pp_qkv_attention_split_ws, pp_gemm_residual_layernorm_ws, pp_ffn_split_residual_layernorm_ws, pp_proj_ffn_split_residual_layernorm_ws (the unsuffixed entry points = scale 1);
  *    CHANGED signatures: pp_qkv_attention_split_folded (centered rows, no column sums, + w_inv_scale), pp_proj_ffn_split_folded (+ residual_stats,
  *    + three weight scales; the rows it leaves are centered); pp_probmap_decode_flags writes NaN results for a map with a non-finite logit;
  *    + pp_skinny_* (the launch plan of small batches); REMOVED: the eight-wave feed-forward kernel and the overlapped-epilogue Linear kernel with
@@ -294,6 +294,11 @@ int pp_gemm_residual_layernorm(int prec, const void* act, const void* weight, co
                                const float* residual, int res_mod, float* x_out, const float* gamma,
                                const float* beta, float eps, void* h_out, int h_bf16, int M, int N, int K,
                                int lda, int ldw, void* stream);
+/* ... with the PP_PREC_F16X3 weights stored as W * 2^e: w_inv_scale = 2^-e (residual + bias enter the accumulators times 2^e, exact). */
+int pp_gemm_residual_layernorm_ws(int prec, const void* act, const void* weight, const float* bias,
+                               const float* residual, int res_mod, float* x_out, const float* gamma,
+                               const float* beta, float eps, void* h_out, int h_bf16, int M, int N, int K,
+                               int lda, int ldw, float w_inv_scale, void* stream);
 
 /* Whole feed-forward block of a ViT layer fused with the LayerNorm that follows it (bf16 operands):
  *   x_out = residual + GELU(h_in W1^T + b1) W2^T + b2 ;  h_out = LayerNorm(x_out; gamma, beta, eps)

@@ -92,6 +92,10 @@ SIGNATURES = {
         c_int,
         [c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     ),
+    "pp_gemm_residual_layernorm_ws": (
+        c_int,
+        [c_int, _P, _P, _P, _P, c_int, _P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
+    ),
     "pp_mlp_residual_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, _P]),
     "pp_proj_mlp_residual_layernorm": (
         c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -72,6 +72,7 @@ struct Params {
     int M, K, lda, ldw, res_mod, h_bf16;
     unsigned a_bytes, w_bytes;
     float eps;
+    float w_s = 1.0f, w_inv = 1.0f;  // split-fp16 weights stored as w * w_s (a power of two): residual + bias enter the accumulators times w_s, the sums leave times w_inv
 };
 
 template <typename T>
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_res_ln_kernel(const 
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + n);
                 if (p.residual && valid(rf)) v += *reinterpret_cast<const f32x4*>(p.residual + rrow + n);
-                acc[h][rf][nf] = v;
+                acc[h][rf][nf] = v * p.w_s;
             }
     }
     __syncthreads();
@@ -238,6 +239,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_res_ln_kernel(const 
     }
 
     // ---- epilogue: row statistics straight from the accumulators; a row's BN values sit in 4 lane groups x CW waves (x NH halves)
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int rf = 0; rf < RFW; ++rf)
+#pragma unroll
+            for (int nf = 0; nf < NFW; ++nf) acc[h][rf][nf] *= p.w_inv;  // (the products carried the weights' power-of-two scale: exact)
     float* stat = reinterpret_cast<float*>(smem + 2 * STAGE);  // [2 passes][CW column groups][BM rows]
     float mean[RFW], rstd[RFW];
 #pragma unroll
@@ -328,7 +335,22 @@ extern "C" int pp_gemm_residual_layernorm(int prec, const void* act, const void*
                                           const float* residual, int res_mod, float* x_out, const float* gamma,
                                           const float* beta, float eps, void* h_out, int h_bf16, int M, int N, int K,
                                           int lda, int ldw, void* stream) {
+    return pp_gemm_residual_layernorm_ws(prec, act, weight, bias, residual, res_mod, x_out, gamma, beta, eps, h_out, h_bf16, M, N, K, lda, ldw, 1.0f,
+                                         stream);
+}
+
+extern "C" int pp_gemm_residual_layernorm_ws(int prec, const void* act, const void* weight, const float* bias,
+                                             const float* residual, int res_mod, float* x_out, const float* gamma,
+                                             const float* beta, float eps, void* h_out, int h_bf16, int M, int N, int K,
+                                             int lda, int ldw, float w_inv_scale, void* stream) {
     using namespace pp;
+    {
+        unsigned u;
+        __builtin_memcpy(&u, &w_inv_scale, 4);
+        PP_REQUIRE((u >> 31) == 0 && (u & 0x007fffffu) == 0 && ((u >> 23) & 0xffu) >= 127 - 40 && ((u >> 23) & 0xffu) <= 127 + 40, PP_ERR_INVALID_ARG,
+                   "pp_gemm_residual_layernorm: the weight scale must be a power of two in [2^-40, 2^40]");
+        PP_REQUIRE(w_inv_scale == 1.0f || prec == PP_PREC_F16X3, PP_ERR_INVALID_ARG, "pp_gemm_residual_layernorm: weight scales belong to the split-fp16 mode");
+    }
     PP_REQUIRE(act && weight && x_out && gamma && beta && h_out, PP_ERR_INVALID_ARG,
                "pp_gemm_residual_layernorm: NULL argument");
     PP_REQUIRE(N == rl::C384::BN || N == rl::C768::BN, PP_ERR_UNSUPPORTED,
@@ -351,6 +373,7 @@ extern "C" int pp_gemm_residual_layernorm(int prec, const void* act, const void*
     p.A = act; p.W = weight; p.bias = bias; p.residual = residual; p.x_out = x_out; p.h_out = h_out;
     p.gamma = gamma; p.beta = beta; p.M = M; p.K = K; p.lda = lda; p.ldw = ldw; p.res_mod = res_mod;
     p.h_bf16 = h_bf16; p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.eps = eps;
+    p.w_inv = w_inv_scale; p.w_s = 1.0f / w_inv_scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool wide = N == rl::C768::BN;
     if (prec == PP_PREC_BF16) return wide ? rl::launch<__bf16, rl::C768>(p, s) : rl::launch<__bf16, rl::C384>(p, s);

@@ -329,14 +329,12 @@ class ProbPoseEngine:
         L = w.num_layers
 
         def res_ln(a, wk, bk, K, gamma, beta, h_out, residual=None, res_mod=0, winv=1.0):
-            """x <- residual + a @ wk^T + bk ; h_out <- LN(x). (A weight tensor stored with a scale - winv != 1 - takes the two-launch route: the
-            row-owner kernel of pp_gemm_ln.hip starts its accumulators from residual + bias and knows no scale; only launch plans with a fusion
-            switched off get here with one.)"""
+            """x <- residual + a @ wk^T + bk ; h_out <- LN(x). ``winv``: the weight tensor's inverse power-of-two scale."""
             residual = ws["x"] if residual is None else residual
-            if fused and winv == 1.0:
-                self._call("gemm_res_ln", "pp_gemm_residual_layernorm", self.prec, a.data_ptr(), wk.data_ptr(),
+            if fused:
+                self._call("gemm_res_ln", "pp_gemm_residual_layernorm_ws", self.prec, a.data_ptr(), wk.data_ptr(),
                            bk.data_ptr(), residual.data_ptr(), res_mod, ws["x"].data_ptr(), gamma.data_ptr(),
-                           beta.data_ptr(), self.ln_eps, h_out.data_ptr(), ob, M, E, K, K, K, st)
+                           beta.data_ptr(), self.ln_eps, h_out.data_ptr(), ob, M, E, K, K, K, float(winv), st)
             else:
                 self._gemm(st, a, wk, bk, ws["x"], M, E, K, residual=residual, res_mod=res_mod, out_bf16=0, winv=winv)
                 self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), gamma.data_ptr(), beta.data_ptr(),

@@ -102,6 +102,8 @@ def _real_flips(out, ref, d, tie=2e-6):
         if conv.max() - near <= tie * conv.max():
             print(f"[trained-stats] near-tie in the reference at crop {b} keypoint {k}: its map holds {near:.9g} where this path peaks, {conv.max():.9g} at its own argmax")
         else:
+            print(f"[trained-stats] FLIP at crop {b} keypoint {k}: the reference's map holds {near:.9g} where this path peaks, {conv.max():.9g} at its own argmax "
+                  f"(relative margin {(conv.max() - near) / conv.max():.2e})")
             flips += 1
     return flips
 
