@@ -32,7 +32,7 @@ extern "C" {
  *    pp_qkv_attention_split_ws, pp_gemm_residual_layernorm_ws, pp_ffn_split_residual_layernorm_ws, pp_proj_ffn_split_residual_layernorm_ws (the unsuffixed entry points = scale 1);
  *    CHANGED signatures: pp_qkv_attention_split_folded (centered rows, no column sums, + w_inv_scale), pp_proj_ffn_split_folded (+ residual_stats,
  *    + three weight scales; the rows it leaves are centered); pp_probmap_decode_flags writes NaN results for a map with a non-finite logit;
- *    + pp_skinny_* (the launch plan of small batches); REMOVED: the eight-wave feed-forward kernel and the overlapped-epilogue Linear kernel with
+ *    + pp_skinny_linear / pp_skinny_linear_tile (the launch plan of small batches); REMOVED: the eight-wave feed-forward kernel and the overlapped-epilogue Linear kernel with
  *    their options "ffn_dma_waves" / "linear_ovl".
  * 3: + pp_launch_count / pp_reset_launch_counts (diagnostics: which kernels a launch plan really ran); pp_linear_ln_folded, the *_folded launches
  *    and PP_WS_LN_STATS (round 5).
@@ -281,6 +281,25 @@ int pp_linear_ln_folded_ws(const void* act, const void* weight, const float* bia
                            void* out, int out_format, int M, int N, int K, int act_fn, const float* ln_stats,
                            const float* ln_colsum, float ln_eps, float* stats_out, float w_inv_scale, void* stream);
 int pp_linear_ln_folded_supported(int M, int N, int K, int with_ln_stats);
+
+/* Dense layer of a SMALL batch (PP_PREC_F16X3), column-parallel: the launch plan of the one-image / few-person callers
+ * (mmpose/apis/inference.py:161-196: one batch per image, B = number of boxes; demo/image_demo.py:36-61: one crop;
+ * demo/topdown_demo_with_mmdet.py:35-41), where the layer kernels of the headline plan - 96 complete rows per workgroup, the layer's whole weight
+ * set streamed through each - would run 4 workgroups on 256 CUs:
+ *   out[m, n] = act_fn((sum_k act[m, k] weight[n, k]) * w_inv_scale + bias[n]) + residual[r(m), n]
+ *   ln_out[m, :] = LayerNorm(out[m, :]; ln_gamma, ln_beta, ln_eps)                       when ln_out != NULL
+ * act (M, K), weight (N, K) PP_OUT_SPLIT; bias fp32 or NULL; residual fp32 (M, N) - it may be `out` (fp32), the residual stream updated in place -
+ * or a (res_mod, N) table (r(m) = m % res_mod: pos_embed) or NULL; out fp32 or PP_OUT_SPLIT. Tiles of 96 x 96, 64 x 64 or 32 x 32 outputs, the
+ * largest that still gives every CU a workgroup (pp_skinny_linear_tile returns the edge). N % 32 == 0, K % 64 == 0.
+ * The LayerNorm tail needs no second launch and no grid barrier: the workgroup that stores the LAST tile of a row block (a counter per block in
+ * ln_counters: ceil(M / 32) int32, zero before the first launch, left at zero) normalises the block's rows - out must be fp32 then, N <= 1024, and
+ * ln_out (M, N) PP_OUT_SPLIT distinct from out and act. The result does not depend on which workgroup arrives last.
+ * Stands in for attn.proj / ffn.layers.0.0 / ffn.layers.1 of mmpretrain's TransformerEncoderLayer [3P] and the patch-embed projection (call site
+ * mmpose/models/pose_estimators/base.py:206) at small M. */
+int pp_skinny_linear(const void* act, const void* weight, const float* bias, const float* residual, int res_mod, void* out, int out_format,
+                     int M, int N, int K, int act_fn, float w_inv_scale, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                     void* ln_out, int* ln_counters, void* stream);
+int pp_skinny_linear_tile(int M, int N);
 
 /* Residual dense layer fused with the LayerNorm that follows it in the ViT block
  * (mmpretrain TransformerEncoderLayer [3P]: x = x + attn(ln1(x)); x = ffn(ln2(x)) + x; final ln1):

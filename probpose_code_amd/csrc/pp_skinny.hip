@@ -1,0 +1,304 @@
+// Linear layers of SMALL batches in the parity precision (PP_PREC_F16X3), column-parallel:
+//     out[m, n] = act_fn((sum_k a[m, k] w[n, k]) * w_inv + bias[n]) + residual[r(m), n]      [ ; h[m, :] = LayerNorm(out[m, :]) ]
+// (the nn.Linear layers of mmpretrain's TransformerEncoderLayer [3P] - attn.proj, ffn.layers.0.0, ffn.layers.1 - and the patch-embed projection;
+// call site mmpose/models/pose_estimators/base.py:206, reached from the one-image / few-person callers mmpose/apis/inference.py:161-196,
+// demo/image_demo.py:36-61, demo/topdown_demo_with_mmdet.py:35-41).
+//
+// Why another GEMM. The layer kernels of the headline plan (pp_qkv_attn_split.hip, pp_ffn_dma.hip) give a workgroup 96 COMPLETE token rows and
+// stream the layer's whole weight set through it: right at bs 64 (256 workgroups), wrong for one crop - 384 rows are 4 workgroups on 256 CUs, each
+// pulling 4.6 MB of weights through one CU: 131 us per layer launch whatever the batch (scripts/r06/small_batch_profile.py: 2.06 ms per step at
+// B = 1, 76 % of it in that launch). Here the OUTPUT is cut in both directions - 32 x 32, 64 x 64 or 96 x 96 tiles, picked so that the chip has at
+// least a workgroup per CU - and every CU streams 1 / (N / BN) of the weights.
+//
+//   * 256 threads = 4 waves as 2 (rows) x 2 (columns); a wave owns RT x CT MFMA tiles of 16 x 16 (v_mfma_f32_16x16x32_f16, three per product:
+//     lo hi + hi lo + hi hi, pp_split.h); the weight fragment is the MFMA's A operand, so a lane ends with 4 consecutive columns of one row;
+//   * K in stages of 64 elements (two 128-byte blocks per row) on a ring of three LDS stages filled by LDS-DMA (`buffer_load ... lds`, 16 bytes per
+//     lane, source chunk XOR-swizzled by the row so that fragment reads are conflict-free); rows past M read as zeros (buffer bounds);
+//   * epilogue in registers: * w_inv (the weights' power-of-two scale), + bias, GELU (A & S 7.1.26 as everywhere in this mode), + fp32 residual
+//     (optionally a table broadcast over the batch: pos_embed), fp32 or split-fp16 rows out;
+//   * OPTIONAL LayerNorm tail without a second launch and without a grid barrier: every workgroup counts itself in on its row block's counter when
+//     its tile is stored; the one that arrives LAST (it waits for nobody) re-reads the block's complete fp32 rows from L2, normalises them and
+//     writes the operand-format rows for the next layer, then puts the counter back to zero. The result does not depend on who arrives last.
+//     A launch costs ~2.7 us of dependency gap in a replayed graph: per layer this saves two of six.
+#include "pp_common.h"
+#include "pp_split.h"
+
+namespace pp {
+namespace sk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int THREADS = 256, KS = 2, NST = 3;  // k-blocks (of 32 elements) per stage, stages in the ring
+constexpr int ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2;
+
+struct Params {
+    const char* a;          // [M, K] split rows
+    const char* w;          // [N, K] split rows (stored times 2^e)
+    const float* bias;      // [N] or NULL
+    const float* residual;  // fp32 [M, N] (may be `out`) or [res_mod, N], or NULL
+    char* out;              // [M, N]: fp32 or split rows
+    int M, N, K, res_mod, act, out_split;
+    unsigned a_bytes, w_bytes;
+    float w_inv;
+    // LayerNorm tail (out is fp32 then)
+    const float* gamma;
+    const float* beta;
+    char* h_out;            // [M, N] split rows
+    float eps;
+    int* counters;          // one per row block, zero on entry, zero on exit
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+template <int RT, int CT, bool LN>
+__global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) {
+    constexpr int BM = 32 * RT, BN = 32 * CT, ROWS = BM + BN;
+    constexpr int STAGE = KS * ROWS * 128;
+    constexpr int NI = KS * ROWS / 8, NIW = NI / 4;  // DMA instructions per stage (8 rows of one k-block each), per wave
+    static_assert(NI % 4 == 0, "DMA instructions must divide over the four waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int f_row = lane & 15, f_kg = lane >> 4;
+    const int ntn = p.N / BN;
+    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nsteps = p.K / (32 * KS);
+
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w), 0, p.w_bytes, 0x00020000);
+    // a DMA instruction moves 8 rows x 128 B: lane (row l = lane >> 3, physical chunk lane & 7) fetches logical chunk (lane & 7) ^ l
+    const unsigned d_row = (unsigned)lane >> 3;
+    const unsigned d_src = d_row * (unsigned)(p.K * 4) + ((((unsigned)lane & 7u) ^ d_row) << 4);
+    auto issue = [&](int s) {
+        if (s >= nsteps) return;
+        char* dst = smem + (s % NST) * STAGE;
+#pragma unroll
+        for (int u = 0; u < NIW; ++u) {
+            const int j = wave + 4 * u;               // (wave-uniform)
+            const int kb = j / (ROWS / 8), r8 = j - kb * (ROWS / 8);
+            const int r = r8 * 8;                     // first of the eight rows: < BN weight rows, then activation rows
+            const unsigned koff = (unsigned)((s * KS + kb) * 128);
+            // (the row part of the address goes into the VGPR offset: the descriptor's range check covers that one, not the scalar offset - rows
+            //  past M must fall outside the tensor's extent to read as zeros)
+            if (r < BN)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + (kb * ROWS + r) * 128), 16, d_src + (unsigned)((n0 + r) * p.K * 4), koff, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dst + (kb * ROWS + r) * 128), 16, d_src + (unsigned)((m0 + r - BN) * p.K * 4), koff, 0,
+                                                         0);
+        }
+    };
+
+    f32x4 acc[CT][RT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    issue(1);
+    const int sw = f_row & 7;
+    const int off_hi = f_row * 128 + ((f_kg ^ sw) << 4), off_lo = f_row * 128 + (((4 + f_kg) ^ sw) << 4);
+    for (int s = 0; s < nsteps; ++s) {
+        // stage s has landed once at most the stage behind it is outstanding (past the last stages nothing is)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nsteps) wait_vm<NIW>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(s + 2);  // into the slot every wave finished reading before this barrier
+        const char* st = smem + (s % NST) * STAGE;
+#pragma unroll
+        for (int kb = 0; kb < KS; ++kb) {
+            const char* wb = st + (kb * ROWS + wn * 16 * CT) * 128;
+            const char* ab = st + (kb * ROWS + BN + wm * 16 * RT) * 128;
+            u32x4 wh[CT], wl[CT], ah[RT], al[RT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                wh[c] = *reinterpret_cast<const u32x4*>(wb + c * 2048 + off_hi);
+                wl[c] = *reinterpret_cast<const u32x4*>(wb + c * 2048 + off_lo);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                ah[r] = *reinterpret_cast<const u32x4*>(ab + r * 2048 + off_hi);
+                al[r] = *reinterpret_cast<const u32x4*>(ab + r * 2048 + off_lo);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    f32x4 v = acc[c][r];
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl[c]), __builtin_bit_cast(f16x8, ah[r]), v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[c]), __builtin_bit_cast(f16x8, al[r]), v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[c]), __builtin_bit_cast(f16x8, ah[r]), v, 0, 0, 0);
+                    acc[c][r] = v;
+                }
+        }
+    }
+
+    // ---- epilogue: lane (f_row, f_kg) of tile (c, r) holds row m0 + 16 (RT wm + r) + f_row, columns n0 + 16 (CT wn + c) + 4 f_kg + (0..3)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int n = n0 + 16 * (CT * wn + c) + 4 * f_kg;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int m = m0 + 16 * (RT * wm + r) + f_row;
+            const bool live = m < p.M;
+            f32x4 v = acc[c][r] * p.w_inv + bv;
+            if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erfc_as(v[e]);
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = relu_keep_nan(v[e]);
+            }
+            if (p.residual && live) {
+                const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+                v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)mr * p.N + n);
+            }
+            const size_t idx = (size_t)m * p.N + n;
+            if (p.out_split) split_store4_rowpair(p.out, idx, v, live);  // (every lane calls it: row swaps inside)
+            else if (live) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + idx) = v;
+        }
+    }
+
+    if constexpr (LN) {
+        // ---- LayerNorm tail: the workgroup that completes the row block normalises it
+        __shared__ int s_last;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's rows are visible device-wide before the count
+        __syncthreads();
+        if (tid == 0) {
+            const int seen = __hip_atomic_fetch_add(p.counters + mt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = seen == ntn - 1;
+            if (seen == ntn - 1) __hip_atomic_store(p.counters + mt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (everybody of this block has counted)
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' tiles: from L2, not from a stale L1 line
+        const float* x = reinterpret_cast<const float*>(p.out);
+        const float inv_n = 1.0f / (float)p.N;
+        for (int r = wave; r < BM; r += 4) {  // a wave per row
+            const int m = m0 + r;
+            if (m >= p.M) break;
+            const float* row = x + (size_t)m * p.N;
+            f32x4 v[4];  // N <= 1024
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = i * 256 + lane * 4;
+                v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (col < p.N) {
+                    v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + col));
+                    sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * inv_n;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i * 256 + lane * 4 < p.N) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[i][e] - mean;
+                        q = __builtin_fmaf(d, d, q);
+                    }
+                }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+            const float rstd = 1.0f / sqrtf(q * inv_n + p.eps);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = i * 256 + lane * 4;
+                if (col < p.N) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + col), b = *reinterpret_cast<const f32x4*>(p.beta + col);
+                    f32x4 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+                    split_store4(p.h_out, (size_t)m * p.N + col, hv);
+                }
+            }
+        }
+    }
+}
+
+// tile edge (32 RT = 32 CT) for a problem: the largest of 96 / 64 / 32 that still gives the chip a workgroup per CU; 32 when none does
+static int pick_tile(int M, int N, int cus) {
+    for (int t = 3; t >= 2; --t) {
+        const int b = 32 * t;
+        if (N % b == 0 && (long long)((M + b - 1) / b) * (N / b) >= cus) return t;
+    }
+    return 1;
+}
+
+}  // namespace sk
+}  // namespace pp
+
+extern "C" int pp_skinny_linear_tile(int M, int N) {
+    if (M <= 0 || N <= 0 || N % 32 != 0) return 0;
+    static int cus = 0;
+    if (!cus) cus = pp_device_cu_count() > 0 ? pp_device_cu_count() : 256;
+    return 32 * pp::sk::pick_tile(M, N, cus);
+}
+
+extern "C" int pp_skinny_linear(const void* act, const void* weight, const float* bias, const float* residual, int res_mod, void* out,
+                                int out_format, int M, int N, int K, int act_fn, float w_inv_scale, const float* ln_gamma, const float* ln_beta,
+                                float ln_eps, void* ln_out, int* ln_counters, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(act && weight && out, PP_ERR_INVALID_ARG, "pp_skinny_linear: act, weight and out must be non-NULL");
+    PP_REQUIRE(M > 0 && N > 0 && K > 0, PP_ERR_INVALID_ARG, "pp_skinny_linear: M, N and K must be positive");
+    PP_REQUIRE(N % 32 == 0 && K % 64 == 0, PP_ERR_UNSUPPORTED, "pp_skinny_linear: needs N % 32 == 0 and K % 64 == 0");
+    PP_REQUIRE(out_format == PP_OUT_F32 || out_format == PP_OUT_SPLIT, PP_ERR_INVALID_ARG, "pp_skinny_linear: out_format is PP_OUT_F32 or PP_OUT_SPLIT");
+    PP_REQUIRE(act_fn == sk::ACT_NONE || act_fn == sk::ACT_GELU || act_fn == sk::ACT_RELU, PP_ERR_INVALID_ARG, "pp_skinny_linear: unknown act_fn");
+    PP_REQUIRE(act != out, PP_ERR_INVALID_ARG, "pp_skinny_linear: act must not alias out (other column tiles still read the rows)");
+    PP_REQUIRE(res_mod >= 0 && (!residual || out_format == PP_OUT_F32 || residual != out), PP_ERR_INVALID_ARG, "pp_skinny_linear: bad residual arguments");
+    PP_REQUIRE((size_t)M * K * 4 < 0x7ffffff0u && (size_t)N * K * 4 < 0x7ffffff0u && (size_t)M * N * 4 < 0x7ffffff0u, PP_ERR_UNSUPPORTED,
+               "pp_skinny_linear: operands must be smaller than 2 GiB");
+    {
+        unsigned u;
+        __builtin_memcpy(&u, &w_inv_scale, 4);
+        PP_REQUIRE((u >> 31) == 0 && (u & 0x007fffffu) == 0 && ((u >> 23) & 0xffu) >= 127 - 40 && ((u >> 23) & 0xffu) <= 127 + 40, PP_ERR_INVALID_ARG,
+                   "pp_skinny_linear: the weight scale must be a power of two in [2^-40, 2^40]");
+    }
+    const bool ln = ln_out != nullptr;
+    if (ln) {
+        PP_REQUIRE(ln_gamma && ln_beta && ln_counters, PP_ERR_INVALID_ARG, "pp_skinny_linear: the LayerNorm tail needs gamma, beta and the counters");
+        PP_REQUIRE(out_format == PP_OUT_F32 && N % 4 == 0 && N <= 1024, PP_ERR_UNSUPPORTED,
+                   "pp_skinny_linear: the LayerNorm tail normalises fp32 output rows of at most 1024 columns");
+        PP_REQUIRE(ln_out != out && ln_out != act, PP_ERR_INVALID_ARG, "pp_skinny_linear: ln_out must not alias out or act");
+    }
+    sk::Params p{};
+    p.a = reinterpret_cast<const char*>(act);
+    p.w = reinterpret_cast<const char*>(weight);
+    p.bias = bias;
+    p.residual = residual;
+    p.out = reinterpret_cast<char*>(out);
+    p.M = M; p.N = N; p.K = K;
+    p.res_mod = res_mod;
+    p.act = act_fn;
+    p.out_split = out_format == PP_OUT_SPLIT;
+    p.a_bytes = (unsigned)((size_t)M * K * 4);
+    p.w_bytes = (unsigned)((size_t)N * K * 4);
+    p.w_inv = w_inv_scale;
+    p.gamma = ln_gamma; p.beta = ln_beta; p.h_out = reinterpret_cast<char*>(ln_out); p.eps = ln_eps; p.counters = ln_counters;
+    const int t = pp_skinny_linear_tile(M, N) / 32;
+    const int b = 32 * t;
+    const int grid = ((M + b - 1) / b) * (N / b);
+    const size_t lds = (size_t)sk::NST * sk::KS * (2 * b) * 128;
+    void (*kern)(const sk::Params) = nullptr;
+    if (t == 3) kern = ln ? sk::skinny_linear_kernel<3, 3, true> : sk::skinny_linear_kernel<3, 3, false>;
+    else if (t == 2) kern = ln ? sk::skinny_linear_kernel<2, 2, true> : sk::skinny_linear_kernel<2, 2, false>;
+    else kern = ln ? sk::skinny_linear_kernel<1, 1, true> : sk::skinny_linear_kernel<1, 1, false>;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(sk::THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);
+    PP_LAUNCH_CHECK();
+    return PP_OK;
+}

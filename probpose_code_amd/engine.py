@@ -37,7 +37,11 @@ CONV3X3, DECONV = 1, 2
 
 # launch-plan switches and their shipped values (fuse_resln: None = on for E = 384 only, True = also the E = 768 row-owner kernel)
 PLAN_DEFAULTS = dict(fuse_mlp=True, fuse_proj=True, fuse_qkv=True, split_k=True, fuse_attn=True, fuse_head=True, fuse_resln=None,
-                     fuse_pool=True, fuse_qkv_attn=True, winograd=True, ln_fold=True)
+                     fuse_pool=True, fuse_qkv_attn=True, winograd=True, ln_fold=True, small_plan=True)
+# f16x3: batches with fewer token rows than this (B * passes * tokens) take the column-parallel plan of small batches (pp_skinny_linear): below it the
+# row-owner layer kernels leave most of the chip idle (96 rows per workgroup: 12 288 rows = 128 workgroups on 256 CUs); measured crossover:
+# scripts/r06/small_batch_profile.py
+SMALL_PLAN_ROWS_BELOW = 12288
 
 
 def plan_from_env() -> Dict[str, object]:
@@ -62,6 +66,16 @@ class ProbPoseEngine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("ProbPoseEngine runs on the MI355X only; there is no CPU fallback")
+        # Launch-plan switches: every fusion below is on in the shipped plan; `plan` (constructor argument) turns single ones off
+        # for A/B timing and for the tests of the unfused kernels, PP_FUSE_* environment variables do the same from outside a
+        # script (read HERE, in the host-side mirror - the C library reads no environment, include/probpose_mi355x.h).
+        pl = dict(PLAN_DEFAULTS)
+        pl.update(plan_from_env())
+        pl.update(plan or {})
+        unknown = set(pl) - set(PLAN_DEFAULTS)
+        if unknown:
+            raise ValueError(f"unknown launch-plan switch(es) {sorted(unknown)}; known: {sorted(PLAN_DEFAULTS)}")
+        self.plan = pl
         self.precision = precision
         self.prec = PREC[precision]
         self.dtype = _DTYPE[precision]
@@ -97,17 +111,10 @@ class ProbPoseEngine:
         self._graph_tick: Dict[tuple, int] = {}
         self.graph_captures = 0  # captures so far (diagnostics; tests assert it stays bounded when more sizes recur than graphs are kept)
         self._opt_epoch = _lib.option_epoch()
-        # Launch-plan switches: every fusion below is on in the shipped plan; `plan` (constructor argument) turns single ones off
-        # for A/B timing and for the tests of the unfused kernels, PP_FUSE_* environment variables do the same from outside a
-        # script (read HERE, in the host-side mirror - the C library reads no environment, include/probpose_mi355x.h).
-        pl = dict(PLAN_DEFAULTS)
-        pl.update(plan_from_env())
-        pl.update(plan or {})
-        unknown = set(pl) - set(PLAN_DEFAULTS)
-        if unknown:
-            raise ValueError(f"unknown launch-plan switch(es) {sorted(unknown)}; known: {sorted(PLAN_DEFAULTS)}")
-        self.plan = pl
         self.fuse_mlp, self.fuse_proj, self.fuse_qkv, self.split_k = pl["fuse_mlp"], pl["fuse_proj"], pl["fuse_qkv"], pl["split_k"]
+        # f16x3: the column-parallel plan of small batches (pp_skinny_linear, _layers_small); small_rows_below: the row count it ends at
+        self.small_plan = bool(precision == "f16x3" and pl["small_plan"])
+        self.small_rows_below = SMALL_PLAN_ROWS_BELOW
         # attention inside the bf16 layer kernel (pp_vit_layer, one launch per layer; 192-token sequences, head dim 32): about 2 %
         # faster per step than pp_attention + the fused rest since the residual rows load under its attention phase
         self.fuse_attn, self.fuse_head, self.fuse_pool = pl["fuse_attn"], pl["fuse_head"], pl["fuse_pool"]
@@ -138,10 +145,12 @@ class ProbPoseEngine:
                                   _lib.stream_ptr(self.device))
                         self._proj_packed[i] = pbuf
                 torch.cuda.synchronize(self.device)
-            # the fused launches read only the packed copies: release the plain ones (55 MiB at ViT-S)
-            for i in range(self.w.num_layers):
-                for name in (f"l{i}.fc1.w", f"l{i}.fc2.w") + ((f"l{i}.proj.w",) if i in self._proj_packed else ()):
-                    self.w.t.pop(name, None)
+            # the fused launches read only the packed copies: release the plain ones (55 MiB at ViT-S) - unless the plan of small batches
+            # (pp_skinny_linear: column-parallel Linear layers on the plain tensors) is on
+            if not (pl["small_plan"]):
+                for i in range(self.w.num_layers):
+                    for name in (f"l{i}.fc1.w", f"l{i}.fc2.w") + ((f"l{i}.proj.w",) if i in self._proj_packed else ()):
+                        self.w.t.pop(name, None)
         # f16x3, 192-token sequences of 32-dim heads: qkv Linear + attention of a layer in one launch, one workgroup per
         # (sequence, head); the qkv tensor never reaches HBM (pp_qkv_attn_split.hip). PP_FUSE_QKV_ATTN=0: pp_gemm + pp_attention
         self.fuse_qkv_attn = precision == "f16x3" and pl["fuse_qkv_attn"] and self.Np == 192 and self.hd == 32 and self.E == 384
@@ -228,15 +237,19 @@ class ProbPoseEngine:
             return t.view(*dims)
 
         e = lambda *s, dt=T: torch.empty(s, dtype=dt, device=dev)  # noqa: E731  (results: sizes fixed by the output contract)
-        fused_layer = self.precision == "f16x3" and self.fuse_qkv_attn and bool(self._proj_packed)
+        small = self._small_at(M)
+        fused_layer = self.precision == "f16x3" and self.fuse_qkv_attn and bool(self._proj_packed) and not small
         ws = dict(
             patches=buf("patches", (M, 3 * self.P * self.P)), x=buf("x", (M, E), f32), h=buf("h", (M, E)),
             feat=buf("feat", (M, E)), logits=buf("logits", (nb, self.K, self.Hh * self.Wh), f32),
             # qkv / hidden activation only where a launch plan without the fused layer kernels needs them
-            qkv=None if fused_layer else buf("qkv", (M, 3 * E)), qkv2=None if fused_layer else buf("qkv", (M, 3 * E)),
-            f=None if (fused_layer or self._ffn_packed) else buf("ffn", (M, Fd)),
-            att=buf("att", (M, E)) if self.fuse_qkv_attn else None,  # attention output of the fused qkv + attention launch
-            hs=buf("ln2", (M, E)) if self._proj_packed else None,  # ln2 rows of the fused projection + FFN launch (scratch, parked in L2 / MALL)
+            qkv=None if (fused_layer or (small and self.fuse_qkv_attn)) else buf("qkv", (M, 3 * E)),
+            qkv2=None if (fused_layer or small) else buf("qkv", (M, 3 * E)),
+            f=None if ((fused_layer or self._ffn_packed) and not small) else buf("ffn", (M, Fd)),
+            att=buf("att", (M, E)) if (self.fuse_qkv_attn or small) else None,  # attention output of the fused qkv + attention launch
+            hs=buf("ln2", (M, E)) if (self._proj_packed or small) else None,  # ln2 rows of the fused projection + FFN launch (scratch, parked in L2 / MALL)
+            # small-batch plan: one arrival counter per 32-row block for pp_skinny_linear's LayerNorm tail (zero between launches)
+            ln_count=torch.zeros((M + 31) // 32, dtype=torch.int32, device=dev) if small else None,
             # folded-LayerNorm plan: the residual stream in the operand format and the row statistics between its Linear layers
             xs=buf("h", (M, E)) if self._ln_fold_at(M) else None,
             lnst=buf("ln_stats", (M, E // 96, 2), f32) if self._ln_fold_at(M) else None,
@@ -265,6 +278,11 @@ class ProbPoseEngine:
             ws[f"p{j}"] = buf("tower_pooled", (4, nb, th // ph, tw // pw_, E), index=j)
         self._ws[key] = ws
         return ws
+
+    def _small_at(self, M: int) -> bool:
+        """The column-parallel plan of small batches: f16x3, fewer than small_rows_below token rows, shapes pp_skinny_linear serves."""
+        return bool(self.small_plan and M < self.small_rows_below and self.E % 64 == 0 and self.w.ffn_dims % 64 == 0 and self.E <= 1024
+                    and self.w.has("l0.fc1.w") and self.w.has("l0.proj.w") and (3 * self.P * self.P) % 64 == 0)
 
     def _ln_fold_at(self, M: int) -> bool:
         """The folded-LayerNorm layer plan runs from the row count at which pp_gemm itself would pick the twelve-wave Linear kernel for the
@@ -340,6 +358,8 @@ class ProbPoseEngine:
                 self._call("layernorm", "pp_layernorm", ws["x"].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                            h_out.data_ptr(), M, E, self.ln_eps, ob, st)
 
+        if self._small_at(M):
+            return self._layers_small(ws, st, B * passes, M)
         res_ln(ws["patches"], w["patch_w"], w["patch_b"], Kp, w["l0.ln1.w"], w["l0.ln1.b"], ws["h"],
                residual=w["pos_embed"], res_mod=self.Np)
         if self._ln_fold_at(M):
@@ -433,6 +453,42 @@ class ProbPoseEngine:
             else:
                 self._gemm(st, ws["h"], w[f"l{i}.fc1.w"], w[f"l{i}.fc1.b"], ws["f"], M, Fd, E, act=ACT_GELU, winv=w.inv(f"l{i}.fc1.w"))
                 res_ln(ws["f"], w[f"l{i}.fc2.w"], w[f"l{i}.fc2.b"], Fd, gn, bn, h_next, winv=w.inv(f"l{i}.fc2.w"))
+        return ws["feat"]
+
+    def _layers_small(self, ws, st, nb: int, M: int) -> torch.Tensor:
+        """Patch embedding and encoder layers of a SMALL batch (pp_skinny_linear: every Linear layer column-parallel over the whole chip, the
+        LayerNorm behind a residual layer done by the workgroup that completes a row block - no LayerNorm launch). Per layer: qkv + attention
+        (one workgroup per sequence and head where the fused kernel applies, else qkv Linear + pp_attention), proj (+ residual, ln2), fc1 (GELU),
+        fc2 (+ residual, next ln1 / ln_f): four launches. ws["patches"] holds the im2col rows on entry."""
+        E, Fd, w, L = self.E, self.w.ffn_dims, self.w, self.w.num_layers
+        F32, SPLIT = 0, 2
+        scale = self.hd ** -0.5
+        cnt = ws["ln_count"]
+
+        def lin(a, wname, bias, out, N, K, act=ACT_NONE, residual=None, res_mod=0, out_fmt=SPLIT, ln=None):
+            g, b, h_out = ln if ln is not None else (None, None, None)
+            self._call("skinny_linear", "pp_skinny_linear", a.data_ptr(), w[wname].data_ptr(), _lib.ptr(bias), _lib.ptr(residual), res_mod,
+                       out.data_ptr(), out_fmt, M, N, K, act, w.inv(wname), _lib.ptr(g), _lib.ptr(b), self.ln_eps, _lib.ptr(h_out),
+                       cnt.data_ptr() if ln is not None else None, st)
+
+        # patch embedding (+ pos_embed) -> x (fp32), ln1 of layer 0 -> h
+        lin(ws["patches"], "patch_w", w["patch_b"], ws["x"], E, 3 * self.P * self.P, residual=w["pos_embed"], res_mod=self.Np, out_fmt=F32,
+            ln=(w["l0.ln1.w"], w["l0.ln1.b"], ws["h"]))
+        for i in range(L):
+            if self.fuse_qkv_attn:
+                self._call("qkv_attention", "pp_qkv_attention_split_ws", ws["h"].data_ptr(), w[f"l{i}.qkv.w"].data_ptr(), w[f"l{i}.qkv.b"].data_ptr(),
+                           ws["att"].data_ptr(), nb, self.Np, self.heads, self.hd, scale, w.inv(f"l{i}.qkv.w"), st)
+            else:
+                lin(ws["h"], f"l{i}.qkv.w", w[f"l{i}.qkv.b"], ws["qkv"], 3 * E, E)
+                self._call("attention", "pp_attention", self.prec, ws["qkv"].data_ptr(), ws["att"].data_ptr(), nb, self.Np, self.heads, self.hd, scale, st)
+            if self.stage_hook is not None:
+                self.stage_hook("embed" if i == 0 else f"layer{i - 1}")
+            lin(ws["att"], f"l{i}.proj.w", w[f"l{i}.proj.b"], ws["x"], E, E, residual=ws["x"], out_fmt=F32,
+                ln=(w[f"l{i}.ln2.w"], w[f"l{i}.ln2.b"], ws["hs"]))
+            lin(ws["hs"], f"l{i}.fc1.w", w[f"l{i}.fc1.b"], ws["f"], Fd, E, act=ACT_GELU)
+            last = i + 1 == L
+            gn, bn = (w["ln_f.w"], w["ln_f.b"]) if last else (w[f"l{i + 1}.ln1.w"], w[f"l{i + 1}.ln1.b"])
+            lin(ws["f"], f"l{i}.fc2.w", w[f"l{i}.fc2.b"], ws["x"], E, Fd, residual=ws["x"], out_fmt=F32, ln=(gn, bn, ws["feat"] if last else ws["h"]))
         return ws["feat"]
 
     def _layers_ln_folded(self, ws, st, nb: int, M: int) -> torch.Tensor:

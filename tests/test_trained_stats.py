@@ -82,10 +82,11 @@ def test_pack_refuses_weights_beyond_the_split_range():
 
 
 # ------------------------------------------------------------------------------------------------- GPU, end to end
-def _real_flips(out, ref, d, tie=2e-6):
+def _real_flips(out, ref, d, tie=2e-5):
     """Keypoints whose argmax differs from the reference's - not counting exact near-ties IN THE REFERENCE: when the reference's own OKS-convolved map
     holds, at the pixel this path picked, a value within `tie` (relative) of its maximum, which of the two pixels wins is decided by the last bit of
-    fp32 arithmetic in either implementation (the reference run in double precision flips those too). Such keypoints are reported, not failed."""
+    fp32 arithmetic in either implementation: the map values carry the network's fp32 noise, ~1e-5 relative between the fp32 reference and its own
+    double-precision run (measured: ViT-B, B = 32, one keypoint of 544 with a margin of 5.5e-6). Such keypoints are reported, not failed."""
     from oracle import decode_ref as D
 
     flips = 0
