@@ -12,7 +12,7 @@
 //
 //   * 256 threads = 4 waves as 2 (rows) x 2 (columns); a wave owns RT x CT MFMA tiles of 16 x 16 (v_mfma_f32_16x16x32_f16, three per product:
 //     lo hi + hi lo + hi hi, pp_split.h); the weight fragment is the MFMA's A operand, so a lane ends with 4 consecutive columns of one row;
-//   * K in stages of 64 elements (two 128-byte blocks per row) on a ring of three LDS stages filled by LDS-DMA (`buffer_load ... lds`, 16 bytes per
+//   * K in stages of 64 elements (two 128-byte blocks per row) on a ring of seven / four / three LDS stages (32 / 64 / 96-edge tiles) filled by LDS-DMA (`buffer_load ... lds`, 16 bytes per
 //     lane, source chunk XOR-swizzled by the row so that fragment reads are conflict-free); rows past M read as zeros (buffer bounds);
 //   * epilogue in registers: * w_inv (the weights' power-of-two scale), + bias, GELU (A & S 7.1.26 as everywhere in this mode), + fp32 residual
 //     (optionally a table broadcast over the batch: pos_embed), fp32 or split-fp16 rows out;
@@ -30,7 +30,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int THREADS = 256, KS = 2, NST = 3;  // k-blocks (of 32 elements) per stage, stages in the ring
+constexpr int THREADS = 256, KS = 2;  // k-blocks (of 32 elements) per stage
+// Stages in the LDS ring per tile edge (32 / 64 / 96): what a workgroup has in flight is what it gets per memory round trip (~2 us from HBM / MALL
+// at these sizes - the first version waited for one 16 KiB stage at a time and spent 2.4 us per 64 columns of K). 32 x 32 tiles keep six stages in
+// flight (a whole K = 384), 64 x 64 three, 96 x 96 two: 112 / 128 / 144 KiB.
+__host__ __device__ constexpr int stages_of(int t) { return t == 1 ? 7 : (t == 2 ? 4 : 3); }
 constexpr int ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2;
 
 struct Params {
@@ -59,6 +63,7 @@ __device__ __forceinline__ void wait_vm() {
 template <int RT, int CT, bool LN>
 __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) {
     constexpr int BM = 32 * RT, BN = 32 * CT, ROWS = BM + BN;
+    constexpr int NST = stages_of(RT), PRE = NST - 1;  // stages in the ring / requested ahead
     constexpr int STAGE = KS * ROWS * 128;
     constexpr int NI = KS * ROWS / 8, NIW = NI / 4;  // DMA instructions per stage (8 rows of one k-block each), per wave
     static_assert(NI % 4 == 0, "DMA instructions must divide over the four waves");
@@ -101,17 +106,25 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue(0);
-    issue(1);
+#pragma unroll
+    for (int s = 0; s < PRE; ++s) issue(s);
     const int sw = f_row & 7;
     const int off_hi = f_row * 128 + ((f_kg ^ sw) << 4), off_lo = f_row * 128 + (((4 + f_kg) ^ sw) << 4);
     for (int s = 0; s < nsteps; ++s) {
-        // stage s has landed once at most the stage behind it is outstanding (past the last stages nothing is)
+        // stage s has landed once only the stages requested behind it are outstanding: PRE - 1 of them, fewer near the end of K
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nsteps) wait_vm<NIW>(); else wait_vm<0>();
+        {
+            const int behind = min(PRE - 1, nsteps - 1 - s);  // (workgroup-uniform)
+            if (behind >= PRE - 1) wait_vm<(PRE - 1) * NIW>();
+            else if (PRE > 2 && behind == 4) wait_vm<(PRE > 4 ? 4 : 0) * NIW>();
+            else if (PRE > 2 && behind == 3) wait_vm<(PRE > 3 ? 3 : 0) * NIW>();
+            else if (PRE > 2 && behind == 2) wait_vm<(PRE > 2 ? 2 : 0) * NIW>();
+            else if (behind == 1) wait_vm<(PRE > 1 ? 1 : 0) * NIW>();
+            else wait_vm<0>();
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        issue(s + 2);  // into the slot every wave finished reading before this barrier
+        issue(s + PRE);  // into the slot every wave finished reading before this barrier
         const char* st = smem + (s % NST) * STAGE;
 #pragma unroll
         for (int kb = 0; kb < KS; ++kb) {
@@ -141,6 +154,7 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
         }
     }
 
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((size_t)p.M * p.N * 4), 0x00020000);
     // ---- epilogue: lane (f_row, f_kg) of tile (c, r) holds row m0 + 16 (RT wm + r) + f_row, columns n0 + 16 (CT wn + c) + 4 f_kg + (0..3)
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -165,67 +179,70 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
             }
             const size_t idx = (size_t)m * p.N + n;
             if (p.out_split) split_store4_rowpair(p.out, idx, v, live);  // (every lane calls it: row swaps inside)
-            else if (live) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + idx) = v;
+            else if (LN) {
+                // DEVICE-scope store (sc1): the rows are read back inside this launch by a workgroup that may sit on another XCD, i.e. behind another
+                // L2. A plain store + an agent-scope release fence does it too - by writing the whole L2 back (buffer_wbl2) and, on the reading side,
+                // invalidating one (buffer_inv): measured 26 us per launch at B = 1 against 13 for the same tiles without the tail.
+                if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (unsigned)(idx * 4), 0, 16);
+            } else if (live) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + idx) = v;
         }
     }
 
     if constexpr (LN) {
         // ---- LayerNorm tail: the workgroup that completes the row block normalises it
         __shared__ int s_last;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's rows are visible device-wide before the count
+        __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | ((0 >> 4) << 14));  // vmcnt(0): this thread's device-scope stores are acknowledged
         __syncthreads();
         if (tid == 0) {
-            const int seen = __hip_atomic_fetch_add(p.counters + mt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const int seen = __hip_atomic_fetch_add(p.counters + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = seen == ntn - 1;
             if (seen == ntn - 1) __hip_atomic_store(p.counters + mt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (everybody of this block has counted)
         }
         __syncthreads();
-        if (!s_last) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' tiles: from L2, not from a stale L1 line
-        const float* x = reinterpret_cast<const float*>(p.out);
+        if (!s_last) return;  // (the reads below are device-scope loads: they bypass this CU's L1 and this XCD's non-coherent L2 lines)
         const float inv_n = 1.0f / (float)p.N;
-        for (int r = wave; r < BM; r += 4) {  // a wave per row
-            const int m = m0 + r;
-            if (m >= p.M) break;
-            const float* row = x + (size_t)m * p.N;
-            f32x4 v[4];  // N <= 1024
+        // A wave takes its BM / 4 rows in groups: LPR lanes per row, every lane's share of the row requested before anything is reduced - one memory
+        // round trip per group, not per row (the first version walked the rows one by one: 20 us of the 28 a launch took at B = 1).
+        const int LPR = p.N <= 512 ? 8 : 16, G = 64 / LPR;       // lanes per row, rows per group
+        const int nv = p.N / (4 * LPR);                            // 16-byte vectors per lane (<= 16)
+        const int lr = lane / LPR, lc = lane - lr * LPR;
+        for (int r0 = wave * (BM / 4); r0 < (wave + 1) * (BM / 4); r0 += G) {
+            const int m = m0 + r0 + lr;
+            const bool live = r0 + lr < (wave + 1) * (BM / 4) && m < p.M;
+            f32x4 v[16];
             float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = i * 256 + lane * 4;
+            for (int i = 0; i < 16; ++i) {
                 v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (col < p.N) {
-                    v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + col));
-                    sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-                }
+                if (i < nv && live)
+                    v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rout, (unsigned)(((size_t)m * p.N + (i * LPR + lc) * 4) * 4), 0, 16));
             }
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+            for (int i = 0; i < 16; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            for (int o = LPR >> 1; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
             const float mean = sum * inv_n;
             float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i * 256 + lane * 4 < p.N) {
+            for (int i = 0; i < 16; ++i)
+                if (i < nv) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float d = v[i][e] - mean;
                         q = __builtin_fmaf(d, d, q);
                     }
                 }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+            for (int o = LPR >> 1; o >= 1; o >>= 1) q += __shfl_xor(q, o);
             const float rstd = 1.0f / sqrtf(q * inv_n + p.eps);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = i * 256 + lane * 4;
-                if (col < p.N) {
+            for (int i = 0; i < 16; ++i)
+                if (i < nv && live) {
+                    const int col = (i * LPR + lc) * 4;
                     const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + col), b = *reinterpret_cast<const f32x4*>(p.beta + col);
                     f32x4 hv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hv[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
                     split_store4(p.h_out, (size_t)m * p.N + col, hv);
                 }
-            }
         }
     }
 }
@@ -271,8 +288,8 @@ extern "C" int pp_skinny_linear(const void* act, const void* weight, const float
     const bool ln = ln_out != nullptr;
     if (ln) {
         PP_REQUIRE(ln_gamma && ln_beta && ln_counters, PP_ERR_INVALID_ARG, "pp_skinny_linear: the LayerNorm tail needs gamma, beta and the counters");
-        PP_REQUIRE(out_format == PP_OUT_F32 && N % 4 == 0 && N <= 1024, PP_ERR_UNSUPPORTED,
-                   "pp_skinny_linear: the LayerNorm tail normalises fp32 output rows of at most 1024 columns");
+        PP_REQUIRE(out_format == PP_OUT_F32 && N % 64 == 0 && N <= 1024, PP_ERR_UNSUPPORTED,
+                   "pp_skinny_linear: the LayerNorm tail normalises fp32 output rows of at most 1024 columns (a multiple of 64)");
         PP_REQUIRE(ln_out != out && ln_out != act, PP_ERR_INVALID_ARG, "pp_skinny_linear: ln_out must not alias out or act");
     }
     sk::Params p{};
@@ -292,7 +309,7 @@ extern "C" int pp_skinny_linear(const void* act, const void* weight, const float
     const int t = pp_skinny_linear_tile(M, N) / 32;
     const int b = 32 * t;
     const int grid = ((M + b - 1) / b) * (N / b);
-    const size_t lds = (size_t)sk::NST * sk::KS * (2 * b) * 128;
+    const size_t lds = (size_t)sk::stages_of(t) * sk::KS * (2 * b) * 128;
     void (*kern)(const sk::Params) = nullptr;
     if (t == 3) kern = ln ? sk::skinny_linear_kernel<3, 3, true> : sk::skinny_linear_kernel<3, 3, false>;
     else if (t == 2) kern = ln ? sk::skinny_linear_kernel<2, 2, true> : sk::skinny_linear_kernel<2, 2, false>;
