@@ -247,23 +247,42 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
     }
 }
 
-// tile edge (32 RT = 32 CT) for a problem: the largest of 96 / 64 / 32 that still gives the chip a workgroup per CU; 32 when none does
-static int pick_tile(int M, int N, int cus) {
-    for (int t = 3; t >= 2; --t) {
+// Tile edge (32 RT = 32 CT) for a problem. A launch of these sizes is a few ROUNDS of one workgroup per CU (the rings take 112 - 144 KiB), each
+// round one trip through "request the stages - MFMAs - epilogue"; the LayerNorm tail adds the last workgroup's trip through its rows. Cost model
+// fitted to scripts/r06/skinny_tile_sweep.py (us per launch inside a replayed graph, MI355X, B = 1 .. 24 crops + flip):
+//     cost = BASE[t] + rounds * ROUND[t] * (0.5 + 0.5 K / 384) + (tail ? TAIL[t] : 0),   ROUND[32] growing beyond three rounds
+// e.g. proj + ln2 at B = 2: 14.7 / 17.2 / 26.9 us measured at 32 / 64 / 96, modelled 14.8 / 17.2 / 27.5. Option "skinny_tile" (32 / 64 / 96)
+// forces one edge for A/B timing.
+static int pick_tile(int M, int N, int K, bool tail, int cus) {
+    const int forced = option("skinny_tile") / 32;
+    if (forced >= 1 && forced <= 3 && N % (32 * forced) == 0) return forced;
+    static const double BASE[4] = {0.0, 4.0, 1.0, 0.0}, ROUND[4] = {0.0, 3.4, 6.2, 11.5}, TAIL[4] = {0.0, 4.0, 10.0, 16.0};
+    const double kf = 0.5 + 0.5 * (double)K / 384.0;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int t = 1; t <= 3; ++t) {
         const int b = 32 * t;
-        if (N % b == 0 && (long long)((M + b - 1) / b) * (N / b) >= cus) return t;
+        if (N % b != 0) continue;
+        const long long wgs = (long long)((M + b - 1) / b) * (N / b);
+        const double rounds = (double)((wgs + cus - 1) / cus);
+        const double per_round = ROUND[t] + (t == 1 && rounds > 3.0 ? 0.8 * (rounds - 3.0) : 0.0);
+        const double cost = BASE[t] + rounds * per_round * kf + (tail ? TAIL[t] : 0.0);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = t;
+        }
     }
-    return 1;
+    return best;
 }
 
 }  // namespace sk
 }  // namespace pp
 
-extern "C" int pp_skinny_linear_tile(int M, int N) {
-    if (M <= 0 || N <= 0 || N % 32 != 0) return 0;
+extern "C" int pp_skinny_linear_tile(int M, int N, int K, int with_layernorm) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 32 != 0) return 0;
     static int cus = 0;
     if (!cus) cus = pp_device_cu_count() > 0 ? pp_device_cu_count() : 256;
-    return 32 * pp::sk::pick_tile(M, N, cus);
+    return 32 * pp::sk::pick_tile(M, N, K, with_layernorm != 0, cus);
 }
 
 extern "C" int pp_skinny_linear(const void* act, const void* weight, const float* bias, const float* residual, int res_mod, void* out,
@@ -306,7 +325,7 @@ extern "C" int pp_skinny_linear(const void* act, const void* weight, const float
     p.w_bytes = (unsigned)((size_t)N * K * 4);
     p.w_inv = w_inv_scale;
     p.gamma = ln_gamma; p.beta = ln_beta; p.h_out = reinterpret_cast<char*>(ln_out); p.eps = ln_eps; p.counters = ln_counters;
-    const int t = pp_skinny_linear_tile(M, N) / 32;
+    const int t = pp_skinny_linear_tile(M, N, K, ln ? 1 : 0) / 32;
     const int b = 32 * t;
     const int grid = ((M + b - 1) / b) * (N / b);
     const size_t lds = (size_t)sk::stages_of(t) * sk::KS * (2 * b) * 128;

@@ -37,7 +37,7 @@ CONV3X3, DECONV = 1, 2
 
 # launch-plan switches and their shipped values (fuse_resln: None = on for E = 384 only, True = also the E = 768 row-owner kernel)
 PLAN_DEFAULTS = dict(fuse_mlp=True, fuse_proj=True, fuse_qkv=True, split_k=True, fuse_attn=True, fuse_head=True, fuse_resln=None,
-                     fuse_pool=True, fuse_qkv_attn=True, winograd=True, ln_fold=True, small_plan=True)
+                     fuse_pool=True, fuse_qkv_attn=True, winograd=True, ln_fold=True, small_plan=True, head_two_streams=True)
 # f16x3: batches with fewer token rows than this (B * passes * tokens) take the column-parallel plan of small batches (pp_skinny_linear): below it the
 # row-owner layer kernels leave most of the chip idle (96 rows per workgroup: 12 288 rows = 128 workgroups on 256 CUs); measured crossover:
 # scripts/r06/small_batch_profile.py
@@ -191,6 +191,7 @@ class ProbPoseEngine:
         if self.w.has("tower0.wino") and not self.winograd:
             self.w.t.pop("tower0.wino")  # (37.7 MB at ViT-S that no launch of this plan reads)
         self._logits_phased = False
+        self._head_stream: Optional[torch.cuda.Stream] = None  # second stream of the head at small batches (run_head)
         self.profile: Optional[Dict[str, list]] = None
         self.stage_hook = None  # callable(name) invoked between stages of the launch plan ("embed", "layer<i>", "backbone"); dev / scheduling experiments
         # tower pooling schedule (probmap_head.py:264) and the spatial sizes it produces
@@ -652,7 +653,19 @@ class ProbPoseEngine:
             raise ValueError("flip_test needs flip_indices (dataset meta)")
         B = nb // passes
         ws = self._workspace(B, passes, slot)
+        # Small batches: the heatmap branch (two deconvolutions, 1x1 conv, decode) and the four scalar towers read the same features and nothing of
+        # each other - none of their launches fills the chip at these sizes, so the towers run on a second stream beside the heatmap branch
+        # (fork / join by events: inside a capture they become two branches of the graph). B = 1: ~0.12 ms of the step.
+        two = self.plan["head_two_streams"] and self._small_at(nb * self.Np)
         with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            scalars = None
+            if two:
+                if self._head_stream is None:
+                    self._head_stream = torch.cuda.Stream(device=self.device)
+                self._head_stream.wait_stream(cur)
+                with torch.cuda.stream(self._head_stream):
+                    scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, _lib.stream_ptr(self.device))
             st = _lib.stream_ptr(self.device)
             logits = self.heatmap_logits(feat_nhwc, nb, ws, st)
             fi = self._flip_indices(flip_indices) if flip_test else None
@@ -663,7 +676,10 @@ class ProbPoseEngine:
                       float(self.input_size[1]), self.temperature, -1.0 if self.normalize is None else float(self.normalize),  # (< 0: no Sparsemax)
                       ws["heatmaps"].data_ptr() if return_heatmaps else None, None, ws["locs"].data_ptr(),
                       ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), flags, st)
-            scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, st)
+            if two:
+                cur.wait_stream(self._head_stream)
+            else:
+                scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, st)
         out = dict(keypoints=ws["keypoints"], scores=ws["scores"], locs=ws["locs"], scalars=scalars)
         if return_heatmaps:
             out["heatmaps"] = ws["heatmaps"]
