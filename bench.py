@@ -90,6 +90,7 @@ def parse(argv=None):
                     help="run ONLY BASELINE config 4 (ViT-B 384x288) - for the profile passes of scripts/collect_profiles.sh; prints its record as the JSON line")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the probed second pass that records the shader clock (profile passes)")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the `drop_in` record (model.test_step / test_step_stream timed)")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the `small_batch` record (latency of B = 1, 2, 4, 8 one step in flight)")
     ap.add_argument("--no-bs512-decode", action="store_true",
                     help="skip roofline_targets.head_decode_bs512 (counter passes: its launches would mix into the step's decode kernel)")
     ap.add_argument("--in-flight", type=int, default=2,
@@ -799,6 +800,45 @@ def drop_in_record(dev, args, sd, B):
     return rec
 
 
+def small_batch_record(dev, args, sd, ref_fn=None):
+    """Latency of the batch sizes the reference's own callers produce (demo/image_demo.py:36-61: one crop; mmpose/apis/inference.py:161-196: the
+    boxes of one image; demo/topdown_demo_with_mmdet.py:35-41: a handful of persons): B = 1, 2, 4, 8 crops + flip test, the replayed hipGraph,
+    strictly ONE step in flight (what a caller who waits for the result sees), with the launch plan the engine picks there (pp_skinny_linear:
+    column-parallel Linear layers, `small_plan`) and with the headline's row-owner plan for comparison. Timed after inputs are resident."""
+    from probpose_code_amd import ProbPoseEngine
+    from probpose_code_amd import synthetic as S
+
+    rec = {"what": "ms per step, one step in flight (replayed hipGraph), ProbPose-small 256x192 flip_test=True, " + args.precision,
+           "reps": 100, "latency_ms": {}, "crops_per_s": {}, "row_owner_plan_latency_ms": {}}
+    engines = {"small": ProbPoseEngine(sd, 12, precision=args.precision, device=dev),
+               "row_owner": ProbPoseEngine(sd, 12, precision=args.precision, device=dev, plan=dict(small_plan=False))}
+    rec["plan_below_rows"] = engines["small"].small_rows_below if engines["small"].small_plan else 0
+    for B in (1, 2, 4, 8):
+        crops = S.synthetic_crops(B, seed=300 + B).to(dev)
+        for name, eng in engines.items():
+            for _ in range(3):
+                out = eng.forward_graph(crops, True, S.COCO_FLIP_INDICES)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(rec["reps"]):
+                out = eng.forward_graph(crops, True, S.COCO_FLIP_INDICES)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / rec["reps"]
+            if name == "small":
+                rec["latency_ms"][str(B)] = round(dt * 1e3, 4)
+                rec["crops_per_s"][str(B)] = round(B / dt, 1)
+                if ref_fn is not None:
+                    ref = ref_fn(crops.cpu())
+                    d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
+                    rec.setdefault("parity_vs_oracle", {})[str(B)] = {"keypoint_linf_px": float(d[d < 2.0].max()), "argmax_flips": int((d >= 2.0).sum()),
+                                                                      "within_1e-3": bool((d < 2.0).all() and d.max() <= 1e-3)}
+            else:
+                rec["row_owner_plan_latency_ms"][str(B)] = round(dt * 1e3, 4)
+    del engines
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
@@ -1009,6 +1049,16 @@ def main(argv=None):
                             line["drop_in"][k]["frac_of_headline"] = line["drop_in"][k]["value"] / line["value"]
                 except Exception as exc:  # noqa: BLE001 -- a secondary record must not take the bench line down
                     line["drop_in"] = {"error": repr(exc)[:300]}
+            if world == 1 and not args.no_small_batch:
+                try:
+                    ref_fn = None
+                    if not args.no_parity:
+                        from oracle import model_ref as M_
+
+                        ref_fn = lambda c: M_.predict(sd, c, 12, S.IMG_MEAN, S.IMG_STD)  # noqa: E731  (the checker, never the thing timed)
+                    line["small_batch"] = small_batch_record(dev, args, sd, ref_fn)
+                except Exception as exc:  # noqa: BLE001 -- a secondary record must not take the bench line down
+                    line["small_batch"] = {"error": repr(exc)[:300]}
             if world == 1 and not args.no_config4:
                 line["config4"] = config4_record(dev, args)
             print(json.dumps(line))

@@ -39,9 +39,10 @@ CONV3X3, DECONV = 1, 2
 PLAN_DEFAULTS = dict(fuse_mlp=True, fuse_proj=True, fuse_qkv=True, split_k=True, fuse_attn=True, fuse_head=True, fuse_resln=None,
                      fuse_pool=True, fuse_qkv_attn=True, winograd=True, ln_fold=True, small_plan=True, head_two_streams=True)
 # f16x3: batches with fewer token rows than this (B * passes * tokens) take the column-parallel plan of small batches (pp_skinny_linear): below it the
-# row-owner layer kernels leave most of the chip idle (96 rows per workgroup: 12 288 rows = 128 workgroups on 256 CUs); measured crossover:
-# scripts/r06/small_batch_profile.py
-SMALL_PLAN_ROWS_BELOW = 12288
+# row-owner layer kernels leave most of the chip idle (96 rows per workgroup). Measured crossover (scripts/r06/small_batch_profile.py, ms per replayed
+# step one in flight, small plan / row-owner plan): B = 1 0.88 / 2.06, 4: 1.19 / 2.13, 8: 1.77 / 2.24, 16: 2.33 / 2.44, 24: 3.96 / 2.85 - 6 912 rows
+# = up to 17 crops with flip test
+SMALL_PLAN_ROWS_BELOW = 6912
 
 
 def plan_from_env() -> Dict[str, object]:
