@@ -6,8 +6,10 @@
 // Round 2's kernel for this shape (pp_attention.hip, attention_split_stream_kernel) stages K and V^T of half the keys through
 // registers - V with a 2-byte transposing scatter - into 115 KiB of LDS: one workgroup per CU, 337 us per ViT-B layer at bs 32
 // for 54 us of MFMA issue. Here K and V stay ROW-MAJOR by key and come in by LDS-DMA:
-//   * a workgroup = (sequence, head, query quarter): seven waves, one 16-query tile each (27 tiles = 7 + 7 + 7 + 6); q
-//     fragments from global memory once;
+//   * a workgroup = (sequence, head, query HALF): seven waves, TWO 16-query tiles each (27 tiles = 14 + 13; round 6 - before: query quarters,
+//     one tile per wave, 42 % matrix-pipe busy at ViT-B: every K and V^T fragment a wave read fed ONE tile's MFMAs, 32 KiB of LDS reads per
+//     wave and 64 keys against 48 MFMAs - the LDS pipe, not the matrix pipe, set the pace. Now a fragment feeds both tiles: half the LDS
+//     reads and half the K / V streamed per MFMA); q fragments from global memory once;
 //   * the keys stream through a ring of four 32-key stages: per stage K and V as HD / 32 sub-tiles of [32 keys][128 B] (the
 //     raw split blocks: 32 hi halves | 32 lo halves, 16-byte chunks XOR-swizzled by key & 7 at the source) = 16 KiB at head
 //     dim 64; the stages go in PAIRS (one barrier, one running-maximum update and one rescale of O per 64 keys: 149 -> 145 us),
@@ -29,7 +31,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
-constexpr int S = 432, NT = S / 16, QSPLIT = 4, TPW = (NT + QSPLIT - 1) / QSPLIT, THREADS = 64 * TPW;  // 7 waves
+constexpr int S = 432, NT = S / 16, TQ = 2, QSPLIT = 2, TPW = (NT + QSPLIT * TQ - 1) / (QSPLIT * TQ), THREADS = 64 * TPW;  // 7 waves x 2 tiles
 constexpr int SK = 32;                         // keys per stage
 constexpr int NSTG = (S + SK - 1) / SK;        // 14 stages (the last one holds 16 keys)
 constexpr int RING = 4;
@@ -49,8 +51,10 @@ __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));  // vmcnt(N) only
 }
 
-template <int HD>
-__global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const char* __restrict__ qkv, char* __restrict__ out, int n_seq,
+// MINW: waves per SIMD the register allocator is held to - 4 (<= 128 registers: two workgroups per CU, six values spilled at head dim 64) or 1
+// (146 registers, one workgroup of seven waves per CU); option "attn_dma_two_wgs" picks, measured in DESIGN.md 5
+template <int HD, int MINW>
+__global__ __launch_bounds__(THREADS, MINW) void attention_split_dma_kernel(const char* __restrict__ qkv, char* __restrict__ out, int n_seq,
                                                                          int heads, unsigned qkv_bytes, float scale_log2e) {
     using C = Cfg<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -67,8 +71,9 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
     const int E = heads * HD;
     const unsigned row_bytes = (unsigned)(3 * E * 4);
     const unsigned base = (unsigned)(seq * S) * row_bytes + (unsigned)(head * HD * 4);  // q block 0 of the sequence's first token
-    const int qt = qs * TPW + wv;       // this wave's query tile
-    const bool live = qt < NT;          // (the last quarter has six tiles: its seventh wave only helps with the DMA)
+    const int qt = (qs * TPW + wv) * TQ;  // this wave's first query tile (it owns qt and qt + 1)
+    const bool live = qt < NT;            // (27 tiles over 2 x 7 x 2 slots: the last wave of the second half has one tile)
+    const bool live1 = qt + 1 < NT;
 
     // ---- DMA: piece j of a stage = sub-tile j / 4 (K blocks 0 .. NB - 1, then V blocks), keys 8 (j % 4) .. + 7; lane (l = lane >> 3,
     // pc = lane & 7) fetches the logical 16-byte chunk pc ^ l of key 8 (j % 4) + l
@@ -90,22 +95,26 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
     };
 
     // ---- q fragments of this wave's tile: lane (query fr, chunk fg) of block g
-    f16x8 qh[C::NB], ql[C::NB];
-    {
-        const char* qrow = qkv + base + (size_t)((live ? qt : 0) * 16 + fr) * row_bytes;
+    f16x8 qh[TQ][C::NB], ql[TQ][C::NB];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+        const int tile = qt + t < NT ? qt + t : 0;  // (a tile that does not exist computes on tile 0's queries and stores nothing)
+        const char* qrow = qkv + base + (size_t)(tile * 16 + fr) * row_bytes;
 #pragma unroll
         for (int g = 0; g < C::NB; ++g) {
-            qh[g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + fg * 16);
-            ql[g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + 64 + fg * 16);
+            qh[t][g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + fg * 16);
+            ql[t][g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + 64 + fg * 16);
         }
     }
     issue_stage(0);
     issue_stage(1);
 
-    f32x4 o[C::DT];
+    f32x4 o[TQ][C::DT];
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -__builtin_inff(), l_run = 0.f;
+    for (int t = 0; t < TQ; ++t)
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[TQ] = {-__builtin_inff(), -__builtin_inff()}, l_run[TQ] = {0.f, 0.f};
 
     const int sw = fr & 7;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte address of the dynamic region (0)
@@ -128,75 +137,83 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
         if (!live) continue;
         const bool tail = pr == NSTG / 2 - 1 && (S % SK) != 0;  // the last stage holds S % 32 = 16 keys: its second key tile does not exist
 
-        // ---- scores of the pair's four key tiles: s[kt][i] = q . k for key 64 pr + 16 kt + 4 fg + i of query fr
-        f32x4 sc[4];
+        // ---- scores of the pair's four key tiles, both query tiles on every K fragment: s[t][kt][i] = q . k for key 64 pr + 16 kt + 4 fg + i of
+        // query fr of tile t
+        f32x4 sc[TQ][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             const char* Ks = smem + ((2 * pr + (kt >> 1)) & (RING - 1)) * C::STAGE;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc[TQ] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             const int r = (kt & 1) * 16 + fr;
 #pragma unroll
             for (int g = 0; g < C::NB; ++g) {
                 const f16x8 kh = *reinterpret_cast<const f16x8*>(Ks + g * C::SUB + r * 128 + ((fg ^ sw) << 4));
                 const f16x8 kl = *reinterpret_cast<const f16x8*>(Ks + g * C::SUB + r * 128 + (((4 + fg) ^ sw) << 4));
-                acc = split_mma(kh, kl, qh[g], ql[g], acc);
+#pragma unroll
+                for (int t = 0; t < TQ; ++t) acc[t] = split_mma(kh, kl, qh[t][g], ql[t][g], acc[t]);
             }
-            sc[kt] = acc;
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) sc[t][kt] = acc[t];
         }
-        if (tail) sc[3] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-        // ---- online softmax
-        float mx = m_run;
+        // ---- online softmax, per query tile
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int t = 0; t < TQ; ++t) {
+            if (tail) sc[t][3] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            float mx = m_run[t];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sc[kt][i]);
-        {  // max over the four lane groups of a query: the gfx950 row swaps (plain VALU) instead of two trips through the LDS queue
-            const unsigned mu = __builtin_bit_cast(unsigned, mx);
-            const auto s16 = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
-            mx = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
-            const unsigned mv = __builtin_bit_cast(unsigned, mx);
-            const auto s32 = __builtin_amdgcn_permlane32_swap(mv, mv, false, false);
-            mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
-        }
-        // (the running maximum of a query stops moving after its first few key blocks: when it has not moved for ANY query of the tile -
-        //  wave-uniform - alpha is exactly 1 for every lane and the rescale of O, 17 multiplications, is skipped)
-        if (__builtin_amdgcn_ballot_w64(mx != m_run) != 0) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);  // (first pair: exp2(-inf) = 0, nothing to rescale)
-            l_run *= alpha;
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt) o[dt] *= alpha;
-            m_run = mx;
-        }
-        const float mb = mx * scale_log2e;
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], scale_log2e, -mb));  // masked keys: exp2(-inf) = 0
-                sc[kt][i] = e;
-                sum += e;
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sc[t][kt][i]);
+            {  // max over the four lane groups of a query: the gfx950 row swaps (plain VALU) instead of two trips through the LDS queue
+                const unsigned mu = __builtin_bit_cast(unsigned, mx);
+                const auto s16 = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
+                mx = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+                const unsigned mv = __builtin_bit_cast(unsigned, mx);
+                const auto s32 = __builtin_amdgcn_permlane32_swap(mv, mv, false, false);
+                mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
             }
-        l_run += sum;  // this lane's keys only; the four lanes of a query are added up at the end
-        // ---- O^T += V^T P^T, one K = 32 block per stage of the pair: keys 4 fg + i and 16 + 4 fg + i per lane on both operands
+            // (the running maximum of a query stops moving after its first few key blocks: when it has not moved for ANY query of the tile -
+            //  wave-uniform - alpha is exactly 1 for every lane and the rescale of O, 17 multiplications, is skipped)
+            if (__builtin_amdgcn_ballot_w64(mx != m_run[t]) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run[t] - mx) * scale_log2e);  // (first pair: exp2(-inf) = 0, nothing to rescale)
+                l_run[t] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) o[t][dt] *= alpha;
+                m_run[t] = mx;
+            }
+            const float mb = mx * scale_log2e;
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][kt][i], scale_log2e, -mb));  // masked keys: exp2(-inf) = 0
+                    sc[t][kt][i] = e;
+                    sum += e;
+                }
+            l_run[t] += sum;  // this lane's keys only; the four lanes of a query are added up at the end
+        }
+        // ---- O^T += V^T P^T, one K = 32 block per stage of the pair: keys 4 fg + i and 16 + 4 fg + i per lane on both operands; every V^T
+        // fragment read serves both query tiles
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int st = 2 * pr + h;
-            f16x8 ph, pl;
-            {   // (hi, lo) of the eight probabilities in 16 VALU instructions (split_pair) instead of 32
+            f16x8 ph[TQ], pl[TQ];
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) {   // (hi, lo) of the eight probabilities in 16 VALU instructions (split_pair) instead of 32
                 u32x4 phu, plu;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     unsigned h_, l_;
-                    split_pair(sc[2 * h][2 * j], sc[2 * h][2 * j + 1], h_, l_);
+                    split_pair(sc[t][2 * h][2 * j], sc[t][2 * h][2 * j + 1], h_, l_);
                     phu[j] = h_; plu[j] = l_;
-                    split_pair(sc[2 * h + 1][2 * j], sc[2 * h + 1][2 * j + 1], h_, l_);
+                    split_pair(sc[t][2 * h + 1][2 * j], sc[t][2 * h + 1][2 * j + 1], h_, l_);
                     phu[2 + j] = h_; plu[2 + j] = l_;
                 }
-                ph = __builtin_bit_cast(f16x8, phu);
-                pl = __builtin_bit_cast(f16x8, plu);
+                ph[t] = __builtin_bit_cast(f16x8, phu);
+                pl[t] = __builtin_bit_cast(f16x8, plu);
             }
-            // two head-dim tiles (16 dims each) per group: eight transposing reads in flight, one wait, six MFMAs.
+            // two head-dim tiles (16 dims each) per group: eight transposing reads in flight, one wait, twelve MFMAs.
             // As asm: the BUILTIN carries no memory operand, so the compiler waits for every LDS-DMA in flight (vmcnt(0)) in front of
             // it - the stages ahead included. The explicit lgkmcnt(0) covers the group's reads.
 #pragma unroll
@@ -217,25 +234,31 @@ __global__ __launch_bounds__(THREADS, 4) void attention_split_dma_kernel(const c
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const u32x4 vh = {h0[e][0], h0[e][1], h1[e][0], h1[e][1]}, vl = {l0[e][0], l0[e][1], l1[e][0], l1[e][1]};
-                    o[2 * d2 + e] = split_mma(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, vl), ph, pl, o[2 * d2 + e]);
+#pragma unroll
+                    for (int t = 0; t < TQ; ++t)
+                        o[t][2 * d2 + e] = split_mma(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, vl), ph[t], pl[t], o[t][2 * d2 + e]);
                 }
             }
         }
     }
     if (!live) return;
-    float sum = l_run;
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
-    const size_t oidx = ((size_t)seq * S + qt * 16 + fr) * E + head * HD;
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) split_store4_rowpair(out, oidx + dt * 16 + 4 * fg, o[dt] * inv, true);
+    for (int t = 0; t < TQ; ++t) {
+        float sum = l_run[t];
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        const bool there = t == 0 || live1;  // (wave-uniform; every lane still takes part in the row swaps of the store)
+        const size_t oidx = ((size_t)seq * S + (there ? qt + t : qt) * 16 + fr) * E + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) split_store4_rowpair(out, oidx + dt * 16 + 4 * fg, o[t][dt] * inv, there);
+    }
 }
 
 template <int HD>
 static int launch(const void* qkv, void* out, int n_seq, int heads, float scale, hipStream_t s) {
     using C = Cfg<HD>;
-    auto kern = attention_split_dma_kernel<HD>;
+    auto kern = option("attn_dma_two_wgs") != 0 ? attention_split_dma_kernel<HD, 4> : attention_split_dma_kernel<HD, 1>;
     const size_t bytes = (size_t)n_seq * S * 3 * heads * HD * 4;
     PP_REQUIRE(bytes < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_attention: qkv tensor exceeds 2 GiB (32-bit buffer offsets)");
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
