@@ -10,10 +10,11 @@
 //     one tile per wave, 42 % matrix-pipe busy at ViT-B: every K and V^T fragment a wave read fed ONE tile's MFMAs, 32 KiB of LDS reads per
 //     wave and 64 keys against 48 MFMAs - the LDS pipe, not the matrix pipe, set the pace. Now a fragment feeds both tiles: half the LDS
 //     reads and half the K / V streamed per MFMA); q fragments from global memory once;
-//   * the keys stream through a ring of four 32-key stages: per stage K and V as HD / 32 sub-tiles of [32 keys][128 B] (the
+//   * the keys stream through a ring of EIGHT 32-key stages (round 6: four, i.e. one pair requested ahead - a pair of stages is ~0.75 us of MFMAs
+//     per wave, a trip to HBM / MALL ~2 us: the kernel waited for memory at every pair, 42 % matrix-pipe busy; three pairs ahead now): per stage K and V as HD / 32 sub-tiles of [32 keys][128 B] (the
 //     raw split blocks: 32 hi halves | 32 lo halves, 16-byte chunks XOR-swizzled by key & 7 at the source) = 16 KiB at head
 //     dim 64; the stages go in PAIRS (one barrier, one running-maximum update and one rescale of O per 64 keys: 149 -> 145 us),
-//     the next pair requested while this one is worked on; 64 KiB of LDS and < 128 registers: two workgroups per CU;
+//     three pairs requested ahead; 128 KiB of LDS at head dim 64: one workgroup per CU;
 //   * S^T = K Q^T (a query's scores lane-local), online softmax over the stages (running maximum / sum, O rescaled when the
 //     maximum moves), P split in registers, O^T = V^T P^T with the V^T fragments read by ds_read_b64_tr_b16 - the gfx950
 //     transposing LDS read (within 16 lanes, lane 4 r + q supplies the address of four consecutive halves M[r][4 q ..], lane i
@@ -34,7 +35,7 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 constexpr int S = 432, NT = S / 16, TQ = 2, QSPLIT = 2, TPW = (NT + QSPLIT * TQ - 1) / (QSPLIT * TQ), THREADS = 64 * TPW;  // 7 waves x 2 tiles
 constexpr int SK = 32;                         // keys per stage
 constexpr int NSTG = (S + SK - 1) / SK;        // 14 stages (the last one holds 16 keys)
-constexpr int RING = 4;
+constexpr int RING = 8;                        // stages in the LDS ring: four pairs - the one worked on and three requested behind it
 
 template <int HD>
 struct Cfg {
@@ -106,8 +107,13 @@ __global__ __launch_bounds__(THREADS, MINW) void attention_split_dma_kernel(cons
             ql[t][g] = *reinterpret_cast<const f16x8*>(qrow + g * 128 + 64 + fg * 16);
         }
     }
-    issue_stage(0);
-    issue_stage(1);
+    constexpr int NP = NSTG / 2, AHEAD = RING / 2 - 1;  // stage pairs; pairs requested ahead of the one worked on
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p) {
+        issue_stage(2 * p);
+        issue_stage(2 * p + 1);
+    }
+    const int npw = wv < C::PIECES ? (C::PIECES - wv + TPW - 1) / TPW : 0;  // DMA pieces this wave issues per stage (wave-uniform)
 
     f32x4 o[TQ][C::DT];
 #pragma unroll
@@ -124,15 +130,28 @@ __global__ __launch_bounds__(THREADS, MINW) void attention_split_dma_kernel(cons
 
     // Two stages (64 keys) between barriers: one running-maximum update, one rescale of O and one barrier per 48 MFMAs instead
     // of per 24. The pair p + 1 is requested at the top of pair p, into the two slots pair p - 1 has just left.
-    static_assert(NSTG % 2 == 0 && RING == 4, "stage pairs on a ring of four");
-    for (int pr = 0; pr < NSTG / 2; ++pr) {
+    static_assert(NSTG % 2 == 0 && RING == 8, "stage pairs on a ring of eight");
+    for (int pr = 0; pr < NP; ++pr) {
         __builtin_amdgcn_sched_barrier(0);
-        wait_vm<0>();                  // this wave's pieces of the pair are in (nothing younger is in flight)
+        {   // this wave's pieces of pair pr are in once only the pairs requested behind it are outstanding
+            // (first pair: everything - the q fragments' plain loads retire out of order with respect to LDS-DMA pieces, so the count says
+            //  nothing while they are in flight; from then on only pieces are)
+            const int n = pr == 0 ? 0 : min(AHEAD - 1, NP - 1 - pr) * 2 * npw;  // (wave-uniform)
+            switch (n) {
+                case 0: wait_vm<0>(); break;
+                case 2: wait_vm<2>(); break;
+                case 4: wait_vm<4>(); break;
+                case 6: wait_vm<6>(); break;
+                case 8: wait_vm<8>(); break;
+                case 12: wait_vm<12>(); break;
+                default: wait_vm<0>(); break;
+            }
+        }
         __builtin_amdgcn_s_barrier();  // every wave's pieces are in; every wave is done with pair pr - 1
         __builtin_amdgcn_sched_barrier(0);
-        if (2 * pr + 2 < NSTG) {
-            issue_stage(2 * pr + 2);
-            issue_stage(2 * pr + 3);
+        if (pr + AHEAD < NP) {         // into the two slots pair pr - 1 has just left
+            issue_stage(2 * (pr + AHEAD));
+            issue_stage(2 * (pr + AHEAD) + 1);
         }
         if (!live) continue;
         const bool tail = pr == NSTG / 2 - 1 && (S % SK) != 0;  // the last stage holds S % 32 = 16 keys: its second key tile does not exist

@@ -450,7 +450,7 @@ def test_vit_small_384x288_layer_plan_is_named_and_within_1e3():
     x = S.synthetic_crops(3, img_size=img, seed=5)
     ref = M.predict(sd, x, 12, S.IMG_MEAN, S.IMG_STD, input_size=(288, 384))
     with pytest.warns(RuntimeWarning, match="432-token sequences .* miss the fused qkv \\+ attention kernel"):
-        eng = ProbPoseEngine(sd, 12, img_size=img, precision="f16x3", input_size=(288, 384))
+        eng = ProbPoseEngine(sd, 12, img_size=img, precision="f16x3", input_size=(288, 384), plan=dict(small_plan=False))  # (3 crops: the row-owner plan is what is named here)
     assert eng.layer_plan.startswith("three launches per layer") and not eng.fuse_qkv_attn
     _lib.reset_launch_counts()
     out = eng.forward(x.cuda(), True, S.COCO_FLIP_INDICES)
@@ -483,7 +483,7 @@ def test_config4_row_owner_residual_layernorm_plan(monkeypatch):
     ref = M.predict(sd, x, 12, S.IMG_MEAN, S.IMG_STD, input_size=(288, 384))
     monkeypatch.setenv("PP_FUSE_RESLN", "1")
     for precision in ("f16x3", "bf16"):
-        eng = ProbPoseEngine(sd, 12, img_size=img, precision=precision, input_size=(288, 384))
+        eng = ProbPoseEngine(sd, 12, img_size=img, precision=precision, input_size=(288, 384), plan=dict(small_plan=False))
         assert eng._resln_768
         eng.profile = {}
         out = eng.forward(x.cuda(), True, S.COCO_FLIP_INDICES)

@@ -299,26 +299,37 @@ def test_linear_ln_folded_row_offsets_vs_fp64(ratio, outliers):
 @gpu
 def test_overflowing_activations_raise_instead_of_decoding_index_zero():
     """An activation beyond fp16's range (|x| > 65504: the high half is inf, the MFMA makes NaN of it) must not come out as keypoint (0, 0) with a
-    plausible score: the decode launch writes NaN keypoints / scores for a map with a non-finite logit, and the host mirror's `predict` raises."""
+    plausible score: the decode launch writes NaN keypoints / scores for a map with a non-finite logit, and the host mirror's `predict` raises. The
+    headline plan hands (centered) residual rows to the MFMAs: a residual channel of 3e5 overflows there. The plan of small batches applies its
+    LayerNorms in fp32 before the split: the same weights run through it, finite and within 1e-3 of the oracle."""
+    from oracle import model_ref as M
     from probpose_code_amd import ProbPoseEngine, apis
     from probpose_code_amd import synthetic as S
 
+    torch.set_num_threads(min(16, os.cpu_count()))
     sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
     sd["backbone.layers.4.ffn.layers.1.bias"][11] = 3.0e5  # one residual channel far beyond the split format's range from layer 5 on
-    crops = S.synthetic_crops(3, seed=7)
+    B = 20  # (the row-owner plan: from 18 crops with flip test)
+    crops = S.synthetic_crops(B, seed=7)
     eng = ProbPoseEngine(sd, 12, precision="f16x3")
+    assert not eng._small_at(B * 2 * 192)
     out = eng.forward(crops.cuda(), True, S.COCO_FLIP_INDICES)
     torch.cuda.synchronize()
     assert torch.isnan(out["keypoints"]).all() and torch.isnan(out["scores"]).all()
     cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "td-pm_ProbPose-small_mi355x_coco-256x192.py")
     model = apis.init_model(cfg, {"state_dict": sd}, device="cuda:0")
-    center, scale = S.whole_image_bbox_meta(3)
+    center, scale = S.whole_image_bbox_meta(B)
     batch = apis.pack_crops(crops, center, scale, model.dataset_meta)
     with pytest.raises(FloatingPointError, match="numeric domain"):
         model.test_step(batch)
     # fp32 mode has fp32's range: the same weights run through
-    out32 = ProbPoseEngine(sd, 12, precision="f32").forward(crops.cuda(), True, S.COCO_FLIP_INDICES)
+    out32 = ProbPoseEngine(sd, 12, precision="f32").forward(crops[:3].cuda(), True, S.COCO_FLIP_INDICES)
     assert torch.isfinite(out32["keypoints"]).all()
+    # ... and so does the small-batch plan of the f16x3 mode (LayerNorm in fp32 in front of every split)
+    small = eng.forward(crops[:3].cuda(), True, S.COCO_FLIP_INDICES)
+    ref = M.predict(sd, crops[:3], 12, S.IMG_MEAN, S.IMG_STD)
+    d = np.abs(small["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
+    assert np.isfinite(d).all() and (d < 2.0).all() and d.max() <= 1e-3
 
 
 @gpu
