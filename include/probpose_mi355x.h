@@ -118,7 +118,7 @@ int pp_get_option(const char* name, int* value);
  * kernel under pp_linear_ln_folded), "ffn_dma_pair" / "ffn_dma_single" / "ffn_dma_fold" (the twelve-wave feed-forward launch in its
  * paired-chunk / one-chunk form / under pp_proj_ffn_split_folded), "winograd_input_transform", "winograd_gemm_pool", "layernorm". Lets a test
  * assert WHICH kernels a launch plan ran (the reference has no counterpart: kernel selection there is cuDNN's, mmpose/models/heads/
- * hybrid_heads/probmap_head.py:261-294 and mmpretrain's VisionTransformer only name the layers). Unknown names count 0. Not thread-safe. */
+ * hybrid_heads/probmap_head.py:261-294 and mmpretrain's VisionTransformer only name the layers). Unknown (and NULL) names count 0. Thread-safe (a mutex around the tally). */
 long long pp_launch_count(const char* kernel);
 int pp_reset_launch_counts(void);
 

@@ -2,6 +2,7 @@
 #include "pp_common.h"
 
 #include <cstring>
+#include <mutex>
 
 namespace pp {
 
@@ -46,8 +47,10 @@ struct LaunchCount {
 };
 static LaunchCount g_launches[96];
 static int g_n_launches = 0;
+static std::mutex g_launch_mutex;  // (ctypes releases the GIL: two host threads may launch at once; the tally is a few string compares under a lock)
 
 void count_launch(const char* file_or_tag) {
+    std::lock_guard<std::mutex> lock(g_launch_mutex);
     const char* base = file_or_tag;
     for (const char* c = file_or_tag; *c; ++c)
         if (*c == '/') base = c + 1;
@@ -119,14 +122,16 @@ long long pp_launch_count(const char* kernel) {
     using namespace pp;
     if (!kernel) {
         set_error("pp_launch_count: NULL name");
-        return PP_ERR_INVALID_ARG;
+        return 0;  // (a count: unknown and NULL names count 0; the message says why)
     }
+    std::lock_guard<std::mutex> lock(g_launch_mutex);
     for (int i = 0; i < g_n_launches; ++i)
         if (std::strcmp(g_launches[i].name, kernel) == 0) return g_launches[i].n;
     return 0;
 }
 
 int pp_reset_launch_counts(void) {
+    std::lock_guard<std::mutex> lock(pp::g_launch_mutex);
     pp::g_n_launches = 0;
     return PP_OK;
 }

@@ -81,7 +81,7 @@ class ProbPoseEngine:
         self.prec = PREC[precision]
         self.dtype = _DTYPE[precision]
         self.fmt = _FMT[precision]
-        self.w: PackedWeights = pack(state_dict, self.dtype, self.device, split=precision == "f16x3", num_heads=int(num_heads))
+        self.w: PackedWeights = pack(state_dict, self.dtype, self.device, split=precision == "f16x3", num_heads=int(num_heads), fold_ln=bool(pl["ln_fold"]))
         self.heads = num_heads
         self.H, self.W = img_size
         self.P, self.pad = patch_size, patch_padding

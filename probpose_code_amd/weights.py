@@ -197,11 +197,12 @@ def winograd_weights(w: torch.Tensor) -> torch.Tensor:
 
 
 def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = False, scale_linear: bool = True,
-         num_heads: int = 0) -> PackedWeights:
+         num_heads: int = 0, fold_ln: bool = True) -> PackedWeights:
     """``dtype``: operand dtype of the MFMA kernels (bf16 / fp32); ``split=True``: split-fp16 operands in a float32
     container (``to_split``); with it ``scale_linear``: the backbone's Linear weights (qkv, proj, fc1, fc2 and their LayerNorm-folded forms) are
     stored times a power of two per tensor, ``PackedWeights.inv(name)`` is what the ``*_ws`` launches are handed (``weight_scale_exponent``), and
-    - given ``num_heads`` - every attention block's q / k and v / proj dimensions are balanced by exact powers of two (``balance_attention_dims``)."""
+    - given ``num_heads`` - every attention block's q / k and v / proj dimensions are balanced by exact powers of two (``balance_attention_dims``).
+    ``fold_ln=False``: no LayerNorm-folded copies (the engine passes its ``ln_fold`` plan switch: ~200 MB at ViT-B that the unfolded plan never reads)."""
     sd = {k: v.detach().cpu() for k, v in normalize_state_dict(sd).items()}
     if split and scale_linear and num_heads > 0:
         n_layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("backbone.layers."))
@@ -244,7 +245,7 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
         t[f"l{i}.fc1.b"] = f32(sd[p + "ffn.layers.0.0.bias"])
         t[f"l{i}.fc2.w"] = op(sd[p + "ffn.layers.1.weight"], f"l{i}.fc2.w", scaled=True)
         t[f"l{i}.fc2.b"] = f32(sd[p + "ffn.layers.1.bias"])
-        if split and E == 384 and i >= 1:
+        if split and fold_ln and E == 384 and i >= 1:
             # ViT-S chain of fused layer kernels: ln1 of layers 1 .. L - 1 folded into the qkv projection (pp_qkv_attention_split_folded; the layer in front
             # leaves raw rows + statistics, pp_proj_ffn_split_folded)
             bb = sd.get(p + "attn.qkv.bias")
@@ -254,7 +255,7 @@ def pack(sd: Dict[str, torch.Tensor], dtype: torch.dtype, device, split: bool = 
             # (no column sums: the rows this projection is handed are centered, pp_qkv_attention_split_folded)
             t[f"l{i}.qkv.wf"], t[f"l{i}.qkv.bf"] = wf.to(device), bf.to(device)
             inv_scale[f"l{i}.qkv.wf"] = 2.0 ** -e
-        if split and E % 192 == 0 and E != 384:
+        if split and fold_ln and E % 192 == 0 and E != 384:
             # widths without a fused layer kernel (ViT-B): the folded form of the two Linear layers that follow a LayerNorm (pp_linear_ln_folded;
             # engine.py takes that plan from the row count at which the twelve-wave Linear kernel engages - the plain copies serve below it)
             for name, wk, bk, ln in (("qkv", "attn.qkv.weight", "attn.qkv.bias", "ln1"), ("fc1", "ffn.layers.0.0.weight", "ffn.layers.0.0.bias", "ln2")):
