@@ -389,7 +389,84 @@ __global__ __launch_bounds__(DEC_THREADS) void probmap_decode_kernel(
         float tau0 = smx ? -1.0f : 0.f, tau1 = tau0;
         int prev = -1;
         bool alive = true;  // the thresholds only rise: a thread without a candidate now has none in any later round
-        for (int iter = 0; iter < (smx ? 64 : 0); ++iter) {
+        // COMPACT form of the threshold search (round 6). The search only ever looks at the candidates of its FIRST threshold (z > max - 1: the
+        // thresholds rise, nothing comes back) - a few dozen of a row's 3 072 logits on a peaked map - yet every round walked all 24 (48 with
+        // the flipped pass) values of every thread and paid a block-wide reduction: ~260 instructions x 4 - 6 rounds of the kernel's ~2 550 per
+        // wave. Now the first threshold's candidates are packed into an LDS list once (a block-wide prefix sum of the per-thread counts) and
+        // every wave runs the rounds on the list by itself: a lane per candidate, wave reductions, no barrier. Same rounds, same thresholds up
+        // to the order of the fp32 sums. Rows with more than SMX_CAP candidates (a flat map) keep the walk below.
+        constexpr int SMX_CAP = 1024;
+        bool compact_done = false;
+        if (smx) {
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < NV; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c += z0[e][j] > -1.0f ? 1 : 0;
+                    if (HAS_FLIP) c += z1[e][j] > -1.0f ? (1 << 16) : 0;
+                }
+            int inc = c;  // inclusive prefix over the wave's lanes (both counts in one word: a row has 3 072 .. 12 288 values)
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane_id() >= o) inc += t;
+            }
+            int* wtot = reinterpret_cast<int*>(smem + 192);
+            if (lane_id() == WAVE - 1) wtot[wave_id()] = inc;
+            __syncthreads();
+            int base = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < DEC_THREADS / WAVE; ++w) {
+                const int t = wtot[w];
+                base += w < wave_id() ? t : 0;
+                tot += t;
+            }
+            const int n0 = tot & 0xffff, n1 = tot >> 16;
+            if (n0 <= SMX_CAP && n1 <= SMX_CAP) {  // (workgroup-uniform)
+                float* L0 = mapf;            // the map region is not written before the thresholds are known
+                float* L1 = mapf + SMX_CAP;
+                const int off = base + inc - c;
+                int o0 = off & 0xffff, o1 = off >> 16;
+#pragma unroll
+                for (int e = 0; e < NV; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (z0[e][j] > -1.0f) L0[o0++] = z0[e][j];
+                        if (HAS_FLIP && z1[e][j] > -1.0f) L1[o1++] = z1[e][j];
+                    }
+                __syncthreads();
+                for (int iter = 0; iter < 64; ++iter) {
+                    float s0 = 0.f, s1 = 0.f;
+                    int n = 0;
+                    for (int i = lane_id(); i < n0; i += WAVE) {
+                        const float d0 = L0[i] - tau0;
+                        if (d0 > 0.f) {
+                            s0 += d0;
+                            n += 1;
+                        }
+                    }
+                    if (HAS_FLIP)
+                        for (int i = lane_id(); i < n1; i += WAVE) {
+                            const float d1 = L1[i] - tau1;
+                            if (d1 > 0.f) {
+                                s1 += d1;
+                                n += 1 << 16;
+                            }
+                        }
+                    s0 = wave_allreduce(s0, [](float x, float y) { return x + y; });
+                    if (HAS_FLIP) s1 = wave_allreduce(s1, [](float x, float y) { return x + y; });
+                    n = wave_allreduce(n, [](int x, int y) { return x + y; });
+                    if (n == prev) break;
+                    prev = n;
+                    tau0 = tau0 + (s0 - 1.0f) / (float)(n & 0xffff);
+                    if (HAS_FLIP) tau1 = tau1 + (s1 - 1.0f) / (float)(n >> 16);
+                }
+                compact_done = true;
+                __syncthreads();  // every wave is through with the lists before the map takes their place
+            }
+        }
+        for (int iter = 0; iter < ((smx && !compact_done) ? 64 : 0); ++iter) {
             SmxStat st{0.f, 0.f, 0};
             if (alive) {
 #pragma unroll
