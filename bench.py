@@ -236,8 +236,8 @@ def pmc_traffic(kernel_mangled, precision, B, prefix=""):
              "_ZN2pp3ffd24proj_ffn_dma_pair_kernelENS_3ffs6ParamsE": "pp::ffd::proj_ffn_dma_pair_kernel(",
              "_ZN2pp3qka26qkv_attention_split_kernelENS0_6ParamsE": "pp::qka::qkv_attention_split_kernel("}.get(kernel_mangled)
     short = short or {"_ZN2pp6psplit18panel_split_kernelILi0ELi8ELi3ELb1ELi2ELb0ELb0EEEvNS_10GemmParamsE": "void pp::psplit::panel_split_kernel<0, 8, 3, true, 2, false, false>("}.get(kernel_mangled)
-    names = (f"r05_{prefix}{precision}_bs64_hbm_traffic.json", f"r04_{prefix}{precision}_bs64_hbm_traffic.json") if prefix else \
-        (f"r05_{precision}_bs64_hbm_traffic.json", f"r04_{precision}_bs64_hbm_traffic.json", f"r03_{precision}_bs64_hbm_traffic.json",
+    names = (f"r06_{prefix}{precision}_bs64_hbm_traffic.json", f"r05_{prefix}{precision}_bs64_hbm_traffic.json", f"r04_{prefix}{precision}_bs64_hbm_traffic.json") if prefix else \
+        (f"r06_{precision}_bs64_hbm_traffic.json", f"r05_{precision}_bs64_hbm_traffic.json", f"r04_{precision}_bs64_hbm_traffic.json", f"r03_{precision}_bs64_hbm_traffic.json",
          f"r02_{precision}_bs64_hbm_traffic.json", f"r01_{precision}_bs64_hbm_traffic.json")
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
@@ -273,6 +273,49 @@ def pmc_traffic(kernel_mangled, precision, B, prefix=""):
             for k, v in ks.items():
                 if "mlp_res_ln_kernel" in k and want in k:
                     return v["hbm_bytes_per_launch"], "profiles/" + name
+    return None, None
+
+
+def profiled_duration(kernel_mangled, precision, B, prefix=""):
+    """Average duration (ms) of `kernel_mangled` in the committed rocprofv3 kernel trace of the one-step-in-flight run
+    (profiles/r06_<prefix><precision>_bs64_kernel_stats_one_in_flight.csv), with the file it came from - what a reader who recomputes `frac` from
+    profiles/ divides by. rocprofv3's tracing itself slows the kernels by a few per cent (the *_under_rocprof*.json runs carry the clock)."""
+    if B != 64:
+        return None, None
+    import csv
+    import re as _re
+
+    def norm(name):  # Itanium-mangled nested name -> its last identifier (the kernel's own name, as rocprofv3 prints it)
+        i, last = (3 if name.startswith("_ZN") else 0), name
+        while i < len(name) and name[i].isdigit():
+            j = i
+            while name[j].isdigit():
+                j += 1
+            n_ = int(name[i:j])
+            last = name[j:j + n_]
+            i = j + n_
+        return last
+
+    wants = [norm(k) for k in kernel_mangled.split("|")]
+    modes = [m[m.index("kernelILi") + len("kernelILi")] for m in kernel_mangled.split("|") if "kernelILi" in m]
+    for rnd in ("r06", "r05"):
+        name = f"{rnd}_{prefix}{precision}_bs64_kernel_stats_one_in_flight.csv"
+        try:
+            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", name))))
+        except OSError:
+            continue
+        hit = []
+        for r in rows:
+            kn = r["Name"]
+            if not any(w in kn for w in wants):
+                continue
+            if modes and not any((f"_kernel<{md}," in kn or f"_kernel<{md}>" in kn) for md in modes):
+                continue
+            if "fold3" in kernel_mangled and "_fold" not in kn:
+                continue
+            hit.append((float(r["TotalDurationNs"]), int(r["Calls"])))
+        if hit:
+            return sum(h[0] for h in hit) / sum(h[1] for h in hit) / 1e6, "profiles/" + name
     return None, None
 
 
@@ -405,6 +448,15 @@ def roofline_record(eng, B, prof, reps):
                           "(`bench.py --in-flight 1`); in the trace of the default run (profiles/*_kernel_stats.csv, two steps in flight) a "
                           "kernel's duration includes the time it shares CUs with the other step's kernels",
     }
+    # the same fraction from the COMMITTED rocprofv3 trace (what a reader recomputing it from profiles/ gets): tracing slows kernels by a few per cent
+    rec["frac_unprofiled"] = rec["frac"]
+    rec["avg_launch_us_unprofiled"] = dom_ms / n * 1e3
+    pms, psrc = profiled_duration(mangled, prec, B)
+    if pms:
+        per = (fl / n / (pms * 1e-3) / 1e12 / peak) if bound == "mfma" else (alg_bytes / n / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        rec["frac_profiled"] = per
+        rec["avg_launch_us_profiled"] = pms * 1e3
+        rec["profiled_from"] = psrc + " (TotalDurationNs / Calls of the kernel's rows; bench.py --in-flight 1 under rocprofv3 --kernel-trace --stats)"
     if bound == "mfma":
         power = sustained_mfma_rate()
         if power:
@@ -718,6 +770,12 @@ def config4_record(dev, args):
                              "frac": fl / n / secs / 1e12 / PEAK_TFLOPS[prec], "traffic": traffic, "traffic_source": src,
                              "algorithmic_mbytes_per_launch": by / n / 1e6,
                              "derived_ceiling_TFLOPs": PEAK_TFLOPS[prec] / MFMA_PER_PRODUCT[prec]}
+            r["roofline"]["frac_unprofiled"] = r["roofline"]["frac"]
+            r["roofline"]["avg_launch_us_unprofiled"] = secs * 1e6
+            pms, psrc = profiled_duration(mangled, prec, B, prefix="config4_")
+            if pms:
+                r["roofline"].update(frac_profiled=fl / n / (pms * 1e-3) / 1e12 / PEAK_TFLOPS[prec], avg_launch_us_profiled=pms * 1e3,
+                                     profiled_from=psrc + " (TotalDurationNs / Calls; bench.py --config4-only --in-flight 1 under rocprofv3)")
         del eng
         torch.cuda.empty_cache()
         return r, snap

@@ -7,7 +7,7 @@ set -u
 tag=${1:-r05_f16x3_bs64}
 prec=${2:-f16x3}
 extra=${3:-}   # appended to every bench.py command, e.g. "--config4-only --config4-quick --no-parity" for BASELINE config 4 (tag r05_config4_f16x3_bs64)
-nodrop="--no-drop-in --no-small-batch --no-clock-probe"
+nodrop="--no-drop-in --no-small-batch"
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/profiles
 mkdir -p $out

@@ -34,6 +34,21 @@ for wseed, cseed, B, scale in ((0, 100, 64, 2.0), (1, 101, 64, 2.0), (2, 102, 64
     rows.append(r)
     print(r, flush=True)
     del eng
+# round 6: trained-like statistics (massive-activation channels, LayerNorm gamma over two decades, token offsets, small weight rows) at the
+# headline batch, at the small-batch plan's sizes, and the harder corners of tests/test_trained_stats.py
+for wseed, cseed, B, kw in ((0, 100, 64, {}), (1, 111, 64, {}), (2, 112, 8, {}), (3, 113, 2, {}), (4, 114, 33, dict(massive=(900.0, -400.0, 150.0, 2500.0))),
+                            (5, 115, 24, dict(row_offset=16.0)), (6, 116, 24, dict(small_rows=1e-3))):
+    sd = S.synthetic_state_dict("small", seed=wseed, logit_scale=2.0, stats="trained", **kw)
+    crops = S.synthetic_crops(B, seed=cseed)
+    ref = M.predict(sd, crops, 12, S.IMG_MEAN, S.IMG_STD)
+    eng = ProbPoseEngine(sd, 12, precision="f16x3")
+    out = eng.forward(crops.cuda(), True, S.COCO_FLIP_INDICES)
+    torch.cuda.synchronize()
+    r = dict(model="ProbPose-small 256x192, stats='trained' " + (str(kw) if kw else ""), weight_seed=wseed, crop_seed=cseed, batch=B, logit_scale=2.0,
+             plan="small-batch (pp_skinny_linear)" if eng._small_at(B * 2 * 192) else "headline (two launches per layer)", **compare(out, ref))
+    rows.append(r)
+    print(r, flush=True)
+    del eng
 img = (384, 288)
 sd = S.synthetic_state_dict("base", img_size=img, seed=0, logit_scale=2.0)
 crops = S.synthetic_crops(4, img_size=img, seed=1)
