@@ -105,6 +105,7 @@ int pp_device_cu_count(void);
  *                            times per launch; taken when F / 128 is even); 0: one chunk at a time
  *   "psplit_tail" (1)        0: split-fp16 Linear layers never send the rows of a ragged last round to a second launch on 128 x 192 tiles
  *   "wino_order" (8)         pp_conv3x3_winograd_maxpool_relu: column tiles per 32-workgroup super tile (0: column tiles fastest)
+ *   "qkv_attn_deep" (1)      pp_qkv_attention_split(_ws) of a small launch (<= 2 workgroups per CU): ring of four stages, one workgroup per CU (0: always two stages)
  *   "skinny_tile" (0)        pp_skinny_linear: 32 / 64 / 96 forces the tile edge (0: the cost rule of pp_skinny.hip)
  *   "ksplit_channels" (1)    pp_conv3x3_splitk_slices: 0 = whole-tap slices only (never the four channel ranges of the wide-tile kernel)
  * Unknown names return PP_ERR_INVALID_ARG. Not thread-safe against concurrent launches (set them before the first call).

@@ -111,7 +111,10 @@ __device__ unsigned long long g_qka_stamps[4][16];
 struct TagF { static constexpr bool value = false; };
 struct TagT { static constexpr bool value = true; };
 
-template <bool FOLD>
+// NSTG: stages of the projection's LDS ring. 2 (74 KiB: two workgroups per CU, one's softmax beside the other's fill - the headline batch) or 4
+// (144 KiB, one workgroup per CU, three stages requested ahead: the launch of a SMALL batch is 24 - 400 workgroups, each alone on its CU, and
+// with one stage ahead its twelve K-steps were twelve memory round trips - 15 us per launch at B = 1 whatever the arithmetic).
+template <bool FOLD, int NSTG = 2>
 __device__ __forceinline__ void qkv_attention_body(const Params& p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -177,9 +180,10 @@ __device__ __forceinline__ void qkv_attention_body(const Params& p) {
     for (int cf = 0; cf < 3; ++cf)
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf) acc[cf][rf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    issue_stage(0, 0);
-    issue_stage(1, 1);
-    if (wv < 4) wait_vm_lgkm<5>(); else wait_vm_lgkm<4>();  // the first stage has landed
+#pragma unroll
+    for (int st = 0; st < NSTG; ++st) issue_stage(st, st);
+    // the first stage has landed: NSTG - 1 younger ones (5 pieces per stage from waves 0-3, 4 from waves 4-7) may fly
+    if (wv < 4) wait_vm_lgkm<5 * (NSTG - 1)>(); else wait_vm_lgkm<4 * (NSTG - 1)>();
     __builtin_amdgcn_s_barrier();
     stamp();  // 1: first stage landed
     u32x4 ah[3], wh[3], al[3], wl[3];
@@ -193,7 +197,7 @@ __device__ __forceinline__ void qkv_attention_body(const Params& p) {
         auto mm = [&](int cf, const u32x4& wf, const u32x4& af, f32x4 c) { return (VT && cf >= 1) ? mma(af, wf, c) : mma(wf, af, c); };
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
-            const int cb = k & 1, nb = cb ^ 1;
+            const int cb = k % NSTG, nb = (k + 1) % NSTG;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cf = 0; cf < 3; ++cf) wl[cf] = frag_w(cb, 1, cf);
@@ -204,11 +208,17 @@ __device__ __forceinline__ void qkv_attention_body(const Params& p) {
 #pragma unroll
                 for (int cf = 0; cf < 3; ++cf) acc[cf][rf] = mm(cf, wh[cf], ah[rf], acc[cf][rf]);
             __builtin_amdgcn_sched_barrier(0);
-            // every wave holds the rest of this stage in registers -> its buffer is free; stage k + 1 (the only one in flight) has landed
-            wait_vm_lgkm<0>();
+            // every wave holds the rest of this stage in registers -> its buffer is free; stage k + 1 has landed once only the stages
+            // requested behind it are outstanding (two stages: none)
+            {
+                const int younger = NSTG == 2 ? 0 : max(0, min(KB - 1, k + NSTG - 1) - (k + 1));  // (a constant after unrolling)
+                if (younger == 0) wait_vm_lgkm<0>();
+                else if (younger == 1) { if (wv < 4) wait_vm_lgkm<5>(); else wait_vm_lgkm<4>(); }
+                else { if (wv < 4) wait_vm_lgkm<10>(); else wait_vm_lgkm<8>(); }
+            }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (k + 2 < KB) issue_stage(k + 2, cb);
+            if (k + NSTG < KB) issue_stage(k + NSTG, cb);
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
@@ -375,6 +385,9 @@ __device__ __forceinline__ void qkv_attention_body(const Params& p) {
 
 __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_kernel(const Params p) { qkv_attention_body<false>(p); }
 __global__ __launch_bounds__(THREADS, 4) void qkv_attention_split_folded_kernel(const Params p) { qkv_attention_body<true>(p); }
+constexpr int LDS_DEEP = 4 * STAGE;  // 144 KiB: the projection's ring of four stages (phase 2 reuses its first 74 KiB)
+static_assert(LDS_DEEP >= LDS && LDS_DEEP <= 160 * 1024, "LDS map of the deep-ring form");
+__global__ __launch_bounds__(THREADS) void qkv_attention_split_deep_kernel(const Params p) { qkv_attention_body<false, 4>(p); }
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -679,6 +692,14 @@ static int qkv_attention_launch(const void* h_in, const void* wqkv, const float*
                                          hipFuncAttributeMaxDynamicSharedMemorySize, qka::two::LDS2));
         hipLaunchKernelGGL(qka::qkv_attention_split2_kernel, dim3(n_seq * (heads / 2)), dim3(qka::THREADS), qka::two::LDS2,
                            reinterpret_cast<hipStream_t>(stream), p);
+    } else if (pp::option("qkv_attn_deep") != 0 && n_seq * heads <= 2 * pp_device_cu_count()) {
+        // at most two workgroups per CU's worth of launch: nothing to overlap with on a CU, the deep ring hides the memory round trips instead
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qka::qkv_attention_split_deep_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, qka::LDS_DEEP));
+        hipLaunchKernelGGL(qka::qkv_attention_split_deep_kernel, dim3(n_seq * heads), dim3(qka::THREADS), qka::LDS_DEEP,
+                           reinterpret_cast<hipStream_t>(stream), p);
+        PP_LAUNCH_CHECK_AS("qkv_attn_deep");
+        return PP_OK;
     } else {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qka::qkv_attention_split_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, qka::LDS));
