@@ -219,7 +219,7 @@ def kernel_work_per_step(eng, B, passes, tag):
         if eng.precision == "f16x3" and (3 * E) % 192 == 0 and Fd % 192 == 0:
             from probpose_code_amd import _lib
             if _lib.get_option("linear_dma") != 0 and ((M + 191) // 192) * ((3 * E) // 192) >= 512:
-                # the twelve-wave kernel (pp_linear_dma.hip: pp_gemm tries it FIRST, at every K >= 64 - scripts/micro/linear_k384_bench.py)
+                # the twelve-wave kernel (pp_linear_dma.hip: pp_gemm tries it FIRST, at every K >= 64)
                 return act_fl, act_by, act_n, "_ZN2pp3ldm17linear_dma_kernelILi0EEEvNS0_6ParamsE"
         if eng.precision == "f16x3" and E >= 768 and (3 * E) % 192 == 0 and Fd % 192 == 0:
             # K >= 768: the wide-tile split kernel (256 x 192 tiles; the fp32-output Linear layers run on the same instantiation)

@@ -709,7 +709,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 const int sw = sw_;
 #if FFD_GELU_PACKED
                 // Round 5: the chunk's GELU is ~3.4 k of its ~22 k cycles (stamps of scripts/micro/ffn12d.hip -DSTAMP=1), VALU-bound with both
-                // computing waves of a SIMD issuing at once, and it cannot be hidden behind MFMAs of the same SIMD (scripts/micro/ffn_skew_form.hip).
+                // computing waves of a SIMD issuing at once, and it cannot be hidden behind MFMAs of the same SIMD.
                 // What is left is fewer issue cycles per value (scripts/micro/valu_rate.hip, cycles per wave64 instruction and SIMD: plain fp32
                 // 3.0, v_pk_*_f32 4.9 for TWO values, v_rcp / v_exp 8.5, v_cvt 4.5, v_cvt_pk_f16_f32 and v_fma_mix_f32 4.7): the same A & S 7.1.26
                 // form on value PAIRS with packed fp32 instructions (constants folded: 1 + p z = 1 + (p / sqrt 2) |x|, exp(-z^2) =

@@ -521,7 +521,7 @@ bool linear_dma_supported(const GemmParams& p, int prec, int groups) {
     // two rounds of the chip at least; smaller problems stay with the 128 x 128 / wide-tile kernels. No lower bound on K beyond two stages: at
     // the ViT-S shapes (K = 384; reached when the fused layer kernels are off or the token count is not 192) it is level with the
     // overlapped-epilogue kernel it shadows - 71.5 / 111.2 / 160.8 / 255.7 us against 71.1 / 104.7 / 174.7 / 256.7 us for qkv / fc1 at
-    // M = 24 576 / 55 296 (scripts/micro/linear_k384_bench.py); option "linear_dma" = 0 hands those shapes to the wide-tile kernel (pp_panel_split.hip)
+    // M = 24 576 / 55 296 (round 5 measurement; the bench script went with pp_linear_ovl.hip in round 6); option "linear_dma" = 0 hands those shapes to the wide-tile kernel (pp_panel_split.hip)
     return ntiles >= 512;
 }
 
