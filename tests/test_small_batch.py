@@ -218,3 +218,36 @@ def test_small_plan_vit_b_384x288():
     assert _lib.launch_count("pp_skinny.hip") == 1 + 4 * 12
     d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
     assert (d < 2.0).all() and d.max() <= 1e-3, f"{int((d >= 2).sum())} flips, {d[d < 2].max():.2e} px"
+
+
+@gpu
+@pytest.mark.parametrize("B", [1, 5])
+def test_small_batches_two_steps_in_flight_equal_serial_launches(B):
+    """The small-batch plan under `StepPipeline(depth=2)` - what `test_step_stream` drives for the persons of consecutive video frames: two steps
+    in flight on two streams, each with its own workspace (arrival counters of the LayerNorm tails included) and captured graph, the towers of
+    both on the engine's second head stream. Every pipelined record must equal the serial eager launch of the same batch bit for bit, over forty
+    batches (the LayerNorm tail's arrival order changes from replay to replay and between the two concurrent steps)."""
+    from probpose_code_amd import ProbPoseEngine
+    from probpose_code_amd import synthetic as S
+    from probpose_code_amd.dist import pack_records
+    from probpose_code_amd.pipeline import StepPipeline
+
+    flip = S.COCO_FLIP_INDICES
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
+    eng = ProbPoseEngine(sd, 12, precision="f16x3", device="cuda:0")
+    assert eng._small_at(B * 2 * 192)
+    batches = [S.synthetic_crops(B, seed=700 + i).cuda() for i in range(6)]
+    want = []
+    for x in batches:
+        want.append(pack_records(eng.forward(x, True, flip)).cpu().numpy().copy())
+    assert not np.array_equal(want[0], want[1])
+    pipe = StepPipeline(eng, B, flip, depth=2)
+    tickets = []
+    for it in range(40):
+        i = (it * 5 + it // 6) % 6
+        tickets.append((pipe.submit(batches[i]), i))
+        if it >= 1:
+            t, j = tickets[it - 1]
+            assert np.array_equal(pipe.result(t)[0].numpy(), want[j]), f"step {it - 1} (batch {j}) differs from the serial launch"
+    t, j = tickets[-1]
+    assert np.array_equal(pipe.result(t)[0].numpy(), want[j])
