@@ -106,7 +106,7 @@ int pp_device_cu_count(void);
  *   "psplit_tail" (1)        0: split-fp16 Linear layers never send the rows of a ragged last round to a second launch on 128 x 192 tiles
  *   "wino_order" (8)         pp_conv3x3_winograd_maxpool_relu: column tiles per 32-workgroup super tile (0: column tiles fastest)
  *   "qkv_attn_deep" (1)      pp_qkv_attention_split(_ws) of a small launch (<= 2 workgroups per CU): ring of four stages, one workgroup per CU (0: always two stages)
- *   "skinny_tile" (0)        pp_skinny_linear: 32 / 64 / 96 forces the tile edge (0: the cost rule of pp_skinny.hip)
+ *   "skinny_tile" (0)        pp_skinny_linear: 10 RT + CT (11, 22, 33, 13, 12, 23) forces a tile of 32 RT rows x 32 CT columns (0: the cost rule of pp_skinny.hip)
  *   "ksplit_channels" (1)    pp_conv3x3_splitk_slices: 0 = whole-tap slices only (never the four channel ranges of the wide-tile kernel)
  * Unknown names return PP_ERR_INVALID_ARG. Not thread-safe against concurrent launches (set them before the first call).
  * (probpose_code_amd/_lib.py forwards PP_OPT_<NAME>=<int> environment variables here at import - host-side convenience.) */
@@ -291,8 +291,9 @@ int pp_linear_ln_folded_supported(int M, int N, int K, int with_ln_stats);
  *   out[m, n] = act_fn((sum_k act[m, k] weight[n, k]) * w_inv_scale + bias[n]) + residual[r(m), n]
  *   ln_out[m, :] = LayerNorm(out[m, :]; ln_gamma, ln_beta, ln_eps)                       when ln_out != NULL
  * act (M, K), weight (N, K) PP_OUT_SPLIT; bias fp32 or NULL; residual fp32 (M, N) - it may be `out` (fp32), the residual stream updated in place -
- * or a (res_mod, N) table (r(m) = m % res_mod: pos_embed) or NULL; out fp32 or PP_OUT_SPLIT. Tiles of 96 x 96, 64 x 64 or 32 x 32 outputs, the
- * one a measured cost rule prices cheapest (rounds of one workgroup per CU x the time of a round; pp_skinny_linear_tile returns the edge). N % 32 == 0, K % 64 == 0.
+ * or a (res_mod, N) table (r(m) = m % res_mod: pos_embed) or NULL; out fp32 or PP_OUT_SPLIT. Tiles of 32 / 64 / 96 rows x 32 / 64 / 96 columns, the
+ * shape a measured cost rule prices cheapest (rounds of one workgroup per CU x the time of a round + the LayerNorm tail of its row block;
+ * pp_skinny_linear_tile returns rows * 1000 + columns). N % 32 == 0, K % 64 == 0.
  * The LayerNorm tail needs no second launch and no grid barrier: the workgroup that stores the LAST tile of a row block (a counter per block in
  * ln_counters: ceil(M / 32) int32, zero before the first launch, left at zero) normalises the block's rows - out must be fp32 then, N <= 1024, and
  * ln_out (M, N) PP_OUT_SPLIT distinct from out and act. The result does not depend on which workgroup arrives last.

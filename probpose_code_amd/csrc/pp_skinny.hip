@@ -34,7 +34,8 @@ constexpr int THREADS = 256, KS = 2;  // k-blocks (of 32 elements) per stage
 // Stages in the LDS ring per tile edge (32 / 64 / 96): what a workgroup has in flight is what it gets per memory round trip (~2 us from HBM / MALL
 // at these sizes - the first version waited for one 16 KiB stage at a time and spent 2.4 us per 64 columns of K). 32 x 32 tiles keep six stages in
 // flight (a whole K = 384), 64 x 64 three, 96 x 96 two: 112 / 128 / 144 KiB.
-__host__ __device__ constexpr int stages_of(int t) { return t == 1 ? 7 : (t == 2 ? 4 : 3); }
+// (by the rows a stage holds, BM + BN: 64 -> 7 stages, 96 -> 5, 128 -> 4, 160 / 192 -> 3)
+__host__ __device__ constexpr int stages_of(int rows) { return rows <= 64 ? 7 : (rows <= 96 ? 5 : (rows <= 128 ? 4 : 3)); }
 constexpr int ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2;
 
 struct Params {
@@ -63,7 +64,7 @@ __device__ __forceinline__ void wait_vm() {
 template <int RT, int CT, bool LN>
 __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) {
     constexpr int BM = 32 * RT, BN = 32 * CT, ROWS = BM + BN;
-    constexpr int NST = stages_of(RT), PRE = NST - 1;  // stages in the ring / requested ahead
+    constexpr int NST = stages_of(ROWS), PRE = NST - 1;  // stages in the ring / requested ahead
     constexpr int STAGE = KS * ROWS * 128;
     constexpr int NI = KS * ROWS / 8, NIW = NI / 4;  // DMA instructions per stage (8 rows of one k-block each), per wave
     static_assert(NI % 4 == 0, "DMA instructions must divide over the four waves");
@@ -247,29 +248,39 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
     }
 }
 
-// Tile edge (32 RT = 32 CT) for a problem. A launch of these sizes is a few ROUNDS of one workgroup per CU (the rings take 112 - 144 KiB), each
-// round one trip through "request the stages - MFMAs - epilogue"; the LayerNorm tail adds the last workgroup's trip through its rows. Cost model
-// fitted to scripts/r06/skinny_tile_sweep.py (us per launch inside a replayed graph, MI355X, B = 1 .. 24 crops + flip):
-//     cost = BASE[t] + rounds * ROUND[t] * (0.5 + 0.5 K / 384) + (tail ? TAIL[t] : 0),   ROUND[32] growing beyond three rounds
-// e.g. proj + ln2 at B = 2: 14.7 / 17.2 / 26.9 us measured at 32 / 64 / 96, modelled 14.8 / 17.2 / 27.5. Option "skinny_tile" (32 / 64 / 96)
-// forces one edge for A/B timing.
-static int pick_tile(int M, int N, int K, bool tail, int cus) {
-    const int forced = option("skinny_tile") / 32;
-    if (forced >= 1 && forced <= 3 && N % (32 * forced) == 0) return forced;
-    static const double BASE[4] = {0.0, 4.0, 1.0, 0.0}, ROUND[4] = {0.0, 3.4, 6.2, 11.5}, TAIL[4] = {0.0, 4.0, 10.0, 16.0};
-    const double kf = 0.5 + 0.5 * (double)K / 384.0;
-    int best = 1;
+// Tile SHAPE (32 RT rows x 32 CT columns) for a problem. A launch of these sizes is a few ROUNDS of one workgroup per CU (the rings take 112 -
+// 144 KiB), each round one trip through "request the stages - MFMAs - epilogue"; with the LayerNorm tail every round also carries the last
+// workgroups' trip through THEIR ROW BLOCKS - 8 rows per wave and memory round trip - which is why launches with a tail prefer FLAT tiles (32
+// rows x 96 columns: a third of the tail of a 96 x 96 tile, three times as many row blocks to spread it over). Cost model fitted to
+// scripts/r06/skinny_tile_sweep.py (us per launch inside a replayed graph, MI355X, B = 1 .. 24 crops + flip, six shapes x four layer shapes):
+//     without tail:  BASE + rounds * ROUND * (0.5 + 0.5 K / 384)
+//     with tail:     (FIRST + (rounds - 1) * NEXT) * (1 + 0.2 (K / 384 - 1))          (K = 1536 measured at 1.5 - 1.65x of K = 384)
+// e.g. proj + ln2 at B = 8: 41.4 / 25.4 / 28.0 / 25.8 / 29.0 / 21.3 us measured at 32x32 / 64x64 / 96x96 / 32x96 / 32x64 / 64x96, modelled
+// 39 / 32 / 27.5 / 25.7 / 32.8 / 20. The results do not depend on the shape (every output sums its K products in the same order), only the time
+// does. Option "skinny_tile" = 10 RT + CT (11, 22, 33, 13, 12, 23) forces a shape for A/B timing.
+struct Shape {
+    int rt, ct;
+    double base, round;   // without the LayerNorm tail
+    double first, next;   // with it
+};
+static const Shape SHAPES[] = {{1, 1, 1.5, 3.3, 11.2, 7.0},  {2, 2, 1.0, 6.2, 17.5, 15.0}, {3, 3, 0.0, 11.3, 27.5, 27.0},
+                               {1, 3, 1.2, 6.0, 13.2, 12.5}, {1, 2, 1.5, 4.25, 11.8, 10.5}, {2, 3, 0.9, 8.3, 20.0, 19.5}};
+static Shape pick_shape(int M, int N, int K, bool tail, int cus) {
+    const int forced = option("skinny_tile");
+    for (const Shape& sh : SHAPES)
+        if (forced == 10 * sh.rt + sh.ct && N % (32 * sh.ct) == 0) return sh;
+    const double kf = 0.5 + 0.5 * (double)K / 384.0, kfl = 1.0 + 0.2 * ((double)K / 384.0 - 1.0);
+    Shape best = SHAPES[0];
     double best_cost = 1e30;
-    for (int t = 1; t <= 3; ++t) {
-        const int b = 32 * t;
-        if (N % b != 0) continue;
-        const long long wgs = (long long)((M + b - 1) / b) * (N / b);
+    for (const Shape& sh : SHAPES) {
+        const int bm = 32 * sh.rt, bn = 32 * sh.ct;
+        if (N % bn != 0) continue;
+        const long long wgs = (long long)((M + bm - 1) / bm) * (N / bn);
         const double rounds = (double)((wgs + cus - 1) / cus);
-        const double per_round = ROUND[t] + (t == 1 && rounds > 3.0 ? 0.8 * (rounds - 3.0) : 0.0);
-        const double cost = BASE[t] + rounds * per_round * kf + (tail ? TAIL[t] : 0.0);
+        const double cost = tail ? (sh.first + (rounds - 1.0) * sh.next) * kfl : sh.base + rounds * sh.round * kf;
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
-            best = t;
+            best = sh;
         }
     }
     return best;
@@ -282,7 +293,8 @@ extern "C" int pp_skinny_linear_tile(int M, int N, int K, int with_layernorm) {
     if (M <= 0 || N <= 0 || K <= 0 || N % 32 != 0) return 0;
     static int cus = 0;
     if (!cus) cus = pp_device_cu_count() > 0 ? pp_device_cu_count() : 256;
-    return 32 * pp::sk::pick_tile(M, N, K, with_layernorm != 0, cus);
+    const pp::sk::Shape sh = pp::sk::pick_shape(M, N, K, with_layernorm != 0, cus);
+    return 32 * sh.rt * 1000 + 32 * sh.ct;  // rows * 1000 + columns of the tile
 }
 
 extern "C" int pp_skinny_linear(const void* act, const void* weight, const float* bias, const float* residual, int res_mod, void* out,
@@ -325,14 +337,21 @@ extern "C" int pp_skinny_linear(const void* act, const void* weight, const float
     p.w_bytes = (unsigned)((size_t)N * K * 4);
     p.w_inv = w_inv_scale;
     p.gamma = ln_gamma; p.beta = ln_beta; p.h_out = reinterpret_cast<char*>(ln_out); p.eps = ln_eps; p.counters = ln_counters;
-    const int t = pp_skinny_linear_tile(M, N, K, ln ? 1 : 0) / 32;
-    const int b = 32 * t;
-    const int grid = ((M + b - 1) / b) * (N / b);
-    const size_t lds = (size_t)sk::stages_of(t) * sk::KS * (2 * b) * 128;
+    const int code = pp_skinny_linear_tile(M, N, K, ln ? 1 : 0);
+    const int bm = code / 1000, bn = code % 1000, rt = bm / 32, ct = bn / 32;
+    const int grid = ((M + bm - 1) / bm) * (N / bn);
+    const size_t lds = (size_t)sk::stages_of(bm + bn) * sk::KS * (bm + bn) * 128;
     void (*kern)(const sk::Params) = nullptr;
-    if (t == 3) kern = ln ? sk::skinny_linear_kernel<3, 3, true> : sk::skinny_linear_kernel<3, 3, false>;
-    else if (t == 2) kern = ln ? sk::skinny_linear_kernel<2, 2, true> : sk::skinny_linear_kernel<2, 2, false>;
-    else kern = ln ? sk::skinny_linear_kernel<1, 1, true> : sk::skinny_linear_kernel<1, 1, false>;
+#define PP_SK_PICK(R, C) \
+    if (rt == R && ct == C) kern = ln ? sk::skinny_linear_kernel<R, C, true> : sk::skinny_linear_kernel<R, C, false>
+    PP_SK_PICK(1, 1);
+    PP_SK_PICK(2, 2);
+    PP_SK_PICK(3, 3);
+    PP_SK_PICK(1, 3);
+    PP_SK_PICK(1, 2);
+    PP_SK_PICK(2, 3);
+#undef PP_SK_PICK
+    PP_REQUIRE(kern != nullptr, PP_ERR_UNSUPPORTED, "pp_skinny_linear: no kernel for the tile shape");
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(sk::THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);
     PP_LAUNCH_CHECK();

@@ -22,11 +22,12 @@ for B in (1, 2, 4, 8, 16, 24):
         h = torch.zeros(M, N, device="cuda")
         cnt = torch.zeros((M + 31) // 32, dtype=torch.int32, device="cuda")
         res = []
-        for t in (32, 64, 96):
-            if N % t:
+        for code in (11, 22, 33, 13, 12, 23):
+            t, tn = 32 * (code // 10), 32 * (code % 10)
+            if N % tn:
                 res.append("    -  ")
                 continue
-            L.set_option("skinny_tile", t)
+            L.set_option("skinny_tile", code)
 
             def go():
                 if ln:
@@ -50,8 +51,8 @@ for B in (1, 2, 4, 8, 16, 24):
                 g_.replay()
             e1.record()
             torch.cuda.synchronize()
-            wgs = ((M + t - 1) // t) * (N // t)
+            wgs = ((M + t - 1) // t) * (N // tn)
             res.append(f"{e0.elapsed_time(e1) * 1e3 / 100:6.1f} ({wgs:4d})")
         L.set_option("skinny_tile", 0)
         auto = L.lib.pp_skinny_linear_tile(M, N, K, int(ln))
-        print(f"B {B:2d} M {M:5d} {name:8s} N {N:4d} K {K:4d}: us per launch (workgroups) at 32 / 64 / 96: {' | '.join(res)}   rule picks {auto}", flush=True)
+        print(f"B {B:2d} M {M:5d} {name:8s} N {N:4d} K {K:4d}: us per launch (workgroups) at 32x32 / 64x64 / 96x96 / 32x96 / 32x64 / 64x96: {' | '.join(res)}   rule picks {auto}", flush=True)
