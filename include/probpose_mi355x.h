@@ -106,7 +106,6 @@ int pp_device_cu_count(void);
  *   "psplit_tail" (1)        0: split-fp16 Linear layers never send the rows of a ragged last round to a second launch on 128 x 192 tiles
  *   "wino_order" (8)         pp_conv3x3_winograd_maxpool_relu: column tiles per 32-workgroup super tile (0: column tiles fastest)
  *   "qkv_attn_deep" (1)      pp_qkv_attention_split(_ws) of a small launch (<= 2 workgroups per CU): ring of four stages, one workgroup per CU (0: always two stages)
- *   "gemm_deep" (256)        generic 128 x 128 GEMM / convolution kernel, split-fp16: launches of at most this many tiles run with four K-tile buffers (0: never)
  *   "skinny_tile" (0)        pp_skinny_linear: 10 RT + CT (11, 22, 33, 13, 12, 23) forces a tile of 32 RT rows x 32 CT columns (0: the cost rule of pp_skinny.hip)
  *   "ksplit_channels" (1)    pp_conv3x3_splitk_slices: 0 = whole-tap slices only (never the four channel ranges of the wide-tile kernel)
  * Unknown names return PP_ERR_INVALID_ARG. Not thread-safe against concurrent launches (set them before the first call).

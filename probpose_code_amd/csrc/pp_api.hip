@@ -37,7 +37,6 @@ static Option g_options[] = {
     {"wino_order", 8},         // pp_conv3x3_winograd_maxpool_relu: column tiles per 32-workgroup super tile (0: column tiles fastest over an XCD's run: 1.19 GB fetched per launch at bs 64; 8 = 4 row blocks x 8 column tiles: 0.72 GB, same launch time)
     {"ksplit_channels", 1},    // pp_conv3x3_splitk_slices: 0 = never the four channel-range slices of the split-fp16 wide-tile kernel (whole-tap slices only)
     {"qkv_attn_deep", 1},      // pp_qkv_attention_split (unfolded form) of a launch of at most two workgroups per CU: 1 = ring of four stages, one workgroup per CU; 0 = the two-stage kernel
-    {"gemm_deep", 256},        // pp_gemm.hip, split-fp16: launches of at most this many 128 x 128 tiles (and one per workgroup) run with four K-tile buffers, three in flight (0: never)
     {"skinny_tile", 0},        // pp_skinny_linear: 10 RT + CT forces the tile shape (0: by the cost rule in pp_skinny.hip)
     {"ksplit9_below", 1024},   // pp_conv3x3_splitk_slices: tower stages with fewer output rows than this take nine K-slices (one tap each) instead of three
 };

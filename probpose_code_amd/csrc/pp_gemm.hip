@@ -90,15 +90,11 @@ struct StageRows {
     __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
 };
 
-// NBUF: K-tile buffers in LDS. 2 (64 KiB: two workgroups per CU - one K-tile in flight under the current one's MFMAs, enough when a CU has two
-// workgroups and the grid many tiles) or 4 (128 KiB, THREE K-tiles in flight: launches of at most one tile per CU - the deconvolutions, small tower
-// stages and the final 1x1 conv of a SMALL batch - are a chain of K / 32 memory round trips otherwise: 54 us for a 48-step deconvolution at B = 1).
-template <typename T, int GATHER, int OUT, int NBUF = 2>
-__global__ __launch_bounds__(GEMM_THREADS, NBUF == 2 ? 2 : 1) void gemm_kernel(const GemmParams p) {
+template <typename T, int GATHER, int OUT>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmParams p) {
     constexpr int BK = Prec<T>::BK;
     constexpr int ESZ = (int)sizeof(T);
-    constexpr int AHEAD = NBUF - 1;  // K-tiles requested ahead of the one being multiplied
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NBUF buffers][W tile | Act tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | Act tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const int f_row = lane & 15, f_kg = lane >> 4;
@@ -194,26 +190,8 @@ __global__ __launch_bounds__(GEMM_THREADS, NBUF == 2 ? 2 : 1) void gemm_kernel(c
     int z, m0, n0;
     decode_tile(tile, z, m0, n0);
     setup_stage(z, m0, n0);
-    // wait until at most `n_tiles_in_flight` younger K-tiles (8 DMA instructions per wave each) are outstanding, then the barrier
-    auto wait_tiles_and_barrier = [&](int n_tiles_in_flight) {
-        __builtin_amdgcn_sched_barrier(0);
-        switch (n_tiles_in_flight) {
-            case 0: __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (0 << 8) | ((0 >> 4) << 14)); break;
-            case 1: __builtin_amdgcn_s_waitcnt((8 & 15) | (7 << 4) | (0 << 8) | ((8 >> 4) << 14)); break;
-            default: __builtin_amdgcn_s_waitcnt((16 & 15) | (7 << 4) | (0 << 8) | ((16 >> 4) << 14)); break;
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    if constexpr (NBUF == 2) {
-        stage(0, 0);
-        __syncthreads();  // the workgroup release waits for the DMA (vmcnt(0)) before the barrier
-    } else {
-        // (the launcher hands this form only problems with nk >= AHEAD and at most one tile per workgroup: no tile seam to prefetch across)
-#pragma unroll
-        for (int d = 0; d < AHEAD; ++d) stage(d, d);
-        wait_tiles_and_barrier(AHEAD - 1);
-    }
+    stage(0, 0);
+    __syncthreads();  // the workgroup release waits for the DMA (vmcnt(0)) before the barrier
     int it = 0;       // global K-step counter: buffer parity runs across tile seams
 
     for (; tile < ntiles; tile += gridDim.x) {
@@ -226,9 +204,9 @@ __global__ __launch_bounds__(GEMM_THREADS, NBUF == 2 ? 2 : 1) void gemm_kernel(c
         const int next_tile = tile + gridDim.x;
         int nz = 0, nm0 = 0, nn0 = 0;
         for (int kt = 0; kt < nk; ++kt, ++it) {
-            const int buf = NBUF == 2 ? (it & 1) : it % NBUF;
+            const int buf = it & 1;
             // next K-tile's DMA flies under this tile's MFMAs -- across the seam it is the next OUTPUT tile's first
-            if constexpr (NBUF == 2) {
+            {
                 if (kt + 1 < nk) {
                     stage(kt + 1, buf ^ 1);
                 } else if (next_tile < ntiles) {
@@ -236,8 +214,6 @@ __global__ __launch_bounds__(GEMM_THREADS, NBUF == 2 ? 2 : 1) void gemm_kernel(c
                     setup_stage(nz, nm0, nn0);
                     stage(0, buf ^ 1);
                 }
-            } else {
-                if (kt + AHEAD < nk) stage(kt + AHEAD, (it + AHEAD) % NBUF);  // into the buffer every wave left at the last barrier
             }
             const char* wbase = smem + buf * BUF_BYTES;
             const char* abase = wbase + TILE_BYTES;
@@ -272,12 +248,11 @@ __global__ __launch_bounds__(GEMM_THREADS, NBUF == 2 ? 2 : 1) void gemm_kernel(c
                         for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mma(fw[nf], fa[mf], acc[nf][mf], T{});
                 }
             }
-            if constexpr (NBUF == 2) __syncthreads();
-            else wait_tiles_and_barrier(max(0, min(AHEAD - 1, nk - 2 - kt)));  // K-tile kt + 1 has landed; the ones behind it may fly
+            __syncthreads();
         }
         // the buffer consumed last, (it - 1) & 1, is free: the C tile is staged there; the other one already
         // holds the next output tile's first K-tile.
-        char* cst = smem + (NBUF == 2 ? ((it - 1) & 1) : (it - 1) % NBUF) * BUF_BYTES;
+        char* cst = smem + ((it - 1) & 1) * BUF_BYTES;
 
         // ---- epilogue. Accumulator layout: lane holds n = nbase + 4*e_kg + (0..3) for m = mbase + e_row.
         // (the lane id is laundered through an empty asm: otherwise LICM hoists every epilogue address out of the
@@ -487,23 +462,17 @@ static int launch_gemm(const GemmParams& p_in, int groups, hipStream_t s) {
                "pp gemm: operand tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     const long long ntiles = (long long)((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * groups;
     PP_REQUIRE(ntiles < (1ll << 30), PP_ERR_UNSUPPORTED, "pp gemm: too many output tiles");
+    const size_t lds = 2 * BUF_BYTES;  // 64 KiB: two workgroups per CU
     int slots = 2 * device_cus();      // persistent grid; a multiple of 8 keeps a workgroup's tiles on one XCD
     slots -= slots % 8;
-    // at most one tile per CU and a K loop worth pipelining: the four-buffer form (split-fp16 only: the small batches of the parity mode)
-    const bool deep = is_split && ntiles <= option("gemm_deep") && ntiles <= slots && p.K / BK >= 3;  // (grid = ntiles: one tile per workgroup)
-    const size_t lds = (deep ? 4 : 2) * BUF_BYTES;  // 64 KiB: two workgroups per CU; 128 KiB: one
     const int grid = (int)(ntiles < slots ? ntiles : slots);
     void (*kern)(const GemmParams) = nullptr;
     const bool ob = p.out_bf16 != 0;
     constexpr int OP = __is_same(T, float) ? FMT_F32 : (is_split ? FMT_SPLIT : FMT_BF16);  // operand-format output of T
-    constexpr int DEEP = is_split ? 4 : 2;  // (only the split-fp16 instantiations carry a deep form)
     switch (p.gather) {
-        case G_LINEAR: kern = ob ? (deep ? gemm_kernel<T, G_LINEAR, OP, DEEP> : gemm_kernel<T, G_LINEAR, OP>)
-                                 : (deep ? gemm_kernel<T, G_LINEAR, FMT_F32, DEEP> : gemm_kernel<T, G_LINEAR, FMT_F32>); break;
-        case G_CONV3: kern = ob ? (deep ? gemm_kernel<T, G_CONV3, OP, DEEP> : gemm_kernel<T, G_CONV3, OP>)
-                                : (deep ? gemm_kernel<T, G_CONV3, FMT_F32, DEEP> : gemm_kernel<T, G_CONV3, FMT_F32>); break;
-        case G_DECONV: kern = ob ? (deep ? gemm_kernel<T, G_DECONV, OP, DEEP> : gemm_kernel<T, G_DECONV, OP>)
-                                 : (deep ? gemm_kernel<T, G_DECONV, FMT_F32, DEEP> : gemm_kernel<T, G_DECONV, FMT_F32>); break;
+        case G_LINEAR: kern = ob ? gemm_kernel<T, G_LINEAR, OP> : gemm_kernel<T, G_LINEAR, FMT_F32>; break;
+        case G_CONV3: kern = ob ? gemm_kernel<T, G_CONV3, OP> : gemm_kernel<T, G_CONV3, FMT_F32>; break;
+        case G_DECONV: kern = ob ? gemm_kernel<T, G_DECONV, OP> : gemm_kernel<T, G_DECONV, FMT_F32>; break;
         default: return fail(PP_ERR_INVALID_ARG, "pp gemm: unknown gather mode");
     }
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
