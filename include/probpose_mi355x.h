@@ -32,7 +32,7 @@ extern "C" {
  *    pp_qkv_attention_split_ws, pp_gemm_residual_layernorm_ws, pp_ffn_split_residual_layernorm_ws, pp_proj_ffn_split_residual_layernorm_ws (the unsuffixed entry points = scale 1);
  *    CHANGED signatures: pp_qkv_attention_split_folded (centered rows, no column sums, + w_inv_scale), pp_proj_ffn_split_folded (+ residual_stats,
  *    + three weight scales; the rows it leaves are centered); pp_probmap_decode_flags writes NaN results for a map with a non-finite logit;
- *    + pp_skinny_linear / pp_skinny_linear_tile (the launch plan of small batches); REMOVED: the eight-wave feed-forward kernel and the overlapped-epilogue Linear kernel with
+ *    + pp_skinny_linear / pp_skinny_linear_tile / pp_skinny_deconv (the launch plan of small batches); REMOVED: the eight-wave feed-forward kernel and the overlapped-epilogue Linear kernel with
  *    their options "ffn_dma_waves" / "linear_ovl".
  * 3: + pp_launch_count / pp_reset_launch_counts (diagnostics: which kernels a launch plan really ran); pp_linear_ln_folded, the *_folded launches
  *    and PP_WS_LN_STATS (round 5).
@@ -303,6 +303,12 @@ int pp_skinny_linear(const void* act, const void* weight, const float* bias, con
                      int M, int N, int K, int act_fn, float w_inv_scale, const float* ln_gamma, const float* ln_beta, float ln_eps,
                      void* ln_out, int* ln_counters, void* stream);
 int pp_skinny_linear_tile(int M, int N, int K, int with_layernorm);
+/* ConvTranspose2d(Cin -> Cout, k4, s2, p1, bias=False) + folded BatchNorm + ReLU of a SMALL batch (mmpose/models/heads/hybrid_heads/
+ * probmap_head.py:435-472): act_nhwc (B, H, W, Cin), out_nhwc (B, 2H, 2W, Cout) PP_OUT_SPLIT; weight / bias as PP_DECONV4X4S2 of pp_conv_gemm
+ * with py < 0 (four phase matrices (Cout, 4 Cin), BatchNorm folded). The four output phases are four column-parallel GEMMs of one launch on
+ * pp_skinny_linear's tiles, the taps gathered by LDS-DMA (zeros outside the map); same sums in the same order as pp_conv_gemm. */
+int pp_skinny_deconv(const void* act_nhwc, const void* weight, const float* bias, void* out_nhwc, int B, int H, int W, int Cin, int Cout,
+                     void* stream);
 
 /* Residual dense layer fused with the LayerNorm that follows it in the ViT block
  * (mmpretrain TransformerEncoderLayer [3P]: x = x + attn(ln1(x)); x = ffn(ln2(x)) + x; final ln1):

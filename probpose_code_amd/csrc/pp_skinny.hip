@@ -53,6 +53,10 @@ struct Params {
     char* h_out;            // [M, N] split rows
     float eps;
     int* counters;          // one per row block, zero on entry, zero on exit
+    // DECONV form (pp_skinny_deconv): `a` is an NHWC map (n_img, H, W, Cin), row m = pixel, K = 4 Cin runs over the 2 x 2 taps of output phase
+    // blockIdx.y = 2 py + px (ConvTranspose2d k4 s2 p1: tap (ty, tx) reads pixel (y + ty - 1 + py, x + tx - 1 + px), zeros outside the map);
+    // `w` holds the four phase matrices (Cout, 4 Cin) one after the other, `out` the NHWC map (n_img, 2 H, 2 W, Cout = N) in the split format
+    int H, Wd, Cin;
 };
 
 template <int N>
@@ -61,8 +65,9 @@ __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
-template <int RT, int CT, bool LN>
+template <int RT, int CT, bool LN, bool DECONV = false>
 __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) {
+    static_assert(!(LN && DECONV), "the deconvolution form has no LayerNorm tail");
     constexpr int BM = 32 * RT, BN = 32 * CT, ROWS = BM + BN;
     constexpr int NST = stages_of(ROWS), PRE = NST - 1;  // stages in the ring / requested ahead
     constexpr int STAGE = KS * ROWS * 128;
@@ -78,10 +83,29 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
     const int nsteps = p.K / (32 * KS);
 
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w), 0, p.w_bytes, 0x00020000);
+    const int phase = DECONV ? (int)blockIdx.y : 0;  // output phase 2 py + px: its own weight matrix
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w) + (DECONV ? (size_t)phase * p.w_bytes : 0), 0, p.w_bytes, 0x00020000);
     // a DMA instruction moves 8 rows x 128 B: lane (row l = lane >> 3, physical chunk lane & 7) fetches logical chunk (lane & 7) ^ l
     const unsigned d_row = (unsigned)lane >> 3;
     const unsigned d_src = d_row * (unsigned)(p.K * 4) + ((((unsigned)lane & 7u) ^ d_row) << 4);
+    // DECONV: the pixel of this lane's activation row in every DMA instruction it takes part in (the row groups a wave serves are the same in
+    // every stage): origin offset of pixel (b, y, x) and its coordinates, or y = -100000 for rows past M (every bounds test then fails)
+    unsigned pix_off[NIW];
+    int pix_y[NIW], pix_x[NIW];
+    if constexpr (DECONV) {
+#pragma unroll
+        for (int u = 0; u < NIW; ++u) {
+            const int j = wave + 4 * u;
+            const int r = (j % (ROWS / 8)) * 8;
+            const int m = m0 + r - BN + (int)d_row;
+            const int hw = p.H * p.Wd;
+            const int b = m / hw, rem = m - b * hw;
+            pix_y[u] = (r >= BN && m < p.M) ? rem / p.Wd : -100000;
+            pix_x[u] = rem - (rem / p.Wd) * p.Wd;
+            pix_off[u] = (unsigned)m * (unsigned)(p.Cin * 4) + ((((unsigned)lane & 7u) ^ d_row) << 4);
+        }
+    }
     auto issue = [&](int s) {
         if (s >= nsteps) return;
         char* dst = smem + (s % NST) * STAGE;
@@ -95,7 +119,15 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
             //  past M must fall outside the tensor's extent to read as zeros)
             if (r < BN)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + (kb * ROWS + r) * 128), 16, d_src + (unsigned)((n0 + r) * p.K * 4), koff, 0, 0);
-            else
+            else if constexpr (DECONV) {
+                const int g = s * KS + kb, cpb = p.Cin >> 5;       // global k-block, k-blocks per tap
+                const int tap = g / cpb, cb = g - tap * cpb;
+                const int dy = (tap >> 1) - 1 + (phase >> 1), dx = (tap & 1) - 1 + (phase & 1);
+                const int yy = pix_y[u] + dy, xx = pix_x[u] + dx;
+                const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+                const unsigned vo = ok ? (unsigned)((int)pix_off[u] + (dy * p.Wd + dx) * p.Cin * 4) : 0x7ffffff0u;  // outside the map: zeros
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dst + (kb * ROWS + r) * 128), 16, vo, (unsigned)(cb * 128), 0, 0);
+            } else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dst + (kb * ROWS + r) * 128), 16, d_src + (unsigned)((m0 + r - BN) * p.K * 4), koff, 0,
                                                          0);
         }
@@ -178,7 +210,13 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
                 const int mr = p.res_mod > 0 ? m % p.res_mod : m;
                 v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)mr * p.N + n);
             }
-            const size_t idx = (size_t)m * p.N + n;
+            size_t idx = (size_t)m * p.N + n;
+            if constexpr (DECONV) {  // pixel (b, y, x) of the input map -> pixel (2 y + py, 2 x + px) of the output map
+                const int hw = p.H * p.Wd;
+                const int mm = live ? m : 0;
+                const int b = mm / hw, rem = mm - b * hw, y = rem / p.Wd, x = rem - y * p.Wd;
+                idx = (((size_t)b * 2 * p.H + 2 * y + (phase >> 1)) * 2 * p.Wd + 2 * x + (phase & 1)) * p.N + n;
+            }
             if (p.out_split) split_store4_rowpair(p.out, idx, v, live);  // (every lane calls it: row swaps inside)
             else if (LN) {
                 // DEVICE-scope store (sc1): the rows are read back inside this launch by a workgroup that may sit on another XCD, i.e. behind another
@@ -265,7 +303,7 @@ struct Shape {
 };
 static const Shape SHAPES[] = {{1, 1, 1.5, 3.3, 11.2, 7.0},  {2, 2, 1.0, 6.2, 17.5, 15.0}, {3, 3, 0.0, 11.3, 27.5, 27.0},
                                {1, 3, 1.2, 6.0, 13.2, 12.5}, {1, 2, 1.5, 4.25, 11.8, 10.5}, {2, 3, 0.9, 8.3, 20.0, 19.5}};
-static Shape pick_shape(int M, int N, int K, bool tail, int cus) {
+static Shape pick_shape(int M, int N, int K, bool tail, int cus, int groups = 1) {
     const int forced = option("skinny_tile");
     for (const Shape& sh : SHAPES)
         if (forced == 10 * sh.rt + sh.ct && N % (32 * sh.ct) == 0) return sh;
@@ -275,7 +313,7 @@ static Shape pick_shape(int M, int N, int K, bool tail, int cus) {
     for (const Shape& sh : SHAPES) {
         const int bm = 32 * sh.rt, bn = 32 * sh.ct;
         if (N % bn != 0) continue;
-        const long long wgs = (long long)((M + bm - 1) / bm) * (N / bn);
+        const long long wgs = (long long)((M + bm - 1) / bm) * (N / bn) * groups;
         const double rounds = (double)((wgs + cus - 1) / cus);
         const double cost = tail ? (sh.first + (rounds - 1.0) * sh.next) * kfl : sh.base + rounds * sh.round * kf;
         if (cost < best_cost - 1e-9) {
@@ -355,5 +393,53 @@ extern "C" int pp_skinny_linear(const void* act, const void* weight, const float
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(sk::THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);
     PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+// ConvTranspose2d(Cin -> Cout, k4, s2, p1, bias=False) + BatchNorm (folded) + ReLU of a SMALL batch: the four output phases as four column-parallel
+// GEMMs of one launch (grid y), the activation operand gathered from the NHWC map by LDS-DMA with zeros outside it (mmpose/models/heads/
+// hybrid_heads/probmap_head.py:435-472). The generic 128 x 128 kernel runs 24 workgroups at B = 1 (3 x 2 tiles x 4 phases), each with 48 K-steps
+// of 48 MFMAs per wave: 55 - 60 us with 90 % of the chip idle; here 32 x 64 tiles are 192 workgroups.
+extern "C" int pp_skinny_deconv(const void* act_nhwc, const void* weight, const float* bias, void* out_nhwc, int B, int H, int W, int Cin, int Cout,
+                                void* stream) {
+    using namespace pp;
+    PP_REQUIRE(act_nhwc && weight && out_nhwc, PP_ERR_INVALID_ARG, "pp_skinny_deconv: NULL argument");
+    PP_REQUIRE(B > 0 && H > 0 && W > 0, PP_ERR_INVALID_ARG, "pp_skinny_deconv: bad shape");
+    PP_REQUIRE(Cin > 0 && Cin % 32 == 0 && (4 * Cin) % 64 == 0 && Cout > 0 && Cout % 32 == 0, PP_ERR_UNSUPPORTED,
+               "pp_skinny_deconv: needs Cin % 32 == 0 and Cout % 32 == 0");
+    const long long M = (long long)B * H * W, K = 4ll * Cin;
+    PP_REQUIRE(M * Cin * 4 < 0x7ffffff0ll && (long long)Cout * K * 4 < 0x7ffffff0ll && 4 * M * Cout * 4 < 0x7ffffff0ll, PP_ERR_UNSUPPORTED,
+               "pp_skinny_deconv: operands must be smaller than 2 GiB");
+    sk::Params p{};
+    p.a = reinterpret_cast<const char*>(act_nhwc);
+    p.w = reinterpret_cast<const char*>(weight);
+    p.bias = bias;
+    p.out = reinterpret_cast<char*>(out_nhwc);
+    p.M = (int)M; p.N = Cout; p.K = (int)K;
+    p.act = sk::ACT_RELU;
+    p.out_split = 1;
+    p.a_bytes = (unsigned)(M * Cin * 4);
+    p.w_bytes = (unsigned)((long long)Cout * K * 4);  // one phase matrix
+    p.w_inv = 1.0f;
+    p.H = H; p.Wd = W; p.Cin = Cin;
+    static int cus = 0;
+    if (!cus) cus = pp_device_cu_count() > 0 ? pp_device_cu_count() : 256;
+    const sk::Shape sh = sk::pick_shape(p.M, Cout, p.K, false, cus, 4);
+    const int bm = 32 * sh.rt, bn = 32 * sh.ct;
+    const size_t lds = (size_t)sk::stages_of(bm + bn) * sk::KS * (bm + bn) * 128;
+    void (*kern)(const sk::Params) = nullptr;
+#define PP_SK_PICK(R, C) \
+    if (sh.rt == R && sh.ct == C) kern = sk::skinny_linear_kernel<R, C, false, true>
+    PP_SK_PICK(1, 1);
+    PP_SK_PICK(2, 2);
+    PP_SK_PICK(3, 3);
+    PP_SK_PICK(1, 3);
+    PP_SK_PICK(1, 2);
+    PP_SK_PICK(2, 3);
+#undef PP_SK_PICK
+    PP_REQUIRE(kern != nullptr, PP_ERR_UNSUPPORTED, "pp_skinny_deconv: no kernel for the tile shape");
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(((p.M + bm - 1) / bm) * (Cout / bn)), 4), dim3(sk::THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);
+    PP_LAUNCH_CHECK_AS("skinny_deconv");
     return PP_OK;
 }

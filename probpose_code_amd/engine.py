@@ -554,6 +554,12 @@ class ProbPoseEngine:
                            self.K, st)
                 self._logits_phased = True
                 return ws["logits"]
+            if ob == 2 and self._small_at(nb * self.Np) and cin % 32 == 0 and cout % 32 == 0:
+                # small batch: the four phases as column-parallel GEMMs on pp_skinny_linear's tiles (the 128 x 128 kernel would run 24 workgroups at B = 1)
+                self._call("deconv", "pp_skinny_deconv", src.data_ptr(), wj.data_ptr(), w[f"deconv{j}.b"].data_ptr(), dst.data_ptr(), nb, hh, ww, cin,
+                           cout, st)
+                src, cin, hh, ww = dst, cout, hh * 2, ww * 2
+                continue
             # all four output phases of the transposed conv in one persistent launch
             self._call("deconv", "pp_conv_gemm", self.prec, DECONV, src.data_ptr(), wj.data_ptr(),
                        w[f"deconv{j}.b"].data_ptr(), dst.data_ptr(), nb, hh, ww, cin, cout, -1, -1, 1, 0, 0, 0, 0, cout,

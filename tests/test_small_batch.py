@@ -251,3 +251,36 @@ def test_small_batches_two_steps_in_flight_equal_serial_launches(B):
             assert np.array_equal(pipe.result(t)[0].numpy(), want[j]), f"step {it - 1} (batch {j}) differs from the serial launch"
     t, j = tickets[-1]
     assert np.array_equal(pipe.result(t)[0].numpy(), want[j])
+
+
+@gpu
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 16, 12, 384), (2, 32, 24, 256), (5, 16, 12, 384), (16, 16, 12, 384), (3, 24, 18, 768)])
+def test_skinny_deconv_vs_fp64_and_the_generic_kernel(B, H, W, Cin):
+    """pp_skinny_deconv (ConvTranspose2d k4 s2 p1 + folded BatchNorm + ReLU, the four output phases as column-parallel GEMMs with the taps gathered
+    by LDS-DMA) against torch fp64 `conv_transpose2d` and against pp_conv_gemm's all-phases launch (same sums in the same order: equal bits)."""
+    L = _lib()
+    Cout = 256
+    x = _rand(B, H, W, Cin, seed=31)
+    wt = _rand(Cin, Cout, 4, 4, seed=32, scale=math.sqrt(2.0 / (4 * Cin)))  # ConvTranspose2d weight (Cin, Cout, 4, 4)
+    shift = _rand(Cout, seed=33, scale=0.2)
+    ref = F.relu(F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wt.double(), None, stride=2, padding=1) + shift.double().view(1, -1, 1, 1))
+    ref = ref.permute(0, 2, 3, 1).contiguous()  # NHWC
+    ph = torch.empty((2, 2, Cout, 4 * Cin))     # the four phase matrices, as weights.pack builds them
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    tap = ty * 2 + tx
+                    ph[py, px, :, tap * Cin:(tap + 1) * Cin] = wt[:, :, 3 - 2 * ty - py, 3 - 2 * tx - px].t()
+    xd, wd, bd = _sp(x), _sp(ph), shift.cuda()
+    out = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
+    L.call("pp_skinny_deconv", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, None)
+    got = _unsp(out)
+    assert not torch.isnan(got).any(), "pixels left unwritten"
+    torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5)
+    gen = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
+    L.call("pp_conv_gemm", 2, 2, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), gen.data_ptr(), B, H, W, Cin, Cout, -1, -1, 1, 0, 0, 0, 0, Cout, 2, 2, None)
+    assert torch.equal(out.cpu().view(torch.int32), gen.cpu().view(torch.int32)), "differs from pp_conv_gemm's deconvolution"
+    again = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
+    L.call("pp_skinny_deconv", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), again.data_ptr(), B, H, W, Cin, Cout, None)
+    assert torch.equal(out.cpu().view(torch.int32), again.cpu().view(torch.int32))
