@@ -106,6 +106,16 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
             pix_off[u] = (unsigned)m * (unsigned)(p.Cin * 4) + ((((unsigned)lane & 7u) ^ d_row) << 4);
         }
     }
+    // DECONV: (tap, channel block) of the k-blocks of the NEXT stage to be requested, advanced by KS per stage - stages are requested in order -
+    // instead of an integer division per DMA instruction (first version: ~240 VALU instructions of address arithmetic per wave and stage
+    // against 24 MFMAs; 447 us against 143 for the generic kernel at 24 576 rows)
+    int nx_tap[KS], nx_cb[KS];
+    const int cpb = DECONV ? (p.Cin >> 5) : 1;  // k-blocks per tap
+#pragma unroll
+    for (int kb = 0; kb < KS; ++kb) {
+        nx_tap[kb] = kb / cpb;
+        nx_cb[kb] = kb - nx_tap[kb] * cpb;
+    }
     auto issue = [&](int s) {
         if (s >= nsteps) return;
         char* dst = smem + (s % NST) * STAGE;
@@ -120,8 +130,7 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
             if (r < BN)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(dst + (kb * ROWS + r) * 128), 16, d_src + (unsigned)((n0 + r) * p.K * 4), koff, 0, 0);
             else if constexpr (DECONV) {
-                const int g = s * KS + kb, cpb = p.Cin >> 5;       // global k-block, k-blocks per tap
-                const int tap = g / cpb, cb = g - tap * cpb;
+                const int tap = nx_tap[kb], cb = nx_cb[kb];
                 const int dy = (tap >> 1) - 1 + (phase >> 1), dx = (tap & 1) - 1 + (phase & 1);
                 const int yy = pix_y[u] + dy, xx = pix_x[u] + dx;
                 const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
@@ -130,6 +139,16 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
             } else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(dst + (kb * ROWS + r) * 128), 16, d_src + (unsigned)((m0 + r - BN) * p.K * 4), koff, 0,
                                                          0);
+        }
+        if constexpr (DECONV) {
+#pragma unroll
+            for (int kb = 0; kb < KS; ++kb) {
+                nx_cb[kb] += KS;
+                if (nx_cb[kb] >= cpb) {  // (KS <= Cin / 32)
+                    nx_cb[kb] -= cpb;
+                    ++nx_tap[kb];
+                }
+            }
         }
     };
 

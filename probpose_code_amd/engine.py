@@ -554,8 +554,10 @@ class ProbPoseEngine:
                            self.K, st)
                 self._logits_phased = True
                 return ws["logits"]
-            if ob == 2 and self._small_at(nb * self.Np) and cin % 32 == 0 and cout % 32 == 0:
-                # small batch: the four phases as column-parallel GEMMs on pp_skinny_linear's tiles (the 128 x 128 kernel would run 24 workgroups at B = 1)
+            if ob == 2 and self._small_at(nb * self.Np) and nb * hh * ww <= 1536 and cin % 32 == 0 and cout % 32 == 0:
+                # a FEW input pixels (<= 1 536: both deconvolutions of one crop, the first one up to four crops with flip test): the four phases as
+                # column-parallel GEMMs on pp_skinny_linear's tiles - 19.6 / 37.1 us against 61.2 / 44.8 for the 128 x 128 kernel's 24 / 96
+                # workgroups at B = 1; from 3 072 pixels on the 128 x 128 kernel wins (scripts/r06/skinny_deconv_sweep.py)
                 self._call("deconv", "pp_skinny_deconv", src.data_ptr(), wj.data_ptr(), w[f"deconv{j}.b"].data_ptr(), dst.data_ptr(), nb, hh, ww, cin,
                            cout, st)
                 src, cin, hh, ww = dst, cout, hh * 2, ww * 2
