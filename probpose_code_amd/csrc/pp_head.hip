@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void maxpool_relu_kernel(const TI* __restrict_
 // + bias[n / images_per_group][c]; the 3x3 convolutions of the later tower stages have so few output rows that one
 // workgroup per output tile leaves most of the chip idle, so their K loop is cut in three (pp_conv3x3_splitk) and the
 // reduction is folded in here.
-template <typename TO>
+// NS > 0: the slice count at compile time - a position's NS loads are then independent and in flight together (with the runtime loop the compiler
+// chains them: 108 dependent L2 round trips per thread on a (4, 3) window of 9 slices, 18 - 22 us for a launch of 48 workgroups)
+template <typename TO, int NS = 0>
 __global__ __launch_bounds__(256) void sum_maxpool_relu_kernel(const float* __restrict__ in, int nsplit, long long split_stride,
                                                                const float* __restrict__ bias, int images_per_group,
                                                                TO* __restrict__ out, int N, int H, int W, int C, int ph,
@@ -73,7 +75,15 @@ __global__ __launch_bounds__(256) void sum_maxpool_relu_kernel(const float* __re
         for (int j = 0; j < pw; ++j) {
             const float* src = in + (((size_t)n * H + yo * ph + i) * W + xo * pw + j) * C + c;
             f32x4 v = *reinterpret_cast<const f32x4*>(src);
-            for (int sp = 1; sp < nsplit; ++sp) v += *reinterpret_cast<const f32x4*>(src + sp * split_stride);
+            if constexpr (NS > 0) {
+                f32x4 part[NS];
+#pragma unroll
+                for (int sp = 1; sp < NS; ++sp) part[sp] = *reinterpret_cast<const f32x4*>(src + sp * split_stride);
+#pragma unroll
+                for (int sp = 1; sp < NS; ++sp) v += part[sp];  // (the same order as the runtime loop: same bits)
+            } else {
+                for (int sp = 1; sp < nsplit; ++sp) v += *reinterpret_cast<const f32x4*>(src + sp * split_stride);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], v[q]);
         }
@@ -186,8 +196,10 @@ extern "C" int pp_sum_maxpool_relu_nhwc(const float* partials, int nsplit, long 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (out_bf16 == 2) {
         PP_REQUIRE(C % 32 == 0, PP_ERR_UNSUPPORTED, "pp_sum_maxpool_relu_nhwc: split-fp16 output needs C % 32 == 0");
-        hipLaunchKernelGGL(sum_maxpool_relu_kernel<SplitH>, grid, block, 0, s, partials, nsplit, split_stride, bias,
-                           images_per_group, reinterpret_cast<SplitH*>(out), N, H, W, C, ph, pw);
+        auto kern = nsplit == 9 ? sum_maxpool_relu_kernel<SplitH, 9> : nsplit == 4 ? sum_maxpool_relu_kernel<SplitH, 4>
+                    : nsplit == 3 ? sum_maxpool_relu_kernel<SplitH, 3> : sum_maxpool_relu_kernel<SplitH, 0>;
+        hipLaunchKernelGGL(kern, grid, block, 0, s, partials, nsplit, split_stride, bias, images_per_group, reinterpret_cast<SplitH*>(out), N, H, W, C, ph,
+                           pw);
     } else if (out_bf16)
         hipLaunchKernelGGL(sum_maxpool_relu_kernel<__bf16>, grid, block, 0, s, partials, nsplit, split_stride, bias,
                            images_per_group, reinterpret_cast<__bf16*>(out), N, H, W, C, ph, pw);
