@@ -32,8 +32,8 @@ extern "C" {
  *    pp_qkv_attention_split_ws, pp_gemm_residual_layernorm_ws, pp_ffn_split_residual_layernorm_ws, pp_proj_ffn_split_residual_layernorm_ws (the unsuffixed entry points = scale 1);
  *    CHANGED signatures: pp_qkv_attention_split_folded (centered rows, no column sums, + w_inv_scale), pp_proj_ffn_split_folded (+ residual_stats,
  *    + three weight scales; the rows it leaves are centered); pp_probmap_decode_flags writes NaN results for a map with a non-finite logit;
- *    + pp_skinny_linear / pp_skinny_linear_tile / pp_skinny_deconv (the launch plan of small batches); REMOVED: the eight-wave feed-forward kernel and the overlapped-epilogue Linear kernel with
- *    their options "ffn_dma_waves" / "linear_ovl".
+ *    + pp_skinny_linear / pp_skinny_linear_tile / pp_skinny_deconv (the launch plan of small batches); REMOVED: the eight-wave feed-forward kernel, the overlapped-epilogue Linear kernel and the
+ *    head-pair qkv + attention kernel with their options "ffn_dma_waves" / "linear_ovl" / "qkv_attn_pair".
  * 3: + pp_launch_count / pp_reset_launch_counts (diagnostics: which kernels a launch plan really ran); pp_linear_ln_folded, the *_folded launches
  *    and PP_WS_LN_STATS (round 5).
  * 2: + pp_clock_probe, pp_conv3x3_splitk_slices, pp_conv3x3_winograd_maxpool_relu, pp_winograd_scratch_bytes, pp_probmap_decode_flags, option "ksplit9_below"; PP_WS_TOWER_PARTIAL sized for the slice count the
@@ -94,7 +94,6 @@ int pp_device_cu_count(void);
  *   "attn_dma" (1)           0: split-fp16 attention of 432-token sequences with the register-staged kernel
  *   "conv_pool_split" (1)    0: split-fp16 first tower stage as two launches (conv, then pooling)
  *   "decode_wgs_per_cu" (3)  pp_probmap_(head_)decode: workgroups per CU its LDS band buffer is sized for (5 .. 1)
- *   "qkv_attn_pair" (0)      1: pp_qkv_attention_split with a head pair per workgroup (measured slower; kept for A/B)
  *   "ksplit9_below" (1024)   pp_conv3x3_splitk_slices: output rows under which a small tower stage is cut into nine K-slices
  *   "linear_dma" (1)         0: large split-fp16 Linear layers (pp_gemm, N % 192 == 0, >= 512 tiles) stay on the wide-tile kernel instead of the
  *                            twelve-wave 192 x 192 kernel (pp_linear_dma.hip: eight computing + four DMA-only waves)

@@ -28,7 +28,6 @@ static Option g_options[] = {
     {"attn_dma", 1},           // 0: split-fp16 attention of 432-token sequences with the register-staged kernel of round 2
     {"conv_pool_split", 1},    // 0: split-fp16 first tower stage as conv + pooling launches instead of pooling in the conv epilogue
     {"decode_wgs_per_cu", 3},  // most workgroups per CU the decode kernel sizes its band buffer for (5 .. 1): more than 3 measured slower at bs 64 (4.25 workgroups per CU are balanced by the dispatcher, not by residency; smaller buffers mean more bands)
-    {"qkv_attn_pair", 0},      // 1: pp_qkv_attention_split with a head PAIR per workgroup (one workgroup per CU; measured slower)
     {"linear_dma", 1},         // large split-fp16 Linear layers (pp_gemm): 1 = the twelve-wave 192 x 192 kernels (pp_linear_dma.hip), 0 = the wide-tile kernel
     {"linear_loop", 1},        // one-tile twelve-wave Linear kernel: 1 = one workgroup per CU walks a column of tiles, the next tile's first stages requested under this tile's epilogue; 0 = a workgroup per tile
     {"psplit_deconv_weight_major", 0},  // dev A/B: deconvolution tiles phase(weight set)-major per XCD instead of row panel -> phase (measured: DESIGN.md 4)

@@ -17,6 +17,11 @@
 //   * the plain-load / LDS-DMA retire-order hazard of the eight-wave kernel (a younger plain load may retire before an older
 //     piece's LDS write) cannot occur: the waves that count pieces issue nothing else.
 // Measured as a skeleton first (scripts/micro/ffn12d.hip MODE=1 GELU=1): 148 - 150 us against 161 us for the eight-wave loop.
+// TOOLCHAIN NOTE: the paired kernels issue their MFMAs as inline assembly (mma_ip), which the compiler's hazard recogniser does not
+// see; the wait states in front of every VALU read of an accumulator are placed by hand (mfma_settle / valu_settle) and the schedule distance
+// between two MFMAs on one accumulator is >= 6 MFMAs by construction of the sweeps. Built and validated with ROCm 7.2.0's hipcc (AMD clang 20);
+// after a compiler upgrade or a change of FFD_PAIR_UNROLL / FFD_GELU_PACKED re-run tests/test_split_fp16.py - its `ffn_form` 1 runs the SAME
+// arithmetic on the builtin-MFMA kernels (hazards handled by the compiler) and both forms are held to the fp64 reference.
 #include "pp_common.h"
 #include "pp_split.h"
 #include "pp_ffn_params.h"

@@ -390,242 +390,9 @@ static_assert(LDS_DEEP >= LDS && LDS_DEEP <= 160 * 1024, "LDS map of the deep-ri
 __global__ __launch_bounds__(THREADS) void qkv_attention_split_deep_kernel(const Params p) { qkv_attention_body<false, 4>(p); }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Head-PAIR form (qka2): one workgroup = (sequence, two heads). The 36 KiB stage of the single-head kernel is two thirds token
-// rows that every head-workgroup of the sequence fetches again: 2.6 MB of L2 -> LDS fill per CU and launch at ~39 B/clk = 31 us,
-// as long as the phase's MFMAs (QKA_DBG ablations). With two heads per workgroup a stage is 192 token rows + 192 weight rows
-// = 48 KiB for twice the MFMAs (1.7 MB per CU), wave tile 96 x 48 (54 MFMAs on 18 fragment reads per stage), and the GEMM phase
-// can afford a THREE-stage ring (144 KiB; two stages in flight): one workgroup per CU, two waves per SIMD, 3 workgroups per CU
-// one after the other. Phase 2 runs the 24 (head, query tile) tasks over the eight waves.
-// MEASURED (round 3, negative): 80.9 - 87 us per launch against 77.7 - 79 for the single-head kernel on the same box. The fill
-// skeleton does drop (24 us from 31), but the GEMM phase alone is no faster (55.4 vs 53.3 us: one workgroup per CU leaves
-// its DMA waits and barriers uncovered - 3 230 cycles per stage for 1 728 of MFMA issue) and the attention phase, with no
-// second workgroup's MFMAs beside it, adds 32 us instead of 26. Kept behind pp_set_option("qkv_attn_pair", 1) for A/B.
-namespace two {
-constexpr int W2_LINES = 2 * 3 * HD;                       // 192 weight rows: [q | k | v] of head 2 hp, then of head 2 hp + 1
-constexpr int STAGE2 = (A_LINES + W2_LINES) * 128;         // 48 KiB
-constexpr int NST = 3;
-constexpr int HEAD_BYTES = 2 * S * 128 + 2 * V_PLANE;      // q, k, V^T planes of one head: 74 240 B
-constexpr int LDS2 = 2 * HEAD_BYTES;                       // 148 480 B (>= the ring's 147 456)
-static_assert(LDS2 >= NST * STAGE2 && LDS2 <= 160 * 1024, "LDS map of the head-pair kernel");
-}  // namespace two
-
-__global__ __launch_bounds__(THREADS, 2) void qkv_attention_split2_kernel(const Params p) {
-    using namespace two;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wv >> 2, cg = wv & 3;  // row half (96 tokens), column quarter (48 of the 192 outputs)
-    const int fr = lane & 15, fg = lane >> 4;
-    const int sw = fr & 7;
-
-    int id = blockIdx.x;
-    const int nblk = gridDim.x;
-    if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);  // the head pairs of a sequence on one XCD, one after the other
-    const int npair = p.heads >> 1;
-    const int seq = id / npair, hp = id - seq * npair;
-
-    // ---- DMA: 48 pieces of 8 lines per stage; wave w issues token pieces w, w + 8, w + 16 and weight pieces w, w + 8, w + 16
-    // (weight piece j: block b = j >> 2 of [q0 k0 v0 q1 k1 v1], rows 8 (j & 3) .. + 7 of that block)
-    const int d_l = lane >> 3;
-    const unsigned d_sw = (unsigned)(((lane & 7) ^ d_l) << 4);
-    const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.h), 0, (DBG & 4) ? 0u : p.h_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (DBG & 4) ? 0u : p.w_bytes, 0x00020000);
-    const unsigned v_h = (unsigned)(seq * S + 8 * wv + d_l) * (unsigned)(E * 4) + d_sw;  // + 64 u token rows
-    unsigned v_w[3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int j = wv + 8 * u, b = j >> 2;
-        const int row = (b % 3) * E + (2 * hp + b / 3) * HD + (j & 3) * 8 + d_l;
-        v_w[u] = (unsigned)row * (unsigned)(E * 4) + d_sw;
-    }
-    auto issue_stage = [&](int kb, int buf) {
-        char* dst = smem + buf * STAGE2 + wv * 1024;
-        const int so = kb * 128;
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(h_rsrc, (lds_ptr_t)(dst + u * 8192), 16, v_h + (unsigned)(u * 64 * E * 4), so, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(dst + (24 + 8 * u) * 1024), 16, v_w[u], so, 0, 0);
-    };
-
-    const int a_off = (96 * rg + fr) * 128, w_off = A_LINES * 128 + (48 * cg + fr) * 128;
-    const int ch_hi = (fg ^ sw) << 4, ch_lo = ((4 + fg) ^ sw) << 4;
-    auto frag_a = [&](int buf, int lo, int rf) -> u32x4 {
-        return *reinterpret_cast<const u32x4*>(smem + buf * STAGE2 + a_off + rf * 2048 + (lo ? ch_lo : ch_hi));
-    };
-    auto frag_w = [&](int buf, int lo, int cf) -> u32x4 {
-        return *reinterpret_cast<const u32x4*>(smem + buf * STAGE2 + w_off + cf * 2048 + (lo ? ch_lo : ch_hi));
-    };
-
-    // ================= phase 1. acc[cf][rf]: tokens 96 rg + 16 rf + fr, outputs 48 cg + 16 cf + 4 fg + (0..3); the column
-    // quarters 1 and 3 hold k[16..31] | v: their fragments cf >= 1 are computed transposed (lane = v dim, four tokens)
-    f32x4 acc[3][6];
-#pragma unroll
-    for (int cf = 0; cf < 3; ++cf)
-#pragma unroll
-        for (int rf = 0; rf < 6; ++rf) acc[cf][rf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    issue_stage(0, 0);
-    issue_stage(1, 1);
-    issue_stage(2, 2);
-    wait_vm_lgkm<12>();  // the first stage has landed (six pieces per wave and stage)
-    __builtin_amdgcn_s_barrier();
-    u32x4 ah[6], wh[3], al[6], wl[3];
-#pragma unroll
-    for (int cf = 0; cf < 3; ++cf) wh[cf] = frag_w(0, 0, cf);
-#pragma unroll
-    for (int rf = 0; rf < 6; ++rf) ah[rf] = frag_a(0, 0, rf);
-
-    auto k_loop = [&](auto vt_tag) {
-        constexpr bool VT = decltype(vt_tag)::value;
-        auto mm = [&](int cf, const u32x4& wf, const u32x4& af, f32x4 c) { return (VT && cf >= 1) ? mma(af, wf, c) : mma(wf, af, c); };
-#pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            const int cb = k % NST, nb = (k + 1) % NST;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cf = 0; cf < 3; ++cf) wl[cf] = frag_w(cb, 1, cf);
-#pragma unroll
-            for (int rf = 0; rf < 6; ++rf) al[rf] = frag_a(cb, 1, rf);
-#pragma unroll
-            for (int rf = 0; rf < 6; ++rf)
-#pragma unroll
-                for (int cf = 0; cf < 3; ++cf) acc[cf][rf] = mm(cf, wh[cf], ah[rf], acc[cf][rf]);
-            __builtin_amdgcn_sched_barrier(0);
-            // every wave holds the rest of this stage in registers -> its buffer is free; stage k + 1 must have landed, stage k + 2 may fly
-            if (k + 2 < KB) wait_vm_lgkm<6>(); else wait_vm_lgkm<0>();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (k + NST < KB) issue_stage(k + NST, cb);
-#pragma unroll
-            for (int rf = 0; rf < 6; ++rf) {
-#pragma unroll
-                for (int cf = 0; cf < 3; ++cf) acc[cf][rf] = mm(cf, wl[cf], ah[rf], acc[cf][rf]);
-                if (k + 1 < KB) ah[rf] = frag_a(nb, 0, rf);
-            }
-#pragma unroll
-            for (int cf = 0; cf < 3; ++cf) {
-#pragma unroll
-                for (int rf = 0; rf < 6; ++rf) acc[cf][rf] = mm(cf, wh[cf], al[rf], acc[cf][rf]);
-                if (k + 1 < KB) wh[cf] = frag_w(nb, 0, cf);
-            }
-        }
-    };
-    if ((cg & 1) == 0) k_loop(TagF{}); else k_loop(TagT{});
-
-    // ---- + bias, out to LDS, per head: q and k as split lines, V^T planes
-    {
-        const int hl = cg >> 1, head = 2 * hp + hl;
-        char* Qs = smem + hl * HEAD_BYTES;
-        char* Ks = Qs + S * 128;
-        _Float16* Vh = reinterpret_cast<_Float16*>(Qs + 2 * S * 128);
-        _Float16* Vl = reinterpret_cast<_Float16*>(Qs + 2 * S * 128 + V_PLANE);
-        const bool odd = (lane & 16) != 0;
-#pragma unroll
-        for (int cf = 0; cf < 3; ++cf) {
-            const int c = 3 * (cg & 1) + cf;  // 16-column fragment of the head's 96 outputs: 0, 1 = q; 2, 3 = k; 4, 5 = v
-            if (c < 4) {
-                const int which = c >> 1, d0 = (c & 1) * 16;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + which * E + head * HD + d0 + 4 * fg);
-                char* dstb = which == 0 ? Qs : Ks;
-                const int chunk = (d0 >> 3) + (fg >> 1);
-#pragma unroll
-                for (int rf = 0; rf < 6; ++rf) {
-                    const int t = 96 * rg + 16 * rf + fr;
-                    const u32x4 q = split_pair16(acc[cf][rf] * p.w_inv + bv);
-                    *reinterpret_cast<u32x4*>(dstb + t * 128 + ((((odd ? 4 : 0) + chunk) ^ sw) << 4)) = q;
-                }
-            } else {
-                const int d = (c - 4) * 16 + fr;
-                const float bs = p.bias ? p.bias[2 * E + head * HD + d] : 0.f;
-#pragma unroll
-                for (int rf = 0; rf < 6; ++rf) {
-                    const int t0 = 96 * rg + 16 * rf + 4 * fg;
-                    const f32x4 v = acc[cf][rf] * p.w_inv + bs;
-                    f16x4 hv, lv;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        hv[j] = split_hi(v[j]);
-                        lv[j] = split_lo(v[j], hv[j]);
-                    }
-                    *reinterpret_cast<f16x4*>(Vh + d * SPV + t0) = hv;
-                    *reinterpret_cast<f16x4*>(Vl + d * SPV + t0) = lv;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (DBG & 1) return;
-
-    // ================= phase 2: 24 (head, query tile) tasks, wave w takes w, w + 8, w + 16
-#pragma unroll 1
-    for (int task = wv; task < 2 * NT; task += THREADS / 64) {
-        const int hl = task / NT, qt = task - hl * NT;
-        const char* Qs = smem + hl * HEAD_BYTES;
-        const char* Ks = Qs + S * 128;
-        const _Float16* Vh = reinterpret_cast<const _Float16*>(Qs + 2 * S * 128);
-        const _Float16* Vl = reinterpret_cast<const _Float16*>(Qs + 2 * S * 128 + V_PLANE);
-        const f16x8 qh = *reinterpret_cast<const f16x8*>(Qs + (qt * 16 + fr) * 128 + ch_hi);
-        const f16x8 ql = *reinterpret_cast<const f16x8*>(Qs + (qt * 16 + fr) * 128 + ch_lo);
-        f32x4 s[NT];
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            if (kt % 3 == 0) __builtin_amdgcn_sched_barrier(0);
-            const f16x8 kh = *reinterpret_cast<const f16x8*>(Ks + (kt * 16 + fr) * 128 + ch_hi);
-            const f16x8 kl = *reinterpret_cast<const f16x8*>(Ks + (kt * 16 + fr) * 128 + ch_lo);
-            s[kt] = split_mma(kh, kl, qh, ql, f32x4{0.f, 0.f, 0.f, 0.f});
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float mx = -__builtin_inff();
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[kt][i]);
-        mx = fmaxf(mx, xor16(mx));  // (the gfx950 row swaps - plain VALU - instead of trips through the LDS queue; same pairing, same bits)
-        mx = fmaxf(mx, xor32(mx));
-        const float mb = mx * p.scale_log2e;
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], p.scale_log2e, -mb));
-                s[kt][i] = e;
-                sum += e;
-            }
-        sum += xor16(sum);
-        sum += xor32(sum);
-        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int blk = 0; blk < NT / 2; ++blk) {
-            if (blk % 2 == 0) __builtin_amdgcn_sched_barrier(0);
-            const f32x4 p0 = s[2 * blk], p1 = s[2 * blk + 1];
-            f16x8 ph, pl;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ph[j] = split_hi(p0[j]);
-                pl[j] = split_lo(p0[j], ph[j]);
-                ph[4 + j] = split_hi(p1[j]);
-                pl[4 + j] = split_lo(p1[j], ph[4 + j]);
-            }
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const int off = (dt * 16 + fr) * SPV + blk * 32 + 4 * fg;
-                const u32x2 h0 = *reinterpret_cast<const u32x2*>(Vh + off), h1 = *reinterpret_cast<const u32x2*>(Vh + off + 16);
-                const u32x2 l0 = *reinterpret_cast<const u32x2*>(Vl + off), l1 = *reinterpret_cast<const u32x2*>(Vl + off + 16);
-                const u32x4 vh = {h0[0], h0[1], h1[0], h1[1]}, vl = {l0[0], l0[1], l1[0], l1[1]};
-                o[dt] = split_mma(__builtin_bit_cast(f16x8, vh), __builtin_bit_cast(f16x8, vl), ph, pl, o[dt]);
-            }
-        }
-        const float inv = 1.0f / sum;
-        const size_t oidx = ((size_t)seq * S + qt * 16 + fr) * E + (2 * hp + hl) * HD;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) split_store4_rowpair(p.out, oidx + dt * 16 + 4 * fg, o[dt] * inv, true);
-    }
-}
-
+// (Round 3's head-PAIR form - one workgroup per (sequence, two heads), a three-stage ring of 48 KiB stages, one workgroup per CU - measured 80.9 -
+// 87 us per launch against 77.7 - 79 for this kernel and was retired in round 6; `git log -S qkv_attention_split2_kernel` has it, the numbers are in
+// DESIGN_NOTEBOOK.md 4.)
 }  // namespace qka
 
 #if QKA_STAMP
@@ -686,11 +453,6 @@ static int qkv_attention_launch(const void* h_in, const void* wqkv, const float*
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qka::qkv_attention_split_folded_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, qka::LDS));
         hipLaunchKernelGGL(qka::qkv_attention_split_folded_kernel, dim3(n_seq * heads), dim3(qka::THREADS), qka::LDS,
-                           reinterpret_cast<hipStream_t>(stream), p);
-    } else if (pp::option("qkv_attn_pair") != 0 && heads % 2 == 0) {  // two heads per workgroup (opt-in: measured slower, see above)
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qka::qkv_attention_split2_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, qka::two::LDS2));
-        hipLaunchKernelGGL(qka::qkv_attention_split2_kernel, dim3(n_seq * (heads / 2)), dim3(qka::THREADS), qka::two::LDS2,
                            reinterpret_cast<hipStream_t>(stream), p);
     } else if (pp::option("qkv_attn_deep") != 0 && n_seq * heads <= 2 * pp_device_cu_count()) {
         // at most two workgroups per CU's worth of launch: nothing to overlap with on a CU, the deep ring hides the memory round trips instead

@@ -621,14 +621,16 @@ def test_proj_ffn_split_fused_vs_fp64(M, F_, ffn_form):
 
 
 @gpu
-@pytest.mark.parametrize("pair", [0, 1])
+@pytest.mark.parametrize("deep", [1, 0])
 @pytest.mark.parametrize("n_seq,bias", [(3, True), (16, False), (128, True)])
-def test_qkv_attention_split_fused_vs_fp64(n_seq, bias, pair):
+def test_qkv_attention_split_fused_vs_fp64(n_seq, bias, deep):
     """pp_qkv_attention_split (qkv Linear + attention of a (sequence, head) per workgroup, qkv never in HBM) against torch fp64
     on the unrounded fp32 inputs, with mmpretrain's packing of the qkv rows; an odd number of sequences (no XCD remap), the
-    bs 64 shape; repeated launches bit-identical."""
+    bs 64 shape; repeated launches bit-identical. `deep`: small launches (at most two workgroups per CU: 3 and 16 sequences here) run the projection on a
+    ring of four stages (option "qkv_attn_deep", shipped) or of two."""
     L = _lib()
-    L.set_option("qkv_attn_pair", pair)  # 1: the head-pair form (opt-in), 0: one head per workgroup (shipped)
+    L.set_option("qkv_attn_deep", deep)
+    L.reset_launch_counts()
     S, E, H, hd = 192, 384, 12, 32
     M = n_seq * S
     h = _rand(M, E, seed=90)
@@ -653,7 +655,8 @@ def test_qkv_attention_split_fused_vs_fp64(n_seq, bias, pair):
             L.call("pp_qkv_attention_split", hd_.data_ptr(), wd.data_ptr(), None, out.data_ptr(), bad[0], bad[1], bad[2], bad[3], 0.1, None)
     with pytest.raises(L.ProbPoseLibraryError):
         L.call("pp_qkv_attention_split", hd_.data_ptr(), wd.data_ptr(), None, hd_.data_ptr(), n_seq, S, H, hd, 0.1, None)
-    L.set_option("qkv_attn_pair", 0)
+    assert (L.launch_count("qkv_attn_deep") > 0) == (deep == 1 and n_seq * H <= 512)
+    L.set_option("qkv_attn_deep", 1)
 
 
 @gpu
