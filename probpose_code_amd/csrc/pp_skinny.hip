@@ -59,10 +59,139 @@ struct Params {
     int H, Wd, Cin;
 };
 
+#ifndef SK_STAMP
+#define SK_STAMP 0  // dev: s_memtime stamps of wave 0 of the workgroup that normalises row block 0 (scripts/r06/skinny_stamps.py)
+#endif
+#if SK_STAMP
+__device__ unsigned long long g_sk_stamps[16];
+#define SK_T(i) do { if (LN && wave == 0 && mt == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); sk_t[i] = t__; } } while (0)
+#else
+#define SK_T(i) do { } while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt immediate");
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+// ---- LayerNorm of the rows m0 + wave * BM / 4 ... of the fp32 output (device-scope loads: the rows were written inside this launch, possibly behind
+// another XCD's L2), operand-format rows to h_out. LPR lanes per row, G = 64 / LPR rows per group, GC groups requested at once; a lane owns NV8
+// pieces of EIGHT consecutive columns: their hi and lo halves leave as one 16-byte store each (this one CU writes the whole row block: with 8-byte
+// stores the tail ran at its store path's ~8 B/clk - 3.2 us per 8 rows per wave, stamps in scripts/r06/skinny_stamps.py).
+template <int BM, int LPR, int NV8, int GC>
+__device__ __forceinline__ void ln_tail_rows(const Params& p, const __amdgpu_buffer_rsrc_t rout, const float* s_gb, int m0, int wave, int lane) {
+    constexpr int G = 64 / LPR, RPW = BM / 4;
+    static_assert(RPW % (G * GC) == 0, "the groups must tile a wave's rows");
+    const float inv_n = 1.0f / (float)p.N;
+    const int lr = lane / LPR, lc = lane - lr * LPR;
+    for (int r0 = wave * RPW; r0 < (wave + 1) * RPW; r0 += G * GC) {
+        f32x4 v[GC][NV8][2];
+#pragma unroll
+        for (int g = 0; g < GC; ++g) {
+            const int m = m0 + r0 + g * G + lr;
+#pragma unroll
+            for (int i = 0; i < NV8; ++i)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    v[g][i][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (m < p.M)
+                        v[g][i][hf] = __builtin_bit_cast(
+                            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rout, (unsigned)(((size_t)m * p.N + (i * LPR + lc) * 8 + 4 * hf) * 4), 0, 16));
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < GC; ++g) {
+            const int m = m0 + r0 + g * G + lr;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV8; ++i)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) sum += (v[g][i][hf][0] + v[g][i][hf][1]) + (v[g][i][hf][2] + v[g][i][hf][3]);
+#pragma unroll
+            for (int o = LPR >> 1; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * inv_n;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV8; ++i)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[g][i][hf][e] - mean;
+                        q = __builtin_fmaf(d, d, q);
+                    }
+#pragma unroll
+            for (int o = LPR >> 1; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+            const float rstd = 1.0f / sqrtf(q * inv_n + p.eps);
+            if (m < p.M) {
+#pragma unroll
+                for (int i = 0; i < NV8; ++i) {
+                    const int col = (i * LPR + lc) * 8;
+                    u32x4 hq, lq;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(s_gb + col + 4 * hf), bt = *reinterpret_cast<const f32x4*>(s_gb + 1024 + col + 4 * hf);
+                        f32x4 hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (v[g][i][hf][e] - mean) * rstd * gm[e] + bt[e];
+                        { unsigned h__, l__; split_pair(hv[0], hv[1], h__, l__); hq[2 * hf] = h__; lq[2 * hf] = l__; }
+                        { unsigned h__, l__; split_pair(hv[2], hv[3], h__, l__); hq[2 * hf + 1] = h__; lq[2 * hf + 1] = l__; }
+                    }
+                    char* dst = split_addr(p.h_out, (size_t)m * p.N + col);
+                    *reinterpret_cast<u32x4*>(dst) = hq;
+                    *reinterpret_cast<u32x4*>(dst + 64) = lq;
+                }
+            }
+        }
+    }
+}
+
+// any N <= 1024 (a multiple of 64): a group of rows per trip
+template <int BM>
+__device__ __forceinline__ void ln_tail_rows_any(const Params& p, const __amdgpu_buffer_rsrc_t rout, const float* s_gb, int m0, int wave, int lane) {
+    const float inv_n = 1.0f / (float)p.N;
+    const int LPR = p.N <= 512 ? 8 : 16, G = 64 / LPR;       // lanes per row, rows per group
+    const int nv = p.N / (4 * LPR);                            // 16-byte vectors per lane (<= 16)
+    const int lr = lane / LPR, lc = lane - lr * LPR;
+    for (int r0 = wave * (BM / 4); r0 < (wave + 1) * (BM / 4); r0 += G) {
+        const int m = m0 + r0 + lr;
+        const bool live = r0 + lr < (wave + 1) * (BM / 4) && m < p.M;
+        f32x4 v[16];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < nv && live)
+                v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rout, (unsigned)(((size_t)m * p.N + (i * LPR + lc) * 4) * 4), 0, 16));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        for (int o = LPR >> 1; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[i][e] - mean;
+                    q = __builtin_fmaf(d, d, q);
+                }
+            }
+        for (int o = LPR >> 1; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q * inv_n + p.eps);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < nv && live) {
+                const int col = (i * LPR + lc) * 4;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(s_gb + col), b = *reinterpret_cast<const f32x4*>(s_gb + 1024 + col);
+                f32x4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+                split_store4(p.h_out, (size_t)m * p.N + col, hv);
+            }
+    }
 }
 
 template <int RT, int CT, bool LN, bool DECONV = false>
@@ -81,6 +210,10 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
     const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
     const int nsteps = p.K / (32 * KS);
+#if SK_STAMP
+    unsigned long long sk_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    SK_T(0);
 
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, p.a_bytes, 0x00020000);
     const int phase = DECONV ? (int)blockIdx.y : 0;  // output phase 2 py + px: its own weight matrix
@@ -160,6 +293,35 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
 
 #pragma unroll
     for (int s = 0; s < PRE; ++s) issue(s);
+    // ---- what the epilogue needs from memory, requested NOW (behind the first stages): bias, residual fragments, LayerNorm parameters. Inside the
+    // epilogue every one of these loads sat between two stores to `out` - which `residual` may alias, so the compiler must keep the order - and
+    // each fragment became its own round trip to the L2 (stamps, scripts/r06/skinny_stamps.py: 5 - 7.6 us of epilogue for six / nine fragments
+    // at B = 8, and 5.7 us of LayerNorm tail per group of 8 rows: twelve gamma / beta fetches, each behind the store before it).
+    f32x4 bvv[CT], resv[CT][RT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int n = n0 + 16 * (CT * wn + c) + 4 * f_kg;
+        bvv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bvv[c] = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            resv[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!DECONV) {
+                const int m = m0 + 16 * (RT * wm + r) + f_row;
+                if (p.residual && m < p.M) {
+                    const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+                    resv[c][r] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mr * p.N + n);
+                }
+            }
+        }
+    }
+    f32x4 ln_g = {0.f, 0.f, 0.f, 0.f}, ln_b = {0.f, 0.f, 0.f, 0.f};  // thread t: columns 4 t .. 4 t + 3 (N <= 1024)
+    if constexpr (LN) {
+        if (4 * tid < p.N) {
+            ln_g = *reinterpret_cast<const f32x4*>(p.gamma + 4 * tid);
+            ln_b = *reinterpret_cast<const f32x4*>(p.beta + 4 * tid);
+        }
+    }
     const int sw = f_row & 7;
     const int off_hi = f_row * 128 + ((f_kg ^ sw) << 4), off_lo = f_row * 128 + (((4 + f_kg) ^ sw) << 4);
     for (int s = 0; s < nsteps; ++s) {
@@ -206,13 +368,13 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
         }
     }
 
+    SK_T(1);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((size_t)p.M * p.N * 4), 0x00020000);
     // ---- epilogue: lane (f_row, f_kg) of tile (c, r) holds row m0 + 16 (RT wm + r) + f_row, columns n0 + 16 (CT wn + c) + 4 f_kg + (0..3)
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int n = n0 + 16 * (CT * wn + c) + 4 * f_kg;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+        const f32x4 bv = bvv[c];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const int m = m0 + 16 * (RT * wm + r) + f_row;
@@ -225,10 +387,7 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = relu_keep_nan(v[e]);
             }
-            if (p.residual && live) {
-                const int mr = p.res_mod > 0 ? m % p.res_mod : m;
-                v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)mr * p.N + n);
-            }
+            v += resv[c][r];  // (zeros without a residual)
             size_t idx = (size_t)m * p.N + n;
             if constexpr (DECONV) {  // pixel (b, y, x) of the input map -> pixel (2 y + py, 2 x + px) of the output map
                 const int hw = p.H * p.Wd;
@@ -249,59 +408,38 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
     if constexpr (LN) {
         // ---- LayerNorm tail: the workgroup that completes the row block normalises it
         __shared__ int s_last;
+        SK_T(2);
         __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | ((0 >> 4) << 14));  // vmcnt(0): this thread's device-scope stores are acknowledged
+        SK_T(3);
         __syncthreads();
+        // (every wave is behind its last read of the ring: its first 8 KiB now hold gamma | beta for the tail - LDS reads do not queue behind the
+        //  tail's global stores the way the parameter fetches did)
+        float* s_gb = reinterpret_cast<float*>(smem);
+        if (4 * tid < p.N) {
+            *reinterpret_cast<f32x4*>(s_gb + 4 * tid) = ln_g;
+            *reinterpret_cast<f32x4*>(s_gb + 1024 + 4 * tid) = ln_b;
+        }
         if (tid == 0) {
             const int seen = __hip_atomic_fetch_add(p.counters + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = seen == ntn - 1;
             if (seen == ntn - 1) __hip_atomic_store(p.counters + mt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (everybody of this block has counted)
         }
         __syncthreads();
+        SK_T(4);
         if (!s_last) return;  // (the reads below are device-scope loads: they bypass this CU's L1 and this XCD's non-coherent L2 lines)
-        const float inv_n = 1.0f / (float)p.N;
-        // A wave takes its BM / 4 rows in groups: LPR lanes per row, every lane's share of the row requested before anything is reduced - one memory
-        // round trip per group, not per row (the first version walked the rows one by one: 20 us of the 28 a launch took at B = 1).
-        const int LPR = p.N <= 512 ? 8 : 16, G = 64 / LPR;       // lanes per row, rows per group
-        const int nv = p.N / (4 * LPR);                            // 16-byte vectors per lane (<= 16)
-        const int lr = lane / LPR, lc = lane - lr * LPR;
-        for (int r0 = wave * (BM / 4); r0 < (wave + 1) * (BM / 4); r0 += G) {
-            const int m = m0 + r0 + lr;
-            const bool live = r0 + lr < (wave + 1) * (BM / 4) && m < p.M;
-            f32x4 v[16];
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (i < nv && live)
-                    v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rout, (unsigned)(((size_t)m * p.N + (i * LPR + lc) * 4) * 4), 0, 16));
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            for (int o = LPR >> 1; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum * inv_n;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i < nv) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = v[i][e] - mean;
-                        q = __builtin_fmaf(d, d, q);
-                    }
-                }
-            for (int o = LPR >> 1; o >= 1; o >>= 1) q += __shfl_xor(q, o);
-            const float rstd = 1.0f / sqrtf(q * inv_n + p.eps);
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i < nv && live) {
-                    const int col = (i * LPR + lc) * 4;
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + col), b = *reinterpret_cast<const f32x4*>(p.beta + col);
-                    f32x4 hv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hv[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-                    split_store4(p.h_out, (size_t)m * p.N + col, hv);
-                }
-        }
+        // N = 384 (ViT-S) / 768 (ViT-B): six 8-column pieces per lane at 8 / 16 lanes per row, and ALL of the wave's rows requested before anything is
+        // reduced - one memory round trip for the block (the first version made one trip per group of 8 rows: two / three dependent trips to the
+        // memory side for 64 / 96-row tiles, ~15 us of tail per launch at B = 8)
+        if (p.N == 384) ln_tail_rows<BM, 8, 6, RT>(p, rout, s_gb, m0, wave, lane);
+        else if (p.N == 768) ln_tail_rows<BM, 16, 6, (RT == 1 ? 2 : RT)>(p, rout, s_gb, m0, wave, lane);
+        else ln_tail_rows_any<BM>(p, rout, s_gb, m0, wave, lane);
+#if SK_STAMP
+        SK_T(5);
+        __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8) | ((0 >> 4) << 14));
+        SK_T(6);
+        if (wave == 0 && mt == 0 && lane == 0)
+            for (int i = 0; i < 7; ++i) g_sk_stamps[i] = sk_t[i];
+#endif
     }
 }
 
@@ -345,6 +483,12 @@ static Shape pick_shape(int M, int N, int K, bool tail, int cus, int groups = 1)
 
 }  // namespace sk
 }  // namespace pp
+
+#if SK_STAMP
+extern "C" int pp_dev_sk_stamps(unsigned long long* out) {  // dev: the stamps of the last launch with a LayerNorm tail (host pointer)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pp::sk::g_sk_stamps), sizeof(unsigned long long) * 16, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int pp_skinny_linear_tile(int M, int N, int K, int with_layernorm) {
     if (M <= 0 || N <= 0 || K <= 0 || N % 32 != 0) return 0;
