@@ -4,7 +4,7 @@ import sys, os, ctypes, math, torch
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import test_split_fp16 as T
 L = T._lib()
-n_seq, S, H, hd = 128, 192, 12, 32
+n_seq, S, H, hd = int(os.environ.get("NSEQ", 128)), 192, 12, 32
 E = H * hd
 h = T._sp(T._rand(n_seq * S, E, seed=1))
 w = T._sp(T._rand(3 * E, E, seed=2, scale=1 / math.sqrt(E)))
