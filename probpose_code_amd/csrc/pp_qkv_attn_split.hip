@@ -36,7 +36,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #ifndef QKA_DBG
-#define QKA_DBG 0  // dev ablations (timing only, wrong results): 1 no attention phase, 2 no GEMM phase MFMAs, 4 no DMA
+#define QKA_DBG 0  // dev ablations (timing only, wrong results): 1 no attention phase, 2 no GEMM phase MFMAs, 4 no DMA (zeros: the MFMAs then run on
+                   // zeros too), 8 the fill stops after the ring's first stages (real data stays in LDS: scripts/r06/qka_ablate.py)
 #endif
 constexpr int DBG = QKA_DBG;
 
@@ -218,7 +219,7 @@ __device__ __forceinline__ void qkv_attention_body(const Params& p) {
             }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (k + NSTG < KB) issue_stage(k + NSTG, cb);
+            if (k + NSTG < KB && !(DBG & 8)) issue_stage(k + NSTG, cb);
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) {
 #pragma unroll
