@@ -395,6 +395,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) acc[rf][half * 3 + nf] = mma(wh[nf], bgl[rf], acc[rf][half * 3 + nf]);
     };
+    (void)b_step;  // (not every instantiation takes this path)
     // LayerNorm of the 96 x 384 block in the accumulators (pp_ffn_split.hip layernorm_rows: same operations in the same order)
     // Stores as buffer stores: the row part of the address (and the lane's column part) in the VGPR offset - rows past M fall out
     // of the descriptor's extent and are dropped by the hardware (the range check covers the VGPR offset, not the scalar one) -

@@ -26,14 +26,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int BM = 96, E = 384, CHUNK = 128, THREADS = 512;
+[[maybe_unused]] constexpr int BM = 96, E = 384, CHUNK = 128, THREADS = 512;
 constexpr int KB = E / 32;                       // 12 k-blocks of the input width
 constexpr int G_KB = BM * 128;                   // 12 KiB: 96 rows x one 128-byte block
-constexpr int OFF_G = 0;                         // [4][96][128 B]
+[[maybe_unused]] constexpr int OFF_G = 0;                         // [4][96][128 B]
 constexpr int OFF_RING = 4 * G_KB;               // 48 KiB
 constexpr int SLOTB = 28 * 1024, NSLOT = 4;
 constexpr int LDS = OFF_RING + NSLOT * SLOTB;    // 163 840 B
-constexpr int X_OFF = 16 * 1024;                 // A slot: the x lines sit behind the 128 weight lines
+[[maybe_unused]] constexpr int X_OFF = 16 * 1024;                 // A slot: the x lines sit behind the 128 weight lines
 constexpr int NA = KB, NB = 8, STEPS = NA + NB;  // steps per chunk
 constexpr int A_BLOCK = CHUNK * 128;             // 16 KiB
 constexpr int B_BLOCK = (E / 2) * 128;           // 24 KiB

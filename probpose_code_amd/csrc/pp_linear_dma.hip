@@ -414,6 +414,7 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int m = m0 + row0 + i * 16;
+            (void)m;
             f32x4 v;
             if (MODE == 1) {
                 const float rsw = rs[i] * p.w_inv;  // (colsum is the sum of the STORED - scaled - weights: the difference carries the scale)
