@@ -4,7 +4,7 @@
 # Kernel timing (--kernel-trace --stats) and the HBM counters (--pmc FETCH_SIZE, --pmc WRITE_SIZE) are separate runs;
 # PMC runs never carry another trace domain.
 set -u
-tag=${1:-r05_f16x3_bs64}
+tag=${1:-r06_f16x3_bs64}
 prec=${2:-f16x3}
 extra=${3:-}   # appended to every bench.py command, e.g. "--config4-only --config4-quick --no-parity" for BASELINE config 4 (tag r05_config4_f16x3_bs64)
 nodrop="--no-drop-in --no-small-batch"
