@@ -53,6 +53,7 @@ struct Params {
     char* h_out;            // [M, N] split rows
     float eps;
     int* counters;          // one per row block, zero on entry, zero on exit
+    int xr, xc;             // > 0: XCD-aware tile order (xr * xc == 8, row blocks % xr == 0, column tiles % xc == 0); 0: row-major
     // DECONV form (pp_skinny_deconv): `a` is an NHWC map (n_img, H, W, Cin), row m = pixel, K = 4 Cin runs over the 2 x 2 taps of output phase
     // blockIdx.y = 2 py + px (ConvTranspose2d k4 s2 p1: tap (ty, tx) reads pixel (y + ty - 1 + py, x + tx - 1 + px), zeros outside the map);
     // `w` holds the four phase matrices (Cout, 4 Cin) one after the other, `out` the NHWC map (n_img, 2 H, 2 W, Cout = N) in the split format
@@ -207,7 +208,19 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
     const int wm = wave >> 1, wn = wave & 1;
     const int f_row = lane & 15, f_kg = lane >> 4;
     const int ntn = p.N / BN;
-    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    if (!DECONV && p.xr > 0) {
+        // XCD-aware tile order. Workgroup b runs on XCD b % 8, each with its own 4 MiB L2: row-major order hands every XCD tiles of every row block
+        // and every column tile, so each L2 pulls ALL of A and ALL of W from the memory side (fc2 at B = 1: 4.7 MB per XCD, more than its L2 - the K
+        // loop ran at what eight copies of that traffic allow, not at what the ring had in flight). Here the eight XCDs are an xr x xc grid over the
+        // tile matrix: an XCD touches 1 / xr of the activation rows and 1 / xc of the weight rows.
+        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        const int xri = xcd / p.xc, xci = xcd - xri * p.xc;
+        const int tc = ntn / p.xc, tr = (int)(gridDim.x / ntn) / p.xr;  // tiles of an XCD along N and along M
+        const int lm = slot / tc;
+        mt = xri * tr + lm;
+        nt = xci * tc + (slot - lm * tc);
+    }
     const int m0 = mt * BM, n0 = nt * BN;
     const int nsteps = p.K / (32 * KS);
 #if SK_STAMP
@@ -541,6 +554,24 @@ extern "C" int pp_skinny_linear(const void* act, const void* weight, const float
     const int code = pp_skinny_linear_tile(M, N, K, ln ? 1 : 0);
     const int bm = code / 1000, bn = code % 1000, rt = bm / 32, ct = bn / 32;
     const int grid = ((M + bm - 1) / bm) * (N / bn);
+    if (pp::option("skinny_xcd_order") != 0 && ln && M >= 2048) {
+        // the split of the eight XCDs over (row blocks, column tiles) that leaves an XCD the fewest distinct operand bytes. Measured (B = 1 .. 16
+        // crops + flip, scripts/r06/skinny_tile_sweep.py with PP_OPT_SKINNY_XCD_ORDER 0 / 1): the launches with a LayerNorm tail gain from ~3 000
+        // rows on (B = 8: proj 16.3 -> 14.8 us, fc2 29.6 -> 28.7; B = 16: 22.2 -> 20.3, 40.6 -> 38.8), smaller ones and the launches without a
+        // tail lose 0.2 - 0.5 us (a workgroup's fill is bounded by what one CU keeps in flight, not by its XCD's distinct bytes)
+        const int nmt = (M + bm - 1) / bm, ntn = N / bn;
+        double best = 0.0;
+        for (int xr = 1; xr <= 8; xr *= 2) {
+            const int xc = 8 / xr;
+            if (nmt % xr != 0 || ntn % xc != 0) continue;
+            const double bytes = (double)M * K / xr + (double)N * K / xc;
+            if (p.xr == 0 || bytes < best) {
+                best = bytes;
+                p.xr = xr;
+                p.xc = xc;
+            }
+        }
+    }
     const size_t lds = (size_t)sk::stages_of(bm + bn) * sk::KS * (bm + bn) * 128;
     void (*kern)(const sk::Params) = nullptr;
 #define PP_SK_PICK(R, C) \
