@@ -32,7 +32,7 @@ extern "C" {
  *    pp_qkv_attention_split_ws, pp_gemm_residual_layernorm_ws, pp_ffn_split_residual_layernorm_ws, pp_proj_ffn_split_residual_layernorm_ws (the unsuffixed entry points = scale 1);
  *    CHANGED signatures: pp_qkv_attention_split_folded (centered rows, no column sums, + w_inv_scale), pp_proj_ffn_split_folded (+ residual_stats,
  *    + three weight scales; the rows it leaves are centered); pp_probmap_decode_flags writes NaN results for a map with a non-finite logit;
- *    + pp_skinny_linear / pp_skinny_linear_tile / pp_skinny_deconv (the launch plan of small batches); REMOVED: the eight-wave feed-forward kernel, the overlapped-epilogue Linear kernel and the
+ *    + pp_skinny_linear / pp_skinny_linear_tile / pp_skinny_deconv / pp_skinny_conv1x1_planar (the launch plan of small batches); REMOVED: the eight-wave feed-forward kernel, the overlapped-epilogue Linear kernel and the
  *    head-pair qkv + attention kernel with their options "ffn_dma_waves" / "linear_ovl" / "qkv_attn_pair".
  * 3: + pp_launch_count / pp_reset_launch_counts (diagnostics: which kernels a launch plan really ran); pp_linear_ln_folded, the *_folded launches
  *    and PP_WS_LN_STATS (round 5).
@@ -304,6 +304,12 @@ int pp_skinny_linear(const void* act, const void* weight, const float* bias, con
                      int M, int N, int K, int act_fn, float w_inv_scale, const float* ln_gamma, const float* ln_beta, float ln_eps,
                      void* ln_out, int* ln_counters, void* stream);
 int pp_skinny_linear_tile(int M, int N, int K, int with_layernorm);
+/* 1x1 convolution to a few channels, planar fp32 out, of a SMALL batch on pp_skinny_linear's 32 x 32 tiles (the final layer of the heatmap branch,
+ * mmpose/models/heads/hybrid_heads/probmap_head.py:244-249, 471-472): out[i, c, p] = sum_k act[i * P + p, k] weight[c, k] * w_inv_scale + bias[c],
+ * c < n_valid. act (n_img * P, K) PP_OUT_SPLIT (an NHWC map); weight_padded (32 * ceil(n_valid / 32), K) PP_OUT_SPLIT with ZERO rows past n_valid,
+ * bias_padded of the same padded length; out fp32 (n_img, n_valid, P). K % 64 == 0. */
+int pp_skinny_conv1x1_planar(const void* act, const void* weight_padded, const float* bias_padded, float* out, int n_img, int P, int K,
+                             int n_valid, float w_inv_scale, void* stream);
 /* ConvTranspose2d(Cin -> Cout, k4, s2, p1, bias=False) + folded BatchNorm + ReLU of a SMALL batch (mmpose/models/heads/hybrid_heads/
  * probmap_head.py:435-472): act_nhwc (B, H, W, Cin), out_nhwc (B, 2H, 2W, Cout) PP_OUT_SPLIT; weight / bias as PP_DECONV4X4S2 of pp_conv_gemm
  * with py < 0 (four phase matrices (Cout, 4 Cin), BatchNorm folded). The four output phases are four column-parallel GEMMs of one launch on

@@ -64,6 +64,7 @@ SIGNATURES = {
     "pp_skinny_linear": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_float, _P, _P, _P]),
     "pp_skinny_linear_tile": (c_int, [c_int, c_int, c_int, c_int]),
     "pp_skinny_deconv": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "pp_skinny_conv1x1_planar": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "pp_clock_probe": (c_int, [_P, _P, ctypes.c_uint, _P]),
     "pp_probmap_decode": (
         c_int,

@@ -53,6 +53,7 @@ struct Params {
     char* h_out;            // [M, N] split rows
     float eps;
     int* counters;          // one per row block, zero on entry, zero on exit
+    int planar_P, n_valid;  // planar_P > 0 (pp_skinny_conv1x1_planar): out is fp32 (rows / planar_P, n_valid, planar_P) planes, columns >= n_valid are padding
     int xr, xc;             // > 0: XCD-aware tile order (xr * xc == 8, row blocks % xr == 0, column tiles % xc == 0); 0: row-major
     // DECONV form (pp_skinny_deconv): `a` is an NHWC map (n_img, H, W, Cin), row m = pixel, K = 4 Cin runs over the 2 x 2 taps of output phase
     // blockIdx.y = 2 py + px (ConvTranspose2d k4 s2 p1: tap (ty, tx) reads pixel (y + ty - 1 + py, x + tx - 1 + px), zeros outside the map);
@@ -408,7 +409,15 @@ __global__ __launch_bounds__(THREADS) void skinny_linear_kernel(const Params p) 
                 const int b = mm / hw, rem = mm - b * hw, y = rem / p.Wd, x = rem - y * p.Wd;
                 idx = (((size_t)b * 2 * p.H + 2 * y + (phase >> 1)) * 2 * p.Wd + 2 * x + (phase & 1)) * p.N + n;
             }
-            if (p.out_split) split_store4_rowpair(p.out, idx, v, live);  // (every lane calls it: row swaps inside)
+            if (!LN && !DECONV && p.planar_P > 0) {  // (image, column, pixel) planes: the 16 rows of a fragment are 16 consecutive pixels of a plane
+                if (live) {
+                    const int img = m / p.planar_P, pix = m - img * p.planar_P;
+                    float* o = reinterpret_cast<float*>(p.out) + ((size_t)img * p.n_valid + n) * p.planar_P + pix;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.n_valid) o[(size_t)e * p.planar_P] = v[e];
+                }
+            } else if (p.out_split) split_store4_rowpair(p.out, idx, v, live);  // (every lane calls it: row swaps inside)
             else if (LN) {
                 // DEVICE-scope store (sc1): the rows are read back inside this launch by a workgroup that may sit on another XCD, i.e. behind another
                 // L2. A plain store + an agent-scope release fence does it too - by writing the whole L2 back (buffer_wbl2) and, on the reading side,
@@ -587,6 +596,43 @@ extern "C" int pp_skinny_linear(const void* act, const void* weight, const float
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(sk::THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);
     PP_LAUNCH_CHECK();
+    return PP_OK;
+}
+
+// 1x1 convolution to a FEW output channels (the final layer of the heatmap branch: 17 keypoint logits, mmpose/models/heads/hybrid_heads/
+// probmap_head.py:244-249, 471-472) of a small batch, planar fp32 out (n_img, n_valid, P) - the layout the decode kernel reads: 32 x 32 tiles over
+// the pixels (192 workgroups for one crop + flip) instead of the 128 x 128 kernel's 48 (14.3 us at B = 1).
+//   act (n_img * P, K) split rows (NHWC map), weight (32 * ceil(n_valid / 32), K) split rows - rows >= n_valid ZERO -, bias of that padded length
+extern "C" int pp_skinny_conv1x1_planar(const void* act, const void* weight_padded, const float* bias_padded, float* out, int n_img, int P, int K,
+                                        int n_valid, float w_inv_scale, void* stream) {
+    using namespace pp;
+    PP_REQUIRE(act && weight_padded && out, PP_ERR_INVALID_ARG, "pp_skinny_conv1x1_planar: NULL argument");
+    PP_REQUIRE(n_img > 0 && P > 0 && K > 0 && K % 64 == 0 && n_valid > 0, PP_ERR_INVALID_ARG, "pp_skinny_conv1x1_planar: bad shape (K % 64 == 0)");
+    const int M = n_img * P, N = 32 * ((n_valid + 31) / 32);
+    PP_REQUIRE((size_t)M * K * 4 < 0x7ffffff0u && (size_t)M * n_valid * 4 < 0x7ffffff0u, PP_ERR_UNSUPPORTED, "pp_skinny_conv1x1_planar: operands must be smaller than 2 GiB");
+    {
+        unsigned u;
+        __builtin_memcpy(&u, &w_inv_scale, 4);
+        PP_REQUIRE((u >> 31) == 0 && (u & 0x007fffffu) == 0 && ((u >> 23) & 0xffu) >= 127 - 40 && ((u >> 23) & 0xffu) <= 127 + 40, PP_ERR_INVALID_ARG,
+                   "pp_skinny_conv1x1_planar: the weight scale must be a power of two in [2^-40, 2^40]");
+    }
+    sk::Params p{};
+    p.a = reinterpret_cast<const char*>(act);
+    p.w = reinterpret_cast<const char*>(weight_padded);
+    p.bias = bias_padded;
+    p.out = reinterpret_cast<char*>(out);
+    p.M = M; p.N = N; p.K = K;
+    p.act = sk::ACT_NONE;
+    p.a_bytes = (unsigned)((size_t)M * K * 4);
+    p.w_bytes = (unsigned)((size_t)N * K * 4);
+    p.w_inv = w_inv_scale;
+    p.planar_P = P;
+    p.n_valid = n_valid;
+    const int grid = ((M + 31) / 32) * (N / 32);
+    const size_t lds = (size_t)sk::stages_of(64) * sk::KS * 64 * 128;
+    PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sk::skinny_linear_kernel<1, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((sk::skinny_linear_kernel<1, 1, false>), dim3(grid), dim3(sk::THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);
+    PP_LAUNCH_CHECK_AS("skinny_conv1x1");
     return PP_OK;
 }
 

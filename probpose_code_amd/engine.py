@@ -115,6 +115,16 @@ class ProbPoseEngine:
         self.fuse_mlp, self.fuse_proj, self.fuse_qkv, self.split_k = pl["fuse_mlp"], pl["fuse_proj"], pl["fuse_qkv"], pl["split_k"]
         # f16x3: the column-parallel plan of small batches (pp_skinny_linear, _layers_small); small_rows_below: the row count it ends at
         self.small_plan = bool(precision == "f16x3" and pl["small_plan"])
+        # the final 1x1 conv's weights padded to 32 rows (zeros) for pp_skinny_conv1x1_planar
+        self._final_padded = None
+        if self.small_plan and self.w.has("final.w") and self.w["final.w"].dim() == 2:
+            fw, fb = self.w["final.w"], self.w["final.b"]
+            rows = 32 * ((fw.shape[0] + 31) // 32)
+            wp = torch.zeros((rows, fw.shape[1]), dtype=fw.dtype, device=fw.device)
+            wp[: fw.shape[0]] = fw
+            bp = torch.zeros(rows, dtype=torch.float32, device=fb.device)
+            bp[: fb.shape[0]] = fb
+            self._final_padded = (wp, bp)
         self.small_rows_below = SMALL_PLAN_ROWS_BELOW
         # attention inside the bf16 layer kernel (pp_vit_layer, one launch per layer; 192-token sequences, head dim 32): about 2 %
         # faster per step than pp_attention + the fused rest since the residual rows load under its attention phase
@@ -568,6 +578,12 @@ class ProbPoseEngine:
                        ACT_RELU, ob, st)
             src, cin, hh, ww = dst, cout, hh * 2, ww * 2
         P = hh * ww
+        if ob == 2 and self._small_at(nb * self.Np) and cin % 64 == 0 and self._final_padded is not None:
+            # small batches: 32 x 32 tiles over the pixels (192 workgroups for one crop + flip) instead of 128 x 128 ones (48)
+            wp, bp = self._final_padded
+            self._call("final_conv", "pp_skinny_conv1x1_planar", src.data_ptr(), wp.data_ptr(), bp.data_ptr(), ws["logits"].data_ptr(), nb, P, cin, self.K,
+                       w.inv("final.w"), st)
+            return ws["logits"]
         self._gemm(st, src, w["final.w"], w["final.b"], ws["logits"], nb * P, self.K, cin, planar=P, out_bf16=0)
         return ws["logits"]
 

@@ -150,7 +150,10 @@ def test_small_batches_take_the_column_parallel_plan_and_match_the_oracle(B, fli
     # patch embedding + 3 Linear layers per layer on the column-parallel kernel, qkv + attention per (sequence, head), no row-owner layer launch
     n_deconv = _lib.launch_count("skinny_deconv")  # (deconvolutions of at most 1 536 input pixels take the skinny kernel too)
     assert n_deconv == sum(B * (2 if flip else 1) * px <= 1536 for px in (192, 768))
-    assert _lib.launch_count("pp_skinny.hip") - n_deconv == 1 + 3 * 12, _lib.launch_count("pp_skinny.hip")
+    # the final 1x1 conv of the heatmap branch on 32 x 32 tiles - unless the batch is large enough for the fused deconvolution + 1x1 launch
+    n_final = int(B * (2 if flip else 1) * 768 * 4 < 192 * 192)
+    assert _lib.launch_count("skinny_conv1x1") == n_final
+    assert _lib.launch_count("pp_skinny.hip") - n_deconv - n_final == 1 + 3 * 12, _lib.launch_count("pp_skinny.hip")
     assert _lib.launch_count("pp_qkv_attn_split.hip") == 12
     assert _lib.launch_count("pp_ffn_dma.hip") == 0 and _lib.launch_count("pp_gemm_ln.hip") == 0 and _lib.launch_count("layernorm") == 0
     d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
@@ -217,7 +220,7 @@ def test_small_plan_vit_b_384x288():
     _lib.reset_launch_counts()
     out = eng.forward(crops.cuda(), True, S.COCO_FLIP_INDICES)
     torch.cuda.synchronize()
-    assert _lib.launch_count("pp_skinny.hip") - _lib.launch_count("skinny_deconv") == 1 + 4 * 12
+    assert _lib.launch_count("pp_skinny.hip") - _lib.launch_count("skinny_deconv") - _lib.launch_count("skinny_conv1x1") == 1 + 4 * 12
     d = np.abs(out["keypoints"].cpu().numpy()[:, None] - ref["keypoints_input_space"]).max(-1)
     assert (d < 2.0).all() and d.max() <= 1e-3, f"{int((d >= 2).sum())} flips, {d[d < 2].max():.2e} px"
 
@@ -286,3 +289,30 @@ def test_skinny_deconv_vs_fp64_and_the_generic_kernel(B, H, W, Cin):
     again = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
     L.call("pp_skinny_deconv", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), again.data_ptr(), B, H, W, Cin, Cout, None)
     assert torch.equal(out.cpu().view(torch.int32), again.cpu().view(torch.int32))
+
+
+@gpu
+@pytest.mark.parametrize("n_img,P,K,n_valid", [(2, 64 * 48, 256, 17), (5, 64 * 48, 256, 17), (3, 1000, 128, 33), (1, 40, 64, 1)])
+def test_skinny_conv1x1_planar_vs_fp64(n_img, P, K, n_valid):
+    """pp_skinny_conv1x1_planar (final layer of the heatmap branch at small batches: 1x1 conv to a few channels, planar fp32 out) against fp64; ragged
+    pixel counts (rows past the end read as zeros and are not stored), the padded weight rows never reach the output, planes past n_valid untouched."""
+    L = _lib()
+    x = _rand(n_img * P, K, seed=41)
+    wt = _rand(n_valid, K, seed=42, scale=1 / math.sqrt(K))
+    b = _rand(n_valid, seed=43, scale=0.3)
+    rows = 32 * ((n_valid + 31) // 32)
+    wp = torch.zeros(rows, K)
+    wp[:n_valid] = wt
+    bp = torch.zeros(rows)
+    bp[:n_valid] = b
+    ref = (x.double() @ wt.double().t() + b.double()).view(n_img, P, n_valid).permute(0, 2, 1).contiguous()
+    out = torch.full((n_img * n_valid * P + 64,), float("nan"), device="cuda")
+    xd, wd, wd_scaled, bd = _sp(x), _sp(wp), _sp(wp * 4096.0), bp.cuda()
+    L.call("pp_skinny_conv1x1_planar", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), n_img, P, K, n_valid, 1.0, None)
+    got = out[: n_img * n_valid * P].view(n_img, n_valid, P).cpu().double()
+    assert torch.isnan(out[n_img * n_valid * P:]).all(), "wrote past the planes"
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+    # the weights stored times 2^12: undone exactly
+    out2 = torch.empty_like(out)
+    L.call("pp_skinny_conv1x1_planar", xd.data_ptr(), wd_scaled.data_ptr(), bd.data_ptr(), out2.data_ptr(), n_img, P, K, n_valid, 1.0 / 4096.0, None)
+    torch.testing.assert_close(out2[: n_img * n_valid * P].cpu().double().view(n_img, n_valid, P), ref, rtol=1e-5, atol=1e-5)
