@@ -105,6 +105,7 @@ int pp_device_cu_count(void);
  *   "psplit_tail" (1)        0: split-fp16 Linear layers never send the rows of a ragged last round to a second launch on 128 x 192 tiles
  *   "wino_order" (8)         pp_conv3x3_winograd_maxpool_relu: column tiles per 32-workgroup super tile (0: column tiles fastest)
  *   "qkv_attn_deep" (1)      pp_qkv_attention_split(_ws) of a small launch (<= 2 workgroups per CU): ring of four stages, one workgroup per CU (0: always two stages)
+ *   "qkv_attn_qsplit" (1)    ... and while 2 x sequences x heads <= 0.8 x CUs: two workgroups per (sequence, head), each attends for half of the query tiles
  *   "skinny_tile" (0)        pp_skinny_linear: 10 RT + CT (11, 22, 33, 13, 12, 23) forces a tile of 32 RT rows x 32 CT columns (0: the cost rule of pp_skinny.hip)
  *   "skinny_xcd_order" (1)   pp_skinny_linear launches with a LayerNorm tail and >= 2 048 rows: tiles ordered so that an XCD touches 1 / xr of the row
  *                            blocks and 1 / xc of the column tiles (xr xc = 8; 0: row-major)

@@ -37,6 +37,7 @@ static Option g_options[] = {
     {"ksplit_channels", 1},    // pp_conv3x3_splitk_slices: 0 = never the four channel-range slices of the split-fp16 wide-tile kernel (whole-tap slices only)
     {"qkv_attn_deep", 1},      // pp_qkv_attention_split (unfolded form) of a launch of at most two workgroups per CU: 1 = ring of four stages, one workgroup per CU; 0 = the two-stage kernel
     {"skinny_tile", 0},        // pp_skinny_linear: 10 RT + CT forces the tile shape (0: by the cost rule in pp_skinny.hip)
+    {"qkv_attn_qsplit", 1},    // pp_qkv_attention_split, deep-ring form: two workgroups per (sequence, head) while 2 x sequences x heads <= 0.8 x CUs
     {"skinny_xcd_order", 1},   // pp_skinny_linear: tiles ordered so that an XCD touches 1 / xr of the rows and 1 / xc of the weights (0: row-major)
     {"ksplit9_below", 1024},   // pp_conv3x3_splitk_slices: tower stages with fewer output rows than this take nine K-slices (one tap each) instead of three
 };

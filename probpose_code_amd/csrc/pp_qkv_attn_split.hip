@@ -66,6 +66,9 @@ struct Params {
     // rstd ((x - mean) W'^T) + b' with no  - mean * colsum(W')  term - that fp32 difference was the folded form's whole excess error.
     const float* ln_stats;   // [n_seq * 192, 2]: (mean, rstd) per row
     float w_inv;             // the weights are stored as w * 2^e (weights.py): accumulators * 2^-e in front of the bias (exact)
+    int q_split;             // 1, or 2 (small launches, deep-ring form): two workgroups per (sequence, head), each projects the whole head and attends for
+                             // HALF of the query tiles - the projection is repeated on a CU that would idle, the attention phase halves (13.9 -> ~12 us
+                             // per launch at B = 1: a launch of 24 workgroups leaves 232 CUs without work)
 };
 
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
@@ -140,6 +143,8 @@ __device__ __forceinline__ void qkv_attention_body(const Params& p) {
     int id = blockIdx.x;
     const int nblk = gridDim.x;
     if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);  // the heads of a sequence on one XCD, one after the other
+    const int qh = p.q_split == 2 ? (id & 1) : 0;  // which half of the query tiles
+    if (p.q_split == 2) id >>= 1;
     const int seq = id / p.heads, head = id - seq * p.heads;
 
     // ---- DMA: 36 instructions of 8 lines per stage (24 token pieces, 12 weight pieces); wave w issues pieces w, w + 8, w + 16
@@ -317,8 +322,9 @@ __device__ __forceinline__ void qkv_attention_body(const Params& p) {
     const char* Ks = smem + OFF_K;
     const _Float16* Vh = reinterpret_cast<const _Float16*>(smem + OFF_V);
     const _Float16* Vl = reinterpret_cast<const _Float16*>(smem + OFF_V + V_PLANE);
+    const int qt_end = p.q_split == 2 ? (qh + 1) * (NT / 2) : NT;
 #pragma unroll 1
-    for (int qt = wv; qt < NT; qt += THREADS / 64) {
+    for (int qt = (p.q_split == 2 ? qh * (NT / 2) : 0) + wv; qt < qt_end; qt += THREADS / 64) {
         const f16x8 qh = *reinterpret_cast<const f16x8*>(Qs + (qt * 16 + fr) * 128 + ch_hi);
         const f16x8 ql = *reinterpret_cast<const f16x8*>(Qs + (qt * 16 + fr) * 128 + ch_lo);
         // ---- scores: s[kt][i] = q . k for key 16 kt + 4 fg + i of query 16 qt + fr
@@ -450,6 +456,7 @@ static int qkv_attention_launch(const void* h_in, const void* wqkv, const float*
     p.scale_log2e = scale * 1.44269504088896340736f;
     p.ln_stats = ln_stats;
     p.w_inv = w_inv_scale;
+    p.q_split = 1;
     if (ln_stats) {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qka::qkv_attention_split_folded_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, qka::LDS));
@@ -459,7 +466,9 @@ static int qkv_attention_launch(const void* h_in, const void* wqkv, const float*
         // at most two workgroups per CU's worth of launch: nothing to overlap with on a CU, the deep ring hides the memory round trips instead
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qka::qkv_attention_split_deep_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, qka::LDS_DEEP));
-        hipLaunchKernelGGL(qka::qkv_attention_split_deep_kernel, dim3(n_seq * heads), dim3(qka::THREADS), qka::LDS_DEEP,
+        // (measured, ms per replayed step: B = 1 0.730 -> 0.718, B = 2 0.832 -> 0.816, B = 4 0.959 -> 0.951; B = 5 - 240 workgroups - 1.091 -> 1.108)
+        if (pp::option("qkv_attn_qsplit") != 0 && 10 * n_seq * heads <= 4 * pp_device_cu_count()) p.q_split = 2;
+        hipLaunchKernelGGL(qka::qkv_attention_split_deep_kernel, dim3(p.q_split * n_seq * heads), dim3(qka::THREADS), qka::LDS_DEEP,
                            reinterpret_cast<hipStream_t>(stream), p);
         PP_LAUNCH_CHECK_AS("qkv_attn_deep");
         return PP_OK;

@@ -656,6 +656,12 @@ def test_qkv_attention_split_fused_vs_fp64(n_seq, bias, deep):
     with pytest.raises(L.ProbPoseLibraryError):
         L.call("pp_qkv_attention_split", hd_.data_ptr(), wd.data_ptr(), None, hd_.data_ptr(), n_seq, S, H, hd, 0.1, None)
     assert (L.launch_count("qkv_attn_deep") > 0) == (deep == 1 and n_seq * H <= 512)
+    # small launches of the deep-ring form use two workgroups per (sequence, head), half of the query tiles each (option "qkv_attn_qsplit"): same bits
+    L.set_option("qkv_attn_qsplit", 0)
+    out = torch.full((M, E), float("nan"), device="cuda")
+    L.call("pp_qkv_attention_split", hd_.data_ptr(), wd.data_ptr(), bd.data_ptr() if bias else None, out.data_ptr(), n_seq, S, H, hd, hd ** -0.5, None)
+    L.set_option("qkv_attn_qsplit", 1)
+    assert torch.equal(out.cpu().view(torch.int32), outs[0].view(torch.int32))
     L.set_option("qkv_attn_deep", 1)
 
 
