@@ -481,17 +481,20 @@ struct Shape {
     double first, next;   // with it
 };
 static const Shape SHAPES[] = {{1, 1, 1.5, 3.3, 11.2, 7.0},  {2, 2, 1.0, 6.2, 17.5, 15.0}, {3, 3, 0.0, 11.3, 27.5, 27.0},
-                               {1, 3, 1.2, 6.0, 13.2, 12.5}, {1, 2, 1.5, 4.25, 11.8, 10.5}, {2, 3, 0.9, 8.3, 20.0, 19.5}};
+                               {1, 3, 1.2, 6.0, 13.2, 12.5}, {1, 2, 1.5, 4.25, 11.8, 10.5}, {2, 3, 0.9, 8.3, 20.0, 19.5},
+                               // 96 x 64: the deconvolutions only (groups == 4; deconv2 of one crop + flip: 1 536 pixels x 256 channels x 4 phases = 256 tiles,
+                               // ONE round of the chip where 64 x 64 tiles are 384 = two)
+                               {3, 2, 0.9, 8.3, 20.0, 19.5}};
 static Shape pick_shape(int M, int N, int K, bool tail, int cus, int groups = 1) {
     const int forced = option("skinny_tile");
     for (const Shape& sh : SHAPES)
-        if (forced == 10 * sh.rt + sh.ct && N % (32 * sh.ct) == 0) return sh;
+        if (forced == 10 * sh.rt + sh.ct && N % (32 * sh.ct) == 0 && !(forced == 32 && groups == 1)) return sh;
     const double kf = 0.5 + 0.5 * (double)K / 384.0, kfl = 1.0 + 0.2 * ((double)K / 384.0 - 1.0);
     Shape best = SHAPES[0];
     double best_cost = 1e30;
     for (const Shape& sh : SHAPES) {
         const int bm = 32 * sh.rt, bn = 32 * sh.ct;
-        if (N % bn != 0) continue;
+        if (N % bn != 0 || (sh.rt == 3 && sh.ct == 2 && groups == 1)) continue;
         const long long wgs = (long long)((M + bm - 1) / bm) * (N / bn) * groups;
         const double rounds = (double)((wgs + cus - 1) / cus);
         const double cost = tail ? (sh.first + (rounds - 1.0) * sh.next) * kfl : sh.base + rounds * sh.round * kf;
@@ -676,6 +679,7 @@ extern "C" int pp_skinny_deconv(const void* act_nhwc, const void* weight, const 
     PP_SK_PICK(1, 3);
     PP_SK_PICK(1, 2);
     PP_SK_PICK(2, 3);
+    PP_SK_PICK(3, 2);
 #undef PP_SK_PICK
     PP_REQUIRE(kern != nullptr, PP_ERR_UNSUPPORTED, "pp_skinny_deconv: no kernel for the tile shape");
     PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -39,10 +39,10 @@ for B in (1, 2, 4, 8, 16):
         b = torch.randn(256).cuda()
         out = torch.zeros(nb, 2 * H, 2 * W, 256, device="cuda")
         res = []
-        for code in (11, 22, 12):
+        for code in (11, 22, 12, 32):
             L.set_option("skinny_tile", code)
             res.append(f"{timed(lambda: L.call('pp_skinny_deconv', x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), nb, H, W, Cin, 256, L.stream_ptr())):6.1f}")
         L.set_option("skinny_tile", 0)
         auto = timed(lambda: L.call('pp_skinny_deconv', x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), nb, H, W, Cin, 256, L.stream_ptr()))
         gen = timed(lambda: L.call("pp_conv_gemm", 2, 2, x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), nb, H, W, Cin, 256, -1, -1, 1, 0, 0, 0, 0, 256, 2, 2, L.stream_ptr()))
-        print(f"B {B:2d} {name} rows {nb * H * W:6d}: skinny 32x32 / 64x64 / 32x64: {' | '.join(res)}  rule {auto:6.1f}   pp_conv_gemm {gen:6.1f} us", flush=True)
+        print(f"B {B:2d} {name} rows {nb * H * W:6d}: skinny 32x32 / 64x64 / 32x64 / 96x64: {' | '.join(res)}  rule {auto:6.1f}   pp_conv_gemm {gen:6.1f} us", flush=True)
