@@ -203,6 +203,8 @@ class ProbPoseEngine:
             self.w.t.pop("tower0.wino")  # (37.7 MB at ViT-S that no launch of this plan reads)
         self._logits_phased = False
         self._head_stream: Optional[torch.cuda.Stream] = None  # second stream of the head at small batches (run_head)
+        self._capture_events: list = []   # fork / join events of the graph being captured (_fork_join)
+        self._eager_events: dict = {}
         self.profile: Optional[Dict[str, list]] = None
         self.stage_hook = None  # callable(name) invoked between stages of the launch plan ("embed", "layer<i>", "backbone"); dev / scheduling experiments
         # tower pooling schedule (probmap_head.py:264) and the spatial sizes it produces
@@ -688,7 +690,7 @@ class ProbPoseEngine:
             if two:
                 if self._head_stream is None:
                     self._head_stream = torch.cuda.Stream(device=self.device)
-                self._head_stream.wait_stream(cur)
+                self._fork_join(cur, self._head_stream)
                 with torch.cuda.stream(self._head_stream):
                     scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, _lib.stream_ptr(self.device))
             st = _lib.stream_ptr(self.device)
@@ -702,7 +704,7 @@ class ProbPoseEngine:
                       ws["heatmaps"].data_ptr() if return_heatmaps else None, None, ws["locs"].data_ptr(),
                       ws["keypoints"].data_ptr(), ws["scores"].data_ptr(), flags, st)
             if two:
-                cur.wait_stream(self._head_stream)
+                self._fork_join(self._head_stream, cur)
             else:
                 scalars = self.towers(feat_nhwc, B, passes, flip_indices, ws, st)
         out = dict(keypoints=ws["keypoints"], scores=ws["scores"], locs=ws["locs"], scalars=scalars)
@@ -723,6 +725,23 @@ class ProbPoseEngine:
         if return_features:
             out["features"] = feat
         return out
+
+    def _fork_join(self, producer: torch.cuda.Stream, consumer: torch.cuda.Stream) -> None:
+        """``consumer.wait_stream(producer)`` with an event that OUTLIVES the call. `Stream.wait_stream` records a temporary event and destroys it on
+        return; inside a stream capture the HIP runtime (ROCm 7.0) keeps referring to that event from the captured graph - after the event's memory
+        had been reused by later host allocations, replaying a graph with the two-stream head crashed inside hipGraphLaunch
+        (scripts/r06/graph_eager_repro2.py: `test_step` graphs + short-lived StepPipeline objects). Events recorded during a capture are kept with
+        the graph being captured (`capture`), the others are two per engine, re-recorded."""
+        if torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            self._capture_events.append(ev)
+        else:
+            key = (producer.cuda_stream, consumer.cuda_stream)
+            ev = self._eager_events.get(key)
+            if ev is None:
+                ev = self._eager_events[key] = torch.cuda.Event()
+        ev.record(producer)
+        consumer.wait_event(ev)
 
     # ------------------------------------------------------------------ hipGraph replay
     def capture(self, B: int, flip_test: bool = True, flip_indices=None, return_heatmaps: bool = False, slot: int = 0,
@@ -746,17 +765,29 @@ class ProbPoseEngine:
             if not any(k[0] == old_key[0] and k[-1] == old_key[-1] and (2 if k[1] else 1) == passes_old for k in self._graphs):
                 self._ws.pop((old_key[0], passes_old, old_key[-1]), None)
         static_in = torch.zeros((B, 3, self.H, self.W), dtype=torch.uint8, device=self.device)
+        # The two-stream head forks to a side stream INSIDE the capture. That stream must not be one an earlier capture used whose graph has been
+        # destroyed since (an eviction): with one engine-wide side stream, the first replay of a graph captured after an eviction crashed inside
+        # hipGraphLaunch (ROCm 7.0; scripts/r06/graph_eager_repro.py: stale capture state on the stream - a stream of its own per capture, or
+        # never destroying a graph, both end it). Every capture therefore takes a fresh stream from torch's pool for its side branch; the
+        # kernel-by-kernel launches keep theirs.
+        eager_head_stream, self._head_stream = self._head_stream, torch.cuda.Stream(device=self.device)
         side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):  # warm-up: allocates the workspace, sets kernel attributes
-            for _ in range(2):
-                self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot, shift_heatmap=shift_heatmap)
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        side.synchronize()  # (this stream's warm-ups only; torch.cuda.graph below still synchronises the device when the capture begins)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot, shift_heatmap=shift_heatmap)
-        self._graphs[key] = (graph, static_in, out)
+        try:
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):  # warm-up: allocates the workspace, sets kernel attributes
+                for _ in range(2):
+                    self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot, shift_heatmap=shift_heatmap)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            side.synchronize()  # (this stream's warm-ups only; torch.cuda.graph below still synchronises the device when the capture begins)
+            graph = torch.cuda.CUDAGraph()
+            self._capture_events = []
+            with torch.cuda.graph(graph):
+                out = self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot, shift_heatmap=shift_heatmap)
+            # (the fork / join events and the side stream live as long as the graph: _fork_join)
+            self._graphs[key] = (graph, static_in, out, self._capture_events, self._head_stream)
+        finally:
+            self._capture_events = []
+            self._head_stream = eager_head_stream
         self._graph_tick[key] = self._tick
         self.graph_captures += 1
         return static_in
@@ -771,14 +802,15 @@ class ProbPoseEngine:
         return self._graph_key(B, flip_test, flip_indices, return_heatmaps, shift_heatmap, slot) in self._graphs
 
     def capture_would_thrash(self) -> bool:
-        """True when a new capture would evict a graph that replayed within the last ``4 * max_graphs`` calls: with more recurring batch sizes
+        """True when a new capture would evict a graph that replayed within the last ``64 * max_graphs`` calls: with more recurring batch sizes
         than graphs kept (the person counts of a video: 0 .. 20 per frame) every call would otherwise evict, re-allocate a workspace, warm up,
-        capture, synchronise the device and replay - several times the cost of launching kernel by kernel, for ever. The caller then runs this
-        size eagerly; a graph nobody replays any more ages out and makes room."""
+        capture, synchronise the device and replay - several times the cost of launching kernel by kernel, for ever (at 4 * max_graphs a random
+        mix of 15 sizes still captured on 8 % of its calls: scripts/r06/chaos_soak.py). The caller then runs this size eagerly; a graph nobody
+        replays any more ages out and makes room."""
         if len(self._graphs) < max(1, int(self.max_graphs)):
             return False
         victim = next(iter(self._graphs))
-        return self._tick - self._graph_tick.get(victim, 0) <= 4 * max(1, int(self.max_graphs))
+        return self._tick - self._graph_tick.get(victim, 0) <= 64 * max(1, int(self.max_graphs))
 
     def forward_graph(self, imgs: torch.Tensor, flip_test: bool = True, flip_indices=None,
                       return_heatmaps: bool = False, slot: int = 0, shift_heatmap: bool = False) -> Dict[str, torch.Tensor]:
@@ -786,7 +818,7 @@ class ProbPoseEngine:
         B = imgs.shape[0]
         static_in = self.capture(B, flip_test, flip_indices, return_heatmaps, slot, shift_heatmap)
         key = self._graph_key(B, flip_test, flip_indices, return_heatmaps, shift_heatmap, slot)
-        graph, _, out = self._graphs[key]
+        graph, _, out = self._graphs[key][:3]
         self._tick += 1
         self._graph_tick[key] = self._tick
         if imgs.data_ptr() != static_in.data_ptr():

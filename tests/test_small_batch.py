@@ -316,3 +316,35 @@ def test_skinny_conv1x1_planar_vs_fp64(n_img, P, K, n_valid):
     out2 = torch.empty_like(out)
     L.call("pp_skinny_conv1x1_planar", xd.data_ptr(), wd_scaled.data_ptr(), bd.data_ptr(), out2.data_ptr(), n_img, P, K, n_valid, 1.0 / 4096.0, None)
     torch.testing.assert_close(out2[: n_img * n_valid * P].cpu().double().view(n_img, n_valid, P), ref, rtol=1e-5, atol=1e-5)
+
+
+@gpu
+def test_graph_eviction_and_recapture_with_the_two_stream_head():
+    """A graph cache smaller than the set of recurring batch sizes: every call evicts (destroys) the least recently used graph and captures a new
+    one - small batches with the towers on a side stream next to sizes on the row-owner plan. With ONE engine-wide side stream the first replay after
+    such an eviction crashed inside hipGraphLaunch (scripts/r06/graph_eager_repro.py); every capture now has a side stream of its own. Results equal
+    the kernel-by-kernel launches bit for bit."""
+    import random
+
+    from probpose_code_amd import ProbPoseEngine
+    from probpose_code_amd import synthetic as S
+
+    sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
+    eng = ProbPoseEngine(sd, 12, precision="f16x3")
+    eng.max_graphs = 3
+    fi = S.COCO_FLIP_INDICES
+    sizes = (1, 2, 3, 6, 8, 17, 18, 24)
+    crops = {B: S.synthetic_crops(B, seed=70 + B).cuda() for B in sizes}
+    want = {}
+    for B in sizes:
+        out = eng.forward(crops[B], True, fi)
+        want[B] = (out["keypoints"].cpu().numpy().copy(), out["scalars"].cpu().numpy().copy())
+    rng = random.Random(5)
+    for it in range(160):
+        B = rng.choice(sizes)
+        if rng.random() < 0.25:
+            out = eng.forward(crops[B], True, fi)
+        else:
+            out = eng.forward_graph(crops[B], True, fi)
+        assert np.array_equal(out["keypoints"].cpu().numpy(), want[B][0]) and np.array_equal(out["scalars"].cpu().numpy(), want[B][1]), (it, B)
+    assert eng.graph_captures > 40 and len(eng._graphs) == 3

@@ -380,8 +380,8 @@ def test_graph_cache_does_not_thrash_when_more_sizes_recur_than_graphs_are_kept(
                     assert np.array_equal(x.pred_instances.keypoints_probs, y.pred_instances.keypoints_probs)
     eng = fast.engine
     assert eng.graph_captures == 3, f"{eng.graph_captures} captures for {len(sizes)} recurring sizes with max_graphs=3"
-    # a graph nobody replays any more ages out: a new size that keeps coming gets its capture after 4 * max_graphs further calls
-    for _ in range(4 * 3 + 4):
+    # a graph nobody replays any more ages out: a new size that keeps coming gets its capture after 64 * max_graphs further calls
+    for _ in range(64 * 3 + 4):
         crops = S.synthetic_crops(7, seed=5)
         center, scale = S.whole_image_bbox_meta(7)
         fast.test_step(apis.pack_crops(crops, center, scale, fast.dataset_meta))
