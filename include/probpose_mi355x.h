@@ -81,6 +81,12 @@ const char* pp_status_string(int status);
 /* Number of compute units of the current device (for callers sizing batches); <0 on error. */
 int pp_device_cu_count(void);
 
+/* A HIP stream of the caller's own (non-blocking), and its end. For hosts that fork work to a second stream INSIDE a stream capture: on ROCm 7.0 a
+ * stream that took part in a capture whose graph has since been destroyed must not be forked to in a later capture (the first launch of the new
+ * graph crashes inside hipGraphLaunch) - a stream per captured graph, destroyed with it, is the safe pattern (probpose_code_amd/engine.py, capture). */
+int pp_stream_create(void** stream_out);
+int pp_stream_destroy(void* stream);
+
 /* Explicit process-wide options. The library NEVER reads the environment: kernel selection depends only on the arguments of a
  * call and on these switches, which exist for A/B timing and default to the shipped plan:
  *   "panel" (1)              0: every GEMM / convolution on the 128 x 128-tile kernel

@@ -52,6 +52,8 @@ SIGNATURES = {
     "pp_last_error": (c_char_p, []),
     "pp_status_string": (c_char_p, [c_int]),
     "pp_device_cu_count": (c_int, []),
+    "pp_stream_create": (c_int, [_P]),
+    "pp_stream_destroy": (c_int, [_P]),
     "pp_set_option": (c_int, [c_char_p, c_int]),
     "pp_get_option": (c_int, [c_char_p, _P]),
     "pp_launch_count": (c_longlong, [c_char_p]),

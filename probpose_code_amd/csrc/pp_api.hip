@@ -225,6 +225,20 @@ int pp_clock_probe(unsigned long long* out_cycles_ticks, const unsigned long lon
     return PP_OK;
 }
 
+int pp_stream_create(void** stream_out) {
+    PP_REQUIRE(stream_out != nullptr, PP_ERR_INVALID_ARG, "pp_stream_create: NULL argument");
+    hipStream_t s = nullptr;
+    PP_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream_out = reinterpret_cast<void*>(s);
+    return PP_OK;
+}
+
+int pp_stream_destroy(void* stream) {
+    if (stream == nullptr) return PP_OK;
+    PP_HIP_CHECK(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+    return PP_OK;
+}
+
 int pp_device_cu_count(void) {
     int dev = 0;
     PP_HIP_CHECK(hipGetDevice(&dev));

@@ -21,6 +21,8 @@ import warnings
 from typing import Dict, Optional, Sequence
 
 import numpy as np
+import ctypes
+
 import torch
 
 from . import _lib
@@ -54,6 +56,39 @@ def plan_from_env() -> Dict[str, object]:
         if v in ("0", "1"):
             out[k] = v == "1"
     return out
+
+
+class _CapturedGraph:
+    """A captured step: the graph, its static input, its outputs, the fork / join events recorded inside the capture and the HIP stream its
+    two-stream head forked to - a stream of this graph's own (``pp_stream_create``), destroyed right after the graph: on ROCm 7.0 forking to a
+    stream that took part in the capture of a graph destroyed since makes the first launch of the new graph crash inside hipGraphLaunch
+    (scripts/r06/graph_eager_repro.py; streams from torch's pool come round again after 32 captures)."""
+
+    def __init__(self, graph, static_in, out, events, side_stream, raw_stream):
+        self.graph, self.static_in, self.out, self.events, self.side_stream, self.raw_stream = graph, static_in, out, events, side_stream, raw_stream
+
+    def release(self):
+        """Device idle -> graph, then its events and its stream (idempotent)."""
+        if self.graph is None and self.raw_stream is None:
+            return
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+        self.graph = None
+        self.out = self.static_in = None
+        self.events = []
+        self.side_stream = None
+        raw, self.raw_stream = self.raw_stream, None
+        if raw:
+            try:
+                _lib.lib.pp_stream_destroy(ctypes.c_void_p(raw))
+            except Exception:
+                pass
+
+    def __del__(self):
+        self.release()
 
 
 class ProbPoseEngine:
@@ -753,24 +788,23 @@ class ProbPoseEngine:
         key = (B, flip_test, tuple(flip_indices) if flip_indices is not None else None, return_heatmaps, bool(shift_heatmap), slot)
         if key in self._graphs:
             self._graphs[key] = self._graphs.pop(key)  # most recently used last
-            return self._graphs[key][1]
+            return self._graphs[key].static_in
         while len(self._graphs) >= max(1, int(self.max_graphs)):  # least recently used out, with the workspace nothing else replays from
             old_key = next(iter(self._graphs))
             # the victim may still be replaying on another slot's stream (StepPipeline depth >= 2): its exec graph and the buffers it reads go
             # back to the allocator below, so the device must be through with it first (an eviction is rare; the capture syncs anyway)
             torch.cuda.synchronize(self.device)
-            del self._graphs[old_key]
+            self._graphs.pop(old_key).release()
             self._graph_tick.pop(old_key, None)
             passes_old = 2 if old_key[1] else 1
             if not any(k[0] == old_key[0] and k[-1] == old_key[-1] and (2 if k[1] else 1) == passes_old for k in self._graphs):
                 self._ws.pop((old_key[0], passes_old, old_key[-1]), None)
         static_in = torch.zeros((B, 3, self.H, self.W), dtype=torch.uint8, device=self.device)
-        # The two-stream head forks to a side stream INSIDE the capture. That stream must not be one an earlier capture used whose graph has been
-        # destroyed since (an eviction): with one engine-wide side stream, the first replay of a graph captured after an eviction crashed inside
-        # hipGraphLaunch (ROCm 7.0; scripts/r06/graph_eager_repro.py: stale capture state on the stream - a stream of its own per capture, or
-        # never destroying a graph, both end it). Every capture therefore takes a fresh stream from torch's pool for its side branch; the
-        # kernel-by-kernel launches keep theirs.
-        eager_head_stream, self._head_stream = self._head_stream, torch.cuda.Stream(device=self.device)
+        # The two-stream head forks to a side stream INSIDE the capture: a HIP stream of this graph's own (_CapturedGraph), never one an earlier
+        # capture used; the kernel-by-kernel launches keep theirs.
+        raw = ctypes.c_void_p()
+        _lib.check("pp_stream_create", _lib.lib.pp_stream_create(ctypes.byref(raw)))
+        eager_head_stream, self._head_stream = self._head_stream, torch.cuda.ExternalStream(raw.value, device=self.device)
         side = torch.cuda.Stream(device=self.device)
         try:
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -783,11 +817,14 @@ class ProbPoseEngine:
             self._capture_events = []
             with torch.cuda.graph(graph):
                 out = self.forward(static_in, flip_test, flip_indices, return_heatmaps, slot=slot, shift_heatmap=shift_heatmap)
-            # (the fork / join events and the side stream live as long as the graph: _fork_join)
-            self._graphs[key] = (graph, static_in, out, self._capture_events, self._head_stream)
+            self._graphs[key] = _CapturedGraph(graph, static_in, out, self._capture_events, self._head_stream, raw.value)
+            raw = None
         finally:
             self._capture_events = []
             self._head_stream = eager_head_stream
+            if raw is not None and raw.value:  # the capture failed: nothing refers to the stream
+                torch.cuda.synchronize(self.device)
+                _lib.lib.pp_stream_destroy(raw)
         self._graph_tick[key] = self._tick
         self.graph_captures += 1
         return static_in
@@ -818,7 +855,7 @@ class ProbPoseEngine:
         B = imgs.shape[0]
         static_in = self.capture(B, flip_test, flip_indices, return_heatmaps, slot, shift_heatmap)
         key = self._graph_key(B, flip_test, flip_indices, return_heatmaps, shift_heatmap, slot)
-        graph, _, out = self._graphs[key][:3]
+        graph, out = self._graphs[key].graph, self._graphs[key].out
         self._tick += 1
         self._graph_tick[key] = self._tick
         if imgs.data_ptr() != static_in.data_ptr():
