@@ -22,6 +22,9 @@ VERBOSE = os.environ.get("CHAOS_VERBOSE", "0") == "1"
 cfg = os.path.join(ROOT, "configs", "td-pm_ProbPose-small_mi355x_coco-256x192.py")
 sd = S.synthetic_state_dict("small", seed=0, logit_scale=2.0)
 model = apis.init_model(cfg, {"state_dict": sd}, device="cuda:0")
+if os.environ.get("CHAOS_HEATMAPS") == "1":  # (test_step only: the stream API does not carry heatmaps)
+    model.test_cfg["output_heatmaps"] = True
+    MODE = "step"
 if os.environ.get("CHAOS_ONE_HEAD_STREAM") == "1":
     model.engine.plan["head_two_streams"] = False
 DEPTH = int(os.environ.get("CHAOS_DEPTH", "2"))
@@ -40,8 +43,13 @@ def make(key):
 
 
 def signature(samples):
-    return np.concatenate([np.concatenate([s.pred_instances.keypoints.ravel(), s.pred_instances.keypoint_scores.ravel(),
-                                           s.pred_instances.keypoints_visible.ravel()]) for s in samples])
+    parts = []
+    for s in samples:
+        parts += [s.pred_instances.keypoints.ravel(), s.pred_instances.keypoint_scores.ravel(), s.pred_instances.keypoints_visible.ravel()]
+        if "pred_fields" in s and "heatmaps" in s.pred_fields:
+            hm = s.pred_fields.heatmaps
+            parts.append(np.asarray(hm.cpu() if hasattr(hm, "cpu") else hm, dtype=np.float64).ravel())
+    return np.concatenate(parts)
 
 
 want, n_calls, n_bad = {}, 0, 0
