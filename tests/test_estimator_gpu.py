@@ -585,3 +585,16 @@ def test_output_keypoint_indices_selects_fields(setup):
         assert pi.keypoints.shape == (1, 5, 2) and pi.keypoints_probs.shape == (1, 5) and pi.keypoint_scores.shape == (1, 5)
         assert np.abs(pi.keypoints - ref["keypoints"][b][:, idx]).max() <= 1e-3
         assert tuple(ds.pred_fields.heatmaps.shape) == (5, 64, 48)
+
+
+def test_chaos_soak_of_the_drop_in_calls():
+    """Seconds of `test_step` / `test_step_stream(depth 2)` on batches of random size (small-batch plan, its boundary, the row-owner plan; eager
+    launches, captures, a full graph cache), every result compared bit for bit with the first one of the same batch - in a subprocess, so that a
+    crash inside the HIP runtime (round 6: hipGraphLaunch after a graph eviction) fails this test instead of ending the run."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-X", "faulthandler", os.path.join(root, "scripts", "r06", "chaos_soak.py"), "8"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "CHAOS SOAK OK" in r.stdout, (r.returncode, r.stdout[-600:], r.stderr[-1200:])
