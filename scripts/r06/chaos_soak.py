@@ -52,10 +52,19 @@ def signature(samples):
     return np.concatenate(parts)
 
 
+def rss_mb():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2 ** 20
+
+
 want, n_calls, n_bad = {}, 0, 0
-t_end = time.time() + seconds
+mem_marks = []
+t_start = time.time()
+t_end = t_start + seconds
 with torch.no_grad():
     while time.time() < t_end:
+        if len(mem_marks) < 4 and time.time() - t_start >= (len(mem_marks) + 1) * seconds / 4.2:
+            mem_marks.append((round(torch.cuda.memory_reserved() / 2 ** 20), round(rss_mb())))
         if MODE == "step" or (MODE == "both" and rng.random() < 0.5):  # a burst of single calls
             for _ in range(rng.randint(1, 12)):
                 key = (rng.choice(sizes), rng.randint(0, 1))
@@ -82,4 +91,5 @@ with torch.no_grad():
                     print(f"MISMATCH test_step_stream B {key[0]} variant {key[1]}: max |diff| {np.nanmax(np.abs(sig - want[key])):.3e}", flush=True)
 eng = getattr(model, "engine", None)
 print(f"{n_calls} batches in {seconds:.0f} s, {len(want)} distinct, {n_bad} mismatches" + (f", graph captures {eng.graph_captures}" if eng is not None and hasattr(eng, "graph_captures") else ""))
+print("device MiB reserved / host RSS MiB at the quarter marks:", mem_marks)
 print("CHAOS SOAK", "FAILED" if n_bad else "OK")
