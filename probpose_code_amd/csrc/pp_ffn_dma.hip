@@ -20,7 +20,7 @@
 // TOOLCHAIN NOTE: the paired kernels issue their MFMAs as inline assembly (mma_ip), which the compiler's hazard recogniser does not
 // see; the wait states in front of every VALU read of an accumulator are placed by hand (mfma_settle / valu_settle) and the schedule distance
 // between two MFMAs on one accumulator is >= 6 MFMAs by construction of the sweeps. Built and validated with ROCm 7.2.0's hipcc (AMD clang 20);
-// after a compiler upgrade or a change of FFD_PAIR_UNROLL / FFD_GELU_PACKED re-run tests/test_split_fp16.py - its `ffn_form` 1 runs the SAME
+// after a compiler upgrade or a change of the loop structure re-run tests/test_split_fp16.py - its `ffn_form` 1 runs the SAME
 // arithmetic on the builtin-MFMA kernels (hazards handled by the compiler) and both forms are held to the fp64 reference.
 #include "pp_common.h"
 #include "pp_split.h"
@@ -52,41 +52,8 @@ constexpr int NPROJ = 2 * KB;  // steps of the projection phase
 static_assert(LDS == 160 * 1024, "LDS map");
 static_assert(STEPS % NSLOT == 0 && NPROJ % NSLOT == 0, "ring positions must repeat");
 
-#ifndef FFD_DMA_PRIO
-#define FFD_DMA_PRIO 0  // dev A/B: priority of the DMA waves (s_setprio)
-#endif
 #ifndef FFD_STAMP
 #define FFD_STAMP 0  // dev: wave 0 of workgroups 0 and 131 leaves s_memtime stamps at the phase boundaries of the paired proj + FFN kernel (scripts/micro/ffd_stamps.sh)
-#endif
-#ifndef FFD_LN_PREFETCH
-#define FFD_LN_PREFETCH 1  // LayerNorm epilogues: gamma / beta of all column fragments fetched ahead of the store loop
-#endif
-#ifndef FFD_GELU_RELU_FORM
-#define FFD_GELU_RELU_FORM 1
-#endif
-#ifndef FFD_GELU_PACKED
-#define FFD_GELU_PACKED 1  // the chunk's GELU on value pairs with packed fp32 instructions and a v_fma_mix_f32 split (round 5); 0: one value per instruction (round 4)
-#endif
-#ifndef FFD_H128
-#define FFD_H128 1
-#endif
-#ifndef FFD_X128
-#define FFD_X128 1
-#endif
-#ifndef FFD_STORE16
-#define FFD_STORE16 0
-#endif
-#ifndef FFD_READS_FIRST
-#define FFD_READS_FIRST 1
-#endif
-#ifndef FFD_PAIR_UNROLL
-#define FFD_PAIR_UNROLL 0  // PAIR form: the k-block loops unrolled (counted lgkmcnt waits) or as run-time loops (the compiler waits lgkmcnt(0) at every loop header)
-#endif
-#ifndef FFD_ROLL
-#define FFD_ROLL 1  // rolling fragment reads, the barrier of a step inside its predecessor (round 5; 0: round 4's barrier | reads | MFMAs steps)
-#endif
-#ifndef FFD_DEPTH
-#define FFD_DEPTH 3  // steps a DMA wave may have in flight behind the one the computing waves are about to read: 2 or 3
 #endif
 
 template <int N>
@@ -145,7 +112,6 @@ __device__ __forceinline__ void mfma_settle(f32x4 (&a)[3][6]) {
 template <bool PROJ, bool PAIR>
 __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int lane, int m0, int nchunks, int c_rot) {
     char* const ring = smem + OFF_RING;
-    if (FFD_DMA_PRIO) __builtin_amdgcn_s_setprio(FFD_DMA_PRIO);
     const int x_l = lane >> 3;
     const unsigned v_w = (unsigned)lane * 16u;
     // an x piece is 8 rows x 128 B: lane (row l = lane >> 3, physical chunk lane & 7) fetches logical chunk (lane & 7) ^ l
@@ -178,7 +144,7 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
         for (int s = 0; s < NPROJ; ++s) {
             // step s must have landed: the pieces of the steps behind it may be out
             __builtin_amdgcn_sched_barrier(0);
-            wait_vm_n((FFD_DEPTH == 3 ? n_proj(s + 1) : 0) + n_proj(s + 2));
+            wait_vm_n(n_proj(s + 1) + n_proj(s + 2));
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             issue_p(s + 3);
@@ -285,12 +251,12 @@ __device__ __forceinline__ void dma_role(const Params& p, char* smem, int d, int
 #pragma unroll
         for (int t = 0; t < STEPS; ++t) {
             __builtin_amdgcn_sched_barrier(0);
-            wait_vm_n((FFD_DEPTH == 3 ? n_main(t + 1) : 0) + n_main(t + 2));
+            wait_vm_n(n_main(t + 1) + n_main(t + 2));
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // (all computing waves are past their reads of step t - 1: its slot takes step t + 3)
             if (t + 3 < STEPS) issue(ci, t + 3); else issue(ci + 1, t + 3 - STEPS);
-            if (FFD_ROLL && t == NA) __builtin_amdgcn_s_barrier();  // the computing waves' G-tile barrier (between their barriers of steps NA and NA + 1)
+            if (t == NA) __builtin_amdgcn_s_barrier();  // the computing waves' G-tile barrier (between their barriers of steps NA and NA + 1)
         }
     }
     }
@@ -373,23 +339,17 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) bgl[rf] = rd(lane_lo, ug, rf * 2048);
         }
-#if FFD_READS_FIRST
         __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wh[nf], bgh[rf], acc[rf][half * 3 + nf]);
-#if FFD_READS_FIRST
         __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int rf = 0; rf < 3; ++rf)
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) acc[rf][half * 3 + nf] = mma(wl[nf], bgh[rf], acc[rf][half * 3 + nf]);
-#if FFD_READS_FIRST
         __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int nf = 0; nf < 3; ++nf)
 #pragma unroll
@@ -466,7 +426,6 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 *reinterpret_cast<f32x2_t*>(p.stats_out + (size_t)(m0 + r) * 2) = f32x2_t{mean[rf], rstd[rf]};
             }
         }
-#if FFD_LN_PREFETCH
         // gamma / beta of all six column fragments in one round trip (48 registers: the operand fragments are dead): inside the store loop every
         // pair of loads sits behind the previous fragment's buffer stores - six dependent trips to the L2 per LayerNorm
         f32x4 gs_[6], bs_[6];
@@ -476,15 +435,10 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             gs_[cf] = FO ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(gamma + cb + fk_ * 4);
             bs_[cf] = FO ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(beta + cb + fk_ * 4);
         }
-#endif
 #pragma unroll
         for (int cf = 0; cf < 6; ++cf) {
             const int cb = (cf / 3) * 192 + cg * 48 + (cf % 3) * 16;  // (wave-uniform)
-#if FFD_LN_PREFETCH
             const f32x4 g = gs_[cf], b = bs_[cf];
-#else
-            const f32x4 g = FO ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(gamma + cb + fk_ * 4), b = FO ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(beta + cb + fk_ * 4);
-#endif
 #pragma unroll
             for (int rf = 0; rf < 3; ++rf) {
                 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -497,24 +451,10 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 if (FO) hv = f32x4{v[0] - mu, v[1] - mu, v[2] - mu, v[3] - mu};  // (the CENTERED rows: the consumer's projection needs no mean * colsum term)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { float t = hv[j]; split_pin(t); hv[j] = t; }
-#if FFD_STORE16
-                {   // dev A/B: 16-byte stores in the FLAT encoding, as the eight-wave kernel does (64-bit addresses, `live` predicate)
-                    const bool live = m0 + rows0_ + rf * 16 < p.M;
-                    const size_t off = (size_t)(m0 + rows0_ + rf * 16) * E + cb + fk_ * 4;
-                    if (store_x && live) *reinterpret_cast<f32x4*>(x_dst + off) = v;
-                    split_store4_rowpair(h_dst, off, hv, live);
-                    continue;
-                }
-#endif
                 if (store_x) {
                     const u32x4 vq = __builtin_bit_cast(u32x4, v);
-#if FFD_X128
                     __builtin_amdgcn_raw_buffer_store_b128(vq, rx, v_rowx + rf * (16 * E * 4), cb * 4, 0);
                     asm volatile("s_nop 3" ::"v"(vq));  // (wait states behind a 16-byte buffer store: scripts/micro/mubuf_store_hazard.hip)
-#else
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{vq[0], vq[1]}, rx, v_rowx + rf * (16 * E * 4), cb * 4, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{vq[2], vq[3]}, rx, v_rowx + rf * (16 * E * 4), cb * 4 + 8, 0);
-#endif
                 }
                 // WAIT STATES BEHIND 16-BYTE BUFFER STORES. A buffer_store_dwordx4 reads its data registers one cycle late for lanes
                 // 12 - 15 of every row; an instruction that writes one of them directly behind the store changes what those lanes store.
@@ -529,7 +469,6 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 { unsigned h__, l__; split_pair(hv[0], hv[1], h__, l__); hu[0] = h__; lu[0] = l__; }
                 { unsigned h__, l__; split_pair(hv[2], hv[3], h__, l__); hu[1] = h__; lu[1] = l__; }
                 const int so = (cb >> 5) * 128 + (cb & 16) * 2;
-#if FFD_H128
                 {   // the row-pair form of split_store4_rowpair (lanes fk_, fk_ ^ 1 exchange halves: the even one stores the 16-byte hi chunk,
                     // the odd one the lo chunk), as ONE 16-byte buffer store followed by the wait states the compiler does not insert
                     const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
@@ -538,10 +477,6 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                     __builtin_amdgcn_raw_buffer_store_b128(q, rh, v_rowh2 + rf * (16 * E * 4), so, 0);
                     asm volatile("s_nop 3" ::"v"(q));
                 }
-#else
-                __builtin_amdgcn_raw_buffer_store_b64(hu, rh, v_rowh + rf * (16 * E * 4), so, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(lu, rh, v_rowh + rf * (16 * E * 4), so + 64, 0);
-#endif
             }
         }
     };
@@ -595,7 +530,6 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
     if constexpr (PROJ) {
         // ---- attention output projection + residual, then ln2:  acc <- x + att Wp^T + bp ;  h <- LN2(acc). 24 steps shaped like
         // the B-steps: step s = 2 kb + half takes the Wp half block from ring slot s & 3, the attention rows' k-block kb from G buffer kb & 3
-#if FFD_ROLL
         // (rolling fragment reads as in the FFN loop below: the same three sweeps, the barrier of step s + 1 behind the second MFMA of step s)
         {
             u32x4 pwh[3], pwl[3];
@@ -646,16 +580,6 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 }
             }
         }
-#else
-#pragma unroll 1
-        for (int kp = 0; kp < NPROJ / 4; ++kp) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                step_barrier();
-                b_step(q, q & 1, ((4 * kp + q) >> 1) & 3, (q & 1) == 0);
-            }
-        }
-#endif
         // + bp (after the sums, as residual + (sum + bias) rounds closest to the reference's x + proj(...))
 #pragma unroll
         for (int cf = 0; cf < 6; ++cf) {
@@ -713,7 +637,6 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 char* gs = smem + OFF_G + cg * G_KB + (rg * 48 + (ln_ & 15) + rf * 16) * 128 + (fk_ & 1) * 8;
                 const int c = 2 * nf + (fk_ >> 1);
                 const int sw = sw_;
-#if FFD_GELU_PACKED
                 // Round 5: the chunk's GELU is ~3.4 k of its ~22 k cycles (stamps of scripts/micro/ffn12d.hip -DSTAMP=1), VALU-bound with both
                 // computing waves of a SIMD issuing at once, and it cannot be hidden behind MFMAs of the same SIMD.
                 // What is left is fewer issue cycles per value (scripts/micro/valu_rate.hip, cycles per wave64 instruction and SIMD: plain fp32
@@ -754,41 +677,6 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
                 *reinterpret_cast<u32x2_t*>(gs + ((c ^ sw) << 4)) = u32x2_t{hq[0], hq[1]};
                 *reinterpret_cast<u32x2_t*>(gs + (((4 + c) ^ sw) << 4)) = u32x2_t{lq[0], lq[1]};
-#else
-                f16x4 hv, lv;
-                float x[4], z[4], tt[4], qq[4], e[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = pa[rf][nf][u] * p.inv_1;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) z[u] = fabsf(x[u]) * 0.70710678118654752440f;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) tt[u] = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z[u], 1.0f));
-#pragma unroll
-                for (int u = 0; u < 4; ++u) e[u] = __builtin_amdgcn_exp2f(-(z[u] * z[u]) * 1.44269504088896340736f);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], 1.061405429f, -1.453152027f);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], 1.421413741f);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], -0.284496736f);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) qq[u] = __builtin_fmaf(tt[u], qq[u], 0.254829592f);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float erfc_z = tt[u] * qq[u] * e[u];
-#if FFD_GELU_RELU_FORM
-                    // 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2): no compare / select, two instructions less per value
-                    float g = __builtin_fmaf(-0.5f * fabsf(x[u]), erfc_z, fmaxf(x[u], 0.f));
-#else
-                    float g = 0.5f * x[u] * (x[u] < 0.f ? erfc_z : 2.0f - erfc_z);
-#endif
-                    split_pin(g);
-                    hv[u] = split_hi(g);
-                    lv[u] = split_lo(g, hv[u]);
-                }
-                *reinterpret_cast<f16x4*>(gs + ((c ^ sw) << 4)) = hv;
-                *reinterpret_cast<f16x4*>(gs + (((4 + c) ^ sw) << 4)) = lv;
-#endif
             }
     };
 
@@ -910,11 +798,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
                     }
                 }
             };
-#if FFD_PAIR_UNROLL
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
             for (int jb = 0; jb < NB / 2 - 1; ++jb) two_steps(jb, false);
             two_steps(NB / 2 - 1, true);
         };
@@ -927,11 +811,7 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             valu_settle(pacc);  // (VALU writes -> MFMA SrcC reads: the wait states the compiler cannot know an asm statement needs)
             valu_settle(pacc1);
             // ---- A-steps of both chunks, k-block by k-block
-#if FFD_PAIR_UNROLL
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
             for (int kbi = 0; kbi < NA - 1; ++kbi) {  // (one k-block's two steps; the last k-block apart: B-steps follow it)
                 a_step(pacc, 2 * kbi + 1, false, false);
                 a_step(pacc1, 2 * kbi + 2, true, false);
@@ -956,7 +836,6 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
         }
         mfma_settle(acc);
     } else {
-#if FFD_ROLL
     {
         // ROLLING FRAGMENT READS (round 5). In the loop below a step is [barrier | ten reads | wait | 18 / 27 MFMAs]: the reads' latency and the
         // barrier skew sit in front of every step's MFMAs - stamps of scripts/micro/ffn12d.hip: 850 - 880 cycles per A-step against 576 of MFMA
@@ -1066,64 +945,6 @@ __device__ __forceinline__ void compute_role(const Params& p, char* smem, int wv
             }
         }
     }
-#else
-
-    for (int ci = 0; ci < nchunks; ++ci) {
-#pragma unroll
-        for (int rf = 0; rf < 3; ++rf)
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = b1v[nf] * p.s_1;
-        load_b1(ci + 1);
-        // ---- A-steps: P += x[:, kb] W1[chunk, kb]^T, wave tile 48 rows x 32 units
-#pragma unroll
-        for (int t = 0; t < NA; ++t) {
-            step_barrier();
-            const int ua = opaque_s(u_a + (t & 3) * SLOTB), ux = opaque_s(u_x + (t & 3) * SLOTB);
-            u32x4 wh[2], wl[2], xh[3], xl[3];
-            // reads in the order the MFMAs want them (LDS returns in order, the first product needs two fragments, not eight)
-            wh[0] = rd(lane_hi, ua, 0);
-            xh[0] = rd(lane_hi, ux, 0);
-            wh[1] = rd(lane_hi, ua, 2048);
-            xh[1] = rd(lane_hi, ux, 2048);
-            xh[2] = rd(lane_hi, ux, 4096);
-            wl[0] = rd(lane_lo, ua, 0);
-            wl[1] = rd(lane_lo, ua, 2048);
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf) xl[rf] = rd(lane_lo, ux, rf * 2048);
-#if FFD_READS_FIRST
-            // every fragment read of the step is issued before its first MFMA (left alone the scheduler loads the lo row fragments
-            // into the registers of the hi ones, i.e. in the MIDDLE of the step, and waits for them there)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf)
-#pragma unroll
-                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wh[nf], xh[rf], pacc[rf][nf]);
-#if FFD_READS_FIRST
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-            for (int rf = 0; rf < 3; ++rf)
-#pragma unroll
-                for (int nf = 0; nf < 2; ++nf) pacc[rf][nf] = mma(wl[nf], xh[rf], pacc[rf][nf]);
-#if FFD_READS_FIRST
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-                for (int rf = 0; rf < 3; ++rf) pacc[rf][nf] = mma(wh[nf], xl[rf], pacc[rf][nf]);
-        }
-        gelu_chunk(pacc);
-        // ---- B-steps (j, half): acc[:, half] += G[:, j] W2[half, chunk j]^T, wave tile 48 rows x 48 outputs (the barrier of the
-        // first one publishes the G tile)
-#pragma unroll
-        for (int sb = 0; sb < NB; ++sb) {
-            step_barrier();
-            b_step((NA + sb) & 3, sb & 1, sb >> 1, (sb & 1) == 0);
-        }
-    }
-#endif
     }
     // ---- LayerNorm epilogue: G is out of use once every wave is past its last B-step
     __syncthreads();  // E1
@@ -1169,7 +990,7 @@ namespace ffs {
 // called from the entry points in pp_ffn_split.hip
 int launch_dma_form(const Params& p, bool proj, hipStream_t s) {
     // an even number of hidden chunks: the paired form (two chunks share every streamed x k-block); option "ffn_pair" = 0 or an odd count: one at a time
-    const bool pair = FFD_ROLL && option("ffn_pair") != 0 && (p.F / ffd::CHUNK) % 2 == 0;
+    const bool pair = option("ffn_pair") != 0 && (p.F / ffd::CHUNK) % 2 == 0;
     auto kern = pair ? (proj ? ffd::proj_ffn_dma_pair_kernel : ffd::ffn_dma_pair_kernel) : (proj ? ffd::proj_ffn_dma_kernel : ffd::ffn_dma_kernel);
     const int fold = (p.res_split ? 1 : 0) | (p.fold_out ? 2 : 0);
     if (fold) {  // pp_proj_ffn_split_folded: the paired projection kernel only (its entry point checks)

@@ -62,9 +62,6 @@ __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 c) {
 }
 
 
-#ifndef LDM_ROLL
-#define LDM_ROLL 1  // rolling fragment reads in the K loop (round 5, as pp_ffn_dma.hip): 0 = round 4's barrier | 18 reads | 54 MFMAs steps
-#endif
 
 // K loop of a computing wave with ROLLING fragment reads (pp_ffn_dma.hip, round 5): the 18 fragment registers of a step are re-read for
 // the next stage right behind the last MFMA of this step that uses them - sweeps hi x lo, hi x hi, lo x hi, so the first sweep's operands
@@ -325,42 +322,7 @@ __global__ __launch_bounds__(THREADS) void linear_dma_kernel(const Params p) {
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if LDM_ROLL
     k_loop_roll(acc, smem, lane_hi, lane_lo, rg, cg, ksteps, slot);
-#else
-    int st = slot;
-    for (int k = 0; k < ksteps; ++k) {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const int ua = opq(st * STAGE + rg * 48 * 128), ub = opq(st * STAGE + B_OFF + cg * 96 * 128);
-        u32x4 ah[3], al[3], bh[6], bl[6];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ah[i] = rd(lane_hi, ua, i * 2048);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) bh[j] = rd(lane_hi, ub, j * 2048);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) al[i] = rd(lane_lo, ua, i * 2048);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) bl[j] = rd(lane_lo, ub, j * 2048);
-        __builtin_amdgcn_sched_barrier(0);  // every fragment read of the step ahead of its first MFMA (pp_ffn_dma.hip)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], ah[i], acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) acc[i][j] = mma(bl[j], ah[i], acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) acc[i][j] = mma(bh[j], al[i], acc[i][j]);
-        st = st + 1 == NSTAGE ? 0 : st + 1;
-    }
-    slot = st;
-
-#endif
 
     stamp();  // 3 i + 1: K loop done
     // ---------------- epilogue: act_fn(sum + bias) + residual, rows out as split fp16 (two 8-byte halves per lane) or fp32 (16 bytes).

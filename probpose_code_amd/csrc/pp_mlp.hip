@@ -47,23 +47,8 @@ namespace mlp {
 // dev ablation switches (scripts/micro/mlp_ablate.sh), 0 in the product build: 2 no GELU, 4 no MFMA, 8 no DMA,
 // 16 no LDS fragment reads, 32 no barriers, 64 no b1 loads, 512 per-step time stamps, 1024 no qkv stores, 2048 no qkv staging / stores at all
 constexpr int DBG = MLP_DBG;
-#ifndef MLP_ROT_MORE
-#define MLP_ROT_MORE 1  // dev A/B switch: rotate the projection's k-steps and the qkv tail's column blocks per workgroup too
-#endif
-#ifndef MLP_ROT_XCD
-#define MLP_ROT_XCD 1
-#endif
-#ifndef MLP_ATT_RR
-#define MLP_ATT_RR 1  // dev A/B switch: 0 = round-2 attention phase (wave w = query tile w for every head, waves 6-7 idle)
-#endif
-#ifndef MLP_DEFER_X
-#define MLP_DEFER_X 1  // dev A/B switch: 0 = every wave stores its residual rows before the tail
-#endif
 #ifndef ATT_DBG
 #define ATT_DBG 0  // dev ablations of the attention rounds: 1 no v_exp, 2 no V reads, 4 no K reads, 8 no P V MFMAs (wrong results)
-#endif
-#ifndef MLP_XCD_PAIR
-#define MLP_XCD_PAIR 1  // dev A/B switch: 0 = tile = blockIdx.x (sequence halves on different XCDs)
 #endif
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_VMEM = 0x010, SG_DS_READ = 0x100;
@@ -200,7 +185,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     // run of tiles [x * G / 8, (x + 1) * G / 8). Without this both halves fetched K / V from HBM on their own
     // (r01: 262 MB per launch of counter traffic against 186 MB algorithmic).
     int tile = blockIdx.x;
-    if (MLP_XCD_PAIR && (gridDim.x & 15) == 0) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
+    if ((gridDim.x & 15) == 0) tile = (tile & 7) * (gridDim.x >> 3) + (tile >> 3);
     const int m0 = tile * BM;
 
     const __amdgpu_buffer_rsrc_t h_rsrc =
@@ -231,10 +216,10 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     // lockstep they would all hit the same L2 lines at the same moment.
     // (the rotation index is the workgroup's rank inside its XCD - blockIdx.x >> 3 - so that the CUs behind one L2 are
     // spread over all rotations; blockIdx.x % nchunks gave the 32 CUs of an XCD only three distinct ones)
-    const int xcd_rank = MLP_ROT_XCD ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int xcd_rank = (int)(blockIdx.x >> 3);
     const int c_rot = xcd_rank % nchunks;
-    const int p_rot = MLP_ROT_MORE ? xcd_rank % 12 : 0;  // k-steps of the projection (a sum: any order)
-    const int q_rot = MLP_ROT_MORE ? xcd_rank % 6 : 0;   // column blocks of the qkv tail
+    const int p_rot = xcd_rank % 12;  // k-steps of the projection (a sum: any order)
+    const int q_rot = xcd_rank % 6;   // column blocks of the qkv tail
     // (tried and dropped: a second level - the k-steps INSIDE a chunk's phase A / phase B rotated too, for the CUs of an
     // XCD that share a chunk rotation - 169 us against 143: the run-time address arithmetic lands in the FFN loop)
     auto chunk_of = [&](int i) { const int c = i + c_rot; return c >= nchunks ? c - nchunks : c; };
@@ -336,7 +321,6 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     bool valid[3];
 #pragma unroll
     for (int rf = 0; rf < 3; ++rf) valid[rf] = m0 + rg * 48 + f_row + rf * 16 < p.M;
-#if MLP_ATT_RR
     if (ATT) {
         // ================= attention of this workgroup's 96 query rows. Sequence = 192 tokens = this workgroup's rows and its
         // neighbour's. The work is 12 heads x 6 query tiles of 16 = 72 (head, tile) tasks, dealt round-robin to the EIGHT waves
@@ -539,147 +523,6 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
 #pragma unroll
         for (int q = 3; q < NSLOT; ++q) issue_rel(0, q - 12 - PRE);  // the rest of the first eight weight slots
     }
-#else
-    if (ATT) {
-        // ================= attention of this workgroup's 96 query rows (waves 0-5: one 16-query tile each). Sequence = 192
-        // tokens = this workgroup's rows and its neighbour's. K and V of one head (192 x 32 each, 24 KiB together) arrive by
-        // LDS-DMA, all eight waves issuing, three heads in rotation (two thirds of the ring region + the G region, which
-        // the FFN only needs later) so that a head has two heads' worth of math to land. Both stay row-major by key:
-        //   * K chunk (key, c) sits at 16-byte position 4 key + (c ^ ((key >> 2) & 3)) - the 16 keys x one chunk a
-        //     ds_read_b128 of the S^T = K Q^T operand touches then hit 16 different bank groups;
-        //   * V chunk (key, c) at 4 key + (c ^ 2 ((key >> 2) & 1)); the O^T = V^T P^T operand - eight keys of one head
-        //     dimension per lane - comes out of two ds_read_b64_tr_b16, the gfx950 transposing read: within 16 lanes, lane
-        //     4 r + q supplies the address of four consecutive 16-bit elements M[r][4 q ..], lane i receives M[0..3][i]
-        //     (scripts/micro/tr_probe.hip). No register staging, no 16-bit scatter.
-        constexpr int SEQ = 192, NKT = SEQ / 16, HEADS = E / 32, RS = 3 * E;
-        constexpr int KBYTES = SEQ * 64, HBYTES = 2 * KBYTES;  // one head: K [192][64 B] + V [192][64 B]
-        static_assert(2 * HBYTES <= NSLOT * SLOT && HBYTES <= 2 * HS_KB, "two heads in the ring region, one in the G region");
-        static_assert((HEADS - 1) % 3 == 2, "the last head sits in the G region (the weight stream starts under it)");
-        const int srow0 = (m0 / SEQ) * SEQ;
-        const __amdgpu_buffer_rsrc_t qkv_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.qkv_in), 0, (unsigned)p.M * (unsigned)(RS * 2), 0x00020000);
-        u32x4 qf[HEADS];
-        auto head_buf = [&](int hd) -> char* { return hd % 3 == 2 ? smem + OFF_GS : ring + (hd % 3) * HBYTES; };
-        // instruction i of a head (24 of 1 KiB): i < 12 K keys 16 i .., else V keys 16 (i - 12) ..; lane = (key, position)
-        const int a_key = lane >> 2, a_pos = lane & 3;
-        auto issue_head = [&](int hd) {
-            char* dst = head_buf(hd);
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int i = wv + 8 * u;
-                const bool isv = i >= 12;
-                const int key = 16 * (isv ? i - 12 : i) + a_key;
-                const int c = isv ? (a_pos ^ (2 * ((key >> 2) & 1))) : (a_pos ^ ((key >> 2) & 3));
-                const unsigned vo = (unsigned)(srow0 + key) * (unsigned)(RS * 2) + (unsigned)((isv ? 2 * E : E) * 2 + hd * 64 + c * 16);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(qkv_rsrc, (lds_ptr_t)(dst + i * 1024), 16, vo, 0, 0, 0);  // rows past M: out of bounds = zeros
-            }
-        };
-        // order of the first requests: K / V of head 0, the Q fragments (all eight waves, so that every wave's count is the
-        // same; waves 6, 7 never use theirs), K / V of head 1 - the first head does not wait for 74 KB of Q behind it
-        issue_head(0);
-        {
-            const int qm = m0 + (wv < 6 ? wv : 0) * 16 + f_row;
-            const __bf16* qrow = p.qkv_in + (size_t)(qm < p.M ? qm : p.M - 1) * RS + f_kg * 8;
-#pragma unroll
-            for (int hd = 0; hd < HEADS; ++hd) qf[hd] = *reinterpret_cast<const u32x4*>(qrow + hd * 32);
-        }
-        issue_head(1);
-        const int k_frag_off = f_row * 64 + ((f_kg ^ ((f_row >> 2) & 3)) << 4);  // + kt * 1024
-        // transposing V read: lane supplies key 4 f_kg + (f_row >> 2) of the 16-key tile, elements 4 (f_row & 3) .. + 3 of the
-        // 16-dimension tile dt: chunk 2 dt + ((f_row & 3) >> 1), swizzled by 2 (f_kg & 1), upper or lower half
-        // (chunk (2 dt + q) ^ 2 (f_kg & 1) = 2 (dt ^ (f_kg & 1)) + q)
-        const int v_frag_off = KBYTES + (4 * f_kg + (f_row >> 2)) * 64 + (((f_row & 3) >> 1) << 4) + (f_row & 1) * 8;
-        const int v_dt_off[2] = {(f_kg & 1) * 32, ((f_kg & 1) ^ 1) * 32};
-#pragma unroll
-        for (int hd = 0; hd < HEADS; ++hd) {
-            stamp(30, hd);
-            // head hd has landed; younger than its DMA and allowed to fly on: the residual loads of iterations hd - 2 and
-            // hd - 1 (three per iteration 1..6, see below) and the DMA of head hd + 1. Past the barrier head hd - 1 is done with.
-            // (head 0: 12 Q loads + 3 - 1: 3 - then 2 residual loads per iteration 1..9: heads 2: 5 - 3..10: 7 - 11: 0;
-            // "at most as many outstanding as there are younger requests" is always a safe count)
-            if (hd + 1 == HEADS) wait_dma_and_barrier<0>();
-            else if (hd == 0) wait_dma_and_barrier<HEADS + 3>();
-            else if (hd >= 3) wait_dma_and_barrier<7>();
-            else if (hd == 2) wait_dma_and_barrier<5>();
-            else wait_dma_and_barrier<3>();
-            stamp(32, hd);
-            stamp(32, hd);
-            if (hd + 2 < HEADS) issue_head(hd + 2);
-            if (hd + 1 == HEADS) {
-                // the last head sits in the G region: the ring is free, the first eight slots of the weight stream fly
-                // under its math
-#pragma unroll
-                for (int q = 0; q < NSLOT; ++q) issue_rel(0, q - 12 - PRE);
-            }
-            if (hd >= 1 && hd <= 9) {
-                // The residual rows (147 KB per workgroup, fp32) trickle in under the attention math, two loads per head
-                // once the first head is through: plain loads into the accumulators - the bias is added after the phase,
-                // an add (or a select: rows past M read row M - 1, nothing of them is ever stored) here would wait for them.
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int i = (hd - 1) * 2 + u, rf = i / 6, nf = i % 6;
-                    const int m = m0 + rg * 48 + f_row + rf * 16;
-                    acc[rf][nf] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(m < p.M ? m : p.M - 1) * E + cg * 96 + nf * 16 + f_kg * 4);
-                }
-            }
-            if (wv < 6) {
-                const char* Ks = head_buf(hd);
-                const u32x4 qh = qf[hd];
-                f32x4 sc[NKT];
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)  // S^T: lane holds keys 16 kt + 4 f_kg + (0..3) of query f_row
-                    sc[kt] = mma(*reinterpret_cast<const u32x4*>(Ks + kt * 1024 + k_frag_off), qh, f32x4{0.f, 0.f, 0.f, 0.f});
-                float mx = -__builtin_inff();
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sc[kt][i]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float mb = mx * p.scale_log2e;
-                float sum = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], p.scale_log2e, -mb));  // arg <= 0
-                        sc[kt][i] = pe;
-                        sum += pe;
-                    }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
-                f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int blk = 0; blk < NKT / 2; ++blk) {  // O^T = V^T P^T; the key order inside a 32-key block is a
-                    const f32x4 p0 = sc[2 * blk], p1 = sc[2 * blk + 1];  // permutation shared by both operands
-                    const bf16x8 pf = {(__bf16)p0[0], (__bf16)p0[1], (__bf16)p0[2], (__bf16)p0[3],
-                                       (__bf16)p1[0], (__bf16)p1[1], (__bf16)p1[2], (__bf16)p1[3]};
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const char* vsrc = Ks + v_frag_off + blk * 2048 + v_dt_off[dt];  // keys 32 blk + .., chunks 2 dt, 2 dt + 1 (swizzled)
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vsrc));
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vsrc + 1024));
-                        const s16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
-                    }
-                }
-                // lane holds d = 16 dt + 4 f_kg + (0..3) of query f_row: 8 bytes into the row-operand image of the projection
-                const float inv = 1.0f / sum;
-                const int row = wv * 16 + f_row;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int n = hd * 32 + dt * 16 + f_kg * 4;
-                    const f32x4 v = o[dt] * inv;
-                    const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(smem + OFF_HS + (n >> 6) * HS_KB + row * ROW_BYTES + (((((n & 63) >> 3)) ^ (row & 7)) << 4) +
-                                               (f_kg & 1) * 8) = ov;
-                }
-            }
-        }
-        stamp(30, HEADS);
-        __syncthreads();  // the last head's math is done: the ring and the G region are free, the rows are in place
-    }
-#endif
 
     // ---- prologue: ring filled with the first eight slots, input rows into LDS, accumulators = residual + b2
     if (!ATT) {
@@ -970,9 +813,9 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
                                (__bf16)((v[2] - mu) * rs * g[2] + b[2]), (__bf16)((v[3] - mu) * rs * g[3] + b[3])};
             if (QKV) *reinterpret_cast<bf16x4*>(hs + rf * 16 * ROW_BYTES) = hv;  // the row operand of the qkv steps
             if (m >= p.M) continue;
-            // (MLP_DEFER_X, QKV: rows 48-95 - waves 4-7, which never count vmcnt in the tail - keep their x in registers across
+            // (QKV: rows 48-95 - waves 4-7, which never count vmcnt in the tail - keep their x in registers across
             // the barrier below and store it at the head of the tail, see there)
-            if (!(MLP_DEFER_X && QKV) || rg == 0) *reinterpret_cast<f32x4*>(p.x_out + off) = v;
+            if (!QKV || rg == 0) *reinterpret_cast<f32x4*>(p.x_out + off) = v;
             if (p.h_out) *reinterpret_cast<bf16x4*>(p.h_out + off) = hv;
         }
     }
@@ -990,7 +833,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_res_ln_kernel(const Params p) 
     // vmcnt with the DMA stream and a counted wait would sit behind them: waves 0-3 issue all the DMA (and count it),
     // waves 4-7 do all the stores (and never wait for them before the end).
     wait_dma_and_barrier<0>();
-    if (MLP_DEFER_X && rg == 1) {
+    if (rg == 1) {
         // The 37.7 MB of fp32 residual rows leave at the ~4.2 TB/s the chip sustains on writes, and the barrier above waits for
         // them (the DMA-issuing waves 0-3 must drain their stores before their counted waits begin): 9 us per launch with
         // no MFMA running. Waves 4-7 never wait on vmcnt in the tail, so THEIR half goes out here, after the barrier, under the

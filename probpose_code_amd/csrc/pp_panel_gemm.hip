@@ -42,10 +42,6 @@ namespace panel {
 // 4 no MFMA, 8 no DMA, 16 no LDS fragment reads, 32 activation DMA out of bounds only, 64 weight DMA out of bounds only,
 // 128 no epilogue, 256 clock probe, 512 fused head without its weight reads
 constexpr int DBG = PANEL_DBG;
-#ifndef PANEL_KROT
-#define PANEL_KROT 0  // dev A/B switch. Measured: rotation ON is 2 - 12 % SLOWER here (conv1 274 -> 283 us, deconv1 83 -> 92) - unlike the layer kernel, these
-                      // tiles gain from sweeping K in step (only the current weight slice is hot in the XCD's L2)
-#endif
 
 constexpr int THREADS = 512;
 constexpr int STAGE = 56 * 1024, NSTAGE = 2;
@@ -115,9 +111,8 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
     __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
     int i_tile = blockIdx.x, i_step = 0, i_tap = 0, i_c0 = 0, i_py = 0, i_px = 0, i_tap_lo = 0;
     bool i_live = true;
-    // The K sweep of a tile starts at a per-workgroup rotation (a sum: any order) and wraps: the 32 workgroups of an XCD
-    // read the same weight slices, in step they would all pull the same L2 lines at the same moment (pp_mlp.hip: 7 %).
-    const int k_rot = PANEL_KROT ? (int)(blockIdx.x >> 3) % nsteps : 0;
+    // (A per-workgroup rotation of the K sweep - the layer kernel's 7 % - was measured 2 - 12 % SLOWER here and is gone: these workgroups of an XCD
+    //  do not run in step.)
     auto setup_issue_tile = [&]() {
         int z = 0, m0 = 0, n0 = 0;
         i_live = i_tile < ntiles;
@@ -149,9 +144,8 @@ __global__ __launch_bounds__(THREADS, 2) void panel_gemm_kernel(const GemmParams
         w_voff = (unsigned)(n0 + 8 * (wv + 8 * JA - NA) + d_l) * (unsigned)(p.ldw * 2) + d_kbytes;  // n < N: N % BN == 0
         i_step = 0;
         i_tap_lo = tap0;
-        const int cps = p.Cin / 64;  // K-steps per tap
-        i_tap = tap0 + k_rot / cps;
-        i_c0 = (k_rot - (k_rot / cps) * cps) * 64;
+        i_tap = tap0;
+        i_c0 = 0;
     };
     // issue instruction j of the stage at the cursor into ring buffer `buf`
     auto issue_instr = [&](int buf, int j) {
