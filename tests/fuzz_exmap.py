@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Differential fuzz of the HIP Ex-mAP evaluator (probpose_code_amd.evaluation.COCOeval) against the oracle (oracle/exmap_ref.py - test infrastructure)
 over random datasets and every switch combination: image counts 1 .. 120, empty images, crowds, score ties, zero-area boxes, keypoints outside the
-box, all-invisible annotations. Exact equality of precision / recall / scores tables and stats.   python scripts/r06/fuzz_exmap.py [seconds]"""
+box, all-invisible annotations. Exact equality of precision / recall / scores tables and stats.   python tests/fuzz_exmap.py [seconds]"""
 import itertools
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import exmap_ref  # noqa: E402
 from probpose_code_amd.evaluation import COCOeval  # noqa: E402

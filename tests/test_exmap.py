@@ -211,3 +211,14 @@ def test_hip_evaluator_empty_and_degenerate_inputs(lib_built):
     assert e.stats[0] == -1 and e.gt_visibilities == []
     with pytest.raises(AssertionError):
         COCOeval(gts, dts, "keypoints", sigmas=SIGMAS, extended_oks=True, padding=0.9).evaluate()
+
+
+@pytest.mark.gpu
+def test_differential_fuzz_against_the_oracle(lib_built):
+    """tests/fuzz_exmap.py for a few seconds: random datasets (empty images, crowds, score ties, zero-area boxes, all-invisible annotations) through
+    every switch combination, the HIP evaluator's tables equal to the oracle's."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_exmap.py"), "12"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "EXMAP FUZZ OK" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
