@@ -249,3 +249,14 @@ def test_empty_batch_and_errors():
     st = _lib.lib.pp_probmap_decode(z.data_ptr(), None, None, t.data_ptr(), r.data_ptr(), 1, 1, 4, 4, 16.0, 16.0,
                                     None, None, z.data_ptr(), t.data_ptr(), z.data_ptr(), None)
     assert st == _lib.PP_ERR_UNSUPPORTED
+
+
+def test_differential_fuzz_against_the_oracle():
+    """tests/fuzz_decode.py for a few seconds: blobs beyond the borders, exact ties, plateaus, hot pixels on corners, all-zero / constant / tiny-valued
+    maps, checkerboards, with and without the flip pass - keypoints and scores equal to the oracle's bit for bit."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_decode.py"), "10"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DECODE FUZZ OK" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
