@@ -336,3 +336,16 @@ def test_inference_topdown_runs_the_configs_pipeline_and_the_demo_script(tmp_pat
     # single-sample path == batched path
     one = pipe(dict(img=img, bbox=bb[0][None].copy(), bbox_score=np.ones(1, np.float32)))
     assert torch.equal(one["inputs"], packed[0]["inputs"])
+
+
+@pytest.mark.gpu
+def test_warp_differential_fuzz_against_the_oracle():
+    """tests/fuzz_warp.py for a few seconds: images down to 1 x 3 pixels, boxes across / outside the image, slivers, huge boxes, rotations, both input
+    sizes - the HIP crops equal the oracle's (cv2.warpAffine's fixed-point bilinear path) byte for byte."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_warp.py"), "8"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "WARP FUZZ OK" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
