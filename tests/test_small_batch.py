@@ -348,3 +348,15 @@ def test_graph_eviction_and_recapture_with_the_two_stream_head():
             out = eng.forward_graph(crops[B], True, fi)
         assert np.array_equal(out["keypoints"].cpu().numpy(), want[B][0]) and np.array_equal(out["scalars"].cpu().numpy(), want[B][1]), (it, B)
     assert eng.graph_captures > 40 and len(eng._graphs) == 3
+
+
+@gpu
+def test_shape_fuzz_of_the_skinny_kernels():
+    """tests/fuzz_skinny.py for a few seconds: pp_skinny_linear / pp_skinny_deconv / pp_skinny_conv1x1_planar over random shapes (M ragged against every
+    tile edge), every epilogue and every tile shape against fp64, outputs between canaries, LayerNorm counters back at zero."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_skinny.py"), "10"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "SKINNY FUZZ OK" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
