@@ -650,3 +650,15 @@ def test_clock_probe_reports_a_plausible_shader_clock():
     assert 400_000 <= int(words[1]) <= 5_000_000
     with pytest.raises(L.ProbPoseLibraryError):
         L.call("pp_clock_probe", None, None, 1000, None)
+
+
+def test_shape_fuzz_of_pp_gemm():
+    """tests/fuzz_gemm.py for a few seconds: pp_gemm in the three precisions over random shapes (the dispatcher's kernels: 128 x 128, wide tiles,
+    twelve-wave Linear), every epilogue and output format against fp64, outputs between canaries."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_gemm.py"), "10"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "GEMM FUZZ OK" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
